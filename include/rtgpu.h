@@ -1,0 +1,337 @@
+/*
+ * rtgpu.h -- C ABI of the MI355X path-tracing core (PathTracerMIS over the two-level BVH).
+ *
+ * This is the drop-in boundary.  The reference (Witek902/Raytracer) has no FFI: the integrator sits
+ * behind the C++ virtual IRenderer::RenderPixel (Core/Rendering/Renderer.h:56) and is called once per
+ * pixel from Viewport::RenderTile (Core/Rendering/Viewport.cpp:338).  A per-pixel virtual is not a GPU
+ * boundary, so the seam is ONE PASS: everything Viewport::Render does between Viewport.cpp:200 and
+ * Viewport.cpp:262 (per-pass sampler seeds -> tile fan-out -> RenderTile -> RenderPixel -> Film).
+ *
+ * Everything crossing this ABI is a plain pointer, size or POD struct.  No C++ types, no torch types,
+ * no exceptions.  All functions return RTGPU_OK (0) or a negative RtgpuStatus; rtgpu_last_error()
+ * returns a human readable message for the last failure on the calling thread.
+ *
+ * Matrices are 4 rows of 4 floats, row-vector convention exactly as rt::math::Matrix4
+ * (Core/Math/Matrix4.h:20-27): point' = p.x*row0 + p.y*row1 + p.z*row2 + row3.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGPU_ABI_VERSION 1u
+
+typedef enum RtgpuStatus
+{
+    RTGPU_OK = 0,
+    RTGPU_ERR_INVALID_ARGUMENT = -1,
+    RTGPU_ERR_NO_DEVICE = -2,
+    RTGPU_ERR_OUT_OF_MEMORY = -3,
+    RTGPU_ERR_DEVICE = -4,      /* a HIP call failed; see rtgpu_last_error() */
+    RTGPU_ERR_NOT_READY = -5,   /* e.g. render_pass before upload_scene / resize */
+    RTGPU_ERR_UNSUPPORTED = -6  /* feature outside the hot-path scope (textures, decals, CSG ...) */
+} RtgpuStatus;
+
+/* sentinel ids, Core/Traversal/HitPoint.h:8-9 */
+#define RT_INVALID_OBJECT 0xFFFFFFFFu
+#define RT_LIGHT_OBJECT   0xFFFFFFFEu
+#define RT_NO_MATERIAL    0xFFFFFFFFu
+
+/* ---------------------------------------------------------------------------------------------
+ * Scene description (flat, read-only after upload).  Replaces the pointer graph the reference walks:
+ * Scene::mTraceableObjects / mLights / mGlobalLights (Core/Scene/Scene.h:83-96), BVH::mNodes
+ * (Core/BVH/BVH.h:22-30), VertexBuffer (Core/Shapes/Mesh/VertexBuffer.h:18-31), Material
+ * (Core/Material/Material.h:47-73).
+ * ------------------------------------------------------------------------------------------- */
+
+/* 32-byte BVH node, bit-identical to rt::BVH::Node (Core/BVH/BVH.h:22-30).
+ * leaves = numLeaves (low 30 bits) | splitAxis << 30.  numLeaves != 0 <=> leaf.
+ * Interior: children are nodes[childIndex], nodes[childIndex+1].
+ * Leaf: items [childIndex, childIndex + numLeaves) of the owning container
+ * (scene objects for the top level, triangles for a mesh). */
+typedef struct RtNode
+{
+    float    min[3];
+    uint32_t childIndex;
+    float    max[3];
+    uint32_t leaves;
+} RtNode;
+
+/* 36 bytes, rt::math::ProcessedTriangle (Core/Math/Triangle.h:25-41) */
+typedef struct RtTriangle
+{
+    float v0[3];
+    float edge1[3];
+    float edge2[3];
+} RtTriangle;
+
+/* 16 bytes, rt::VertexIndices (Core/Shapes/Mesh/VertexBuffer.h:18-24).
+ * i0..i2 are relative to the owning mesh's first vertex; materialIndex is a GLOBAL index into
+ * RtSceneDesc::materials or RT_NO_MATERIAL (=> the object's default material,
+ * Core/Shapes/MeshShape.cpp:288-291). */
+typedef struct RtVertexIndices
+{
+    uint32_t i0, i1, i2;
+    uint32_t materialIndex;
+} RtVertexIndices;
+
+/* 32 bytes, rt::VertexShadingData (Core/Shapes/Mesh/VertexBuffer.h:26-31) */
+typedef struct RtVertexShading
+{
+    float normal[3];
+    float tangent[3];
+    float texCoord[2];
+} RtVertexShading;
+
+typedef struct RtMesh
+{
+    uint32_t firstNode;     /* into RtSceneDesc::meshNodes; node childIndex values are mesh-relative */
+    uint32_t numNodes;
+    uint32_t firstTriangle; /* into triangles[] and vertexIndices[] (same order: BVH leaf order) */
+    uint32_t numTriangles;
+    uint32_t firstVertex;   /* into vertexShading[] */
+    uint32_t numVertices;
+    uint32_t _pad[2];
+} RtMesh;
+
+typedef enum RtShapeKind
+{
+    RT_SHAPE_SPHERE = 0, /* param = { radius, 1/radius, 0, 0 }            Core/Shapes/SphereShape.cpp:13 */
+    RT_SHAPE_BOX    = 1, /* param = { size.xyz (half extents), 0 }        Core/Shapes/BoxShape.cpp:91   */
+    RT_SHAPE_RECT   = 2, /* param = { size.x, size.y, texScale.x, .y }    Core/Shapes/RectShape.cpp:14  */
+    RT_SHAPE_MESH   = 3  /* meshIndex valid                               Core/Shapes/MeshShape.cpp:34  */
+} RtShapeKind;
+
+typedef enum RtObjectKind
+{
+    RT_OBJECT_SHAPE = 0, /* rt::ShapeSceneObject  Core/Scene/Object/SceneObject_Shape.cpp */
+    RT_OBJECT_LIGHT = 1  /* rt::LightSceneObject  Core/Scene/Object/SceneObject_Light.cpp (finite lights only) */
+} RtObjectKind;
+
+/* One traceable scene object, in top-level-BVH leaf order (Core/Scene/Scene.cpp:87-95). */
+typedef struct RtObject
+{
+    float    transform[16];     /* local -> world, ISceneObject::mTransform         */
+    float    invTransform[16];  /* world -> local, Matrix4::Inverse() of the above  (SceneObject.cpp:22) */
+    uint32_t objectKind;        /* RtObjectKind */
+    uint32_t shapeKind;         /* RtShapeKind (for lights: shape of the area light; unused for point/spot) */
+    uint32_t materialIndex;     /* default material (shapes); RT_NO_MATERIAL for lights */
+    uint32_t meshIndex;         /* RT_SHAPE_MESH only */
+    uint32_t lightIndex;        /* RT_OBJECT_LIGHT only: index into RtSceneDesc::lights */
+    uint32_t _pad[3];
+    float    shapeParam[4];
+    float    shapeParam2[4];    /* box: 1/size (w=0); others unused */
+} RtObject;
+
+typedef enum RtLightType /* rt::ILight::Type, Core/Scene/Light/Light.h:27-34 */
+{
+    RT_LIGHT_AREA = 0,
+    RT_LIGHT_BACKGROUND = 1,
+    RT_LIGHT_DIRECTIONAL = 2,
+    RT_LIGHT_POINT = 3,
+    RT_LIGHT_SPOT = 4
+} RtLightType;
+
+#define RT_LIGHT_FLAG_FINITE 1u /* ILight::Flag_IsFinite */
+#define RT_LIGHT_FLAG_DELTA  2u /* ILight::Flag_IsDelta  */
+
+/* One light, in Scene::mLights order (= AddObject order, Core/Scene/Scene.cpp:45-48). */
+typedef struct RtLight
+{
+    float    transform[16];
+    float    invTransform[16];
+    float    color[4];       /* Spectrum::rgbValues; all FOUR lanes are significant (RayColor::AlmostZero) */
+    uint32_t type;           /* RtLightType */
+    uint32_t flags;          /* RT_LIGHT_FLAG_* as returned by ILight::GetFlags() */
+    uint32_t shapeKind;      /* area lights: RT_SHAPE_SPHERE / BOX / RECT */
+    uint32_t isDelta;        /* directional / spot: mIsDelta (cos > 0.9999, Light.h:25) */
+    float    cosAngle;       /* directional / spot: cosf(angle) computed by the host */
+    float    _pad[3];
+    float    shapeParam[4];
+    float    shapeParam2[4];
+} RtLight;
+
+typedef enum RtBsdf /* string names of Material::SetBsdf, Core/Material/Material.cpp:40-83 */
+{
+    RT_BSDF_NULL = 0,
+    RT_BSDF_DIFFUSE = 1,
+    RT_BSDF_ROUGH_DIFFUSE = 2,
+    RT_BSDF_DIELECTRIC = 3,
+    RT_BSDF_ROUGH_DIELECTRIC = 4,
+    RT_BSDF_METAL = 5,
+    RT_BSDF_ROUGH_METAL = 6,
+    RT_BSDF_PLASTIC = 7,
+    RT_BSDF_ROUGH_PLASTIC = 8
+} RtBsdf;
+
+/* 64 bytes; scalar part of rt::Material after Compile() (Core/Material/Material.cpp:105-117). */
+typedef struct RtMaterial
+{
+    float    emission[4];   /* all four lanes significant */
+    float    baseColor[4];
+    float    roughness;
+    float    metalness;
+    float    IoR;
+    float    K;
+    uint32_t bsdf;          /* RtBsdf */
+    uint32_t _pad[3];
+} RtMaterial;
+
+typedef struct RtSceneDesc
+{
+    uint32_t abiVersion;           /* RTGPU_ABI_VERSION */
+    uint32_t numObjects;           /* traceable objects (shapes + finite lights) */
+    uint32_t numTopNodes;          /* 0 when numObjects == 0 */
+    uint32_t numLights;
+    uint32_t numGlobalLights;
+    uint32_t numMaterials;
+    uint32_t numMeshes;
+    uint32_t numMeshNodes;
+    uint32_t numTriangles;
+    uint32_t numVertices;
+    uint32_t _pad[2];
+
+    const RtNode*          topNodes;       /* [numTopNodes]  Scene::mTraceableObjectsBVH */
+    const RtObject*        objects;        /* [numObjects]   */
+    const RtLight*         lights;         /* [numLights]    Scene::mLights */
+    const uint32_t*        globalLights;   /* [numGlobalLights] indices into lights[], Scene::mGlobalLights */
+    const RtMaterial*      materials;      /* [numMaterials] */
+    const RtMesh*          meshes;         /* [numMeshes]    */
+    const RtNode*          meshNodes;      /* [numMeshNodes] */
+    const RtTriangle*      triangles;      /* [numTriangles] */
+    const RtVertexIndices* vertexIndices;  /* [numTriangles] */
+    const RtVertexShading* vertexShading;  /* [numVertices]  */
+    /* 128*128*4 uint16 = 131072 bytes, contents of Data/BlueNoise128_RGBA16.dat
+     * (Core/Sampling/GenericSampler.cpp:13-52).  NULL => blue-noise dithering silently off (:72). */
+    const uint16_t*        blueNoise;
+} RtSceneDesc;
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-pass constants: what Viewport::Render computes on the host before the tile fan-out
+ * (Core/Rendering/Viewport.cpp:200-242) plus the RenderingParams fields the path reads
+ * (Core/Rendering/Context.h:55-90) and the camera (Core/Scene/Camera.cpp:81-118).
+ * ------------------------------------------------------------------------------------------- */
+
+#define RTGPU_MAX_DIMENSIONS 4096u /* HaltonSequence::MaxDimensions */
+
+typedef struct RtCamera
+{
+    float    localToWorld[16];   /* Camera::mLocalToWorld */
+    float    aspectRatio;
+    float    tanHalfFoV;         /* tanf(fov/2) computed by the host (Camera.cpp:37) */
+    uint32_t dofEnable;
+    uint32_t bokehShape;         /* 0 = circle (the only shape in scope) */
+    float    focalPlaneDistance;
+    float    aperture;
+    float    _pad[2];
+} RtCamera;
+
+typedef enum RtLightSampling { RT_LIGHT_SAMPLING_SINGLE = 0, RT_LIGHT_SAMPLING_ALL = 1 } RtLightSampling;
+
+typedef struct RtPassParams
+{
+    RtCamera camera;
+    const uint32_t* seed;          /* [numDimensions] HaltonSequence::GetInt(d), Viewport.cpp:200-205 */
+    uint32_t numDimensions;        /* SamplingParams::dimensions */
+    uint32_t useBlueNoise;         /* SamplingParams::useBlueNoiseDithering */
+    float    sampleOffset[2];      /* GetFloatNormal2(u) * antiAliasingSpread, Viewport.cpp:235-242 */
+    uint32_t passIndex;            /* mProgress.passesFinished; even => also accumulate secondary sum */
+    uint32_t maxRayDepth;
+    uint32_t minRussianRouletteDepth;
+    uint32_t lightSamplingStrategy;/* RtLightSampling */
+    float    lightSamplingWeight[4]; /* PathTracerMIS::mLightSamplingWeight */
+    float    bsdfSamplingWeight[4];  /* PathTracerMIS::mBSDFSamplingWeight  */
+    /* Key of the per-pixel fallback generator.  The reference draws light picks
+     * (PathTracerMIS.cpp:136) and samples past numDimensions (GenericSampler.cpp:108) from a
+     * PER-THREAD xoroshiro128+ whose consumption order depends on dynamic tile scheduling; here every
+     * pixel owns a xoroshiro128+ stream seeded from (rngKey, x, y) so the result is schedule-free. */
+    uint64_t rngKey[2];
+} RtPassParams;
+
+/* rt::RayTracingCounters (Core/Rendering/Counters.h:36-93), intersection counters always on. */
+typedef struct RtCounters
+{
+    uint64_t numRays;            /* sum over paths of depth+1  (PathTracerMIS.cpp:412) -- THE metric */
+    uint64_t numShadowRays;
+    uint64_t numShadowRaysHit;   /* reference naming: shadow rays that reached the light */
+    uint64_t numPrimaryRays;
+    /* The next four count CLOSEST-HIT traversals only, like the reference: Scene::Traverse resets and appends
+     * the local counters (Scene.cpp:223,242) while Scene::Traverse_Shadow does neither, so the tests done by
+     * shadow rays never reach RayTracingCounters there. */
+    uint64_t numRayBoxTests;
+    uint64_t numPassedRayBoxTests;
+    uint64_t numRayTriangleTests;
+    uint64_t numPassedRayTriangleTests;
+    /* additions used by the roofline model */
+    uint64_t numMeshHits;        /* EvaluateIntersection on a mesh triangle */
+    uint64_t numAnalyticHits;    /* EvaluateIntersection on sphere/box/rect (incl. area lights) */
+    uint64_t numShadowRayBoxTests;      /* box tests done by shadow rays (not counted by the reference) */
+    uint64_t numShadowRayTriangleTests; /* triangle tests done by shadow rays */
+    uint64_t _reserved[4];
+} RtCounters;
+
+typedef struct RtgpuContext RtgpuContext;
+
+/* Optional tile-interleaved ownership for multi-GPU: this context renders only pixels whose 64x64
+ * tile index (row-major) satisfies tile % worldSize == rank.  Non-owned pixels of the sum buffers
+ * stay zero, so a sum-reduction (or gather) over ranks reproduces the 1-GPU image bit-exactly. */
+typedef struct RtgpuShard
+{
+    uint32_t rank;
+    uint32_t worldSize;
+} RtgpuShard;
+
+/* --- lifetime --------------------------------------------------------------------------------*/
+/* Creates a context on HIP device `deviceIndex` (one context = one device = one host thread at a time). */
+int  rtgpu_create(int deviceIndex, RtgpuContext** outCtx);
+void rtgpu_destroy(RtgpuContext* ctx);
+const char* rtgpu_last_error(void);
+uint32_t rtgpu_abi_version(void);
+
+/* --- scene: replaces Scene::BuildBVH's pointer graph; copies everything, host memory may be freed */
+int rtgpu_upload_scene(RtgpuContext* ctx, const RtSceneDesc* scene);
+
+/* --- film: Viewport::Resize (Viewport.cpp:52-107) / Viewport::Reset (:120-138) ------------------*/
+int rtgpu_resize(RtgpuContext* ctx, uint32_t width, uint32_t height);
+int rtgpu_set_shard(RtgpuContext* ctx, RtgpuShard shard);
+int rtgpu_reset(RtgpuContext* ctx);
+
+/* --- the hot path: one pass over every owned pixel (Viewport.cpp:244-262 -> RenderTile :291-357 ->
+ *     PathTracerMIS::RenderPixel PathTracerMIS.cpp:254-415 -> Film::AccumulateColor Film.cpp:31-39).
+ *     Asynchronous on the context's stream; the params (incl. seed[]) are copied before return. */
+int rtgpu_render_pass(RtgpuContext* ctx, const RtPassParams* params);
+
+/* Blocks until all queued passes have finished. */
+int rtgpu_synchronize(RtgpuContext* ctx);
+
+/* --- readback: Viewport::GetSumBuffer (R32G32B32_Float, tight stride; row y of the bitmap is film
+ *     row H-1-y, Viewport.cpp:309,354).  sumRGB / secondaryRGB: width*height*3 floats, either may be
+ *     NULL.  Synchronises. */
+int rtgpu_read_sum(RtgpuContext* ctx, float* sumRGB, float* secondaryRGB);
+
+/* Device pointers of the float3 sum buffers (for RCCL gather/reduce by the caller). */
+int rtgpu_get_device_sum(RtgpuContext* ctx, void** sumDevice, void** secondaryDevice, size_t* numFloats);
+
+/* Counters accumulated since the last rtgpu_reset (Viewport::GetCounters is per pass; callers
+ * difference two reads).  Synchronises. */
+int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
+
+/* --- measurement hooks (bench.py) ---------------------------------------------------------------
+ * Per-kernel-class GPU time in milliseconds accumulated since rtgpu_reset, measured with HIP events
+ * on the context's own stream when timing is enabled.  names[i] are static strings. */
+#define RTGPU_NUM_KERNEL_CLASSES 8
+int rtgpu_enable_timing(RtgpuContext* ctx, int enable);
+int rtgpu_get_kernel_times(RtgpuContext* ctx, double ms[RTGPU_NUM_KERNEL_CLASSES],
+                           uint64_t launches[RTGPU_NUM_KERNEL_CLASSES],
+                           const char* names[RTGPU_NUM_KERNEL_CLASSES]);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RTGPU_H */

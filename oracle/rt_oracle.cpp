@@ -1,0 +1,361 @@
+// oracle/rt_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// C entry points of the CPU oracle (a scalar restatement of the reference's PathTracerMIS pass, see
+// rto_core.h / rto_math.h for the per-function file:line citations).
+//
+// Pinning status: the FULL reference renderer cannot be built in this image without stand-in headers
+// (Core/Scene/Scene.cpp and Core/Rendering/Renderer.cpp include <Windows.h> through
+// Core/Utils/Profiler.h:11; Core/Utils/Memory.cpp:8 includes it directly), so the oracle is pinned
+//   (a) function by function against golden vectors produced by the reference's OWN translation units
+//       that do compile unmodified (oracle/ref_harness -> oracle/_ref/, fixtures in tests/golden/), and
+//   (b) end to end against the reference's own six RenderingTest furnace cases
+//       (Tests/RaytracingTests.cpp:263-523), restated in tests/test_furnace_oracle.py.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+#include "rto_core.h"
+
+#include <stdlib.h>
+#include <stdio.h>
+#include <vector>
+#include <thread>
+#include <atomic>
+
+using namespace rto;
+
+extern "C" {
+
+// Viewport::RenderTile pixel loop (Core/Rendering/Viewport.cpp:305-357) over rows [y0, y1)
+static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                       uint32_t shardRank, uint32_t shardWorld, uint32_t y0, uint32_t y1,
+                       float* sum, float* secondary, Counters* counters)
+{
+    RenderCtx ctx;
+    ctx.scene = scene; ctx.params = params; ctx.counters = counters;
+    ctx.lightSamplingWeight = load4(params->lightSamplingWeight);
+    ctx.bsdfSamplingWeight = load4(params->bsdfSamplingWeight);
+    ctx.sampler.seed = params->seed;
+    ctx.sampler.numDims = params->numDimensions;
+    ctx.sampler.blueNoise = scene->blueNoise;
+    ctx.sampler.blueNoiseLayers = (scene->blueNoise && params->useBlueNoise) ? 4u : 0u;   // GenericSampler.cpp:69-73
+
+    // filmSize = FromIntegers(w, h, 1, 1); invSize = VECTOR_ONE2 / filmSize   (Viewport.cpp:300-301)
+    const V4 invSize(1.0f / (float)(int32_t)width, 1.0f / (float)(int32_t)height, 0.0f / 1.0f, 0.0f / 1.0f);
+    const V4 sampleOffset(params->sampleOffset[0], params->sampleOffset[1], 0.0f, 0.0f);
+    const bool evenPass = (params->passIndex % 2u) == 0u;
+    const uint32_t tilesX = (width + 63u) / 64u;
+
+    for (uint32_t y = y0; y < y1; ++y)
+    {
+        const uint32_t realY = height - 1u - y;
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            if (shardWorld > 1)
+            {
+                const uint32_t tile = (y / 64u) * tilesX + (x / 64u);
+                if (tile % shardWorld != shardRank) continue;
+            }
+            const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
+            ctx.sampler.resetPixel(x, y, params->rngKey);
+            const Ray ray = cameraGenerateRay(params->camera, coords, ctx.sampler);
+            const V4 color = renderPixel(ctx, ray);
+            float* px = sum + 3 * ((size_t)y * width + x);                 // Film::AccumulateColor Film.cpp:25-39
+            px[0] = px[0] + color.x; px[1] = px[1] + color.y; px[2] = px[2] + color.z;
+            if (evenPass && secondary)
+            {
+                float* sx = secondary + 3 * ((size_t)y * width + x);
+                sx[0] = sx[0] + color.x; sx[1] = sx[1] + color.y; sx[2] = sx[2] + color.z;
+            }
+            counters->c[C_PRIMARY]++;
+        }
+    }
+}
+
+// One pass of the hot path on the CPU.  counters: uint64[16] accumulated (layout of RtCounters).
+// numThreads <= 1: single thread.  Rows are split statically; the result does not depend on numThreads.
+int rto_render_pass(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                    uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads)
+{
+    if (!scene || !params || !sum || !counters || width == 0 || height == 0) return -1;
+    if (numThreads <= 1)
+    {
+        Counters c; memset(&c, 0, sizeof(c));
+        renderRows(scene, params, width, height, shardRank, shardWorld, 0, height, sum, secondary, &c);
+        for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
+        return 0;
+    }
+    std::vector<std::thread> threads;
+    std::vector<Counters> cs((size_t)numThreads);
+    std::atomic<uint32_t> nextRow(0);
+    const uint32_t chunk = 4;
+    for (int t = 0; t < numThreads; ++t)
+    {
+        memset(&cs[(size_t)t], 0, sizeof(Counters));
+        threads.emplace_back([&, t]() {
+            for (;;)
+            {
+                const uint32_t r = nextRow.fetch_add(chunk);
+                if (r >= height) break;
+                const uint32_t r1 = r + chunk < height ? r + chunk : height;
+                renderRows(scene, params, width, height, shardRank, shardWorld, r, r1, sum, secondary, &cs[(size_t)t]);
+            }
+        });
+    }
+    for (auto& th : threads) th.join();
+    for (int t = 0; t < numThreads; ++t) for (int i = 0; i < 16; ++i) counters[i] += cs[(size_t)t].c[i];
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Known-answer-test dispatcher: evaluates one restated function on n records.
+// in: n * inStride floats (uint32 payloads are bit-cast), out: n * outStride floats.
+// The record layouts are the ones oracle/ref_harness/kat_gen.cpp writes (tests/golden/README.md).
+// ---------------------------------------------------------------------------------------------------
+enum
+{
+    KAT_SIN_LANE = 1, KAT_SINCOS = 2, KAT_FASTLOG = 3, KAT_FASTACOS = 4, KAT_FASTATAN2 = 5,
+    KAT_FLOAT_NORMAL2 = 6, KAT_HEMISPHERE_COS = 7, KAT_SPHERE = 8, KAT_CIRCLE = 9, KAT_ORTHO_BASIS = 10,
+    KAT_FRESNEL_DIELECTRIC = 11, KAT_FRESNEL_METAL = 12, KAT_REFRACT3 = 13, KAT_REFLECT3 = 14,
+    KAT_BOX_RAY = 20, KAT_BOX_RAY_TWOSIDED = 21, KAT_TRIANGLE_RAY = 22, KAT_MAKE_RAY = 23, KAT_TRANSFORM_RAY = 24,
+    KAT_FAST_INVERSE = 25,
+    KAT_SHAPE_INTERSECT = 30, KAT_SHAPE_SAMPLE = 31, KAT_SHAPE_PDF = 32, KAT_SHAPE_EVAL = 33,
+    KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41,
+    KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
+    KAT_CAMERA_RAY = 60,
+    KAT_SAMPLER = 70,
+};
+
+static inline uint32_t fbits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static void putV4(float* o, V4 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+
+int rto_kat(int func, const float* in, int inStride, float* out, int outStride, int n)
+{
+    for (int r = 0; r < n; ++r)
+    {
+        const float* i = in + (size_t)r * inStride;
+        float* o = out + (size_t)r * outStride;
+        switch (func)
+        {
+        case KAT_SIN_LANE: o[0] = sinLane(i[0]); break;
+        case KAT_SINCOS: putV4(o, sinCos(i[0])); break;
+        case KAT_FASTLOG: o[0] = fastLog(i[0]); break;
+        case KAT_FASTACOS: o[0] = fastACos(i[0]); break;
+        case KAT_FASTATAN2: o[0] = fastATan2(i[0], i[1]); break;
+        case KAT_FLOAT_NORMAL2: putV4(o, getFloatNormal2(i[0], i[1])); break;
+        case KAT_HEMISPHERE_COS: putV4(o, getHemisphereCos(i[0], i[1])); break;
+        case KAT_SPHERE: putV4(o, getSphere(i[0], i[1])); break;
+        case KAT_CIRCLE: putV4(o, getCircle(i[0], i[1])); break;
+        case KAT_ORTHO_BASIS: { V4 u, v; buildOrthonormalBasis(load4(i), u, v); putV4(o, u); putV4(o + 4, v); break; }
+        case KAT_FRESNEL_DIELECTRIC: o[0] = fresnelDielectric(i[0], i[1]); break;
+        case KAT_FRESNEL_METAL: o[0] = fresnelMetal(i[0], i[1], i[2]); break;
+        case KAT_REFRACT3: putV4(o, refract3(load4(i), load4(i + 4), i[8])); break;
+        case KAT_REFLECT3: putV4(o, reflect3(load4(i), load4(i + 4))); break;
+        case KAT_MAKE_RAY:
+        {
+            const Ray ray = makeRay(load4(i), load4(i + 4));
+            putV4(o, ray.dir); putV4(o + 4, ray.invDir); putV4(o + 8, ray.originDivDir); break;
+        }
+        case KAT_TRANSFORM_RAY:   // in: matrix[16], origin[4], dir[4] (normalized world ray)  out: origin, dir, invDir, originDivDir
+        {
+            const M4 m = loadM4(i);
+            Ray w; w.origin = load4(i + 16); w.dir = load4(i + 20); w.invDir = zero4(); w.originDivDir = zero4();
+            const Ray l = transformRayUnsafe(m, w);
+            putV4(o, l.origin); putV4(o + 4, l.dir); putV4(o + 8, l.invDir); putV4(o + 12, l.originDivDir); break;
+        }
+        case KAT_FAST_INVERSE: { const M4 m = fastInverseNoScale(loadM4(i)); for (int k = 0; k < 4; ++k) putV4(o + 4 * k, m.r[k]); break; }
+        case KAT_BOX_RAY:         // in: origin[4], direction[4] (unnormalized), bmin[3], bmax[3]
+        {
+            const Ray ray = makeRay(load4(i), load4(i + 4));
+            float d = 0.0f; const bool h = intersectBoxRay(ray, load3(i + 8), load3(i + 11), d);
+            o[0] = bitsf(h ? 1u : 0u); o[1] = d; break;
+        }
+        case KAT_BOX_RAY_TWOSIDED:
+        {
+            const Ray ray = makeRay(load4(i), load4(i + 4));
+            float a = 0.0f, b = 0.0f; const bool h = intersectBoxRayTwoSided(ray, load3(i + 8), load3(i + 11), a, b);
+            o[0] = bitsf(h ? 1u : 0u); o[1] = a; o[2] = b; break;
+        }
+        case KAT_TRIANGLE_RAY:    // in: origin[4], direction[4], v0[3], e1[3], e2[3]
+        {
+            const Ray ray = makeRay(load4(i), load4(i + 4));
+            float u = 0, v = 0, t = 0; const bool h = intersectTriangleRay(ray, load3(i + 8), load3(i + 11), load3(i + 14), u, v, t);
+            o[0] = bitsf(h ? 1u : 0u); o[1] = u; o[2] = v; o[3] = t; break;
+        }
+        case KAT_SHAPE_INTERSECT: // in: kind(bits), param[4], origin[4], direction[4]
+        {
+            const Ray ray = makeRay(load4(i + 5), load4(i + 9));
+            ShapeHit sh; sh.nearDist = 0; sh.farDist = 0;
+            const bool h = shapeIntersect(fbits(i[0]), i + 1, ray, sh);
+            o[0] = bitsf(h ? 1u : 0u); o[1] = h ? sh.nearDist : 0.0f; o[2] = h ? sh.farDist : 0.0f; o[3] = bitsf(sh.subObjectId); break;
+        }
+        case KAT_SHAPE_SAMPLE:    // in: kind, param[4], ref[4], u[3]
+        {
+            ShapeSample s; s.direction = zero4(); s.distance = s.pdf = s.cosAtSurface = -1.0f;
+            const bool h = shapeSampleFrom(fbits(i[0]), i + 1, load4(i + 5), i + 9, s);
+            o[0] = bitsf(h ? 1u : 0u);
+            if (h) { putV4(o + 1, s.direction); o[5] = s.distance; o[6] = s.pdf; o[7] = s.cosAtSurface; }
+            else { for (int k = 1; k < 8; ++k) o[k] = 0.0f; }
+            break;
+        }
+        case KAT_SHAPE_PDF: o[0] = shapePdf(fbits(i[0]), i + 1, load4(i + 5), load4(i + 9)); break;
+        case KAT_SHAPE_EVAL:      // in: kind, param[4], param2[4], localPos[4]   out: frame rows 0..2, texCoord
+        {
+            Intersection is; for (int k = 0; k < 4; ++k) is.frame.r[k] = zero4();
+            is.frame.r[3] = load4(i + 9); is.texCoord = zero4(); is.material = 0;
+            shapeEvaluateIntersection(fbits(i[0]), i + 1, i + 5, is);
+            putV4(o, is.frame.r[0]); putV4(o + 4, is.frame.r[1]); putV4(o + 8, is.frame.r[2]); putV4(o + 12, is.texCoord); break;
+        }
+        case KAT_LIGHT_ILLUMINATE: // in: RtLight as floats (sizeof/4), frame[16], u[3]
+        {
+            const int LW = (int)(sizeof(RtLight) / 4);
+            RtLight L; memcpy(&L, i, sizeof(RtLight));
+            Intersection is; is.frame = loadM4(i + LW); is.texCoord = zero4(); is.material = 0;
+            IlluminateResult ir;
+            const V4 rad = lightIlluminate(L, is, i + LW + 16, ir);
+            putV4(o, rad); putV4(o + 4, ir.directionToLight); o[8] = ir.distance; o[9] = ir.directPdfW; o[10] = ir.cosAtLight; break;
+        }
+        case KAT_LIGHT_RADIANCE:  // in: RtLight, ray origin[4], dir[4] (light space), hitPoint[4], cosAtLight
+        {
+            const int LW = (int)(sizeof(RtLight) / 4);
+            RtLight L; memcpy(&L, i, sizeof(RtLight));
+            Ray ray; ray.origin = load4(i + LW); ray.dir = load4(i + LW + 4); ray.invDir = zero4(); ray.originDivDir = zero4();
+            float pdf = 0.0f;
+            const V4 rad = lightGetRadiance(L, ray, load4(i + LW + 8), i[LW + 12], pdf);
+            putV4(o, rad); o[4] = pdf; break;
+        }
+        case KAT_BSDF_SAMPLE:     // in: RtMaterial (16 floats), outgoingDir[4] (local), u[3]
+        {
+            RtMaterial m; memcpy(&m, i, sizeof(RtMaterial));
+            ShadingData sd; materialEvaluateShadingData(m, sd);
+            BsdfSample s;
+            const bool ok = bsdfSampleImpl(m.bsdf, m, sd.mp, i + 20, load4(i + 16), s);
+            o[0] = bitsf(ok ? 1u : 0u);
+            if (ok) { putV4(o + 1, s.color); putV4(o + 5, s.incomingDir); o[9] = s.pdf; o[10] = bitsf(s.event); }
+            else { for (int k = 1; k < 11; ++k) o[k] = 0.0f; }
+            break;
+        }
+        case KAT_BSDF_EVALUATE:   // in: RtMaterial, outgoingDir[4], incomingDir[4] (local)
+        {
+            RtMaterial m; memcpy(&m, i, sizeof(RtMaterial));
+            ShadingData sd; materialEvaluateShadingData(m, sd);
+            float pdf = 0.0f;
+            const V4 c = bsdfEvaluate(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), pdf);
+            putV4(o, c); o[4] = almostZero4(c) ? 0.0f : pdf; break;
+        }
+        case KAT_CAMERA_RAY:      // in: RtCamera (sizeof/4 floats), coords[2], dof samples come from seed {u0,u1} bits
+        {
+            const int CW = (int)(sizeof(RtCamera) / 4);
+            RtCamera cam; memcpy(&cam, i, sizeof(RtCamera));
+            uint32_t seeds[2] = { fbits(i[CW + 2]), fbits(i[CW + 3]) };
+            Sampler s; s.seed = seeds; s.numDims = 2; s.blueNoiseLayers = 0; s.blueNoise = nullptr;
+            s.bx = s.by = 0; s.salt = 0; s.generated = 0; s.fallback.s[0] = 1; s.fallback.s[1] = 2;
+            const Ray ray = cameraGenerateRay(cam, V4(i[CW], i[CW + 1], 0.0f, 0.0f), s);
+            putV4(o, ray.origin); putV4(o + 4, ray.dir); putV4(o + 8, ray.invDir); putV4(o + 12, ray.originDivDir); break;
+        }
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
+// Sampler KAT: ints for dims [0, count) at pixel (x, y).
+int rto_kat_sampler(const uint32_t* seed, uint32_t numDims, const uint16_t* blueNoise, uint32_t useBlueNoise,
+                    uint32_t x, uint32_t y, uint32_t count, uint32_t* outInts, float* outFloats)
+{
+    Sampler s; s.seed = seed; s.numDims = numDims; s.blueNoise = blueNoise;
+    s.blueNoiseLayers = (blueNoise && useBlueNoise) ? 4u : 0u;
+    const uint64_t key[2] = { 0, 0 };
+    s.resetPixel(x, y, key);
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        Sampler copy = s;
+        outInts[i] = s.getInt();
+        if (outFloats) outFloats[i] = copy.getFloat();
+    }
+    return 0;
+}
+
+// xoroshiro128+ KAT (Random::GetLong / GetFloat, Core/Math/Random.cpp:33-59)
+int rto_kat_xoroshiro(uint64_t s0, uint64_t s1, uint32_t count, uint64_t* outLongs)
+{
+    Xoroshiro g; g.s[0] = s0; g.s[1] = s1;
+    for (uint32_t i = 0; i < count; ++i) outLongs[i] = xoroshiroNext(g);
+    return 0;
+}
+
+// Per-pixel debug trace: renders ONE pixel and returns its radiance (for path-level parity debugging).
+int rto_render_pixel(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                     uint32_t x, uint32_t y, float outRGBA[4], uint64_t* counters)
+{
+    Counters c; memset(&c, 0, sizeof(c));
+    RenderCtx ctx;
+    ctx.scene = scene; ctx.params = params; ctx.counters = &c;
+    ctx.lightSamplingWeight = load4(params->lightSamplingWeight);
+    ctx.bsdfSamplingWeight = load4(params->bsdfSamplingWeight);
+    ctx.sampler.seed = params->seed; ctx.sampler.numDims = params->numDimensions; ctx.sampler.blueNoise = scene->blueNoise;
+    ctx.sampler.blueNoiseLayers = (scene->blueNoise && params->useBlueNoise) ? 4u : 0u;
+    const V4 invSize(1.0f / (float)(int32_t)width, 1.0f / (float)(int32_t)height, 0.0f, 0.0f);
+    const V4 sampleOffset(params->sampleOffset[0], params->sampleOffset[1], 0.0f, 0.0f);
+    const uint32_t realY = height - 1u - y;
+    const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
+    ctx.sampler.resetPixel(x, y, params->rngKey);
+    const Ray ray = cameraGenerateRay(params->camera, coords, ctx.sampler);
+    const V4 color = renderPixel(ctx, ray);
+    outRGBA[0] = color.x; outRGBA[1] = color.y; outRGBA[2] = color.z; outRGBA[3] = color.w;
+    if (counters) for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
+    return 0;
+}
+
+// Mesh-path KAT (layout of tests/golden/mesh_kat.bin, written by oracle/ref_harness/kat_gen.cpp::genMesh):
+// rays: n * 7 floats (origin, direction, tmax); out: n * 19 uint32 words
+//   [objectId, subObjectId, distance, u, v, shadowHit, frame0.xyzw, frame2.xyzw, texCoord.xyzw, material]
+// Calls the restated MeshShape::Traverse / Traverse_Shadow / EvaluateIntersection on mesh `meshIndex`
+// with objectID = 7, exactly like the generator does with the reference's MeshShape.
+int rto_kat_mesh(const RtSceneDesc* scene, uint32_t meshIndex, const float* rays, uint32_t n, uint32_t* out)
+{
+    if (!scene || meshIndex >= scene->numMeshes) return -1;
+    const RtMesh& mesh = scene->meshes[meshIndex];
+    Counters cnt; memset(&cnt, 0, sizeof(cnt));
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const float* r = rays + 7 * (size_t)i;
+        uint32_t* o = out + 19 * (size_t)i;
+        const Ray ray = makeRay(V4(r[0], r[1], r[2], 0.0f), V4(r[3], r[4], r[5], 0.0f));
+        Hit hp; hp.objectId = RT_INVALID_OBJECT; hp.subObjectId = 0; hp.distance = r[6]; hp.u = 0.0f; hp.v = 0.0f;
+        meshTraverse(scene, mesh, ray, hp, 7, cnt);
+        const bool hit = hp.objectId == 7;
+        o[0] = hp.objectId; o[1] = hit ? hp.subObjectId : 0u; o[2] = fbits(hp.distance); o[3] = fbits(hit ? hp.u : 0.0f); o[4] = fbits(hit ? hp.v : 0.0f);
+        Hit hs; hs.objectId = RT_INVALID_OBJECT; hs.subObjectId = 0; hs.distance = r[6]; hs.u = hs.v = 0.0f;
+        o[5] = meshTraverseShadow(scene, mesh, ray, hs, cnt) ? 1u : 0u;
+        for (int k = 6; k < 18; ++k) o[k] = 0;
+        o[18] = 0xFFFFFFFFu;
+        if (hit)
+        {
+            Intersection is; for (int k = 0; k < 4; ++k) is.frame.r[k] = zero4();
+            is.texCoord = zero4(); is.material = RT_NO_MATERIAL;
+            meshEvaluateIntersection(scene, mesh, hp, is);
+            const V4 f0 = is.frame.r[0], f2 = is.frame.r[2], tc = is.texCoord;
+            o[6] = fbits(f0.x); o[7] = fbits(f0.y); o[8] = fbits(f0.z); o[9] = fbits(f0.w);
+            o[10] = fbits(f2.x); o[11] = fbits(f2.y); o[12] = fbits(f2.z); o[13] = fbits(f2.w);
+            o[14] = fbits(tc.x); o[15] = fbits(tc.y); o[16] = fbits(tc.z); o[17] = fbits(tc.w);
+            o[18] = is.material;
+        }
+    }
+    return 0;
+}
+
+uint32_t rto_sizeof(int what)
+{
+    switch (what)
+    {
+    case 0: return (uint32_t)sizeof(RtSceneDesc);
+    case 1: return (uint32_t)sizeof(RtPassParams);
+    case 2: return (uint32_t)sizeof(RtObject);
+    case 3: return (uint32_t)sizeof(RtLight);
+    case 4: return (uint32_t)sizeof(RtMaterial);
+    case 5: return (uint32_t)sizeof(RtCamera);
+    default: return 0;
+    }
+}
+
+} // extern "C"

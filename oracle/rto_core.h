@@ -1,0 +1,1276 @@
+// oracle/rto_core.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of the PathTracerMIS hot path over the flat RtSceneDesc of include/rtgpu.h:
+// sampler, camera, two-level BVH traversal, analytic shapes, lights, BSDFs and the integrator.
+// Every function cites the reference file:line it follows (relative to /root/reference/).
+// One thread, one pixel at a time, exactly the reference's control flow.
+#pragma once
+
+#include "rto_math.h"
+#include "../include/rtgpu.h"
+
+namespace rto {
+
+// =====================================================================================================
+// Sampler -- GenericSampler (Core/Sampling/GenericSampler.cpp:69-113, .h:29-42) + per-pixel fallback RNG
+// =====================================================================================================
+struct Sampler
+{
+    const uint32_t* seed; uint32_t numDims; uint32_t blueNoiseLayers; const uint16_t* blueNoise;
+    uint32_t bx, by, salt, generated;
+    Xoroshiro fallback;   // per-pixel stream (see RtPassParams::rngKey)
+
+    void resetPixel(uint32_t x, uint32_t y, const uint64_t rngKey[2])
+    {
+        bx = x & 127u; by = y & 127u;                                   // :77-78
+        salt = (uint32_t)murmurFmix64((uint64_t)(x | (y << 16)));       // :79
+        generated = 0;                                                  // :80
+        // per-pixel fallback generator: two fmix64 of (key ^ pixel id); never all-zero
+        const uint64_t pix = (uint64_t)x | ((uint64_t)y << 32);
+        fallback.s[0] = murmurFmix64(rngKey[0] ^ pix);
+        fallback.s[1] = murmurFmix64(rngKey[1] + 0x9E3779B97F4A7C15ULL * (pix + 1)) | 1ULL;
+    }
+    uint32_t fallbackInt() { return (uint32_t)xoroshiroNext(fallback); }   // Random::GetInt Random.cpp:49-52
+    uint32_t getInt()                                                   // GenericSampler.cpp:83-113
+    {
+        uint32_t sample;
+        if (generated < numDims)
+        {
+            sample = seed[generated];
+            if (generated < blueNoiseLayers)
+            {
+                const uint32_t pixelIndex = 128u * by + bx;
+                sample += (uint32_t)blueNoise[4u * pixelIndex + generated] << 16;
+            }
+            else
+            {
+                const uint32_t s = salt;
+                salt = xorShift32(s);
+                sample += s;
+            }
+            generated++;
+        }
+        else
+        {
+            sample = fallbackInt();
+        }
+        return sample;
+    }
+    float getFloat() { return Min(0.999999940395f, (float)getInt() / 4294967296.0f); }   // GenericSampler.h:29-32
+};
+
+// =====================================================================================================
+// Hit record / intersection data
+// =====================================================================================================
+struct Hit { uint32_t objectId, subObjectId; float distance, u, v; };   // Core/Traversal/HitPoint.h:14-51
+struct Intersection { M4 frame; V4 texCoord; uint32_t material; };      // Core/Traversal/Intersection.h:8-13
+
+static inline V4 worldToLocal(const Intersection& in, V4 w)   // Intersection.h:20-31
+{
+    V4 X = in.frame.r[0], Y = in.frame.r[1], Z = in.frame.r[2];
+    transpose3(X, Y, Z);
+    V4 r = X * w.x;
+    r = mulAdd(Y, w.y, r);
+    r = mulAdd(Z, w.z, r);
+    return r;
+}
+static inline V4 localToWorld(const Intersection& in, V4 l) { return transformVector(in.frame, l); }  // :15-18
+
+struct Counters { uint64_t c[16]; };
+enum { C_RAYS = 0, C_SHADOW = 1, C_SHADOW_HIT = 2, C_PRIMARY = 3, C_BOX = 4, C_BOX_PASS = 5, C_TRI = 6, C_TRI_PASS = 7, C_MESH_HITS = 8, C_ANALYTIC_HITS = 9, C_BOX_SHADOW = 10, C_TRI_SHADOW = 11 };
+
+// =====================================================================================================
+// Analytic shapes -- Core/Shapes/{SphereShape,BoxShape,RectShape,Shape}.cpp
+// =====================================================================================================
+struct ShapeHit { float nearDist, farDist; uint32_t subObjectId; };
+
+static inline bool shapeIntersect(uint32_t kind, const float* p, const Ray& ray, ShapeHit& out)
+{
+    out.subObjectId = 0xFFFFFFFFu;   // ShapeIntersection default, Shape.h:24-29
+    if (kind == RT_SHAPE_SPHERE)     // SphereShape.cpp:29-46 (double precision island)
+    {
+        const double radiusD = (double)p[0];
+        const double v = (double)dot3(ray.dir, neg(ray.origin));
+        const double det = radiusD * radiusD - (double)sqrLength3(ray.origin) + v * v;
+        if (det <= 0.0) return false;
+        const double sqrtDet = sqrt(det);
+        out.nearDist = (float)(v - sqrtDet);
+        out.farDist = (float)(v + sqrtDet);
+        out.subObjectId = 0;
+        return out.farDist > out.nearDist;
+    }
+    if (kind == RT_SHAPE_BOX)        // BoxShape.cpp:118-125
+    {
+        const V4 size(p[0], p[1], p[2], 0.0f);
+        out.subObjectId = 0;
+        return intersectBoxRayTwoSided(ray, neg(size), size, out.nearDist, out.farDist);
+    }
+    // RT_SHAPE_RECT, RectShape.cpp:32-49
+    const float t = -ray.origin.z * ray.invDir.z;
+    if (t > FLT_EPSILON)
+    {
+        const V4 pos = rayAt(ray, t);
+        if (absf(pos.x) < p[0] && absf(pos.y) < p[1])
+        {
+            out.nearDist = t; out.farDist = t;
+            return true;
+        }
+    }
+    return false;
+}
+
+static inline float shapeSurfaceArea(uint32_t kind, const float* p)
+{
+    if (kind == RT_SHAPE_SPHERE) return 4.0f * RTO_PI * Sqr(p[0]);                       // SphereShape.cpp:24-27
+    if (kind == RT_SHAPE_BOX) return 8.0f * (p[0] * (p[1] + p[2]) + p[1] * p[2]);        // BoxShape.cpp:113-116
+    return 4.0f * p[0] * p[1];                                                           // RectShape.cpp:27-30
+}
+
+// IShape::Sample(u, &normal)  (area sampling): BoxShape.cpp:127-179, RectShape.cpp:51-64
+static inline V4 shapeSampleArea(uint32_t kind, const float* p, const float u[3], V4& outNormal)
+{
+    if (kind == RT_SHAPE_RECT)
+    {
+        outNormal = V4(0.0f, 0.0f, 1.0f, 0.0f);
+        // Vector4(mSize) * (2.0f * Vector4(Float2(u)) - VECTOR_ONE)
+        const V4 size(p[0], p[1], 0.0f, 0.0f);
+        return size * ((2.0f * V4(u[0], u[1], 0.0f, 0.0f)) - splat(1.0f));
+    }
+    // RT_SHAPE_BOX
+    const float sx = p[0], sy = p[1], sz = p[2];
+    const float cdfx = sy * sz;                 // BoxShape.cpp:103-107
+    const float cdfy = cdfx + sz * sx;
+    const float cdfz = cdfy + sx * sy;
+    float v = u[2];
+    uint32_t zAxis;
+    v *= cdfz;
+    if (v < cdfx) { v /= cdfx; zAxis = 0; }
+    else if (v < cdfy) { v = (v - cdfx) / (cdfy - cdfx); zAxis = 1; }
+    else { v = (v - cdfy) / (cdfz - cdfy); zAxis = 2; }
+    const uint32_t xAxis = (zAxis + 1) % 3u, yAxis = (zAxis + 2) % 3u;
+    V4 normal = zero4();
+    normal[zAxis] = v < 0.5f ? -1.0f : 1.0f;
+    V4 pos = zero4();
+    pos[xAxis] = (2.0f * u[0] - 1.0f) * p[xAxis];
+    pos[yAxis] = (2.0f * u[1] - 1.0f) * p[yAxis];
+    pos[zAxis] = normal[zAxis] * p[zAxis];
+    outNormal = normal;
+    return pos;
+}
+
+struct ShapeSample { V4 direction; float distance, pdf, cosAtSurface; };
+
+// IShape::Sample(ref, u, result): solid-angle sampling as seen from `ref` (light space)
+static inline bool shapeSampleFrom(uint32_t kind, const float* p, V4 ref, const float u[3], ShapeSample& r)
+{
+    if (kind == RT_SHAPE_SPHERE)   // SphereShape.cpp:65-108 (cone sampling)
+    {
+        const float radius = p[0];
+        const V4 centerDir = neg(ref);
+        const float centerDistSqr = sqrLength3(centerDir);
+        const float centerDist = sqrtf(centerDistSqr);
+        if (centerDistSqr < Sqr(radius)) return false;
+        const float phi = RTO_2PI * u[1];
+        const V4 sinCosPhi = sinCos(phi);
+        float sinThetaMaxSqr = Sqr(radius) / centerDistSqr;
+        float cosThetaMax = sqrtf(1.0f - Clamp(sinThetaMaxSqr, 0.0f, 1.0f));
+        float cosTheta = Lerp(cosThetaMax, 1.0f, u[0]);
+        float sinThetaSqr = 1.0f - Sqr(cosTheta);
+        float sinTheta = sqrtf(sinThetaSqr);
+        const V4 w = centerDir / centerDist;
+        V4 tangent, bitangent;
+        buildOrthonormalBasis(w, tangent, bitangent);
+        r.direction = (tangent * sinCosPhi.y + bitangent * sinCosPhi.x) * sinTheta + w * cosTheta;
+        r.direction = normalized3(r.direction);
+        r.distance = centerDist * cosTheta - sqrtf(Max(0.0f, Sqr(radius) - centerDistSqr * sinThetaSqr));
+        r.cosAtSurface = cosTheta;
+        if (cosThetaMax > 0.999999f) r.pdf = FLT_MAX; else r.pdf = sphereCapPdf(cosThetaMax);
+        return true;
+    }
+    // IShape::Sample generic (rect with solid-angle sampling off RectShape.cpp:16,66-94; box), Shape.cpp:65-91
+    V4 normal;
+    const V4 position = shapeSampleArea(kind, p, u, normal);
+    V4 dir = ref - position;
+    const float sqrDistance = sqrLength3(dir);
+    if (sqrDistance > Sqr(FLT_EPSILON))
+    {
+        const float distance = sqrtf(sqrDistance);
+        dir = dir / distance;
+        const float cosNormalDir = dot3(normal, dir);
+        if (cosNormalDir > FLT_EPSILON)
+        {
+            const float invArea = 1.0f / shapeSurfaceArea(kind, p);
+            r.pdf = invArea * sqrDistance / cosNormalDir;
+            r.distance = distance;
+            r.cosAtSurface = cosNormalDir;
+            r.direction = neg(dir);
+            return true;
+        }
+    }
+    return false;
+}
+
+// IShape::Pdf(ref, point): Shape.cpp:93-99, SphereShape.cpp:110-125
+static inline float shapePdf(uint32_t kind, const float* p, V4 ref, V4 point)
+{
+    if (kind == RT_SHAPE_SPHERE)
+    {
+        const float radius = p[0];
+        const V4 rayDir = normalized3(point - ref);
+        const V4 centerDir = neg(ref);
+        const float centerDistSqr = sqrLength3(centerDir);
+        const V4 normal = normalized3(point);
+        const float cosAtLight = Max(0.0f, dot3(neg(rayDir), normal));
+        const float sinThetaMaxSqr = Clamp(Sqr(radius) / centerDistSqr, 0.0f, 1.0f);
+        const float cosThetaMax = sqrtf(1.0f - sinThetaMaxSqr);
+        const float pdfW = sphereCapPdf(cosThetaMax);
+        return pdfW * cosAtLight / sqrLength3(point - ref);
+    }
+    return 1.0f / shapeSurfaceArea(kind, p);
+}
+
+// face frames of the box, BoxShape.cpp:15-23 (rows 0..2 of each 4x4)
+static const float kBoxFaceFrames[6][3][4] = {
+    { { 0, 0, 1, 0 }, { 0, 1, 0, 0 }, { -1, 0, 0, 0 } },
+    { { 0, 0, -1, 0 }, { 0, 1, 0, 0 }, { +1, 0, 0, 0 } },
+    { { +1, 0, 0, 0 }, { 0, 0, 1, 0 }, { 0, -1, 0, 0 } },
+    { { +1, 0, 0, 0 }, { 0, 0, -1, 0 }, { 0, +1, 0, 0 } },
+    { { -1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, -1, 0 } },
+    { { +1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, +1, 0 } },
+};
+
+// IShape::EvaluateIntersection for analytic shapes; frame[3] holds the local-space hit position on entry
+static inline void shapeEvaluateIntersection(uint32_t kind, const float* p, const float* p2, Intersection& out)
+{
+    const V4 pos = out.frame.r[3];
+    if (kind == RT_SHAPE_SPHERE)     // SphereShape.cpp:159-175
+    {
+        out.texCoord = cartesianToSpherical(neg(pos));
+        out.frame.r[2] = pos * p[1];   // * mInvRadius
+        const V4 n = out.frame.r[2];
+        // (n.Swizzle<2,0,0,0>() & mask<1,0,1,0>).ChangeSign<1,0,0,0>()  ==  [-n.z, 0, n.x, 0]
+        out.frame.r[0] = V4(-n.z, 0.0f, n.x, 0.0f);
+        out.frame.r[1] = neg(cross3(out.frame.r[0], out.frame.r[2]));
+        out.frame.r[0] = fastNormalized3(out.frame.r[0]);
+        out.frame.r[1] = fastNormalized3(out.frame.r[1]);
+        out.frame.r[2] = fastNormalized3(out.frame.r[2]);
+        return;
+    }
+    if (kind == RT_SHAPE_BOX)        // BoxShape.cpp:181-191 + ConvertXYZtoCubeUV :25-85
+    {
+        const V4 q = pos * V4(p2[0], p2[1], p2[2], 0.0f);
+        const V4 a = abs4(q);
+        const int isXPositive = q.x > 0 ? 1 : 0, isYPositive = q.y > 0 ? 1 : 0, isZPositive = q.z > 0 ? 1 : 0;
+        float maxAxis, uc, vc; int side;
+        if (a.x >= a.y && a.x >= a.z) { uc = isXPositive ? -q.z : q.z; side = isXPositive; maxAxis = a.x; vc = q.y; }
+        else if (a.y >= a.x && a.y >= a.z) { vc = isYPositive ? -q.z : q.z; side = isYPositive + 2; maxAxis = a.y; uc = q.x; }
+        else { uc = isZPositive ? q.x : -q.x; side = isZPositive + 4; maxAxis = a.z; vc = q.y; }
+        out.texCoord = V4(uc, vc, 0.0f, 0.0f) / (2.0f * maxAxis) + splat(0.5f);
+        for (int i = 0; i < 3; ++i) out.frame.r[i] = load4(kBoxFaceFrames[side][i]);
+        return;
+    }
+    // RT_SHAPE_RECT, RectShape.cpp:124-132
+    out.texCoord = V4(pos.x, pos.y, 0.0f, 0.0f) * V4(p[2], p[3], 0.0f, 0.0f);
+    out.frame.r[0] = V4(1, 0, 0, 0); out.frame.r[1] = V4(0, 1, 0, 0); out.frame.r[2] = V4(0, 0, 1, 0);
+}
+
+// =====================================================================================================
+// Scene traversal -- Core/Scene/Scene.cpp:128-261, Core/Traversal/Traversal_Single.h, MeshShape.cpp
+// =====================================================================================================
+struct SceneView { const RtSceneDesc* d; };
+
+static inline bool nodeIsLeaf(const RtNode& n) { return (n.leaves & 0x3FFFFFFFu) != 0; }
+static inline uint32_t nodeNumLeaves(const RtNode& n) { return n.leaves & 0x3FFFFFFFu; }
+
+// MeshShape::Traverse_Leaf, MeshShape.cpp:134-168
+static inline void meshLeaf(const RtSceneDesc* d, const RtMesh& mesh, const Ray& ray, Hit& hit, uint32_t objectID, const RtNode& node, Counters& cnt)
+{
+    const uint32_t n = nodeNumLeaves(node);
+    cnt.c[C_TRI] += n;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const uint32_t triangleIndex = node.childIndex + i;
+        const RtTriangle& tri = d->triangles[mesh.firstTriangle + triangleIndex];
+        float u, v, dist;
+        if (intersectTriangleRay(ray, load3(tri.v0), load3(tri.edge1), load3(tri.edge2), u, v, dist))
+        {
+            if (dist < hit.distance)
+            {
+                hit.distance = dist; hit.subObjectId = triangleIndex; hit.objectId = objectID; hit.u = u; hit.v = v;
+                cnt.c[C_TRI_PASS]++;
+            }
+        }
+    }
+}
+// MeshShape::Traverse_Leaf_Shadow, MeshShape.cpp:175-207
+static inline bool meshLeafShadow(const RtSceneDesc* d, const RtMesh& mesh, const Ray& ray, Hit& hit, const RtNode& node, Counters& cnt)
+{
+    const uint32_t n = nodeNumLeaves(node);
+    cnt.c[C_TRI_SHADOW] += n;
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const RtTriangle& tri = d->triangles[mesh.firstTriangle + node.childIndex + i];
+        float u, v, dist;
+        if (intersectTriangleRay(ray, load3(tri.v0), load3(tri.edge1), load3(tri.edge2), u, v, dist))
+        {
+            if (dist < hit.distance) { hit.distance = dist; return true; }
+        }
+    }
+    return false;
+}
+
+// GenericTraverse<MeshShape>, Traversal_Single.h:16-96
+static inline void meshTraverse(const RtSceneDesc* d, const RtMesh& mesh, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
+{
+    if (mesh.numNodes == 0) return;
+    const RtNode* nodes = d->meshNodes + mesh.firstNode;
+    uint32_t stackSize = 0; const RtNode* stack[128];   // BVH::MaxDepth
+    for (const RtNode* cur = nodes;;)
+    {
+        if (nodeIsLeaf(*cur)) meshLeaf(d, mesh, ray, hit, objectID, *cur, cnt);
+        else
+        {
+            const RtNode* childA = nodes + cur->childIndex; const RtNode* childB = childA + 1;
+            float distanceA, distanceB;
+            bool hitA = intersectBoxRay(ray, load3(childA->min), load3(childA->max), distanceA);
+            bool hitB = intersectBoxRay(ray, load3(childB->min), load3(childB->max), distanceB);
+            hitA &= (distanceA < hit.distance);
+            hitB &= (distanceB < hit.distance);
+            cnt.c[C_BOX] += 2; cnt.c[C_BOX_PASS] += (hitA ? 1 : 0) + (hitB ? 1 : 0);
+            if (hitA && hitB)
+            {
+                if (distanceB < distanceA) { const RtNode* t = childA; childA = childB; childB = t; }
+                cur = childA; stack[stackSize++] = childB; continue;
+            }
+            if (hitA) { cur = childA; continue; }
+            if (hitB) { cur = childB; continue; }
+        }
+        if (stackSize == 0) break;
+        cur = stack[--stackSize];
+    }
+}
+// GenericTraverse_Shadow<MeshShape>, Traversal_Single.h:99-179
+static inline bool meshTraverseShadow(const RtSceneDesc* d, const RtMesh& mesh, const Ray& ray, Hit& hit, Counters& cnt)
+{
+    if (mesh.numNodes == 0) return false;
+    const RtNode* nodes = d->meshNodes + mesh.firstNode;
+    uint32_t stackSize = 0; const RtNode* stack[128];
+    for (const RtNode* cur = nodes;;)
+    {
+        if (nodeIsLeaf(*cur)) { if (meshLeafShadow(d, mesh, ray, hit, *cur, cnt)) return true; }
+        else
+        {
+            const RtNode* childA = nodes + cur->childIndex; const RtNode* childB = childA + 1;
+            float distanceA, distanceB;
+            bool hitA = intersectBoxRay(ray, load3(childA->min), load3(childA->max), distanceA);
+            bool hitB = intersectBoxRay(ray, load3(childB->min), load3(childB->max), distanceB);
+            hitA &= (distanceA < hit.distance);
+            hitB &= (distanceB < hit.distance);
+            cnt.c[C_BOX_SHADOW] += 2;
+            if (hitA && hitB) { cur = childA; stack[stackSize++] = childB; continue; }
+            if (hitA) { cur = childA; continue; }
+            if (hitB) { cur = childB; continue; }
+        }
+        if (stackSize == 0) break;
+        cur = stack[--stackSize];
+    }
+    return false;
+}
+
+// ILight::TestRayHit: AreaLight.cpp:43-53 (nearDist, may be negative); Point/Spot never hit (PointLight.cpp:35, SpotLight.cpp:41)
+static inline bool lightTestRayHit(const RtLight& L, const Ray& ray, float& outDistance)
+{
+    if (L.type != RT_LIGHT_AREA) return false;
+    ShapeHit sh;
+    if (shapeIntersect(L.shapeKind, L.shapeParam, ray, sh)) { outDistance = sh.nearDist; return true; }
+    return false;
+}
+
+// Scene::Traverse_Object, Scene.cpp:128-145 -> ShapeSceneObject/LightSceneObject::Traverse
+static inline void traverseObject(const RtSceneDesc* d, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
+{
+    const RtObject& obj = d->objects[objectID];
+    const M4 inv = loadM4(obj.invTransform);
+    const Ray lray = transformRayUnsafe(inv, ray);
+    if (obj.objectKind == RT_OBJECT_LIGHT)   // SceneObject_Light.cpp:27-38
+    {
+        float lightDistance;
+        if (lightTestRayHit(d->lights[obj.lightIndex], lray, lightDistance))
+        {
+            if (lightDistance > 0.0f && lightDistance < hit.distance)
+            {
+                hit.distance = lightDistance; hit.objectId = objectID; hit.subObjectId = RT_LIGHT_OBJECT;
+            }
+        }
+        return;
+    }
+    if (obj.shapeKind == RT_SHAPE_MESH) { meshTraverse(d, d->meshes[obj.meshIndex], lray, hit, objectID, cnt); return; }
+    ShapeHit sh;                              // IShape::Traverse, Shape.cpp:19-45
+    if (shapeIntersect(obj.shapeKind, obj.shapeParam, lray, sh))
+    {
+        if (sh.nearDist > 0.0f && sh.nearDist < hit.distance) { hit.distance = sh.nearDist; hit.objectId = objectID; hit.subObjectId = sh.subObjectId; return; }
+        if (sh.farDist > 0.0f && sh.farDist < hit.distance) { hit.distance = sh.farDist; hit.objectId = objectID; hit.subObjectId = sh.subObjectId; return; }
+    }
+}
+// Scene::Traverse_Object_Shadow, Scene.cpp:147-165
+static inline bool traverseObjectShadow(const RtSceneDesc* d, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
+{
+    const RtObject& obj = d->objects[objectID];
+    const M4 inv = loadM4(obj.invTransform);
+    const Ray lray = transformRayUnsafe(inv, ray);
+    if (obj.objectKind == RT_OBJECT_LIGHT)   // SceneObject_Light.cpp:40-53
+    {
+        float lightDistance;
+        if (lightTestRayHit(d->lights[obj.lightIndex], lray, lightDistance))
+        {
+            if (lightDistance < hit.distance) { hit.distance = lightDistance; return true; }
+        }
+        return false;
+    }
+    if (obj.shapeKind == RT_SHAPE_MESH) return meshTraverseShadow(d, d->meshes[obj.meshIndex], lray, hit, cnt);
+    ShapeHit sh;                              // IShape::Traverse_Shadow, Shape.cpp:47-57
+    if (!shapeIntersect(obj.shapeKind, obj.shapeParam, lray, sh)) return false;
+    return sh.farDist > 0.0f && sh.nearDist < hit.distance;
+}
+
+// Scene::Traverse, Scene.cpp:219-243 (+ GenericTraverse<Scene>)
+static inline void sceneTraverse(const RtSceneDesc* d, const Ray& ray, Hit& hit, Counters& cnt)
+{
+    const uint32_t numObjects = d->numObjects;
+    if (numObjects == 0) return;
+    if (numObjects == 1) { traverseObject(d, ray, hit, 0, cnt); return; }
+    const RtNode* nodes = d->topNodes;
+    if (d->numTopNodes == 0) return;
+    uint32_t stackSize = 0; const RtNode* stack[128];
+    for (const RtNode* cur = nodes;;)
+    {
+        if (nodeIsLeaf(*cur))
+        {
+            const uint32_t n = nodeNumLeaves(*cur);   // Scene::Traverse_Leaf, Scene.cpp:167-178
+            for (uint32_t i = 0; i < n; ++i) traverseObject(d, ray, hit, cur->childIndex + i, cnt);
+        }
+        else
+        {
+            const RtNode* childA = nodes + cur->childIndex; const RtNode* childB = childA + 1;
+            float distanceA, distanceB;
+            bool hitA = intersectBoxRay(ray, load3(childA->min), load3(childA->max), distanceA);
+            bool hitB = intersectBoxRay(ray, load3(childB->min), load3(childB->max), distanceB);
+            hitA &= (distanceA < hit.distance);
+            hitB &= (distanceB < hit.distance);
+            cnt.c[C_BOX] += 2; cnt.c[C_BOX_PASS] += (hitA ? 1 : 0) + (hitB ? 1 : 0);
+            if (hitA && hitB)
+            {
+                if (distanceB < distanceA) { const RtNode* t = childA; childA = childB; childB = t; }
+                cur = childA; stack[stackSize++] = childB; continue;
+            }
+            if (hitA) { cur = childA; continue; }
+            if (hitB) { cur = childB; continue; }
+        }
+        if (stackSize == 0) break;
+        cur = stack[--stackSize];
+    }
+}
+// Scene::Traverse_Shadow, Scene.cpp:245-261
+static inline bool sceneTraverseShadow(const RtSceneDesc* d, const Ray& ray, Hit& hit, Counters& cnt)
+{
+    const uint32_t numObjects = d->numObjects;
+    if (numObjects == 0) return false;
+    if (numObjects == 1) return traverseObjectShadow(d, ray, hit, 0, cnt);
+    const RtNode* nodes = d->topNodes;
+    if (d->numTopNodes == 0) return false;
+    uint32_t stackSize = 0; const RtNode* stack[128];
+    for (const RtNode* cur = nodes;;)
+    {
+        if (nodeIsLeaf(*cur))
+        {
+            const uint32_t n = nodeNumLeaves(*cur);   // Scene::Traverse_Leaf_Shadow, Scene.cpp:180-194
+            for (uint32_t i = 0; i < n; ++i) if (traverseObjectShadow(d, ray, hit, cur->childIndex + i, cnt)) return true;
+        }
+        else
+        {
+            const RtNode* childA = nodes + cur->childIndex; const RtNode* childB = childA + 1;
+            float distanceA, distanceB;
+            bool hitA = intersectBoxRay(ray, load3(childA->min), load3(childA->max), distanceA);
+            bool hitB = intersectBoxRay(ray, load3(childB->min), load3(childB->max), distanceB);
+            hitA &= (distanceA < hit.distance);
+            hitB &= (distanceB < hit.distance);
+            cnt.c[C_BOX_SHADOW] += 2;
+            if (hitA && hitB) { cur = childA; stack[stackSize++] = childB; continue; }
+            if (hitA) { cur = childA; continue; }
+            if (hitB) { cur = childB; continue; }
+        }
+        if (stackSize == 0) break;
+        cur = stack[--stackSize];
+    }
+    return false;
+}
+
+// MeshShape::EvaluateIntersection, MeshShape.cpp:283-328
+static inline void meshEvaluateIntersection(const RtSceneDesc* d, const RtMesh& mesh, const Hit& hit, Intersection& out)
+{
+    const RtVertexIndices& idx = d->vertexIndices[mesh.firstTriangle + hit.subObjectId];
+    if (idx.materialIndex != RT_NO_MATERIAL) out.material = idx.materialIndex;
+    const RtVertexShading* vs = d->vertexShading + mesh.firstVertex;
+    const RtVertexShading& a = vs[idx.i0]; const RtVertexShading& b = vs[idx.i1]; const RtVertexShading& c = vs[idx.i2];
+    const V4 coeff1 = splat(hit.u), coeff2 = splat(hit.v);
+    const V4 coeff0 = splat(1.0f) - (coeff1 + coeff2);
+    V4 texCoord = coeff1 * V4(b.texCoord[0], b.texCoord[1], 0.0f, 0.0f);
+    texCoord = mulAdd(coeff2, V4(c.texCoord[0], c.texCoord[1], 0.0f, 0.0f), texCoord);
+    texCoord = mulAdd(coeff0, V4(a.texCoord[0], a.texCoord[1], 0.0f, 0.0f), texCoord);
+    out.texCoord = texCoord;
+    V4 tangent = coeff1 * load3(b.tangent);
+    tangent = mulAdd(coeff2, load3(c.tangent), tangent);
+    tangent = mulAdd(coeff0, load3(a.tangent), tangent);
+    out.frame.r[0] = fastNormalized3(tangent);
+    V4 normal = coeff1 * load3(b.normal);
+    normal = mulAdd(coeff2, load3(c.normal), normal);
+    normal = mulAdd(coeff0, load3(a.normal), normal);
+    out.frame.r[2] = normalized3(normal);
+}
+
+// Scene::EvaluateIntersection, Scene.cpp:305-365 (normal maps are outside the hot-path scope)
+static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
+{
+    const RtObject& obj = d->objects[hit.objectId];
+    const M4 transform = loadM4(obj.transform);
+    const M4 invTransform = fastInverseNoScale(transform);
+    const V4 worldPosition = rayAt(ray, hit.distance);
+    out.frame.r[3] = transformPoint(invTransform, worldPosition);
+
+    if (obj.objectKind == RT_OBJECT_LIGHT)       // LightSceneObject::EvaluateIntersection, SceneObject_Light.cpp:62-73
+    {
+        const RtLight& L = d->lights[obj.lightIndex];
+        shapeEvaluateIntersection(L.shapeKind, L.shapeParam, L.shapeParam2, out);
+        cnt.c[C_ANALYTIC_HITS]++;
+    }
+    else
+    {
+        out.material = obj.materialIndex;        // ShapeSceneObject::EvaluateIntersection, SceneObject_Shape.cpp:60-64
+        if (obj.shapeKind == RT_SHAPE_MESH) { meshEvaluateIntersection(d, d->meshes[obj.meshIndex], hit, out); cnt.c[C_MESH_HITS]++; }
+        else { shapeEvaluateIntersection(obj.shapeKind, obj.shapeParam, obj.shapeParam2, out); cnt.c[C_ANALYTIC_HITS]++; }
+    }
+
+    V4 localSpaceTangent = out.frame.r[0];
+    const V4 localSpaceNormal = out.frame.r[2];
+    localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
+    out.frame.r[2] = transformVector(transform, localSpaceNormal);
+    out.frame.r[0] = transformVector(transform, localSpaceTangent);
+    out.frame.r[1] = cross3(out.frame.r[0], out.frame.r[2]);
+    out.frame.r[3] = worldPosition;
+}
+
+// =====================================================================================================
+// Lights -- Core/Scene/Light/*.cpp
+// =====================================================================================================
+struct IlluminateResult { V4 directionToLight; float distance, directPdfW, cosAtLight; };
+
+// ILight::Illuminate; returns radiance (4 lanes)
+static inline V4 lightIlluminate(const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
+{
+    out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
+    const V4 color = load4(L.color);
+    switch (L.type)
+    {
+    case RT_LIGHT_AREA:          // AreaLight.cpp:55-107 (rendererSupportsSolidAngleSampling = true)
+    {
+        const M4 worldToLight = loadM4(L.invTransform), lightToWorld = loadM4(L.transform);
+        const V4 ref = transformPoint(worldToLight, isect.frame.r[3]);
+        ShapeSample s;
+        if (!shapeSampleFrom(L.shapeKind, L.shapeParam, ref, u, s)) return zero4();
+        out.directionToLight = transformVector(lightToWorld, s.direction);
+        out.distance = s.distance; out.cosAtLight = s.cosAtSurface; out.directPdfW = s.pdf;
+        return color;
+    }
+    case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:63-76
+    {
+        const V4 dirLocal = getHemisphere(u[0], u[1]);
+        out.directionToLight = localToWorld(isect, dirLocal);
+        out.directPdfW = uniformHemispherePdf();
+        out.distance = FLT_MAX;
+        out.cosAtLight = 1.0f;
+        return color;
+    }
+    case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:48-92
+    {
+        V4 dir = zero4();
+        if (L.isDelta) { out.directPdfW = 1.0f; dir = V4(0, 0, 1, 0); }
+        else
+        {
+            out.directPdfW = sphereCapPdf(L.cosAngle);
+            const float phi = RTO_2PI * u[1];
+            const V4 sinCosPhi = sinCos(phi);
+            float cosTheta = Lerp(L.cosAngle, 1.0f, u[0]);
+            float sinThetaSqr = 1.0f - Sqr(cosTheta);
+            float sinTheta = sqrtf(sinThetaSqr);
+            dir.x = sinTheta * sinCosPhi.x; dir.y = sinTheta * sinCosPhi.y; dir.z = cosTheta;
+            dir = normalized3(dir);
+        }
+        out.directionToLight = transformVectorNeg(loadM4(L.transform), dir);
+        out.cosAtLight = 1.0f;
+        out.distance = FLT_MAX;
+        return color;
+    }
+    case RT_LIGHT_POINT:         // PointLight.cpp:35-49
+    {
+        out.directionToLight = load4(L.transform + 12) - isect.frame.r[3];
+        const float sqrDistance = sqrLength3(out.directionToLight);
+        out.directPdfW = sqrDistance;
+        out.distance = sqrtf(sqrDistance);
+        out.directionToLight = out.directionToLight / out.distance;
+        out.cosAtLight = 1.0f;
+        return color;
+    }
+    default:                     // RT_LIGHT_SPOT, SpotLight.cpp:41-61
+    {
+        out.directionToLight = load4(L.transform + 12) - isect.frame.r[3];
+        const float sqrDistance = sqrLength3(out.directionToLight);
+        out.directPdfW = sqrDistance;
+        out.distance = sqrtf(sqrDistance);
+        out.directionToLight = out.directionToLight / out.distance;
+        out.cosAtLight = 1.0f;
+        const float angle = dot3(out.directionToLight, neg(V4(0, 0, 1, 0)));
+        if (angle < L.cosAngle) return zero4();
+        return color;
+    }
+    }
+}
+
+// ILight::GetRadiance for a ray that hit / escaped; ray and hitPoint are in light space.
+static inline V4 lightGetRadiance(const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
+{
+    switch (L.type)
+    {
+    case RT_LIGHT_AREA:          // AreaLight.cpp:109-147
+        if (cosAtLight < RTO_EPSILON) return zero4();
+        outDirectPdfA = shapePdf(L.shapeKind, L.shapeParam, lray.origin, hitPoint);
+        return load4(L.color);
+    case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:78-92
+        outDirectPdfA = uniformHemispherePdf();
+        return load4(L.color);
+    case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:94-121
+        if (L.isDelta) return zero4();
+        if (dot3(lray.dir, V4(0, 0, 1, 0)) > -L.cosAngle) return zero4();
+        outDirectPdfA = sphereCapPdf(L.cosAngle);
+        return load4(L.color);
+    default:                     // point/spot cannot be hit (ILight::GetRadiance Light.cpp:28-32 is fatal)
+        return zero4();
+    }
+}
+
+// =====================================================================================================
+// Materials / BSDFs -- Core/Material/Material.cpp, Core/Material/BSDF/*.cpp
+// =====================================================================================================
+static const float kCosEpsilon = 1.0e-5f;                       // BSDF.h:53
+static const float kSpecularEventRoughnessTreshold = 0.005f;     // BSDF.h:57
+enum { EV_NULL = 0, EV_DIFFUSE_REFLECTION = 1, EV_GLOSSY_REFLECTION = 4, EV_GLOSSY_REFRACTION = 8, EV_SPECULAR_REFLECTION = 16, EV_SPECULAR_REFRACTION = 32,
+       EV_SPECULAR = 48 };   // BSDF.h:25-43
+
+struct MatParams { V4 baseColor, emission; float roughness, metalness, IoR; };   // SampledMaterialParameters ShadingData.h:12-19
+
+// GGX microfacet, Core/Material/BSDF/Microfacet.h:10-60 (alpha = roughness^2)
+struct Microfacet
+{
+    float alphaSqr;
+    explicit Microfacet(float alpha) : alphaSqr(alpha * alpha) {}
+    float D(V4 m) const
+    {
+        const float NdotH = m.z;
+        const float cosThetaSq = Sqr(NdotH);
+        const float tanThetaSq = Max(1.0f - cosThetaSq, 0.0f) / cosThetaSq;
+        const float cosThetaQu = cosThetaSq * cosThetaSq;
+        return alphaSqr * RTO_INV_PI / (cosThetaQu * Sqr(alphaSqr + tanThetaSq));
+    }
+    float Pdf(V4 m) const { return D(m) * Abs(m.z); }
+    float G(float NdotV, float NdotL) const
+    {
+        float tanThetaSqV = (1.0f - NdotV * NdotV) / (NdotV * NdotV);
+        float tanThetaSqL = (1.0f - NdotL * NdotL) / (NdotL * NdotL);
+        return 4.0f / ((1.0f + sqrtf(1.0f + alphaSqr * tanThetaSqV)) * (1.0f + sqrtf(1.0f + alphaSqr * tanThetaSqL)));
+    }
+    V4 Sample(float ux, float uy) const
+    {
+        const float cosThetaSqr = (1.0f - ux) / (1.0f + (alphaSqr - 1.0f) * ux);
+        const float cosTheta = sqrtf(cosThetaSqr);
+        const float sinTheta = sqrtf(1.0f - cosThetaSqr);
+        const float phi = RTO_2PI * uy;
+        const V4 xy = sinTheta * sinCos(phi);
+        return V4(xy.x, xy.y, cosTheta, xy.w);   // Select<0,0,1,0>(xy, splat(cosTheta))
+    }
+};
+
+struct BsdfSample { V4 color, incomingDir; float pdf; uint32_t event; };
+
+static bool bsdfSampleImpl(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, const float u[3], V4 outgoingDir, BsdfSample& out);
+
+static inline bool bsdfSampleMetal(const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, BsdfSample& out)   // MetalBSDF.cpp:15-35
+{
+    const float NdotV = outgoingDir.z;
+    if (NdotV < kCosEpsilon) return false;
+    const float F = fresnelMetal(NdotV, mat.IoR, mat.K);
+    out.color = mp.baseColor * splat(F);
+    out.incomingDir = neg(reflect3(outgoingDir, V4(0, 0, 1, 0)));
+    out.pdf = 1.0f;
+    out.event = EV_SPECULAR_REFLECTION;
+    return true;
+}
+static inline bool bsdfSampleDielectric(const MatParams& mp, const float u[3], V4 outgoingDir, BsdfSample& out)   // DielectricBSDF.cpp:15-103
+{
+    const float NdotV = outgoingDir.z;
+    if (Abs(NdotV) < kCosEpsilon) return false;
+    const float ior = mp.IoR;
+    const float F = fresnelDielectric(NdotV, ior);
+    const float minReflectionProbability = 0.25f;
+    const float reflectionProbability = minReflectionProbability + (1.0f - minReflectionProbability) * F;
+    const float refractionProbability = 1.0f - reflectionProbability;
+    const bool reflection = (reflectionProbability >= 1.0f) || u[0] < reflectionProbability;
+    if (reflection) { out.incomingDir = neg(reflect3(outgoingDir, V4(0, 0, 1, 0))); out.event = EV_SPECULAR_REFLECTION; }
+    else { out.incomingDir = refract3(neg(outgoingDir), V4(0, 0, 1, 0), ior); out.event = EV_SPECULAR_REFRACTION; }
+    const float NdotL = out.incomingDir.z;
+    if ((NdotV * NdotL > 0.0f) != reflection) return false;
+    if (reflection) { out.pdf = reflectionProbability; out.color = splat(1.0f); out.color = out.color * (F / reflectionProbability); }
+    else { out.pdf = refractionProbability; out.color = mp.baseColor; out.color = out.color * ((1.0f - F) / refractionProbability); }
+    return true;
+}
+static inline bool bsdfSamplePlastic(const MatParams& mp, const float u[3], V4 outgoingDir, BsdfSample& out)   // PlasticBSDF.cpp:15-64
+{
+    const float NdotV = outgoingDir.z;
+    if (NdotV < kCosEpsilon) return false;
+    const float ior = mp.IoR;
+    const float Fi = fresnelDielectric(NdotV, ior);
+    const float minSpecularWeight = 0.25f;
+    const float specularWeight = minSpecularWeight + Fi * (1.0f - minSpecularWeight);
+    const float diffuseWeight = (1.0f - Fi) * colorMax(mp.baseColor);
+    const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
+    const float diffuseProbability = 1.0f - specularProbability;
+    const bool specular = (specularProbability >= 1.0f) || (u[2] < specularProbability);
+    if (specular)
+    {
+        out.color = splat(Fi / specularProbability);
+        out.incomingDir = neg(reflect3(outgoingDir, V4(0, 0, 1, 0)));
+        out.pdf = specularProbability;
+        out.event = EV_SPECULAR_REFLECTION;
+    }
+    else
+    {
+        out.incomingDir = getHemisphereCos(u[0], u[1]);
+        const float NdotL = out.incomingDir.z;
+        out.pdf = out.incomingDir.z * RTO_INV_PI * diffuseProbability;
+        const float Fo = fresnelDielectric(NdotL, ior);
+        out.color = mp.baseColor * ((1.0f - Fi) * (1.0f - Fo) / diffuseProbability);
+        out.event = EV_DIFFUSE_REFLECTION;
+    }
+    return true;
+}
+
+static bool bsdfSampleImpl(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, const float u[3], V4 outgoingDir, BsdfSample& out)
+{
+    out.color = zero4(); out.incomingDir = zero4(); out.pdf = 0.0f; out.event = EV_NULL;   // BSDF.h:71-75
+    switch (bsdf)
+    {
+    case RT_BSDF_NULL: return false;                              // NullBSDF.cpp:11-16
+    case RT_BSDF_DIFFUSE:                                         // DiffuseBSDF.cpp:14-29
+    {
+        const float NdotV = outgoingDir.z;
+        if (NdotV < kCosEpsilon) return false;
+        out.incomingDir = getHemisphereCos(u[0], u[1]);
+        out.pdf = out.incomingDir.z * RTO_INV_PI;
+        out.color = mp.baseColor;
+        out.event = EV_DIFFUSE_REFLECTION;
+        return true;
+    }
+    case RT_BSDF_ROUGH_DIFFUSE:                                   // RoughDiffuseBSDF.cpp:14-49
+    {
+        const float NdotV = outgoingDir.z;
+        if (NdotV < kCosEpsilon) return false;
+        out.incomingDir = getHemisphereCos(u[0], u[1]);
+        const float NdotL = out.incomingDir.z;
+        const float LdotV = Max(0.0f, dot3(outgoingDir, neg(out.incomingDir)));
+        const float roughness = mp.roughness;
+        const float s2 = roughness * roughness;
+        const float A = 1.0f - 0.50f * s2 / (0.33f + s2);
+        const float B = 0.45f * s2 / (0.09f + s2);
+        const float s = LdotV - NdotL * NdotV;
+        const float stinv = s > 0.0f ? s / Max(NdotL, NdotV) : 0.0f;
+        const float value = Max(A + B * stinv, 0.0f);
+        out.pdf = NdotL * RTO_INV_PI;
+        out.color = mp.baseColor * value;
+        out.event = EV_DIFFUSE_REFLECTION;
+        return true;
+    }
+    case RT_BSDF_DIELECTRIC: return bsdfSampleDielectric(mp, u, outgoingDir, out);
+    case RT_BSDF_ROUGH_DIELECTRIC:                                // RoughDielectricBSDF.cpp:17-115
+    {
+        const float NdotV = outgoingDir.z;
+        if (Abs(NdotV) < kCosEpsilon) return false;
+        const float ior = mp.IoR;
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfSampleDielectric(mp, u, outgoingDir, out);
+        const Microfacet microfacet(roughness * roughness);
+        const V4 m = microfacet.Sample(u[0], u[1]);
+        const float microfacetPdf = microfacet.Pdf(m);
+        const float VdotH = dot3(m, outgoingDir);
+        const float F = fresnelDielectric(VdotH, ior);
+        const bool reflection = u[2] < F;
+        if (reflection) { out.incomingDir = neg(reflect3(outgoingDir, m)); out.event = EV_GLOSSY_REFLECTION; }
+        else { out.incomingDir = refract3(neg(outgoingDir), m, ior); out.event = EV_GLOSSY_REFRACTION; }
+        const float NdotL = out.incomingDir.z;
+        const float LdotH = dot3(m, out.incomingDir);
+        if ((NdotV * NdotL > 0.0f) != reflection) return false;
+        const float D = microfacet.D(m);
+        const float G = microfacet.G(NdotV, NdotL);
+        out.color = splat(Abs(VdotH) * G * D / (microfacetPdf * Abs(NdotV)));
+        if (reflection) out.pdf = F * microfacetPdf / (4.0f * Abs(VdotH));
+        else
+        {
+            const float eta = NdotV < 0.0f ? ior : 1.0f / ior;
+            const float denom = Sqr(eta * VdotH + LdotH);
+            out.pdf = (1.0f - F) * microfacetPdf * Abs(LdotH) / denom;
+            out.color = out.color * mp.baseColor;
+        }
+        return true;
+    }
+    case RT_BSDF_METAL: return bsdfSampleMetal(mat, mp, outgoingDir, out);
+    case RT_BSDF_ROUGH_METAL:                                     // RoughMetalBSDF.cpp:17-65
+    {
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfSampleMetal(mat, mp, outgoingDir, out);
+        const float NdotV = outgoingDir.z;
+        if (NdotV < kCosEpsilon) return false;
+        const Microfacet microfacet(roughness * roughness);
+        const V4 m = microfacet.Sample(u[0], u[1]);
+        out.incomingDir = neg(reflect3(outgoingDir, m));
+        if (out.incomingDir.z < kCosEpsilon) return false;
+        const float NdotL = out.incomingDir.z;
+        const float VdotH = dot3(m, outgoingDir);
+        const float pdf = microfacet.Pdf(m);
+        const float D = microfacet.D(m);
+        const float G = microfacet.G(NdotV, NdotL);
+        const float F = fresnelMetal(VdotH, mat.IoR, mat.K);
+        out.pdf = pdf / (4.0f * VdotH);
+        out.color = mp.baseColor * splat(VdotH * F * G * D / (pdf * NdotV));
+        out.event = EV_GLOSSY_REFLECTION;
+        return true;
+    }
+    case RT_BSDF_PLASTIC: return bsdfSamplePlastic(mp, u, outgoingDir, out);
+    default:                                                      // RT_BSDF_ROUGH_PLASTIC, RoughPlasticBSDF.cpp:18-88
+    {
+        const float NdotV = outgoingDir.z;
+        if (NdotV < kCosEpsilon) return false;
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfSamplePlastic(mp, u, outgoingDir, out);
+        const float ior = mp.IoR;
+        const float Fi = fresnelDielectric(NdotV, ior);
+        const float specularWeight = Fi;
+        const float diffuseWeight = (1.0f - Fi) * colorMax(mp.baseColor);
+        const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
+        const float diffuseProbability = 1.0f - specularProbability;
+        const bool specular = u[2] < specularProbability;
+        if (specular)
+        {
+            const Microfacet microfacet(roughness * roughness);
+            const V4 m = microfacet.Sample(u[0], u[1]);
+            out.incomingDir = neg(reflect3(outgoingDir, m));
+            const float NdotL = out.incomingDir.z;
+            const float VdotH = dot3(m, outgoingDir);
+            if (NdotL < kCosEpsilon || VdotH < kCosEpsilon) return false;
+            const float pdf = microfacet.Pdf(m);
+            const float D = microfacet.D(m);
+            const float G = microfacet.G(NdotV, NdotL);
+            const float F = fresnelDielectric(VdotH, mat.IoR);
+            out.pdf = pdf / (4.0f * VdotH) * specularProbability;
+            out.color = splat(VdotH * F * G * D / (pdf * NdotV * specularProbability));
+            out.event = EV_GLOSSY_REFLECTION;
+        }
+        else
+        {
+            out.incomingDir = getHemisphereCos(u[0], u[1]);
+            const float NdotL = out.incomingDir.z;
+            out.pdf = out.incomingDir.z * RTO_INV_PI * diffuseProbability;
+            const float Fo = fresnelDielectric(NdotL, ior);
+            out.color = mp.baseColor * ((1.0f - Fi) * (1.0f - Fo) / diffuseProbability);
+            out.event = EV_DIFFUSE_REFLECTION;
+        }
+        return true;
+    }
+    }
+}
+
+static inline V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)   // PlasticBSDF.cpp:66-99
+{
+    const float NdotV = outgoingDir.z;
+    const float NdotL = -incomingDir.z;
+    if (NdotV < kCosEpsilon || NdotL < kCosEpsilon) return zero4();
+    const float ior = mp.IoR;
+    const float Fi = fresnelDielectric(NdotV, ior);
+    const float Fo = fresnelDielectric(NdotL, ior);
+    const float specularWeight = Fi;
+    const float diffuseWeight = (1.0f - Fi) * colorMax(mp.baseColor);
+    const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
+    const float diffuseProbability = 1.0f - specularProbability;
+    outPdf = NdotL * RTO_INV_PI * diffuseProbability;
+    return mp.baseColor * (NdotL * RTO_INV_PI * (1.0f - Fi) * (1.0f - Fo));
+}
+
+// BSDF::Evaluate.  outPdf is left untouched on the early-out paths exactly like the reference (the
+// caller only reads it when the returned colour is not AlmostZero).
+static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)
+{
+    switch (bsdf)
+    {
+    case RT_BSDF_NULL: return zero4();
+    case RT_BSDF_DIFFUSE:                                         // DiffuseBSDF.cpp:31-54
+    {
+        const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
+        if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
+        {
+            outPdf = NdotL * RTO_INV_PI;
+            return mp.baseColor * splat(NdotL * RTO_INV_PI);
+        }
+        return zero4();
+    }
+    case RT_BSDF_ROUGH_DIFFUSE:                                   // RoughDiffuseBSDF.cpp:51-73
+    {
+        const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
+        if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
+        {
+            outPdf = NdotL * RTO_INV_PI;
+            const float LdotV = Max(0.0f, dot3(outgoingDir, neg(incomingDir)));
+            const float roughness = mp.roughness;
+            const float s2 = roughness * roughness;
+            const float A = 1.0f - 0.50f * s2 / (0.33f + s2);
+            const float B = 0.45f * s2 / (0.09f + s2);
+            const float s = LdotV - NdotL * NdotV;
+            const float stinv = s > 0.0f ? s / Max(NdotL, NdotV) : 0.0f;
+            const float value = NdotL * RTO_INV_PI * Max(A + B * stinv, 0.0f);
+            return mp.baseColor * value;
+        }
+        return zero4();
+    }
+    case RT_BSDF_DIELECTRIC: outPdf = 0.0f; return zero4();       // DielectricBSDF.cpp:105-121
+    case RT_BSDF_ROUGH_DIELECTRIC:                                // RoughDielectricBSDF.cpp:117-193
+    {
+        const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
+        if (Abs(NdotV) < kCosEpsilon || Abs(NdotL) < kCosEpsilon) return zero4();
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) return zero4();
+        const float ior = mp.IoR;
+        const float eta = NdotV < 0.0f ? ior : 1.0f / ior;
+        const bool reflection = NdotV * NdotL >= 0.0f;
+        V4 m;
+        if (reflection) m = outgoingDir - incomingDir; else m = eta * outgoingDir - incomingDir;
+        m = m * Signum(m.z);
+        m = normalized3(m);
+        if (Abs(m.z) < kCosEpsilon) return zero4();
+        const float VdotH = dot3(m, outgoingDir);
+        const float LdotH = dot3(m, neg(incomingDir));
+        float color, pdf;
+        const Microfacet microfacet(roughness * roughness);
+        const float F = fresnelDielectric(VdotH, ior);
+        const float D = microfacet.D(m);
+        const float G = microfacet.G(NdotV, NdotL);
+        if (reflection)
+        {
+            pdf = F * microfacet.Pdf(m) / (4.0f * Abs(VdotH));
+            color = F * G * D / (4.0f * Abs(NdotV));
+        }
+        else
+        {
+            const float denom = Sqr(eta * VdotH + LdotH);
+            pdf = (1.0f - F) * microfacet.Pdf(m) * Abs(LdotH) / denom;
+            color = Abs(VdotH * LdotH) * (1.0f - F) * G * D / (denom * Abs(NdotV));
+        }
+        outPdf = pdf;
+        return splat(color);
+    }
+    case RT_BSDF_METAL: outPdf = 0.0f; return zero4();            // MetalBSDF.cpp:37-54
+    case RT_BSDF_ROUGH_METAL:                                     // RoughMetalBSDF.cpp:67-107
+    {
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) { outPdf = 0.0f; return zero4(); }
+        const V4 m = normalized3(outgoingDir - incomingDir);
+        const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
+        const float VdotH = dot3(m, outgoingDir);
+        if (NdotV < kCosEpsilon || NdotL < kCosEpsilon || VdotH < kCosEpsilon) return zero4();
+        const Microfacet microfacet(roughness * roughness);
+        const float D = microfacet.D(m);
+        const float G = microfacet.G(NdotV, NdotL);
+        const float F = fresnelMetal(VdotH, mat.IoR, mat.K);
+        outPdf = microfacet.Pdf(m) / (4.0f * VdotH);
+        return mp.baseColor * splat(F * G * D / (4.0f * NdotV));
+    }
+    case RT_BSDF_PLASTIC: return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+    default:                                                      // RT_BSDF_ROUGH_PLASTIC, RoughPlasticBSDF.cpp:90-158
+    {
+        const float roughness = mp.roughness;
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+        const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
+        if (NdotV < kCosEpsilon || NdotL < kCosEpsilon) return zero4();
+        const float ior = mp.IoR;
+        const float Fi = fresnelDielectric(NdotV, ior);
+        const float Fo = fresnelDielectric(NdotL, ior);
+        const float specularWeight = Fi;
+        const float diffuseWeight = (1.0f - Fi) * colorMax(mp.baseColor);
+        const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
+        const float diffuseProbability = 1.0f - specularProbability;
+        float diffusePdf = NdotL * RTO_INV_PI;
+        float specularPdf = 0.0f;
+        V4 diffuseTerm = mp.baseColor * (NdotL * RTO_INV_PI * (1.0f - Fi) * (1.0f - Fo));
+        V4 specularTerm = zero4();
+        {
+            const V4 m = normalized3(outgoingDir - incomingDir);
+            const float VdotH = dot3(m, outgoingDir);
+            if (VdotH >= kCosEpsilon)
+            {
+                const Microfacet microfacet(roughness * roughness);
+                const float D = microfacet.D(m);
+                const float G = microfacet.G(NdotV, NdotL);
+                const float F = fresnelDielectric(VdotH, mat.IoR);
+                specularPdf = microfacet.Pdf(m) / (4.0f * VdotH);
+                specularTerm = splat(F * G * D / (4.0f * NdotV));
+            }
+        }
+        outPdf = diffusePdf * diffuseProbability + specularPdf * specularProbability;
+        return diffuseTerm + specularTerm;
+    }
+    }
+}
+
+struct ShadingData { Intersection intersection; V4 outgoingDirWorldSpace; MatParams mp; };   // ShadingData.h:21-30
+
+// Material::EvaluateShadingData (no textures), Material.cpp:151-158
+static inline void materialEvaluateShadingData(const RtMaterial& mat, ShadingData& sd)
+{
+    sd.mp.baseColor = load4(mat.baseColor);
+    sd.mp.emission = load4(mat.emission);
+    sd.mp.roughness = mat.roughness;
+    sd.mp.metalness = mat.metalness;
+    sd.mp.IoR = mat.IoR;
+}
+// Material::Evaluate, Material.cpp:160-180
+static inline V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW)
+{
+    const V4 incomingLocal = worldToLocal(sd.intersection, incomingDirWorldSpace);
+    const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
+    return bsdfEvaluate(mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW);
+}
+// Material::Sample, Material.cpp:182-232
+static inline V4 materialSample(const RtMaterial& mat, const ShadingData& sd, const float u[3], V4& outIncomingDirWorldSpace, float& outPdfW, uint32_t& outEvent)
+{
+    BsdfSample s;
+    const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
+    if (!bsdfSampleImpl(mat.bsdf, mat, sd.mp, u, outgoingLocal, s)) { outEvent = EV_NULL; return zero4(); }
+    outIncomingDirWorldSpace = localToWorld(sd.intersection, s.incomingDir);
+    outPdfW = s.pdf;
+    outEvent = s.event;
+    return s.color;
+}
+
+// =====================================================================================================
+// Camera -- Camera::GenerateRay, Core/Scene/Camera.cpp:81-118 (pinhole + circular DOF; no barrel distortion)
+// =====================================================================================================
+static inline Ray cameraGenerateRay(const RtCamera& cam, V4 coords, Sampler& sampler)
+{
+    const M4 transform = loadM4(cam.localToWorld);
+    const V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));   // UnipolarToBipolar Vector4ImplSSE.h:598-601
+    V4 origin = transform.r[3];
+    V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * cam.aspectRatio, transform.r[1] * offsetedCoords.y), cam.tanHalfFoV, transform.r[2]);
+    if (cam.dofEnable)
+    {
+        const V4 focusPoint = mulAdd(direction, cam.focalPlaneDistance, origin);
+        const V4 right = transform.r[0], up = transform.r[1];
+        const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
+        const V4 randomPointOnCircle = getCircle(sx, sy) * cam.aperture;
+        origin = mulAdd(splat(randomPointOnCircle.x), right, origin);
+        origin = mulAdd(splat(randomPointOnCircle.y), up, origin);
+        direction = focusPoint - origin;
+    }
+    return makeRay(origin, direction);
+}
+
+// =====================================================================================================
+// Integrator -- PathTracerMIS, Core/Rendering/PathTracerMIS.cpp
+// =====================================================================================================
+static inline float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }   // :16-24
+static inline float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
+
+struct PathState { uint32_t depth; float lastPdfW; bool lastSpecular; };   // PathTracerMIS.h:29-34
+
+struct RenderCtx
+{
+    const RtSceneDesc* scene; const RtPassParams* params; Sampler sampler; Counters* counters;
+    V4 lightSamplingWeight, bsdfSamplingWeight;
+};
+
+// PathTracerMIS::SampleLight, :43-123
+static inline V4 sampleLight(RenderCtx& ctx, const RtLight& light, const ShadingData& sd, const PathState& ps, float lightPickProbability)
+{
+    float u[3]; u[0] = ctx.sampler.getFloat(); u[1] = ctx.sampler.getFloat(); u[2] = ctx.sampler.getFloat();
+    IlluminateResult ir;
+    const V4 radiance = lightIlluminate(light, sd.intersection, u, ir);
+    if (almostZero4(radiance)) return zero4();
+    float bsdfPdfW = 0.0f;
+    const RtMaterial& mat = ctx.scene->materials[sd.intersection.material];
+    const V4 factor = materialEvaluate(mat, sd, neg(ir.directionToLight), bsdfPdfW);
+    if (almostZero4(factor)) return zero4();
+    {
+        Hit hp; hp.objectId = RT_INVALID_OBJECT; hp.subObjectId = 0; hp.u = hp.v = 0;
+        hp.distance = ir.distance * 0.999f;
+        Ray shadowRay = makeRay(sd.intersection.frame.r[3], ir.directionToLight);
+        shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
+        ctx.counters->c[C_SHADOW]++;
+        if (sceneTraverseShadow(ctx.scene, shadowRay, hp, *ctx.counters)) return zero4();
+        ctx.counters->c[C_SHADOW_HIT]++;
+    }
+    float weight = 1.0f;
+    const bool isLastPathSegment = ps.depth >= ctx.params->maxRayDepth;
+    if (!(light.flags & RT_LIGHT_FLAG_DELTA) && !isLastPathSegment)
+    {
+        const float continuationProbability = 1.0f;
+        bsdfPdfW *= continuationProbability;
+        weight = CombineMis(ir.directPdfW * lightPickProbability, bsdfPdfW);
+    }
+    return (radiance * factor) * FastDivide(weight, lightPickProbability * ir.directPdfW);
+}
+
+// PathTracerMIS::SampleLights, :125-155
+static inline V4 sampleLights(RenderCtx& ctx, const ShadingData& sd, const PathState& ps, float lightPickProbability)
+{
+    V4 accumulated = zero4();
+    const uint32_t numLights = ctx.scene->numLights;
+    if (numLights != 0)
+    {
+        if (ctx.params->lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE)
+        {
+            // reference: ctx.randomGenerator.GetInt() % N  (per-thread stream).  With N == 1 the draw cannot
+            // reach the image; the per-pixel stream is only advanced when N > 1.
+            uint32_t lightIndex = 0;
+            if (numLights > 1) lightIndex = ctx.sampler.fallbackInt() % numLights;
+            accumulated = sampleLight(ctx, ctx.scene->lights[lightIndex], sd, ps, lightPickProbability);
+        }
+        else
+        {
+            for (uint32_t i = 0; i < numLights; ++i) accumulated = accumulated + sampleLight(ctx, ctx.scene->lights[i], sd, ps, lightPickProbability);
+        }
+        accumulated = accumulated * ctx.lightSamplingWeight;
+    }
+    return accumulated;
+}
+
+// PathTracerMIS::EvaluateLight, :174-212
+static inline V4 evaluateLight(RenderCtx& ctx, const RtObject& obj, const Ray& ray, float dist, const Intersection& isect, const PathState& ps, float lightPickProbability)
+{
+    const RtLight& light = ctx.scene->lights[obj.lightIndex];
+    const M4 worldToLight = loadM4(obj.invTransform);
+    const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+    const V4 lightSpaceHitPoint = transformPoint(worldToLight, isect.frame.r[3]);
+    const float cosAtLight = -dot3(isect.frame.r[2], ray.dir);
+    float directPdfA = 0.0f;
+    V4 lightContribution = lightGetRadiance(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+    if (almostZero4(lightContribution)) return zero4();
+    float misWeight = 1.0f;
+    if (ps.depth > 0 && !ps.lastSpecular)
+    {
+        const float directPdfW = PdfAtoW(directPdfA, dist, cosAtLight);
+        misWeight = CombineMis(ps.lastPdfW, directPdfW * lightPickProbability);
+    }
+    lightContribution = lightContribution * ctx.bsdfSamplingWeight;
+    return lightContribution * misWeight;
+}
+
+// PathTracerMIS::EvaluateGlobalLights, :214-252
+static inline V4 evaluateGlobalLights(RenderCtx& ctx, const Ray& ray, const PathState& ps, float lightPickProbability)
+{
+    V4 result = zero4();
+    for (uint32_t g = 0; g < ctx.scene->numGlobalLights; ++g)
+    {
+        const RtLight& light = ctx.scene->lights[ctx.scene->globalLights[g]];
+        const M4 worldToLight = loadM4(light.invTransform);
+        const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+        float directPdfW = 0.0f;
+        const V4 lightContribution = lightGetRadiance(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+        if (!almostZero4(lightContribution))
+        {
+            float misWeight = 1.0f;
+            if (ps.depth > 0 && !ps.lastSpecular) misWeight = CombineMis(ps.lastPdfW, directPdfW * lightPickProbability);
+            result = mulAdd(lightContribution, misWeight, result);
+        }
+    }
+    result = result * ctx.bsdfSamplingWeight;
+    return result;
+}
+
+// PathTracerMIS::RenderPixel, :254-415
+static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
+{
+    Hit hitPoint; hitPoint.subObjectId = 0; hitPoint.u = hitPoint.v = 0.0f;
+    Ray ray = primaryRay;
+    ShadingData shadingData; shadingData.intersection.material = RT_NO_MATERIAL;
+    V4 resultColor = zero4();
+    V4 throughput = splat(1.0f);
+    PathState pathState; pathState.depth = 0; pathState.lastPdfW = 1.0f; pathState.lastSpecular = true;
+    const RtSceneDesc* scene = ctx.scene;
+
+    // GetLightPickingProbability, :157-172
+    const float lightPickProbability = ctx.params->lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1.0f / (float)scene->numLights : 1.0f;
+
+    for (;;)
+    {
+        hitPoint.objectId = RT_INVALID_OBJECT;
+        hitPoint.distance = INFINITY;
+        sceneTraverse(scene, ray, hitPoint, *ctx.counters);
+
+        if (hitPoint.objectId == RT_INVALID_OBJECT)
+        {
+            resultColor = mulAdd(throughput, evaluateGlobalLights(ctx, ray, pathState, lightPickProbability), resultColor);
+            break;
+        }
+        if (hitPoint.distance < FLT_MAX) sceneEvaluateIntersection(scene, ray, hitPoint, shadingData.intersection, *ctx.counters);
+
+        if (hitPoint.subObjectId == RT_LIGHT_OBJECT)
+        {
+            const V4 lightColor = evaluateLight(ctx, scene->objects[hitPoint.objectId], ray, hitPoint.distance, shadingData.intersection, pathState, lightPickProbability);
+            resultColor = mulAdd(throughput, lightColor, resultColor);
+            break;
+        }
+
+        shadingData.outgoingDirWorldSpace = neg(ray.dir);
+        const RtMaterial& mat = scene->materials[shadingData.intersection.material];
+        materialEvaluateShadingData(mat, shadingData);
+
+        {
+            V4 emissionColor = shadingData.mp.emission;
+            emissionColor = emissionColor * ctx.bsdfSamplingWeight;
+            resultColor = mulAdd(throughput, emissionColor, resultColor);
+        }
+
+        resultColor = mulAdd(throughput, sampleLights(ctx, shadingData, pathState, lightPickProbability), resultColor);
+
+        if (pathState.depth >= ctx.params->maxRayDepth) break;
+
+        if (pathState.depth >= ctx.params->minRussianRouletteDepth)
+        {
+            const float minColorValue = 0.125f;
+            float threshold = minColorValue + (1.0f - minColorValue) * colorMax(shadingData.mp.baseColor);
+            if (ctx.sampler.getFloat() > threshold) break;
+            throughput = throughput * (1.0f / threshold);
+        }
+
+        float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t lastSampledBsdfEvent = EV_NULL;
+        float u[3]; u[0] = ctx.sampler.getFloat(); u[1] = ctx.sampler.getFloat(); u[2] = ctx.sampler.getFloat();
+        const V4 bsdfValue = materialSample(mat, shadingData, u, incomingDirWorldSpace, pdf, lastSampledBsdfEvent);
+        if (lastSampledBsdfEvent == EV_NULL) break;
+        throughput = throughput * bsdfValue;
+        if (almostZero4(throughput)) break;
+        pathState.lastSpecular = (lastSampledBsdfEvent & EV_SPECULAR) != 0;
+        pathState.lastPdfW = pdf;
+
+        ray = makeRay(shadingData.intersection.frame.r[3], incomingDirWorldSpace);
+        ray.origin = ray.origin + ray.dir * 0.001f;
+        pathState.depth++;
+    }
+
+    ctx.counters->c[C_RAYS] += (uint64_t)pathState.depth + 1;
+    return resultColor;
+}
+
+} // namespace rto

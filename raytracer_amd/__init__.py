@@ -1,0 +1,351 @@
+"""raytracer_amd -- MI355X-native PathTracerMIS core behind the reference's Scene/Viewport API.
+
+Python is plumbing only: ctypes bindings over
+  * lib/librtgpu.so               the C-ABI of include/rtgpu.h (hand-written HIP wavefront path tracer)
+  * lib/libraytracer_amd_host.so  the C++ mirror of the reference's host API (rt::Scene, rt::Viewport ...)
+                                  through its flat ``rth_*`` facade (host/src/c_api.cpp)
+
+There is NO CPU fallback: creating a renderer without the HIP library / a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_DIR = os.path.join(_PKG_DIR, "lib")
+DATA_DIR = os.path.join(_PKG_DIR, "data")
+os.environ.setdefault("RT_DATA_DIR", DATA_DIR)
+
+RTGPU_LIB_PATH = os.path.join(_LIB_DIR, "librtgpu.so")
+HOST_LIB_PATH = os.path.join(_LIB_DIR, "libraytracer_amd_host.so")
+
+
+class BuildError(RuntimeError):
+    pass
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise BuildError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "raytracer_amd has no CPU fallback." % path)
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+_rtgpu = None
+_host = None
+
+
+def rtgpu_lib():
+    """The device C-ABI library (include/rtgpu.h)."""
+    global _rtgpu
+    if _rtgpu is None:
+        _rtgpu = _load(RTGPU_LIB_PATH)
+        _rtgpu.rtgpu_last_error.restype = C.c_char_p
+        _rtgpu.rtgpu_abi_version.restype = C.c_uint32
+    return _rtgpu
+
+
+def host_lib():
+    """The C++ host mirror (rt::Scene / rt::Viewport ...) through its rth_* facade."""
+    global _host
+    if _host is None:
+        rtgpu_lib()
+        _host = _load(HOST_LIB_PATH)
+        h = _host
+        for name in ("rth_scene_create", "rth_camera_create", "rth_viewport_create", "rth_viewport_device_ctx"):
+            getattr(h, name).restype = C.c_void_p
+        h.rth_scene_desc.restype = C.POINTER(RtSceneDesc)
+        h.rth_viewport_passes_finished.restype = C.c_uint32
+    return _host
+
+
+# --------------------------------------------------------------------------------------------------
+# ctypes mirrors of the PODs in include/rtgpu.h
+# --------------------------------------------------------------------------------------------------
+class RtNode(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("childIndex", C.c_uint32), ("max", C.c_float * 3), ("leaves", C.c_uint32)]
+
+
+class RtMesh(C.Structure):
+    _fields_ = [("firstNode", C.c_uint32), ("numNodes", C.c_uint32), ("firstTriangle", C.c_uint32), ("numTriangles", C.c_uint32),
+                ("firstVertex", C.c_uint32), ("numVertices", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+
+
+class RtObject(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("invTransform", C.c_float * 16), ("objectKind", C.c_uint32), ("shapeKind", C.c_uint32),
+                ("materialIndex", C.c_uint32), ("meshIndex", C.c_uint32), ("lightIndex", C.c_uint32), ("_pad", C.c_uint32 * 3),
+                ("shapeParam", C.c_float * 4), ("shapeParam2", C.c_float * 4)]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("invTransform", C.c_float * 16), ("color", C.c_float * 4), ("type", C.c_uint32),
+                ("flags", C.c_uint32), ("shapeKind", C.c_uint32), ("isDelta", C.c_uint32), ("cosAngle", C.c_float), ("_pad", C.c_float * 3),
+                ("shapeParam", C.c_float * 4), ("shapeParam2", C.c_float * 4)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("emission", C.c_float * 4), ("baseColor", C.c_float * 4), ("roughness", C.c_float), ("metalness", C.c_float),
+                ("IoR", C.c_float), ("K", C.c_float), ("bsdf", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("abiVersion", C.c_uint32), ("numObjects", C.c_uint32), ("numTopNodes", C.c_uint32), ("numLights", C.c_uint32),
+                ("numGlobalLights", C.c_uint32), ("numMaterials", C.c_uint32), ("numMeshes", C.c_uint32), ("numMeshNodes", C.c_uint32),
+                ("numTriangles", C.c_uint32), ("numVertices", C.c_uint32), ("_pad", C.c_uint32 * 2),
+                ("topNodes", C.POINTER(RtNode)), ("objects", C.POINTER(RtObject)), ("lights", C.POINTER(RtLight)),
+                ("globalLights", C.POINTER(C.c_uint32)), ("materials", C.POINTER(RtMaterial)), ("meshes", C.POINTER(RtMesh)),
+                ("meshNodes", C.POINTER(RtNode)), ("triangles", C.c_void_p), ("vertexIndices", C.c_void_p),
+                ("vertexShading", C.c_void_p), ("blueNoise", C.c_void_p)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("localToWorld", C.c_float * 16), ("aspectRatio", C.c_float), ("tanHalfFoV", C.c_float), ("dofEnable", C.c_uint32),
+                ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2)]
+
+
+class RtPassParams(C.Structure):
+    _fields_ = [("camera", RtCamera), ("seed", C.POINTER(C.c_uint32)), ("numDimensions", C.c_uint32), ("useBlueNoise", C.c_uint32),
+                ("sampleOffset", C.c_float * 2), ("passIndex", C.c_uint32), ("maxRayDepth", C.c_uint32),
+                ("minRussianRouletteDepth", C.c_uint32), ("lightSamplingStrategy", C.c_uint32),
+                ("lightSamplingWeight", C.c_float * 4), ("bsdfSamplingWeight", C.c_float * 4), ("rngKey", C.c_uint64 * 2)]
+
+
+class RtCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests",
+                                          "numPassedRayBoxTests", "numRayTriangleTests", "numPassedRayTriangleTests",
+                                          "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
+                                          "numShadowRayTriangleTests")] + [("_reserved", C.c_uint64 * 4)]
+
+
+COUNTER_NAMES = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests", "numPassedRayBoxTests",
+                 "numRayTriangleTests", "numPassedRayTriangleTests", "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
+                 "numShadowRayTriangleTests")
+
+BSDF_NAMES = ("null", "diffuse", "roughDiffuse", "dielectric", "roughDielectric", "metal", "roughMetal", "plastic", "roughPlastic")
+
+
+def load_blue_noise():
+    """128*128*4 uint16 blue-noise table (Data/BlueNoise128_RGBA16.dat of the reference, a data asset)."""
+    return np.fromfile(os.path.join(DATA_DIR, "BlueNoise128_RGBA16.dat"), dtype=np.uint16)
+
+
+def _f(values, n):
+    arr = (C.c_float * n)()
+    for i, v in enumerate(values):
+        arr[i] = float(v)
+    return arr
+
+
+def _color(c):
+    c = list(c)
+    if len(c) == 3:
+        c = c + [0.0]   # Vector4(x, y, z) leaves w = 0, like the reference's constructors / JSON loader
+    return _f(c, 4)
+
+
+def transform_from_euler(translation=(0.0, 0.0, 0.0), orientation_deg=(0.0, 0.0, 0.0)):
+    """4x4 row-major local->world matrix from translation + Euler angles in degrees (reference JSON convention)."""
+    out = (C.c_float * 16)()
+    host_lib().rth_transform_from_euler(_f(translation, 3), _f(orientation_deg, 3), out)
+    return out
+
+
+_IDENTITY = _f([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1], 16)
+
+
+class Scene:
+    """rt::Scene: add objects, BuildBVH(), then hand it to a Viewport (reference: Core/Scene/Scene.h)."""
+
+    def __init__(self):
+        self._h = C.c_void_p(host_lib().rth_scene_create())
+        self._keep = []
+        self.built = False
+
+    def __del__(self):
+        try:
+            if self._h:
+                host_lib().rth_scene_destroy(self._h)
+        except Exception:
+            pass
+
+    def add_material(self, bsdf="diffuse", base_color=(0.7, 0.7, 0.7), emission=(0.0, 0.0, 0.0), roughness=0.1, metalness=0.0,
+                     ior=1.5, k=4.0):
+        mid = host_lib().rth_material_create(self._h, bsdf.encode(), _color(base_color), _color(emission), C.c_float(roughness),
+                                             C.c_float(metalness), C.c_float(ior), C.c_float(k))
+        if mid < 0:
+            raise ValueError("unknown BSDF name %r" % bsdf)
+        return mid
+
+    def add_sphere(self, radius, transform=None, material=-1):
+        host_lib().rth_add_sphere(self._h, C.c_float(radius), transform or _IDENTITY, int(material))
+
+    def add_box(self, size, transform=None, material=-1):
+        host_lib().rth_add_box(self._h, _f(size, 3), transform or _IDENTITY, int(material))
+
+    def add_rect(self, size, transform=None, material=-1, tex_scale=(1.0, 1.0)):
+        host_lib().rth_add_rect(self._h, _f(size, 2), _f(tex_scale, 2), transform or _IDENTITY, int(material))
+
+    def add_mesh(self, positions, indices, normals=None, tangents=None, tex_coords=None, material_indices=None, materials=(),
+                 transform=None, default_material=-1):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+
+        def opt(a, w):
+            if a is None:
+                return None, None
+            arr = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w)
+            if arr.shape[0] != pos.shape[0]:
+                raise ValueError("per-vertex array has the wrong length")
+            return arr, arr.ctypes.data_as(C.POINTER(C.c_float))
+
+        nrm, nrm_p = opt(normals, 3)
+        tan, tan_p = opt(tangents, 3)
+        uv, uv_p = opt(tex_coords, 2)
+        mi, mi_p = None, None
+        if material_indices is not None:
+            mi = np.ascontiguousarray(material_indices, dtype=np.uint32).reshape(-1)
+            mi_p = mi.ctypes.data_as(C.POINTER(C.c_uint32))
+        mats = (C.c_int * max(1, len(materials)))(*materials)
+        r = host_lib().rth_add_mesh(self._h, C.c_uint32(pos.shape[0]), C.c_uint32(idx.shape[0]), pos.ctypes.data_as(C.POINTER(C.c_float)),
+                                    nrm_p, tan_p, uv_p, idx.ctypes.data_as(C.POINTER(C.c_uint32)), mi_p, C.c_uint32(len(materials)), mats,
+                                    transform or _IDENTITY, int(default_material))
+        if r != 0:
+            raise ValueError("mesh rejected (code %d)" % r)
+
+    def add_area_light(self, shape, params, color, transform=None):
+        kind = {"sphere": 0, "box": 1, "rect": 2, "plane": 2}[shape]
+        p = list(params) + [0.0] * (4 - len(params))
+        if host_lib().rth_add_light_area(self._h, kind, _f(p, 4), _color(color), transform or _IDENTITY) != 0:
+            raise ValueError("bad area light")
+
+    def add_background_light(self, color):
+        host_lib().rth_add_light_background(self._h, _color(color))
+
+    def add_directional_light(self, color, angle_rad=0.2, transform=None):
+        host_lib().rth_add_light_directional(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)
+
+    def add_point_light(self, color, transform=None):
+        host_lib().rth_add_light_point(self._h, _color(color), transform or _IDENTITY)
+
+    def add_spot_light(self, color, angle_rad, transform=None):
+        host_lib().rth_add_light_spot(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)
+
+    def build(self):
+        if host_lib().rth_scene_build(self._h) != 0:
+            raise RuntimeError("Scene::BuildBVH failed")
+        self.built = True
+        return self
+
+    @property
+    def desc(self):
+        """Pointer to the flat RtSceneDesc (valid until the scene is rebuilt / destroyed)."""
+        return host_lib().rth_scene_desc(self._h)
+
+
+class Camera:
+    """rt::Camera (reference: Core/Scene/Camera.h)."""
+
+    def __init__(self, translation=(0.0, 0.0, 0.0), orientation_deg=(0.0, 0.0, 0.0), aspect=1.0, fov_deg=20.0):
+        self._h = C.c_void_p(host_lib().rth_camera_create())
+        self.set_transform(translation, orientation_deg)
+        self.set_perspective(aspect, np.float32(fov_deg) / np.float32(180.0) * np.float32(3.14159265359))
+
+    def __del__(self):
+        try:
+            if self._h:
+                host_lib().rth_camera_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_transform(self, translation, orientation_deg=(0.0, 0.0, 0.0)):
+        host_lib().rth_camera_set_transform(self._h, _f(translation, 3), _f(orientation_deg, 3))
+
+    def set_perspective(self, aspect, fov_rad):
+        host_lib().rth_camera_set_perspective(self._h, C.c_float(aspect), C.c_float(fov_rad))
+
+    def set_dof(self, enable, focal_plane_distance=2.0, aperture=0.1):
+        host_lib().rth_camera_set_dof(self._h, int(bool(enable)), C.c_float(focal_plane_distance), C.c_float(aperture))
+
+
+class Viewport:
+    """rt::Viewport driving the GPU "Path Tracer MIS" renderer (reference: Core/Rendering/Viewport.h)."""
+
+    def __init__(self, width, height, seed=None, dimensions=64, use_blue_noise=True, anti_aliasing_spread=0.5, max_ray_depth=20,
+                 min_russian_roulette_depth=1, light_sampling_all=False):
+        self._h = C.c_void_p(host_lib().rth_viewport_create())
+        self.width, self.height = int(width), int(height)
+        self._scene = None
+        self.has_renderer = False
+        if host_lib().rth_viewport_set_params(self._h, C.c_uint32(dimensions), int(bool(use_blue_noise)), C.c_float(anti_aliasing_spread),
+                                              C.c_uint32(max_ray_depth), C.c_uint32(min_russian_roulette_depth), int(bool(light_sampling_all))) != 0:
+            raise ValueError("invalid rendering params")
+        if seed is not None:
+            host_lib().rth_viewport_set_seed(self._h, C.c_uint64(seed))
+        if host_lib().rth_viewport_resize(self._h, C.c_uint32(width), C.c_uint32(height)) != 0:
+            raise ValueError("invalid viewport size")
+
+    def __del__(self):
+        try:
+            if self._h:
+                host_lib().rth_viewport_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_renderer(self, scene, name="Path Tracer MIS", device=-1):
+        """CreateRenderer(name, scene) + SetRenderer.  Raises when the GPU renderer cannot be created."""
+        self._scene = scene
+        r = host_lib().rth_viewport_set_renderer(self._h, scene._h, name.encode(), int(device))
+        if r != 0:
+            err = rtgpu_lib().rtgpu_last_error()
+            raise RuntimeError("CreateRenderer(%r) failed (%d): %s" % (name, r, err.decode() if err else ""))
+        self.has_renderer = True
+        self.reset()
+
+    def set_shard(self, rank, world_size):
+        if host_lib().rth_viewport_set_shard(self._h, C.c_uint32(rank), C.c_uint32(world_size)) != 0:
+            raise RuntimeError("set_shard failed")
+
+    def reset(self):
+        host_lib().rth_viewport_reset(self._h)
+
+    def render(self, camera, passes=1):
+        if host_lib().rth_viewport_render(self._h, camera._h, C.c_uint32(passes)) != 0:
+            raise RuntimeError("Viewport::Render failed: %s" % (rtgpu_lib().rtgpu_last_error() or b"").decode())
+
+    def next_pass_params(self, camera):
+        """Per-pass constants (Halton seeds, AA offset ...) exactly as Render() would use them; advances the state."""
+        p = RtPassParams()
+        if host_lib().rth_viewport_next_pass_params(self._h, camera._h, C.byref(p)) != 0:
+            raise RuntimeError("NextPassParams failed")
+        # copy the seeds: the pointer refers to storage reused by the next call
+        seeds = np.ctypeslib.as_array(p.seed, shape=(p.numDimensions,)).copy()
+        p._seed_keepalive = seeds
+        p.seed = seeds.ctypes.data_as(C.POINTER(C.c_uint32))
+        return p
+
+    def render_pass_with(self, params):
+        """Submit one pass with explicit constants (used by the parity tests)."""
+        if host_lib().rth_viewport_render_pass_with(self._h, C.byref(params)) != 0:
+            raise RuntimeError("render pass failed: %s" % (rtgpu_lib().rtgpu_last_error() or b"").decode())
+
+    def device_context(self):
+        return C.c_void_p(host_lib().rth_viewport_device_ctx(self._h))
+
+    def sum_buffer(self, secondary=False):
+        """Accumulated float3 image, shape (H, W, 3); row y as in the reference's sum bitmap.  Synchronises."""
+        s = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        s2 = np.zeros((self.height, self.width, 3), dtype=np.float32) if secondary else None
+        host_lib().rth_viewport_read_sum(self._h, s.ctypes.data_as(C.POINTER(C.c_float)),
+                                         s2.ctypes.data_as(C.POINTER(C.c_float)) if secondary else None)
+        return (s, s2) if secondary else s
+
+    def counters(self):
+        out = (C.c_uint64 * 16)()
+        host_lib().rth_viewport_counters(self._h, out)
+        return {n: int(out[i]) for i, n in enumerate(COUNTER_NAMES)}
+
+    @property
+    def passes_finished(self):
+        return int(host_lib().rth_viewport_passes_finished(self._h))

@@ -1,0 +1,997 @@
+// rt_kernels.hip -- wavefront PathTracerMIS for MI355X (gfx950) and the C-ABI of include/rtgpu.h.
+//
+// One pass (= one sample per owned pixel) is a fixed sequence of launches on the context's stream:
+//
+//   generate                               camera ray + sampler reset per path            (Viewport.cpp:305-331)
+//   for depth = 0 .. maxRayDepth:
+//       trace_closest                      two-level BVH closest hit                      (Scene.cpp:219)
+//       shade                              miss / light hit / emission / NEE set-up / Russian roulette /
+//                                          BSDF sample; compacts survivors into the next queue
+//                                                                                         (PathTracerMIS.cpp:270-396)
+//       trace_shadow                       any-hit occlusion of the NEE rays + accumulate (PathTracerMIS.cpp:81-119)
+//   accumulate                             film sum (+ secondary sum on even passes)      (Film.cpp:25-39)
+//
+// Path state lives in HBM as structure-of-arrays indexed by path slot, so a wave reads 64 consecutive
+// dwords per field; queues hold slot indices and are compacted with wave ballots (one atomic per wave).
+// Per-path arithmetic is kept in the reference's operation order (see rt_device_math.h), which makes the
+// result independent of the wavefront schedule and reproducible against the CPU oracle.
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+#include "rt_device_core.h"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace rtd;
+
+// =====================================================================================================
+// Device-side data
+// =====================================================================================================
+enum PathField : uint32_t
+{
+    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,          // ray: origin BEFORE the 1e-3 offset, direction as passed to Ray()
+    F_TPX, F_TPY, F_TPZ, F_TPW,                  // throughput (4 lanes: RayColor::AlmostZero tests all four)
+    F_RX, F_RY, F_RZ,                            // accumulated radiance of this path
+    F_PIXEL,                                     // x | y << 16
+    F_SALT, F_GENERATED,                         // GenericSampler state
+    F_RNG0L, F_RNG0H, F_RNG1L, F_RNG1H,          // per-pixel xoroshiro128+ state
+    F_FLAGS,                                     // depth (bits 0-7) | lastSpecular << 8
+    F_LASTPDFW,
+    F_HIT_OBJ, F_HIT_SUB, F_HIT_DIST, F_HIT_U, F_HIT_V,
+    F_SH_COUNT,                                  // number of NEE requests pending for this vertex
+    F_SH_PX, F_SH_PY, F_SH_PZ,                   // shading point (shadow ray origin before the 1e-4 offset)
+    F_SH_TPX, F_SH_TPY, F_SH_TPZ,                // throughput at the vertex (the NEE fma uses it)
+    F_NUM_BASE
+};
+// per NEE request (RT_SHADOW_STRIDE floats each, light-major): direction xyz, tmax (<0 = no ray), contribution rgb
+#define RT_SHADOW_STRIDE 7
+
+struct Paths
+{
+    float* base;        // F_NUM_BASE * capacity floats, then maxLights * RT_SHADOW_STRIDE * capacity
+    uint32_t capacity;
+    uint32_t maxLights; // NEE requests per vertex (1 for LightSamplingStrategy::Single)
+};
+
+RT_DEV float& pf(const Paths& p, uint32_t field, uint32_t slot) { return p.base[(size_t)field * p.capacity + slot]; }
+RT_DEV uint32_t& pu(const Paths& p, uint32_t field, uint32_t slot) { return reinterpret_cast<uint32_t*>(p.base)[(size_t)field * p.capacity + slot]; }
+RT_DEV float& psh(const Paths& p, uint32_t light, uint32_t k, uint32_t slot)
+{
+    return p.base[((size_t)F_NUM_BASE + (size_t)light * RT_SHADOW_STRIDE + k) * p.capacity + slot];
+}
+
+struct DevPass
+{
+    RtCamera camera;
+    const uint32_t* seed;
+    uint32_t numDimensions;
+    uint32_t blueNoiseLayers;
+    float sampleOffset[2];
+    uint32_t passIndex;
+    uint32_t maxRayDepth;
+    uint32_t minRussianRouletteDepth;
+    uint32_t lightSamplingStrategy;
+    float lightSamplingWeight[4];
+    float bsdfSamplingWeight[4];
+    uint64_t rngKey[2];
+    uint32_t width, height;
+};
+
+#define RT_BLOCK 256
+
+// per-block counter flush: LDS tally, then one 64-bit atomic per counter per block
+RT_DEV void flushCounters(const Counters& c, unsigned long long* global)
+{
+    __shared__ uint32_t sC[RT_NUM_COUNTERS];
+    if (threadIdx.x < RT_NUM_COUNTERS) sC[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RT_NUM_COUNTERS; ++k) if (c.c[k]) atomicAdd(&sC[k], c.c[k]);
+    __syncthreads();
+    if (threadIdx.x < RT_NUM_COUNTERS && sC[threadIdx.x]) atomicAdd(&global[threadIdx.x], (unsigned long long)sC[threadIdx.x]);
+}
+RT_DEV void zeroCounters(Counters& c) {
+#pragma unroll
+    for (int k = 0; k < RT_NUM_COUNTERS; ++k) c.c[k] = 0;
+}
+
+RT_DEV void loadSampler(Sampler& s, const Paths& p, uint32_t slot, const DevPass& pass, const uint16_t* blueNoise)
+{
+    const uint32_t pix = pu(p, F_PIXEL, slot);
+    s.seed = pass.seed; s.numDims = pass.numDimensions; s.blueNoiseLayers = pass.blueNoiseLayers; s.blueNoise = blueNoise;
+    s.bx = (pix & 0xFFFFu) & 127u; s.by = (pix >> 16) & 127u;
+    s.salt = pu(p, F_SALT, slot); s.generated = pu(p, F_GENERATED, slot);
+    s.fallback.s[0] = (uint64_t)pu(p, F_RNG0L, slot) | ((uint64_t)pu(p, F_RNG0H, slot) << 32);
+    s.fallback.s[1] = (uint64_t)pu(p, F_RNG1L, slot) | ((uint64_t)pu(p, F_RNG1H, slot) << 32);
+}
+RT_DEV void storeSampler(const Sampler& s, const Paths& p, uint32_t slot)
+{
+    pu(p, F_SALT, slot) = s.salt; pu(p, F_GENERATED, slot) = s.generated;
+    pu(p, F_RNG0L, slot) = (uint32_t)s.fallback.s[0]; pu(p, F_RNG0H, slot) = (uint32_t)(s.fallback.s[0] >> 32);
+    pu(p, F_RNG1L, slot) = (uint32_t)s.fallback.s[1]; pu(p, F_RNG1H, slot) = (uint32_t)(s.fallback.s[1] >> 32);
+}
+
+// The path's current ray exactly as the reference holds it: Ray(origin, direction) -- which normalises and
+// computes invDir / originDivDir from the UN-offset origin -- and then origin += dir * 0.001f for
+// secondary rays, leaving originDivDir stale (PathTracerMIS.cpp:392-393).
+RT_DEV Ray loadPathRay(const Paths& p, uint32_t slot, uint32_t depth)
+{
+    const V4 o(pf(p, F_OX, slot), pf(p, F_OY, slot), pf(p, F_OZ, slot), 0.0f);
+    const V4 d(pf(p, F_DX, slot), pf(p, F_DY, slot), pf(p, F_DZ, slot), 0.0f);
+    Ray ray = makeRay(o, d);
+    if (depth > 0) ray.origin = ray.origin + ray.dir * 0.001f;
+    return ray;
+}
+
+// =====================================================================================================
+// Kernels
+// =====================================================================================================
+
+// Viewport::RenderTile per-pixel prologue + Camera::GenerateRay (Viewport.cpp:305-331, Camera.cpp:81-118)
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, const DevPass pass, const Paths paths,
+                                                       const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
+                                                       uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount,
+                                                       unsigned long long* counters)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    {
+        const uint32_t pix = slotPixel[slot];
+        const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
+        const uint32_t realY = pass.height - 1u - y;
+        // invSize = VECTOR_ONE2 / FromIntegers(w, h, 1, 1); coords = (FromIntegers(x, realY) + sampleOffset) * invSize
+        const float invW = 1.0f / (float)(int32_t)pass.width, invH = 1.0f / (float)(int32_t)pass.height;
+        const V4 coords(((float)(int32_t)x + pass.sampleOffset[0]) * invW, ((float)(int32_t)realY + pass.sampleOffset[1]) * invH, 0.0f, 0.0f);
+
+        Sampler sampler;
+        sampler.seed = pass.seed; sampler.numDims = pass.numDimensions; sampler.blueNoiseLayers = pass.blueNoiseLayers; sampler.blueNoise = scene.blueNoise;
+        sampler.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
+
+        // Camera::GenerateRay up to (not including) the Ray constructor, which trace/shade re-run from origin+direction
+        const M4 transform = loadM4(pass.camera.localToWorld);
+        const V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));
+        V4 origin = transform.r[3];
+        V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * pass.camera.aspectRatio, transform.r[1] * offsetedCoords.y), pass.camera.tanHalfFoV, transform.r[2]);
+        if (pass.camera.dofEnable)
+        {
+            const V4 focusPoint = mulAdd(direction, pass.camera.focalPlaneDistance, origin);
+            const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
+            const V4 randomPointOnCircle = getCircle(sx, sy) * pass.camera.aperture;
+            origin = mulAdd(splat(randomPointOnCircle.x), transform.r[0], origin);
+            origin = mulAdd(splat(randomPointOnCircle.y), transform.r[1], origin);
+            direction = focusPoint - origin;
+        }
+
+        pf(paths, F_OX, slot) = origin.x; pf(paths, F_OY, slot) = origin.y; pf(paths, F_OZ, slot) = origin.z;
+        pf(paths, F_DX, slot) = direction.x; pf(paths, F_DY, slot) = direction.y; pf(paths, F_DZ, slot) = direction.z;
+        pf(paths, F_TPX, slot) = 1.0f; pf(paths, F_TPY, slot) = 1.0f; pf(paths, F_TPZ, slot) = 1.0f; pf(paths, F_TPW, slot) = 1.0f;
+        pf(paths, F_RX, slot) = 0.0f; pf(paths, F_RY, slot) = 0.0f; pf(paths, F_RZ, slot) = 0.0f;
+        pu(paths, F_PIXEL, slot) = pix;
+        pu(paths, F_FLAGS, slot) = 0x100u;   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
+        pf(paths, F_LASTPDFW, slot) = 1.0f;
+        pu(paths, F_SH_COUNT, slot) = 0;
+        storeSampler(sampler, paths, slot);
+        queue[slot] = slot;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        *queueCount = numSlots;
+        atomicAdd(&counters[C_PRIMARY], (unsigned long long)numSlots);
+    }
+}
+
+// Scene::Traverse for every active path (Scene.cpp:219-243)
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(const RtSceneDesc scene, const Paths paths,
+                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                            unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const uint32_t count = *queueCount;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    {
+        const uint32_t slot = queue[i];
+        const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
+        const Ray ray = loadPathRay(paths, slot, depth);
+        Hit hit; hit.objectId = RT_INVALID_OBJECT; hit.subObjectId = 0; hit.distance = __uint_as_float(0x7f800000u); hit.u = 0.0f; hit.v = 0.0f;
+        sceneTraverse(scene, ray, hit, cnt);
+        pu(paths, F_HIT_OBJ, slot) = hit.objectId; pu(paths, F_HIT_SUB, slot) = hit.subObjectId;
+        pf(paths, F_HIT_DIST, slot) = hit.distance; pf(paths, F_HIT_U, slot) = hit.u; pf(paths, F_HIT_V, slot) = hit.v;
+    }
+    flushCounters(cnt, counters);
+}
+
+RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
+RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
+
+// PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
+// request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
+RT_DEV void prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
+                               const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
+                               const Paths& paths, uint32_t slot, uint32_t requestIndex)
+{
+    float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
+    float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
+    IlluminateResult ir;
+    const V4 radiance = lightIlluminate(light, sd.intersection, u, ir);
+    if (!almostZero4(radiance))
+    {
+        float bsdfPdfW = 0.0f;
+        const V4 factor = materialEvaluate(mat, sd, neg(ir.directionToLight), bsdfPdfW);
+        if (!almostZero4(factor))
+        {
+            float weight = 1.0f;
+            const bool isLastPathSegment = depth >= pass.maxRayDepth;
+            if (!(light.flags & RT_LIGHT_FLAG_DELTA) && !isLastPathSegment)
+            {
+                const float continuationProbability = 1.0f;
+                bsdfPdfW *= continuationProbability;
+                weight = CombineMis(ir.directPdfW * lightPickProbability, bsdfPdfW);
+            }
+            contribution = (radiance * factor) * FastDivide(weight, lightPickProbability * ir.directPdfW);
+            dir = ir.directionToLight;
+            tmax = ir.distance * 0.999f;
+        }
+    }
+    psh(paths, requestIndex, 0, slot) = dir.x; psh(paths, requestIndex, 1, slot) = dir.y; psh(paths, requestIndex, 2, slot) = dir.z;
+    psh(paths, requestIndex, 3, slot) = tmax;
+    psh(paths, requestIndex, 4, slot) = contribution.x; psh(paths, requestIndex, 5, slot) = contribution.y; psh(paths, requestIndex, 6, slot) = contribution.z;
+}
+
+// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395)
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass pass, const Paths paths,
+                                                    const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                    uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                    unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const uint32_t count = *countIn;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
+    // GetLightPickingProbability, PathTracerMIS.cpp:157-172
+    const float lightPickProbability = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1.0f / (float)scene.numLights : 1.0f;
+
+    // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
+    const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        bool alive = false;
+        uint32_t slot = 0;
+        if (i < count)
+        {
+            slot = queueIn[i];
+            const uint32_t flags = pu(paths, F_FLAGS, slot);
+            uint32_t depth = flags & 0xFFu;
+            const bool lastSpecular = (flags & 0x100u) != 0;
+            const float lastPdfW = pf(paths, F_LASTPDFW, slot);
+            const Ray ray = loadPathRay(paths, slot, depth);
+            V4 throughput(pf(paths, F_TPX, slot), pf(paths, F_TPY, slot), pf(paths, F_TPZ, slot), pf(paths, F_TPW, slot));
+            V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
+            Hit hit;
+            hit.objectId = pu(paths, F_HIT_OBJ, slot); hit.subObjectId = pu(paths, F_HIT_SUB, slot);
+            hit.distance = pf(paths, F_HIT_DIST, slot); hit.u = pf(paths, F_HIT_U, slot); hit.v = pf(paths, F_HIT_V, slot);
+
+            do
+            {
+                if (hit.objectId == RT_INVALID_OBJECT)
+                {
+                    // EvaluateGlobalLights, PathTracerMIS.cpp:214-252
+                    V4 result = zero4();
+                    for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
+                    {
+                        const RtLight& light = scene.lights[scene.globalLights[g]];
+                        const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
+                        float directPdfW = 0.0f;
+                        const V4 lightContribution = lightGetRadiance(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+                        if (!almostZero4(lightContribution))
+                        {
+                            float misWeight = 1.0f;
+                            if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                            result = mulAdd(lightContribution, misWeight, result);
+                        }
+                    }
+                    result = result * bsdfSamplingWeight;
+                    resultColor = mulAdd(throughput, result, resultColor);
+                    break;
+                }
+
+                ShadingData sd;
+                sd.intersection.material = RT_NO_MATERIAL;
+                if (hit.distance < FLT_MAX) sceneEvaluateIntersection(scene, ray, hit, sd.intersection, cnt);
+
+                if (hit.subObjectId == RT_LIGHT_OBJECT)
+                {
+                    // EvaluateLight, PathTracerMIS.cpp:174-212
+                    const RtObject& obj = scene.objects[hit.objectId];
+                    const RtLight& light = scene.lights[obj.lightIndex];
+                    const M4 worldToLight = loadM4(obj.invTransform);
+                    const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+                    const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
+                    const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
+                    float directPdfA = 0.0f;
+                    V4 lightContribution = lightGetRadiance(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+                    if (!almostZero4(lightContribution))
+                    {
+                        float misWeight = 1.0f;
+                        if (depth > 0 && !lastSpecular)
+                        {
+                            const float directPdfW = PdfAtoW(directPdfA, hit.distance, cosAtLight);
+                            misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                        }
+                        lightContribution = lightContribution * bsdfSamplingWeight;
+                        resultColor = mulAdd(throughput, lightContribution * misWeight, resultColor);
+                    }
+                    else
+                    {
+                        resultColor = mulAdd(throughput, zero4(), resultColor);
+                    }
+                    break;
+                }
+
+                sd.outgoingDirWorldSpace = neg(ray.dir);
+                const RtMaterial& mat = scene.materials[sd.intersection.material];
+                materialEvaluateShadingData(mat, sd);
+
+                // emission, PathTracerMIS.cpp:309-317
+                resultColor = mulAdd(throughput, sd.mp.emission * bsdfSamplingWeight, resultColor);
+
+                Sampler sampler; loadSampler(sampler, paths, slot, pass, scene.blueNoise);
+
+                // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
+                uint32_t numRequests = 0;
+                if (scene.numLights != 0)
+                {
+                    if (pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE)
+                    {
+                        uint32_t lightIndex = 0;
+                        if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
+                        prepareLightSample(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0);
+                        numRequests = 1;
+                    }
+                    else
+                    {
+                        for (uint32_t l = 0; l < scene.numLights; ++l)
+                            prepareLightSample(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
+                        numRequests = scene.numLights;
+                    }
+                    pu(paths, F_SH_COUNT, slot) = numRequests;
+                    pf(paths, F_SH_PX, slot) = sd.intersection.frame.r[3].x; pf(paths, F_SH_PY, slot) = sd.intersection.frame.r[3].y; pf(paths, F_SH_PZ, slot) = sd.intersection.frame.r[3].z;
+                    pf(paths, F_SH_TPX, slot) = throughput.x; pf(paths, F_SH_TPY, slot) = throughput.y; pf(paths, F_SH_TPZ, slot) = throughput.z;
+                }
+
+                bool cont = true;
+                if (depth >= pass.maxRayDepth) cont = false;
+
+                // Russian roulette, PathTracerMIS.cpp:330-347
+                if (cont && depth >= pass.minRussianRouletteDepth)
+                {
+                    const float minColorValue = 0.125f;
+                    const float threshold = minColorValue + (1.0f - minColorValue) * colorMax(sd.mp.baseColor);
+                    if (sampler.getFloat() > threshold) cont = false;
+                    else throughput = throughput * (1.0f / threshold);
+                }
+
+                // BSDF sampling, PathTracerMIS.cpp:349-395
+                if (cont)
+                {
+                    float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
+                    float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
+                    const V4 bsdfValue = materialSample(mat, sd, u, incomingDirWorldSpace, pdf, event);
+                    if (event == EV_NULL) cont = false;
+                    else
+                    {
+                        throughput = throughput * bsdfValue;
+                        if (almostZero4(throughput)) cont = false;
+                        else
+                        {
+                            pf(paths, F_OX, slot) = sd.intersection.frame.r[3].x; pf(paths, F_OY, slot) = sd.intersection.frame.r[3].y; pf(paths, F_OZ, slot) = sd.intersection.frame.r[3].z;
+                            pf(paths, F_DX, slot) = incomingDirWorldSpace.x; pf(paths, F_DY, slot) = incomingDirWorldSpace.y; pf(paths, F_DZ, slot) = incomingDirWorldSpace.z;
+                            pf(paths, F_TPX, slot) = throughput.x; pf(paths, F_TPY, slot) = throughput.y; pf(paths, F_TPZ, slot) = throughput.z; pf(paths, F_TPW, slot) = throughput.w;
+                            pf(paths, F_LASTPDFW, slot) = pdf;
+                            pu(paths, F_FLAGS, slot) = (depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u);
+                            alive = true;
+                        }
+                    }
+                }
+                storeSampler(sampler, paths, slot);
+            } while (false);
+
+            pf(paths, F_RX, slot) = resultColor.x; pf(paths, F_RY, slot) = resultColor.y; pf(paths, F_RZ, slot) = resultColor.z;
+            if (!alive) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
+        }
+
+        // wave-level compaction of the survivors into the next queue: ballot + prefix popcount + one atomic per wave
+        const unsigned long long ballot = __ballot(alive);
+        if (ballot)
+        {
+            const uint32_t lane = threadIdx.x & 63u;
+            const uint32_t prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((long long)ballot) - 1)) base = atomicAdd(countOut, (uint32_t)__popcll(ballot));
+            base = __shfl(base, __ffsll((long long)ballot) - 1);
+            if (alive) queueOut[base + prefix] = slot;
+        }
+    }
+    flushCounters(cnt, counters);
+}
+
+// Occlusion of the NEE requests of one vertex + accumulation (PathTracerMIS.cpp:81-96,119,141-151,320)
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(const RtSceneDesc scene, const DevPass pass, const Paths paths,
+                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                           unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const uint32_t count = *queueCount;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    {
+        const uint32_t slot = queue[i];
+        const uint32_t n = pu(paths, F_SH_COUNT, slot);
+        if (n == 0) continue;
+        pu(paths, F_SH_COUNT, slot) = 0;
+        const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
+        V4 accumulated = zero4();
+        bool any = false;
+        for (uint32_t l = 0; l < n; ++l)
+        {
+            const float tmax = psh(paths, l, 3, slot);
+            if (tmax < 0.0f) continue;   // SampleLight returned early: no shadow ray was cast
+            const V4 dir(psh(paths, l, 0, slot), psh(paths, l, 1, slot), psh(paths, l, 2, slot), 0.0f);
+            Ray shadowRay = makeRay(origin, dir);
+            shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
+            Hit hp; hp.objectId = RT_INVALID_OBJECT; hp.subObjectId = 0; hp.u = 0.0f; hp.v = 0.0f; hp.distance = tmax;
+            cnt.c[C_SHADOW]++;
+            if (sceneTraverseShadow(scene, shadowRay, hp, cnt)) continue;   // occluded
+            cnt.c[C_SHADOW_HIT]++;
+            accumulated = accumulated + V4(psh(paths, l, 4, slot), psh(paths, l, 5, slot), psh(paths, l, 6, slot), 0.0f);
+            any = true;
+        }
+        if (any)
+        {
+            accumulated = accumulated * lightSamplingWeight;
+            const V4 tp(pf(paths, F_SH_TPX, slot), pf(paths, F_SH_TPY, slot), pf(paths, F_SH_TPZ, slot), 0.0f);
+            pf(paths, F_RX, slot) = __fmaf_rn(tp.x, accumulated.x, pf(paths, F_RX, slot));
+            pf(paths, F_RY, slot) = __fmaf_rn(tp.y, accumulated.y, pf(paths, F_RY, slot));
+            pf(paths, F_RZ, slot) = __fmaf_rn(tp.z, accumulated.z, pf(paths, F_RZ, slot));
+        }
+    }
+    flushCounters(cnt, counters);
+}
+
+// Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t numSlots, float* __restrict__ sum,
+                                                         float* __restrict__ secondary, uint32_t width, uint32_t evenPass)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    {
+        const uint32_t pix = pu(paths, F_PIXEL, slot);
+        const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
+        const float r = pf(paths, F_RX, slot), g = pf(paths, F_RY, slot), b = pf(paths, F_RZ, slot);
+        sum[idx + 0] = sum[idx + 0] + r; sum[idx + 1] = sum[idx + 1] + g; sum[idx + 2] = sum[idx + 2] + b;
+        if (evenPass)
+        {
+            secondary[idx + 0] = secondary[idx + 0] + r; secondary[idx + 1] = secondary[idx + 1] + g; secondary[idx + 2] = secondary[idx + 2] + b;
+        }
+    }
+}
+
+// =====================================================================================================
+// Host side of the C-ABI
+// =====================================================================================================
+static thread_local std::string gLastError;
+
+static int fail(int code, const std::string& msg) { gLastError = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(_e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_DEVICE,          \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                             \
+    } while (0)
+
+enum KernelClass { KC_GENERATE = 0, KC_TRACE_CLOSEST, KC_SHADE, KC_TRACE_SHADOW, KC_ACCUMULATE, KC_COUNT };
+static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace_closest", "shade", "trace_shadow", "accumulate", "", "", "" };
+
+#define RT_SEED_RING 32
+
+struct RtgpuContext
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t numCUs = 256;
+
+    // scene (device copies); sceneDev holds DEVICE pointers
+    RtSceneDesc sceneDev;
+    std::vector<void*> sceneAllocs;
+    bool sceneReady = false;
+    uint32_t numLights = 0;
+
+    // film
+    uint32_t width = 0, height = 0;
+    RtgpuShard shard = { 0, 1 };
+    float* sum = nullptr;
+    float* secondary = nullptr;
+    uint32_t* slotPixel = nullptr;
+    uint32_t numSlots = 0;
+
+    // paths
+    Paths paths = { nullptr, 0, 0 };
+    uint32_t* queues[2] = { nullptr, nullptr };
+    uint32_t* queueCounts = nullptr;   // [maxDepth + 3] one counter per bounce so that no reset races with a reader
+    uint32_t queueCountCapacity = 0;
+    unsigned long long* counters = nullptr;   // 16 x u64
+
+    // per-pass seed ring
+    uint32_t* seedRingDev = nullptr;
+    uint32_t* seedRingHost = nullptr;   // pinned
+    hipEvent_t seedEvents[RT_SEED_RING];
+    bool seedEventUsed[RT_SEED_RING];
+    uint32_t seedCursor = 0;
+
+    // timing
+    bool timing = false;
+    struct Timed { int kc; hipEvent_t a, b; };
+    std::vector<Timed> pendingTimed;
+    std::vector<hipEvent_t> eventPool;
+    double kernelMs[RTGPU_NUM_KERNEL_CLASSES];
+    uint64_t kernelLaunches[RTGPU_NUM_KERNEL_CLASSES];
+};
+
+static void freeScene(RtgpuContext* c)
+{
+    for (void* p : c->sceneAllocs) (void)hipFree(p);
+    c->sceneAllocs.clear();
+    memset(&c->sceneDev, 0, sizeof(c->sceneDev));
+    c->sceneReady = false;
+}
+
+static void freeFilm(RtgpuContext* c)
+{
+    if (c->sum) (void)hipFree(c->sum);
+    if (c->secondary) (void)hipFree(c->secondary);
+    if (c->slotPixel) (void)hipFree(c->slotPixel);
+    c->sum = c->secondary = nullptr; c->slotPixel = nullptr; c->numSlots = 0;
+}
+
+static void freePaths(RtgpuContext* c)
+{
+    if (c->paths.base) (void)hipFree(c->paths.base);
+    if (c->queues[0]) (void)hipFree(c->queues[0]);
+    if (c->queues[1]) (void)hipFree(c->queues[1]);
+    c->paths.base = nullptr; c->paths.capacity = 0; c->paths.maxLights = 0;
+    c->queues[0] = c->queues[1] = nullptr;
+}
+
+static int resolveTimed(RtgpuContext* c)
+{
+    for (auto& t : c->pendingTimed)
+    {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+        c->kernelMs[t.kc] += ms;
+        c->kernelLaunches[t.kc]++;
+        c->eventPool.push_back(t.a); c->eventPool.push_back(t.b);
+    }
+    c->pendingTimed.clear();
+    return RTGPU_OK;
+}
+
+static hipEvent_t acquireEvent(RtgpuContext* c)
+{
+    if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct LaunchTimer
+{
+    RtgpuContext* c; int kc; hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(RtgpuContext* ctx, int k) : c(ctx), kc(k)
+    {
+        if (c->timing) { a = acquireEvent(c); b = acquireEvent(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~LaunchTimer()
+    {
+        if (c->timing) { (void)hipEventRecord(b, c->stream); c->pendingTimed.push_back({ kc, a, b }); }
+    }
+};
+
+template <typename T>
+static int uploadArray(RtgpuContext* c, const T* host, size_t count, const T** outDev)
+{
+    *outDev = nullptr;
+    if (count == 0) return RTGPU_OK;
+    if (!host) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene array pointer is NULL but its count is not zero");
+    void* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, count * sizeof(T)));
+    c->sceneAllocs.push_back(dev);
+    HIP_TRY(hipMemcpy(dev, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *outDev = static_cast<const T*>(dev);
+    return RTGPU_OK;
+}
+
+// depth of a BVH in stack entries: the traversal pushes at most one node per interior level
+static uint32_t bvhDepth(const RtNode* nodes, uint32_t numNodes)
+{
+    if (numNodes == 0) return 0;
+    uint32_t maxDepth = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> stack;
+    stack.push_back({ 0u, 0u });
+    while (!stack.empty())
+    {
+        const auto [idx, depth] = stack.back(); stack.pop_back();
+        if (idx >= numNodes) return 0xFFFFFFFFu;
+        const RtNode& n = nodes[idx];
+        if ((n.leaves & 0x3FFFFFFFu) != 0) { if (depth > maxDepth) maxDepth = depth; continue; }
+        if (depth > 4096) return 0xFFFFFFFFu;
+        stack.push_back({ n.childIndex, depth + 1 }); stack.push_back({ n.childIndex + 1, depth + 1 });
+    }
+    return maxDepth;
+}
+
+extern "C" {
+
+#define RTGPU_API __attribute__((visibility("default")))
+
+RTGPU_API const char* rtgpu_last_error(void) { return gLastError.c_str(); }
+RTGPU_API uint32_t rtgpu_abi_version(void) { return RTGPU_ABI_VERSION; }
+
+RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
+{
+    if (!outCtx) return fail(RTGPU_ERR_INVALID_ARGUMENT, "outCtx is NULL");
+    *outCtx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RTGPU_ERR_NO_DEVICE, "no HIP device available");
+    if (deviceIndex < 0 || deviceIndex >= n) return fail(RTGPU_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(deviceIndex));
+    RtgpuContext* c = new RtgpuContext();
+    c->device = deviceIndex;
+    memset(&c->sceneDev, 0, sizeof(c->sceneDev));
+    memset(c->kernelMs, 0, sizeof(c->kernelMs)); memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
+    for (int i = 0; i < RT_SEED_RING; ++i) { c->seedEvents[i] = nullptr; c->seedEventUsed[i] = false; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, deviceIndex) == hipSuccess) c->numCUs = (uint32_t)prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->seedRingDev, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->seedRingHost, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t), hipHostMallocDefault);
+    for (int i = 0; i < RT_SEED_RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->seedEvents[i], hipEventDisableTiming);
+    if (e != hipSuccess)
+    {
+        const std::string msg = std::string("context creation failed: ") + hipGetErrorString(e);
+        delete c;
+        return fail(RTGPU_ERR_DEVICE, msg);
+    }
+    *outCtx = c;
+    return RTGPU_OK;
+}
+
+RTGPU_API void rtgpu_destroy(RtgpuContext* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeScene(c); freeFilm(c); freePaths(c);
+    if (c->queueCounts) (void)hipFree(c->queueCounts);
+    if (c->counters) (void)hipFree(c->counters);
+    if (c->seedRingDev) (void)hipFree(c->seedRingDev);
+    if (c->seedRingHost) (void)hipHostFree(c->seedRingHost);
+    for (int i = 0; i < RT_SEED_RING; ++i) if (c->seedEvents[i]) (void)hipEventDestroy(c->seedEvents[i]);
+    for (auto& t : c->pendingTimed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
+{
+    if (!c || !s) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (s->abiVersion != RTGPU_ABI_VERSION) return fail(RTGPU_ERR_INVALID_ARGUMENT, "RtSceneDesc::abiVersion mismatch");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // validation: indices in range, stacks deep enough
+    if (s->numObjects > 1 && s->numTopNodes == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene with more than one object needs a top-level BVH");
+    if (bvhDepth(s->topNodes, s->numTopNodes) > RT_TOP_STACK_SIZE) return fail(RTGPU_ERR_UNSUPPORTED, "top-level BVH deeper than the traversal stack");
+    for (uint32_t i = 0; i < s->numMeshes; ++i)
+    {
+        const RtMesh& m = s->meshes[i];
+        if ((uint64_t)m.firstNode + m.numNodes > s->numMeshNodes || (uint64_t)m.firstTriangle + m.numTriangles > s->numTriangles || (uint64_t)m.firstVertex + m.numVertices > s->numVertices)
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "mesh ranges out of bounds");
+        if (bvhDepth(s->meshNodes + m.firstNode, m.numNodes) > RT_MESH_STACK_SIZE) return fail(RTGPU_ERR_UNSUPPORTED, "mesh BVH deeper than the traversal stack");
+    }
+    for (uint32_t i = 0; i < s->numObjects; ++i)
+    {
+        const RtObject& o = s->objects[i];
+        if (o.objectKind == RT_OBJECT_LIGHT) { if (o.lightIndex >= s->numLights) return fail(RTGPU_ERR_INVALID_ARGUMENT, "object light index out of range"); }
+        else
+        {
+            if (o.materialIndex >= s->numMaterials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "object material index out of range");
+            if (o.shapeKind == RT_SHAPE_MESH && o.meshIndex >= s->numMeshes) return fail(RTGPU_ERR_INVALID_ARGUMENT, "object mesh index out of range");
+            if (o.shapeKind > RT_SHAPE_MESH) return fail(RTGPU_ERR_UNSUPPORTED, "unknown shape kind");
+        }
+    }
+    for (uint32_t i = 0; i < s->numTriangles; ++i)
+        if (s->vertexIndices[i].materialIndex != RT_NO_MATERIAL && s->vertexIndices[i].materialIndex >= s->numMaterials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "triangle material index out of range");
+    for (uint32_t i = 0; i < s->numGlobalLights; ++i) if (s->globalLights[i] >= s->numLights) return fail(RTGPU_ERR_INVALID_ARGUMENT, "global light index out of range");
+    for (uint32_t i = 0; i < s->numMaterials; ++i) if (s->materials[i].bsdf > RT_BSDF_ROUGH_PLASTIC) return fail(RTGPU_ERR_UNSUPPORTED, "unknown BSDF kind");
+
+    freeScene(c);
+    RtSceneDesc d = *s;
+    int r;
+    if ((r = uploadArray(c, s->topNodes, s->numTopNodes, &d.topNodes))) return r;
+    if ((r = uploadArray(c, s->objects, s->numObjects, &d.objects))) return r;
+    if ((r = uploadArray(c, s->lights, s->numLights, &d.lights))) return r;
+    if ((r = uploadArray(c, s->globalLights, s->numGlobalLights, &d.globalLights))) return r;
+    if ((r = uploadArray(c, s->materials, s->numMaterials, &d.materials))) return r;
+    if ((r = uploadArray(c, s->meshes, s->numMeshes, &d.meshes))) return r;
+    if ((r = uploadArray(c, s->meshNodes, s->numMeshNodes, &d.meshNodes))) return r;
+    if ((r = uploadArray(c, s->triangles, s->numTriangles, &d.triangles))) return r;
+    if ((r = uploadArray(c, s->vertexIndices, s->numTriangles, &d.vertexIndices))) return r;
+    if ((r = uploadArray(c, s->vertexShading, s->numVertices, &d.vertexShading))) return r;
+    if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
+    c->sceneDev = d;
+    c->numLights = s->numLights;
+    c->sceneReady = true;
+    return RTGPU_OK;
+}
+
+// slot -> pixel table: owned 64x64 tiles (tile % worldSize == rank), 8x8 blocks inside a tile, so that a
+// wave covers an 8x8 pixel block (coherent primary rays)
+static std::vector<uint32_t> buildSlotTable(uint32_t width, uint32_t height, RtgpuShard shard)
+{
+    std::vector<uint32_t> slots;
+    slots.reserve((size_t)width * height / (shard.worldSize ? shard.worldSize : 1) + 4096);
+    const uint32_t tilesX = (width + 63u) / 64u, tilesY = (height + 63u) / 64u;
+    for (uint32_t ty = 0; ty < tilesY; ++ty)
+        for (uint32_t tx = 0; tx < tilesX; ++tx)
+        {
+            const uint32_t tile = ty * tilesX + tx;
+            if (shard.worldSize > 1 && tile % shard.worldSize != shard.rank) continue;
+            for (uint32_t by = 0; by < 8; ++by)
+                for (uint32_t bx = 0; bx < 8; ++bx)
+                    for (uint32_t py = 0; py < 8; ++py)
+                        for (uint32_t px = 0; px < 8; ++px)
+                        {
+                            const uint32_t x = tx * 64 + bx * 8 + px, y = ty * 64 + by * 8 + py;
+                            if (x < width && y < height) slots.push_back(x | (y << 16));
+                        }
+        }
+    return slots;
+}
+
+static int rebuildFilm(RtgpuContext* c)
+{
+    freeFilm(c);
+    if (c->width == 0 || c->height == 0) return RTGPU_OK;
+    const size_t n = (size_t)c->width * c->height * 3;
+    HIP_TRY(hipMalloc((void**)&c->sum, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->secondary, n * sizeof(float)));
+    HIP_TRY(hipMemset(c->sum, 0, n * sizeof(float)));
+    HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
+    const std::vector<uint32_t> slots = buildSlotTable(c->width, c->height, c->shard);
+    c->numSlots = (uint32_t)slots.size();
+    if (c->numSlots)
+    {
+        HIP_TRY(hipMalloc((void**)&c->slotPixel, slots.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->slotPixel, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_resize(RtgpuContext* c, uint32_t width, uint32_t height)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (width == 0 || height == 0 || width > 65536u || height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid viewport size");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->width = width; c->height = height;
+    return rebuildFilm(c);
+}
+
+RTGPU_API int rtgpu_set_shard(RtgpuContext* c, RtgpuShard shard)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (shard.worldSize == 0 || shard.rank >= shard.worldSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid shard");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->shard = shard;
+    return rebuildFilm(c);
+}
+
+RTGPU_API int rtgpu_reset(RtgpuContext* c)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->sum)
+    {
+        const size_t n = (size_t)c->width * c->height * 3;
+        HIP_TRY(hipMemset(c->sum, 0, n * sizeof(float)));
+        HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
+    }
+    HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
+    int r = resolveTimed(c); if (r) return r;
+    memset(c->kernelMs, 0, sizeof(c->kernelMs)); memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
+    return RTGPU_OK;
+}
+
+static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
+{
+    if (maxLights == 0) maxLights = 1;
+    if (!c->paths.base || c->paths.capacity < c->numSlots || c->paths.maxLights < maxLights)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        freePaths(c);
+        const size_t cap = c->numSlots ? c->numSlots : 1;
+        const size_t floats = ((size_t)F_NUM_BASE + (size_t)maxLights * RT_SHADOW_STRIDE) * cap;
+        HIP_TRY(hipMalloc((void**)&c->paths.base, floats * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&c->queues[0], cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->queues[1], cap * sizeof(uint32_t)));
+        c->paths.capacity = (uint32_t)cap; c->paths.maxLights = maxLights;
+    }
+    if (c->queueCountCapacity < maxDepth + 3)
+    {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->queueCounts) (void)hipFree(c->queueCounts);
+        c->queueCountCapacity = maxDepth + 3;
+        HIP_TRY(hipMalloc((void**)&c->queueCounts, c->queueCountCapacity * sizeof(uint32_t)));
+    }
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
+{
+    if (!c || !p) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->sceneReady) return fail(RTGPU_ERR_NOT_READY, "rtgpu_upload_scene has not been called");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    if (p->numDimensions > RTGPU_MAX_DIMENSIONS) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numDimensions exceeds RTGPU_MAX_DIMENSIONS");
+    if (p->numDimensions > 0 && !p->seed) return fail(RTGPU_ERR_INVALID_ARGUMENT, "seed is NULL");
+    if (p->maxRayDepth >= 255u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxRayDepth must be < 255");
+    if (p->camera.dofEnable && p->camera.bokehShape != 0) return fail(RTGPU_ERR_UNSUPPORTED, "only circular bokeh is implemented");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
+
+    const uint32_t maxLights = p->lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
+    int r = ensurePaths(c, maxLights, p->maxRayDepth); if (r) return r;
+
+    // stage the seeds in the ring slot (wait until the pass that last used the slot has consumed it)
+    const uint32_t slot = c->seedCursor; c->seedCursor = (c->seedCursor + 1) % RT_SEED_RING;
+    if (c->seedEventUsed[slot]) HIP_TRY(hipEventSynchronize(c->seedEvents[slot]));
+    uint32_t* seedHost = c->seedRingHost + (size_t)slot * RTGPU_MAX_DIMENSIONS;
+    uint32_t* seedDev = c->seedRingDev + (size_t)slot * RTGPU_MAX_DIMENSIONS;
+    if (p->numDimensions)
+    {
+        memcpy(seedHost, p->seed, p->numDimensions * sizeof(uint32_t));
+        HIP_TRY(hipMemcpyAsync(seedDev, seedHost, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
+
+    DevPass pass;
+    memset(&pass, 0, sizeof(pass));
+    pass.camera = p->camera;
+    pass.seed = seedDev;
+    pass.numDimensions = p->numDimensions;
+    pass.blueNoiseLayers = (c->sceneDev.blueNoise && p->useBlueNoise) ? 4u : 0u;   // GenericSampler.cpp:69-73
+    pass.sampleOffset[0] = p->sampleOffset[0]; pass.sampleOffset[1] = p->sampleOffset[1];
+    pass.passIndex = p->passIndex;
+    pass.maxRayDepth = p->maxRayDepth;
+    pass.minRussianRouletteDepth = p->minRussianRouletteDepth;
+    pass.lightSamplingStrategy = p->lightSamplingStrategy;
+    memcpy(pass.lightSamplingWeight, p->lightSamplingWeight, 16);
+    memcpy(pass.bsdfSamplingWeight, p->bsdfSamplingWeight, 16);
+    pass.rngKey[0] = p->rngKey[0]; pass.rngKey[1] = p->rngKey[1];
+    pass.width = c->width; pass.height = c->height;
+
+    const uint32_t blocksNeeded = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
+    const uint32_t maxBlocks = c->numCUs * 8u;
+    const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), block(RT_BLOCK);
+
+    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, c->queueCountCapacity * sizeof(uint32_t), c->stream));
+    {
+        LaunchTimer t(c, KC_GENERATE);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, c->slotPixel, c->numSlots, c->queues[0], c->queueCounts + 0, c->counters);
+    }
+    for (uint32_t depth = 0; depth <= p->maxRayDepth; ++depth)
+    {
+        uint32_t* qIn = c->queues[depth & 1u]; uint32_t* qOut = c->queues[(depth + 1u) & 1u];
+        uint32_t* cntIn = c->queueCounts + depth; uint32_t* cntOut = c->queueCounts + depth + 1;
+        {
+            LaunchTimer t(c, KC_TRACE_CLOSEST);
+            hipLaunchKernelGGL(k_trace_closest, grid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, c->counters);
+        }
+        {
+            LaunchTimer t(c, KC_SHADE);
+            hipLaunchKernelGGL(k_shade, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, qOut, cntOut, c->counters);
+        }
+        if (c->numLights)
+        {
+            LaunchTimer t(c, KC_TRACE_SHADOW);
+            hipLaunchKernelGGL(k_trace_shadow, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, c->counters);
+        }
+    }
+    {
+        LaunchTimer t(c, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_accumulate, grid, block, 0, c->stream, c->paths, c->numSlots, c->sum, c->secondary, c->width, (p->passIndex % 2u) == 0u ? 1u : 0u);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->seedEvents[slot], c->stream));
+    c->seedEventUsed[slot] = true;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return resolveTimed(c);
+}
+
+RTGPU_API int rtgpu_read_sum(RtgpuContext* c, float* sumRGB, float* secondaryRGB)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    const size_t bytes = (size_t)c->width * c->height * 3 * sizeof(float);
+    if (sumRGB) HIP_TRY(hipMemcpy(sumRGB, c->sum, bytes, hipMemcpyDeviceToHost));
+    if (secondaryRGB) HIP_TRY(hipMemcpy(secondaryRGB, c->secondary, bytes, hipMemcpyDeviceToHost));
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_get_device_sum(RtgpuContext* c, void** sumDevice, void** secondaryDevice, size_t* numFloats)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    if (sumDevice) *sumDevice = c->sum;
+    if (secondaryDevice) *secondaryDevice = c->secondary;
+    if (numFloats) *numFloats = (size_t)c->width * c->height * 3;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
+{
+    if (!c || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    unsigned long long host[16];
+    HIP_TRY(hipMemcpy(host, c->counters, sizeof(host), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->numRays = host[C_RAYS]; out->numShadowRays = host[C_SHADOW]; out->numShadowRaysHit = host[C_SHADOW_HIT];
+    out->numPrimaryRays = host[C_PRIMARY]; out->numRayBoxTests = host[C_BOX]; out->numPassedRayBoxTests = host[C_BOX_PASS];
+    out->numRayTriangleTests = host[C_TRI]; out->numPassedRayTriangleTests = host[C_TRI_PASS];
+    out->numMeshHits = host[C_MESH_HITS]; out->numAnalyticHits = host[C_ANALYTIC_HITS];
+    out->numShadowRayBoxTests = host[C_BOX_SHADOW]; out->numShadowRayTriangleTests = host[C_TRI_SHADOW];
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_enable_timing(RtgpuContext* c, int enable)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    c->timing = enable != 0;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_get_kernel_times(RtgpuContext* c, double ms[RTGPU_NUM_KERNEL_CLASSES], uint64_t launches[RTGPU_NUM_KERNEL_CLASSES],
+                                     const char* names[RTGPU_NUM_KERNEL_CLASSES])
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    for (int i = 0; i < RTGPU_NUM_KERNEL_CLASSES; ++i)
+    {
+        if (ms) ms[i] = c->kernelMs[i];
+        if (launches) launches[i] = c->kernelLaunches[i];
+        if (names) names[i] = kKernelClassNames[i];
+    }
+    return RTGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,36 @@
+// Unidirectional path tracer with NEE + MIS, running on the GPU through include/rtgpu.h
+// (reference: Core/Rendering/PathTracerMIS.h).
+#pragma once
+
+#include "Renderer.h"
+
+namespace rt {
+
+class RAYLIB_API PathTracerMIS : public IRenderer
+{
+public:
+    explicit PathTracerMIS(const Scene& scene);
+    ~PathTracerMIS() override;
+    const char* GetName() const override;
+
+    bool Resize(uint32 width, uint32 height) override;
+    bool Reset() override;
+    bool RenderPass(const RtPassParams& params) override;
+    bool ReadSum(float* sumRGB, float* secondaryRGB) override;
+    bool GetCounters(RayTracingCounters& outTotals) override;
+
+    // for debugging (the reference's UI pokes these: Demo/Demo_UserInterface.cpp:467-469)
+    math::Vector4 mLightSamplingWeight;
+    math::Vector4 mBSDFSamplingWeight;
+
+    RtgpuContext* GetDeviceContext() const { return mCtx; }
+    bool SetShard(uint32 rank, uint32 worldSize);
+
+private:
+    bool EnsureSceneUploaded();
+    RtgpuContext* mCtx = nullptr;
+    uint64 mUploadedBuildId = ~0ull;
+    std::vector<uint16> mBlueNoise;
+};
+
+} // namespace rt

@@ -1,0 +1,44 @@
+// Renderer interface and factory (reference: Core/Rendering/Renderer.h:18-69, Renderer.cpp:45-69).
+//
+// The reference calls IRenderer::RenderPixel once per pixel from Viewport::RenderTile; a per-pixel
+// virtual cannot be a device boundary, so the batch entry the reference leaves as a TODO
+// (Renderer.h:33 "TODO batch & multisample rendering") is the one implemented here: RenderPass().
+#pragma once
+
+#include "Context.h"
+#include "../Scene/Scene.h"
+#include "../Scene/Camera.h"
+#include "../Utils/Bitmap.h"
+
+namespace rt {
+
+class RAYLIB_API IRenderer
+{
+public:
+    explicit IRenderer(const Scene& scene) : mScene(scene) {}
+    virtual ~IRenderer();
+    virtual const char* GetName() const = 0;
+
+    // device-pass interface used by Viewport
+    virtual bool Resize(uint32 width, uint32 height) = 0;
+    virtual bool Reset() = 0;
+    virtual bool RenderPass(const RtPassParams& params) = 0;                 // asynchronous
+    virtual bool ReadSum(float* sumRGB, float* secondaryRGB) = 0;            // synchronises
+    virtual bool GetCounters(RayTracingCounters& outTotals) = 0;             // totals since Reset; synchronises
+
+protected:
+    const Scene& mScene;
+private:
+    IRenderer(const IRenderer&) = delete;
+    IRenderer& operator=(const IRenderer&) = delete;
+};
+using RendererPtr = std::shared_ptr<IRenderer>;
+
+// "Path Tracer MIS" -> the MI355X path tracer.  Every other name of the reference's factory
+// ("Path Tracer", "Light Tracer", "Debug", "VCM") is outside the hot-path scope: returns nullptr and logs.
+RAYLIB_API RendererPtr CreateRenderer(const std::string& name, const Scene& scene);
+
+// Device selection for renderers created afterwards (default 0, or LOCAL_RANK when set).
+RAYLIB_API void SetRendererDevice(int deviceIndex);
+
+} // namespace rt

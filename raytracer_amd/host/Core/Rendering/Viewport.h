@@ -1,0 +1,67 @@
+// Viewport: progressive accumulation driver (reference: Core/Rendering/Viewport.h:37-58).
+// Render() performs the pass prologue of Viewport::Render (Core/Rendering/Viewport.cpp:200-242) on the
+// host -- Halton seeds, anti-aliasing offset -- then hands ONE pass to the renderer instead of fanning
+// 32x32 tiles out to a thread pool.  Post-processing / adaptive rendering are outside the hot-path scope.
+#pragma once
+
+#include "Renderer.h"
+#include "../Sampling/HaltonSampler.h"
+
+namespace rt {
+
+struct RenderingProgress
+{
+    uint32 passesFinished = 0;
+    uint32 activePixels = 0;
+    uint32 activeBlocks = 0;
+    float converged = 0.0f;
+    float averageError = std::numeric_limits<float>::infinity();
+};
+
+class RAYLIB_API Viewport
+{
+public:
+    Viewport();
+    ~Viewport();
+
+    bool Resize(uint32 width, uint32 height);
+    bool SetRenderingParams(const RenderingParams& params);
+    const RenderingParams& GetRenderingParams() const { return mParams; }
+    bool SetRenderer(const RendererPtr& renderer);
+    bool Render(const Camera& camera);
+    void Reset();
+
+    // Synchronises with the device and returns the accumulated (not tone-mapped) image.
+    const Bitmap& GetSumBuffer();
+    const Bitmap& GetSecondarySumBuffer();
+    uint32 GetWidth() const { return mWidth; }
+    uint32 GetHeight() const { return mHeight; }
+    const RenderingProgress& GetProgress() const { return mProgress; }
+    // counters of the LAST pass (synchronises), like the reference
+    const RayTracingCounters& GetCounters();
+    // totals since Reset (synchronises)
+    RayTracingCounters GetTotalCounters();
+
+    // Extension (the reference has no seed API): re-seed the Viewport's generators.
+    void SetSeed(uint64 seed);
+
+    // The per-pass constants Render() would use next; advances the Halton sequence and the generator
+    // exactly like Render().  Exposed so parity tests can feed identical constants to the CPU oracle.
+    bool NextPassParams(const Camera& camera, RtPassParams& outParams);
+    void FinishPass() { mProgress.passesFinished++; mSumDirty = true; }
+
+private:
+    RendererPtr mRenderer;
+    math::Random mRandomGenerator;
+    HaltonSequence mHaltonSequence;
+    RenderingParams mParams;
+    RenderingProgress mProgress;
+    Bitmap mSum, mSecondarySum;
+    uint32 mWidth = 0, mHeight = 0;
+    bool mSumDirty = false;
+    std::vector<uint32> mSeedStorage;
+    uint64 mRngKey[2];
+    RayTracingCounters mCounters, mTotalsAtLastPass, mTotalsBeforeLastPass;
+};
+
+} // namespace rt

@@ -1,0 +1,46 @@
+// Camera (reference: Core/Scene/Camera.h).  Ray generation runs on the device; the host keeps the
+// parameters and hands them over as RtCamera.
+#pragma once
+
+#include "../Math/Math.h"
+#include "../../../../include/rtgpu.h"
+
+namespace rt {
+
+enum class BokehShape : uint8 { Circle = 0, Hexagon, Square, NGon, Texture };
+
+struct DOFSettings
+{
+    float focalPlaneDistance = 2.0f;
+    float aperture = 0.1f;
+    bool enable = false;
+    BokehShape bokehShape = BokehShape::Circle;
+    uint32 apertureBlades = 5;
+};
+
+class RAYLIB_API Camera
+{
+public:
+    Camera();
+    void SetTransform(const math::Transform& transform);
+    void SetPerspective(float aspectRatio, float FoV);
+    const math::Transform& GetTransform() const { return mTransform; }
+    const math::Matrix4& GetLocalToWorld() const { return mLocalToWorld; }
+
+    // false if the configuration needs a feature outside the device scope (non-circular bokeh, barrel distortion)
+    bool GetDesc(RtCamera& out) const;
+
+    math::Transform mTransform;
+    float mAspectRatio;
+    float mFieldOfView;
+    DOFSettings mDOF;
+    float barrelDistortionConstFactor;
+    float barrelDistortionVariableFactor;
+    bool enableBarellDistortion;
+
+private:
+    float mTanHalfFoV;
+    math::Matrix4 mLocalToWorld;
+};
+
+} // namespace rt

@@ -1,0 +1,3 @@
+// reference include path compatibility
+#pragma once
+#include "SceneObject.h"

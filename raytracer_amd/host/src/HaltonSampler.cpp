@@ -1,0 +1,148 @@
+// Scrambled Halton sequence, host side (double precision).  See Core/Sampling/HaltonSampler.h.
+// The arithmetic (expression order, double rounding) follows the reference's
+// Core/Sampling/HaltonSampler.cpp:61-206 so that seed[d] is reproduced bit-exactly from the same
+// generator state.
+#include "../Core/Sampling/HaltonSampler.h"
+
+#include <algorithm>
+
+namespace rt {
+
+HaltonSequence::HaltonSequence() = default;
+HaltonSequence::~HaltonSequence() = default;
+
+void HaltonSequence::Initialize(uint32 dimensions)
+{
+    mDimensions = dimensions > MaxDimensions ? MaxDimensions : dimensions;
+    mRnd.assign(mDimensions, std::vector<double>(Width + 1, 0.0));   // +1: rnd[j + 1] is read at j = Width - 1
+    mDigit.assign(mDimensions, std::vector<uint64>(Width, 0));
+    mPowerBuffer.assign(mDimensions, std::vector<uint64>(Width, 0));
+    mStarts.assign(mDimensions, 0);
+    mBase.assign(mDimensions, 0);
+    mPermutations.clear();
+
+    if (mDimensions > 0)
+    {
+        InitPrimes();
+        InitStart();
+        InitPowerBuffer();
+        InitPermutation();
+        InitExpansion();
+    }
+}
+
+// first mDimensions primes by trial division (HaltonSampler.cpp:138-158)
+void HaltonSequence::InitPrimes()
+{
+    uint32 found = 0;
+    for (uint32 candidate = 2; found < mDimensions; ++candidate)
+    {
+        bool isPrime = true;
+        for (uint64 i = 2; i <= sqrt(candidate); i++)
+        {
+            if (candidate % i == 0) { isPrime = false; break; }
+        }
+        if (isPrime) mBase[found++] = candidate;
+    }
+}
+
+// random start index per dimension: digits of a uniform double in the dimension's base (:160-183)
+void HaltonSequence::InitStart()
+{
+    for (uint32 i = 0; i < mDimensions; i++)
+    {
+        double r = mRandom.GetDouble();
+        const uint64 base = mBase[i];
+        uint64 z = 0;
+        uint64 b = base;
+        while (r > 1.0e-16)
+        {
+            uint64 cnt = 0;
+            if (r >= 1.0 / b)
+            {
+                cnt = (uint64)floor(r * b);
+                r = r - cnt * 1.0 / b;
+                z += cnt * b / base;
+            }
+            b *= base;
+        }
+        mStarts[i] = z;
+    }
+}
+
+void HaltonSequence::InitPowerBuffer()   // :31-59
+{
+    for (uint32 d = 0; d < mDimensions; d++)
+    {
+        for (uint32 j = 0; j < Width; j++)
+        {
+            mPowerBuffer[d][j] = (j == 0) ? (uint64)mBase[d] : mPowerBuffer[d][j - 1] * mBase[d];
+        }
+    }
+    for (auto& v : mRnd) std::fill(v.begin(), v.end(), 0.0);
+    for (auto& v : mDigit) std::fill(v.begin(), v.end(), 0);
+}
+
+// random digit permutation per base, digit 0 may move too (:113-136)
+void HaltonSequence::InitPermutation()
+{
+    mPermutations.resize(mDimensions);
+    for (uint32 i = 0; i < mDimensions; i++)
+    {
+        std::vector<uint64>& perm = mPermutations[i];
+        perm.resize(mBase[i]);
+        for (uint64 j = 0; j < mBase[i]; j++) perm[j] = j;
+        for (uint64 j = 1; j < mBase[i]; j++)
+        {
+            const uint64 tmp = (uint64)floor(mRandom.GetDouble() * mBase[i]);
+            if (tmp != 0)
+            {
+                const uint64 k = perm[j];
+                perm[j] = perm[tmp];
+                perm[tmp] = k;
+            }
+        }
+    }
+}
+
+void HaltonSequence::InitExpansion()   // :61-82
+{
+    for (uint32 i = 0; i < mDimensions; i++)
+    {
+        uint64 n = mStarts[i] - 1;
+        int32 j = 0;
+        while (n > 0)
+        {
+            mDigit[i][j] = n % mBase[i];
+            n = n / mBase[i];
+            j++;
+        }
+        j--;
+        while (j >= 0)
+        {
+            const uint64 d = Permute(i, (uint32)j);
+            mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
+            j--;
+        }
+    }
+}
+
+void HaltonSequence::NextSample()   // :84-106
+{
+    for (uint32 i = 0; i < mDimensions; i++)
+    {
+        int32 j = 0;
+        while (mDigit[i][j] + 1 >= mBase[i]) j++;
+        mDigit[i][j]++;
+        uint64 d = Permute(i, (uint32)j);
+        mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
+        for (j = j - 1; j >= 0; j--)
+        {
+            mDigit[i][j] = 0;
+            d = Permute(i, (uint32)j);
+            mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
+        }
+    }
+}
+
+} // namespace rt

@@ -1,0 +1,365 @@
+// Camera, Bitmap, Viewport and the renderer factory.  Host side.
+#include "../Core/Rendering/Viewport.h"
+#include "../Core/Rendering/PathTracerMIS.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace rt {
+
+using namespace math;
+
+static const uint32 MAX_IMAGE_SIZE = 1u << 16;
+
+// ---------------------------------------------------------------------------------------------------
+// Camera
+// ---------------------------------------------------------------------------------------------------
+Camera::Camera()
+    : mAspectRatio(1.0f)
+    , mFieldOfView(DegToRad(20.0f))
+    , barrelDistortionConstFactor(0.01f)
+    , barrelDistortionVariableFactor(0.0f)
+    , enableBarellDistortion(false)
+    , mTanHalfFoV(tanf(DegToRad(20.0f) * 0.5f))
+    , mLocalToWorld(Matrix4::Identity())
+{
+}
+
+void Camera::SetTransform(const Transform& transform)
+{
+    mTransform = transform;
+    mLocalToWorld = transform.ToMatrix4();
+}
+
+void Camera::SetPerspective(float aspectRatio, float FoV)
+{
+    mAspectRatio = aspectRatio;
+    mFieldOfView = FoV;
+    mTanHalfFoV = tanf(mFieldOfView * 0.5f);
+}
+
+bool Camera::GetDesc(RtCamera& out) const
+{
+    memset(&out, 0, sizeof(out));
+    mLocalToWorld.Store(out.localToWorld);
+    out.aspectRatio = mAspectRatio;
+    out.tanHalfFoV = mTanHalfFoV;
+    out.dofEnable = mDOF.enable ? 1u : 0u;
+    out.bokehShape = 0;
+    out.focalPlaneDistance = mDOF.focalPlaneDistance;
+    out.aperture = mDOF.aperture;
+    if (mDOF.enable && mDOF.bokehShape != BokehShape::Circle)
+    {
+        fprintf(stderr, "[rt] ERROR: only circular bokeh is supported by the device path\n");
+        return false;
+    }
+    if (barrelDistortionVariableFactor != 0.0f)
+    {
+        fprintf(stderr, "[rt] ERROR: barrel distortion is not supported by the device path\n");
+        return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bitmap
+// ---------------------------------------------------------------------------------------------------
+bool Bitmap::Init(uint32 width, uint32 height)
+{
+    mWidth = width; mHeight = height;
+    mData.assign((size_t)width * height * 3, 0.0f);
+    return true;
+}
+
+void Bitmap::Clear() { std::fill(mData.begin(), mData.end(), 0.0f); }
+
+const Vector4 Bitmap::GetPixel(uint32 x, uint32 y, const bool) const
+{
+    const float* p = mData.data() + 3 * ((size_t)y * mWidth + x);
+    return Vector4(p[0], p[1], p[2], 0.0f);
+}
+
+bool Bitmap::Scale(const Vector4& factor)
+{
+    for (size_t i = 0; i < (size_t)mWidth * mHeight; ++i)
+    {
+        mData[3 * i + 0] *= factor.x; mData[3 * i + 1] *= factor.y; mData[3 * i + 2] *= factor.z;
+    }
+    return true;
+}
+
+bool Bitmap::SaveRaw(const char* path) const
+{
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    const uint32 header[3] = { 0x33465452u /* "RTF3" */, mWidth, mHeight };
+    bool ok = fwrite(header, sizeof(header), 1, f) == 1;
+    ok = ok && (mData.empty() || fwrite(mData.data(), mData.size() * sizeof(float), 1, f) == 1);
+    fclose(f);
+    return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Viewport
+// ---------------------------------------------------------------------------------------------------
+Viewport::Viewport()
+{
+    Entropy entropy;
+    mRngKey[0] = ((uint64)entropy.GetInt() << 32) | entropy.GetInt();
+    mRngKey[1] = ((uint64)entropy.GetInt() << 32) | entropy.GetInt();
+}
+
+Viewport::~Viewport() = default;
+
+void Viewport::SetSeed(uint64 seed)
+{
+    mRandomGenerator.Reset(seed);
+    mHaltonSequence.GetRandom().Reset(seed ^ 0xA5A5A5A55A5A5A5AULL);
+    mRngKey[0] = seed * 0x9E3779B97F4A7C15ULL + 1;
+    mRngKey[1] = (seed ^ 0xD1B54A32D192ED03ULL) * 0xBF58476D1CE4E5B9ULL + 7;
+}
+
+bool Viewport::Resize(uint32 width, uint32 height)
+{
+    if (width > MAX_IMAGE_SIZE || height > MAX_IMAGE_SIZE || width == 0 || height == 0)
+    {
+        fprintf(stderr, "[rt] ERROR: Invalid viewport size\n");
+        return false;
+    }
+    if (width == mWidth && height == mHeight) return true;
+    mWidth = width; mHeight = height;
+    mSum.Init(width, height);
+    mSecondarySum.Init(width, height);
+    if (mRenderer && !mRenderer->Resize(width, height)) return false;
+    Reset();
+    return true;
+}
+
+void Viewport::Reset()
+{
+    mProgress = RenderingProgress();
+    mHaltonSequence.Initialize(mParams.samplingParams.dimensions);
+    mSum.Clear();
+    mSecondarySum.Clear();
+    mSumDirty = false;
+    mCounters.Reset(); mTotalsAtLastPass.Reset(); mTotalsBeforeLastPass.Reset();
+    if (mRenderer) mRenderer->Reset();
+}
+
+bool Viewport::SetRenderer(const RendererPtr& renderer)
+{
+    mRenderer = renderer;
+    if (mRenderer && mWidth && mHeight) return mRenderer->Resize(mWidth, mHeight);
+    return true;
+}
+
+bool Viewport::SetRenderingParams(const RenderingParams& params)
+{
+    if (params.maxRayDepth >= 255u || params.antiAliasingSpread < 0.0f) return false;
+    if (params.samplingParams.dimensions > HaltonSequence::MaxDimensions) return false;
+    mParams = params;
+    return true;
+}
+
+bool Viewport::NextPassParams(const Camera& camera, RtPassParams& p)
+{
+    memset(&p, 0, sizeof(p));
+    if (!camera.GetDesc(p.camera)) return false;
+
+    mHaltonSequence.NextSample();
+    const uint32 dims = mHaltonSequence.GetNumDimensions();
+    mSeedStorage.resize(dims);
+    for (uint32 i = 0; i < dims; ++i) mSeedStorage[i] = mHaltonSequence.GetInt(i);
+    p.seed = mSeedStorage.data();
+    p.numDimensions = dims;
+    p.useBlueNoise = mParams.samplingParams.useBlueNoiseDithering ? 1u : 0u;
+
+    // randomize pixel offset: normal-distributed, scaled by the anti-aliasing spread
+    const Vector4 u = GetFloatNormal2(mRandomGenerator.GetFloat2());
+    const Vector4 offset = u * mParams.antiAliasingSpread;
+    p.sampleOffset[0] = offset.x; p.sampleOffset[1] = offset.y;
+
+    p.passIndex = mProgress.passesFinished;
+    p.maxRayDepth = mParams.maxRayDepth;
+    p.minRussianRouletteDepth = mParams.minRussianRouletteDepth;
+    p.lightSamplingStrategy = mParams.lightSamplingStrategy == LightSamplingStrategy::All ? RT_LIGHT_SAMPLING_ALL : RT_LIGHT_SAMPLING_SINGLE;
+    Vector4 lw(1.0f), bw(1.0f);
+    if (PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(mRenderer.get())) { lw = pt->mLightSamplingWeight; bw = pt->mBSDFSamplingWeight; }
+    memcpy(p.lightSamplingWeight, &lw, 16);
+    memcpy(p.bsdfSamplingWeight, &bw, 16);
+    // a fresh key per pass so that per-pixel fallback streams do not repeat across passes
+    p.rngKey[0] = mRngKey[0] + 0x9E3779B97F4A7C15ULL * (uint64)(mProgress.passesFinished + 1);
+    p.rngKey[1] = mRngKey[1] ^ (0xC2B2AE3D27D4EB4FULL * (uint64)(mProgress.passesFinished + 1));
+    return true;
+}
+
+bool Viewport::Render(const Camera& camera)
+{
+    if (mWidth == 0 || mHeight == 0) return false;
+    if (!mRenderer)
+    {
+        fprintf(stderr, "[rt] ERROR: Viewport: Missing renderer\n");
+        return false;
+    }
+    RtPassParams params;
+    if (!NextPassParams(camera, params)) return false;
+    if (!mRenderer->RenderPass(params)) return false;
+    FinishPass();
+    return true;
+}
+
+const Bitmap& Viewport::GetSumBuffer()
+{
+    if (mSumDirty && mRenderer)
+    {
+        mRenderer->ReadSum(mSum.GetData(), mSecondarySum.GetData());
+        mSumDirty = false;
+    }
+    return mSum;
+}
+
+const Bitmap& Viewport::GetSecondarySumBuffer()
+{
+    GetSumBuffer();
+    return mSecondarySum;
+}
+
+RayTracingCounters Viewport::GetTotalCounters()
+{
+    RayTracingCounters totals;
+    if (mRenderer) mRenderer->GetCounters(totals);
+    return totals;
+}
+
+const RayTracingCounters& Viewport::GetCounters()
+{
+    // The device keeps running totals; the per-pass figure of the reference is only exact when this is
+    // polled after every pass.
+    const RayTracingCounters totals = GetTotalCounters();
+    mCounters = totals;
+    mCounters.numRays -= mTotalsAtLastPass.numRays; mCounters.numShadowRays -= mTotalsAtLastPass.numShadowRays;
+    mCounters.numShadowRaysHit -= mTotalsAtLastPass.numShadowRaysHit; mCounters.numPrimaryRays -= mTotalsAtLastPass.numPrimaryRays;
+    mCounters.numRayBoxTests -= mTotalsAtLastPass.numRayBoxTests; mCounters.numPassedRayBoxTests -= mTotalsAtLastPass.numPassedRayBoxTests;
+    mCounters.numRayTriangleTests -= mTotalsAtLastPass.numRayTriangleTests; mCounters.numPassedRayTriangleTests -= mTotalsAtLastPass.numPassedRayTriangleTests;
+    mCounters.numMeshHits -= mTotalsAtLastPass.numMeshHits; mCounters.numAnalyticHits -= mTotalsAtLastPass.numAnalyticHits;
+    mCounters.numShadowRayBoxTests -= mTotalsAtLastPass.numShadowRayBoxTests; mCounters.numShadowRayTriangleTests -= mTotalsAtLastPass.numShadowRayTriangleTests;
+    mTotalsAtLastPass = totals;
+    return mCounters;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Renderer factory + the device renderer
+// ---------------------------------------------------------------------------------------------------
+IRenderer::~IRenderer() = default;
+
+static int gRendererDevice = -1;
+
+void SetRendererDevice(int deviceIndex) { gRendererDevice = deviceIndex; }
+
+static int DefaultDevice()
+{
+    if (gRendererDevice >= 0) return gRendererDevice;
+    if (const char* lr = getenv("LOCAL_RANK")) return atoi(lr);
+    return 0;
+}
+
+RendererPtr CreateRenderer(const std::string& name, const Scene& scene)
+{
+    if (name == "Path Tracer MIS")
+    {
+        std::shared_ptr<PathTracerMIS> r(new PathTracerMIS(scene));
+        if (!r->GetDeviceContext()) return nullptr;
+        return r;
+    }
+    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer MIS\")\n", name.c_str());
+    return nullptr;
+}
+
+static bool LoadBlueNoise(std::vector<uint16>& out)
+{
+    // search order: RT_DATA_DIR, ../Data (the reference's cwd-relative path, GenericSampler.cpp:13), the package data dir
+    std::vector<std::string> candidates;
+    if (const char* dir = getenv("RT_DATA_DIR")) candidates.push_back(std::string(dir) + "/BlueNoise128_RGBA16.dat");
+    candidates.push_back("../Data/BlueNoise128_RGBA16.dat");
+#ifdef RT_PACKAGE_DATA_DIR
+    candidates.push_back(std::string(RT_PACKAGE_DATA_DIR) + "/BlueNoise128_RGBA16.dat");
+#endif
+    for (const std::string& path : candidates)
+    {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) continue;
+        out.resize(128 * 128 * 4);
+        const bool ok = fread(out.data(), out.size() * sizeof(uint16), 1, f) == 1;
+        fclose(f);
+        if (ok) return true;
+    }
+    out.clear();
+    fprintf(stderr, "[rt] ERROR: Failed to load blue noise texture\n");   // like the reference: dithering silently off
+    return false;
+}
+
+PathTracerMIS::PathTracerMIS(const Scene& scene)
+    : IRenderer(scene)
+    , mLightSamplingWeight(1.0f)
+    , mBSDFSamplingWeight(1.0f)
+{
+    if (rtgpu_create(DefaultDevice(), &mCtx) != RTGPU_OK)
+    {
+        fprintf(stderr, "[rt] ERROR: cannot create device context: %s\n", rtgpu_last_error());
+        mCtx = nullptr;
+    }
+    LoadBlueNoise(mBlueNoise);
+}
+
+PathTracerMIS::~PathTracerMIS()
+{
+    if (mCtx) rtgpu_destroy(mCtx);
+}
+
+const char* PathTracerMIS::GetName() const { return "Path Tracer MIS"; }
+
+bool PathTracerMIS::EnsureSceneUploaded()
+{
+    if (!mCtx) return false;
+    if (mUploadedBuildId == mScene.GetBuildId()) return true;
+    RtSceneDesc desc = mScene.GetDesc();
+    desc.blueNoise = mBlueNoise.empty() ? nullptr : mBlueNoise.data();
+    if (rtgpu_upload_scene(mCtx, &desc) != RTGPU_OK)
+    {
+        fprintf(stderr, "[rt] ERROR: scene upload failed: %s\n", rtgpu_last_error());
+        return false;
+    }
+    mUploadedBuildId = mScene.GetBuildId();
+    return true;
+}
+
+bool PathTracerMIS::Resize(uint32 width, uint32 height) { return mCtx && rtgpu_resize(mCtx, width, height) == RTGPU_OK; }
+bool PathTracerMIS::Reset() { return mCtx && rtgpu_reset(mCtx) == RTGPU_OK; }
+bool PathTracerMIS::SetShard(uint32 rank, uint32 worldSize) { RtgpuShard s = { rank, worldSize }; return mCtx && rtgpu_set_shard(mCtx, s) == RTGPU_OK; }
+
+bool PathTracerMIS::RenderPass(const RtPassParams& params)
+{
+    if (!EnsureSceneUploaded()) return false;
+    if (rtgpu_render_pass(mCtx, &params) != RTGPU_OK)
+    {
+        fprintf(stderr, "[rt] ERROR: render pass failed: %s\n", rtgpu_last_error());
+        return false;
+    }
+    return true;
+}
+
+bool PathTracerMIS::ReadSum(float* sumRGB, float* secondaryRGB) { return mCtx && rtgpu_read_sum(mCtx, sumRGB, secondaryRGB) == RTGPU_OK; }
+
+bool PathTracerMIS::GetCounters(RayTracingCounters& out)
+{
+    RtCounters c;
+    if (!mCtx || rtgpu_get_counters(mCtx, &c) != RTGPU_OK) return false;
+    out.numRays = c.numRays; out.numShadowRays = c.numShadowRays; out.numShadowRaysHit = c.numShadowRaysHit;
+    out.numPrimaryRays = c.numPrimaryRays; out.numRayBoxTests = c.numRayBoxTests; out.numPassedRayBoxTests = c.numPassedRayBoxTests;
+    out.numRayTriangleTests = c.numRayTriangleTests; out.numPassedRayTriangleTests = c.numPassedRayTriangleTests;
+    out.numMeshHits = c.numMeshHits; out.numAnalyticHits = c.numAnalyticHits;
+    out.numShadowRayBoxTests = c.numShadowRayBoxTests; out.numShadowRayTriangleTests = c.numShadowRayTriangleTests;
+    return true;
+}
+
+} // namespace rt

@@ -1,0 +1,331 @@
+// rth_* : a flat C facade over the C++ host mirror (rt::Scene / rt::Viewport / ...), used by the Python
+// test and benchmark drivers through ctypes.  Plumbing only: everything here forwards to the classes in
+// Core/ which in turn call the device C-ABI of include/rtgpu.h.
+#include "../Core/Rendering/Viewport.h"
+#include "../Core/Rendering/PathTracerMIS.h"
+#include "../Core/BVH/BVHBuilder.h"
+
+#include <stdio.h>
+
+using namespace rt;
+using namespace rt::math;
+
+namespace {
+
+struct SceneHandle
+{
+    Scene scene;
+    std::vector<MaterialPtr> materials;
+};
+
+struct ViewportHandle
+{
+    Viewport viewport;
+    RendererPtr renderer;
+};
+
+Matrix4 LoadMatrix(const float* m)
+{
+    if (!m) return Matrix4::Identity();
+    Matrix4 r;
+    memcpy(r.rows, m, 64);
+    return r;
+}
+
+Vector4 LoadColor(const float* c) { return Vector4(c[0], c[1], c[2], c[3]); }
+
+MaterialPtr GetMaterial(SceneHandle* s, int id)
+{
+    if (id < 0 || id >= (int)s->materials.size()) return nullptr;
+    return s->materials[(size_t)id];
+}
+
+} // namespace
+
+extern "C" {
+
+#define RTH_API __attribute__((visibility("default")))
+
+// ---- transforms ------------------------------------------------------------------------------------
+// translation + Euler orientation in DEGREES (pitch, yaw, roll), like the reference's JSON loader
+// (Demo/SceneLoader.cpp:189-216)
+RTH_API void rth_transform_from_euler(const float translation[3], const float orientationDeg[3], float out[16])
+{
+    Vector4 orientation(orientationDeg[0], orientationDeg[1], orientationDeg[2], 0.0f);
+    orientation *= (RT_PI / 180.0f);
+    const Transform t(Vector4(translation[0], translation[1], translation[2], 0.0f), Quaternion::FromEulerAngles(orientation.ToFloat3()));
+    t.ToMatrix4().Store(out);
+}
+
+RTH_API void rth_matrix_inverse(const float in[16], float out[16]) { LoadMatrix(in).Inverse().Store(out); }
+
+// ---- scene -----------------------------------------------------------------------------------------
+RTH_API void* rth_scene_create() { return new SceneHandle(); }
+RTH_API void rth_scene_destroy(void* s) { delete static_cast<SceneHandle*>(s); }
+
+RTH_API int rth_material_create(void* sh, const char* bsdf, const float baseColor[4], const float emission[4],
+                                float roughness, float metalness, float IoR, float K)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    MaterialPtr m = std::make_shared<Material>();
+    m->SetBsdf(bsdf);
+    if (m->GetBsdfKind() < 0) return -1;
+    m->baseColor = LoadColor(baseColor);
+    m->emission = LoadColor(emission);
+    m->roughness = roughness;
+    m->metalness = metalness;
+    m->IoR = IoR;
+    m->K = K;
+    m->Compile();
+    s->materials.push_back(m);
+    return (int)s->materials.size() - 1;
+}
+
+static int AddShape(SceneHandle* s, const ShapePtr& shape, const float* transform, int material)
+{
+    ShapeSceneObjectPtr obj = std::make_unique<ShapeSceneObject>(shape);
+    obj->SetDefaultMaterial(GetMaterial(s, material));
+    obj->SetTransform(LoadMatrix(transform));
+    s->scene.AddObject(std::move(obj));
+    return 0;
+}
+
+RTH_API int rth_add_sphere(void* sh, float radius, const float transform[16], int material)
+{
+    return AddShape(static_cast<SceneHandle*>(sh), std::make_shared<SphereShape>(radius), transform, material);
+}
+
+RTH_API int rth_add_box(void* sh, const float size[3], const float transform[16], int material)
+{
+    return AddShape(static_cast<SceneHandle*>(sh), std::make_shared<BoxShape>(Vector4(size[0], size[1], size[2], 0.0f)), transform, material);
+}
+
+RTH_API int rth_add_rect(void* sh, const float size[2], const float texScale[2], const float transform[16], int material)
+{
+    return AddShape(static_cast<SceneHandle*>(sh), std::make_shared<RectShape>(Float2(size[0], size[1]), Float2(texScale[0], texScale[1])), transform, material);
+}
+
+// positions/normals/tangents: numVertices*3 floats, texCoords: numVertices*2 (normals/tangents/texCoords may be NULL),
+// indices: numTriangles*3, materialIndices: numTriangles (may be NULL => default material), materialIds: scene material ids
+RTH_API int rth_add_mesh(void* sh, uint32_t numVertices, uint32_t numTriangles, const float* positions, const float* normals,
+                         const float* tangents, const float* texCoords, const uint32_t* indices, const uint32_t* materialIndices,
+                         uint32_t numMaterials, const int* materialIds, const float transform[16], int defaultMaterial)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    std::vector<MaterialPtr> mats;
+    for (uint32_t i = 0; i < numMaterials; ++i)
+    {
+        MaterialPtr m = GetMaterial(s, materialIds[i]);
+        if (!m) return -1;
+        mats.push_back(m);
+    }
+    std::vector<uint32_t> noMaterial;
+    if (!materialIndices) { noMaterial.assign(numTriangles, UINT32_MAX); materialIndices = noMaterial.data(); }
+    MeshDesc desc;
+    desc.vertexBufferDesc.numVertices = numVertices;
+    desc.vertexBufferDesc.numTriangles = numTriangles;
+    desc.vertexBufferDesc.numMaterials = numMaterials;
+    desc.vertexBufferDesc.vertexIndexBuffer = indices;
+    desc.vertexBufferDesc.positions = reinterpret_cast<const Float3*>(positions);
+    desc.vertexBufferDesc.normals = reinterpret_cast<const Float3*>(normals);
+    desc.vertexBufferDesc.tangents = reinterpret_cast<const Float3*>(tangents);
+    desc.vertexBufferDesc.texCoords = reinterpret_cast<const Float2*>(texCoords);
+    desc.vertexBufferDesc.materialIndexBuffer = materialIndices;
+    desc.vertexBufferDesc.materials = mats.data();
+    std::shared_ptr<MeshShape> mesh = std::make_shared<MeshShape>();
+    if (!mesh->Initialize(desc)) return -2;
+    return AddShape(s, mesh, transform, defaultMaterial);
+}
+
+static int AddLight(SceneHandle* s, LightPtr light, const float* transform)
+{
+    LightSceneObjectPtr obj = std::make_unique<LightSceneObject>(std::move(light));
+    obj->SetTransform(LoadMatrix(transform));
+    s->scene.AddObject(std::move(obj));
+    return 0;
+}
+
+// shapeKind: 0 sphere (p[0] = radius), 1 box (p[0..2] = half extents), 2 rect (p[0..1] = half size)
+RTH_API int rth_add_light_area(void* sh, int shapeKind, const float p[4], const float color[4], const float transform[16])
+{
+    ShapePtr shape;
+    if (shapeKind == 0) shape = std::make_shared<SphereShape>(p[0]);
+    else if (shapeKind == 1) shape = std::make_shared<BoxShape>(Vector4(p[0], p[1], p[2], 0.0f));
+    else if (shapeKind == 2) shape = std::make_shared<RectShape>(Float2(p[0], p[1]));
+    else return -1;
+    return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<AreaLight>(shape, LoadColor(color)), transform);
+}
+RTH_API int rth_add_light_background(void* sh, const float color[4])
+{
+    return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<BackgroundLight>(LoadColor(color)), nullptr);
+}
+RTH_API int rth_add_light_directional(void* sh, const float color[4], float angleRad, const float transform[16])
+{
+    return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<DirectionalLight>(LoadColor(color), angleRad), transform);
+}
+RTH_API int rth_add_light_point(void* sh, const float color[4], const float transform[16])
+{
+    return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<PointLight>(LoadColor(color)), transform);
+}
+RTH_API int rth_add_light_spot(void* sh, const float color[4], float angleRad, const float transform[16])
+{
+    return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<SpotLight>(LoadColor(color), angleRad), transform);
+}
+
+RTH_API int rth_scene_build(void* sh) { return static_cast<SceneHandle*>(sh)->scene.BuildBVH() ? 0 : -1; }
+RTH_API const RtSceneDesc* rth_scene_desc(void* sh) { return &static_cast<SceneHandle*>(sh)->scene.GetDesc(); }
+
+// ---- camera -----------------------------------------------------------------------------------------
+RTH_API void* rth_camera_create() { return new Camera(); }
+RTH_API void rth_camera_destroy(void* c) { delete static_cast<Camera*>(c); }
+RTH_API void rth_camera_set_transform(void* c, const float translation[3], const float orientationDeg[3])
+{
+    Vector4 orientation(orientationDeg[0], orientationDeg[1], orientationDeg[2], 0.0f);
+    orientation *= (RT_PI / 180.0f);
+    static_cast<Camera*>(c)->SetTransform(Transform(Vector4(translation[0], translation[1], translation[2], 0.0f), Quaternion::FromEulerAngles(orientation.ToFloat3())));
+}
+RTH_API void rth_camera_set_perspective(void* c, float aspect, float fovRad) { static_cast<Camera*>(c)->SetPerspective(aspect, fovRad); }
+RTH_API void rth_camera_set_dof(void* c, int enable, float focalPlaneDistance, float aperture)
+{
+    Camera* cam = static_cast<Camera*>(c);
+    cam->mDOF.enable = enable != 0; cam->mDOF.focalPlaneDistance = focalPlaneDistance; cam->mDOF.aperture = aperture;
+}
+RTH_API int rth_camera_desc(void* c, RtCamera* out) { return static_cast<Camera*>(c)->GetDesc(*out) ? 0 : -1; }
+
+// ---- viewport ---------------------------------------------------------------------------------------
+RTH_API void* rth_viewport_create() { return new ViewportHandle(); }
+RTH_API void rth_viewport_destroy(void* v) { delete static_cast<ViewportHandle*>(v); }
+RTH_API int rth_viewport_resize(void* v, uint32_t w, uint32_t h) { return static_cast<ViewportHandle*>(v)->viewport.Resize(w, h) ? 0 : -1; }
+RTH_API int rth_viewport_set_params(void* v, uint32_t dimensions, int useBlueNoise, float antiAliasingSpread,
+                                    uint32_t maxRayDepth, uint32_t minRussianRouletteDepth, int lightSamplingAll)
+{
+    RenderingParams p;
+    p.samplingParams.dimensions = dimensions;
+    p.samplingParams.useBlueNoiseDithering = useBlueNoise != 0;
+    p.antiAliasingSpread = antiAliasingSpread;
+    p.maxRayDepth = maxRayDepth;
+    p.minRussianRouletteDepth = minRussianRouletteDepth;
+    p.lightSamplingStrategy = lightSamplingAll ? LightSamplingStrategy::All : LightSamplingStrategy::Single;
+    return static_cast<ViewportHandle*>(v)->viewport.SetRenderingParams(p) ? 0 : -1;
+}
+RTH_API void rth_viewport_set_seed(void* v, uint64_t seed) { static_cast<ViewportHandle*>(v)->viewport.SetSeed(seed); }
+// device < 0: default (LOCAL_RANK or 0).  Returns -2 when no renderer could be created (no GPU / unknown name).
+RTH_API int rth_viewport_set_renderer(void* v, void* sh, const char* name, int device)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    if (device >= 0) SetRendererDevice(device);
+    vh->renderer = CreateRenderer(name, static_cast<SceneHandle*>(sh)->scene);
+    if (!vh->renderer) return -2;
+    return vh->viewport.SetRenderer(vh->renderer) ? 0 : -1;
+}
+RTH_API void rth_viewport_reset(void* v) { static_cast<ViewportHandle*>(v)->viewport.Reset(); }
+RTH_API int rth_viewport_render(void* v, void* camera, uint32_t numPasses)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    for (uint32_t i = 0; i < numPasses; ++i) if (!vh->viewport.Render(*static_cast<Camera*>(camera))) return -1;
+    return 0;
+}
+// out->seed points into storage owned by the viewport, valid until the next call
+RTH_API int rth_viewport_next_pass_params(void* v, void* camera, RtPassParams* out)
+{
+    return static_cast<ViewportHandle*>(v)->viewport.NextPassParams(*static_cast<Camera*>(camera), *out) ? 0 : -1;
+}
+// one pass with explicit constants (uploads the scene on first use); the caller owns params->seed
+RTH_API int rth_viewport_render_pass_with(void* v, const RtPassParams* params)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    if (!vh->renderer || !vh->renderer->RenderPass(*params)) return -1;
+    vh->viewport.FinishPass();
+    return 0;
+}
+RTH_API void rth_viewport_finish_pass(void* v) { static_cast<ViewportHandle*>(v)->viewport.FinishPass(); }
+RTH_API int rth_viewport_read_sum(void* v, float* sum, float* secondary)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    const Bitmap& s = vh->viewport.GetSumBuffer();
+    const Bitmap& s2 = vh->viewport.GetSecondarySumBuffer();
+    if (sum) memcpy(sum, s.GetData(), s.GetDataSize());
+    if (secondary) memcpy(secondary, s2.GetData(), s2.GetDataSize());
+    return 0;
+}
+RTH_API int rth_viewport_counters(void* v, uint64_t out[16])
+{
+    const RayTracingCounters c = static_cast<ViewportHandle*>(v)->viewport.GetTotalCounters();
+    memset(out, 0, 16 * sizeof(uint64_t));
+    out[0] = c.numRays; out[1] = c.numShadowRays; out[2] = c.numShadowRaysHit; out[3] = c.numPrimaryRays;
+    out[4] = c.numRayBoxTests; out[5] = c.numPassedRayBoxTests; out[6] = c.numRayTriangleTests; out[7] = c.numPassedRayTriangleTests;
+    out[8] = c.numMeshHits; out[9] = c.numAnalyticHits; out[10] = c.numShadowRayBoxTests; out[11] = c.numShadowRayTriangleTests;
+    return 0;
+}
+RTH_API void* rth_viewport_device_ctx(void* v)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(vh->renderer.get());
+    return pt ? pt->GetDeviceContext() : nullptr;
+}
+RTH_API int rth_viewport_set_shard(void* v, uint32_t rank, uint32_t world)
+{
+    ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(vh->renderer.get());
+    return (pt && pt->SetShard(rank, world)) ? 0 : -1;
+}
+RTH_API uint32_t rth_viewport_passes_finished(void* v) { return static_cast<ViewportHandle*>(v)->viewport.GetProgress().passesFinished; }
+
+// ---- known-answer-test entry points for the host-side algorithms -----------------------------------
+// boxes: n * 6 floats (min xyz, max xyz).  outNodes: capacity 2n nodes of 8 uint32.  outOrder: n.
+RTH_API int rth_kat_bvh_build(const float* boxes, uint32_t n, uint32_t* outNodes, uint32_t* outNumNodes, uint32_t* outOrder)
+{
+    std::vector<Box> b(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        b[i].min = Vector4(boxes[6 * i + 0], boxes[6 * i + 1], boxes[6 * i + 2], 0.0f);
+        b[i].max = Vector4(boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5], 0.0f);
+    }
+    BVH bvh;
+    BVHBuilder builder(bvh);
+    BVHBuilder::Indices order;
+    if (!builder.Build(b.data(), n, BvhBuildingParams(), order)) return -1;
+    *outNumNodes = bvh.GetNumNodes();
+    if (bvh.GetNumNodes()) memcpy(outNodes, bvh.GetNodes(), (size_t)bvh.GetNumNodes() * 32);
+    for (uint32_t i = 0; i < n; ++i) outOrder[i] = order[i];
+    return 0;
+}
+
+// Halton seeds: state = scalar xoroshiro state of the sequence's private generator; out: numPasses * dims uint32
+RTH_API int rth_kat_halton(const uint64_t scalarState[2], uint32_t dims, uint32_t numPasses, uint32_t* out)
+{
+    HaltonSequence h;
+    const uint64_t simd[4] = { 1, 2, 3, 4 };
+    h.GetRandom().SetState(scalarState, simd);
+    h.Initialize(dims);
+    for (uint32_t p = 0; p < numPasses; ++p)
+    {
+        h.NextSample();
+        for (uint32_t d = 0; d < dims; ++d) out[(size_t)p * dims + d] = h.GetInt(d);
+    }
+    return 0;
+}
+
+// Random: outLongs[count] from GetLong, outVec4[count*4] from GetVector4 (independent streams of one state)
+RTH_API int rth_kat_random(const uint64_t scalarState[2], const uint64_t simd4State[4], uint32_t count, uint64_t* outLongs, float* outVec4)
+{
+    Random r;
+    r.SetState(scalarState, simd4State);
+    for (uint32_t i = 0; i < count; ++i) outLongs[i] = r.GetLong();
+    for (uint32_t i = 0; i < count; ++i)
+    {
+        const Vector4 v = r.GetVector4();
+        outVec4[4 * i + 0] = v.x; outVec4[4 * i + 1] = v.y; outVec4[4 * i + 2] = v.z; outVec4[4 * i + 3] = v.w;
+    }
+    return 0;
+}
+
+RTH_API void rth_kat_float_normal2(float ux, float uy, float out[4])
+{
+    const Vector4 v = GetFloatNormal2(Float2(ux, uy));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
+RTH_API void rth_set_global_seed(uint64_t seed) { Entropy::SetGlobalSeed(seed); }
+
+} // extern "C"

@@ -1,0 +1,347 @@
+"""Scene construction helpers: the BASELINE.json configurations, the reference's furnace-test scenes, a
+loader for the reference's JSON scene format (analytic subset) and the procedural "Sponza-class" mesh.
+
+Everything goes through the rt::Scene mirror (raytracer_amd.Scene) exactly like the reference's
+Demo/SceneLoader.cpp goes through rt::Scene.
+"""
+import json
+import math
+
+import numpy as np
+
+from . import Camera, Scene, transform_from_euler
+
+
+# --------------------------------------------------------------------------------------------------
+# reference JSON scene format (Demo/SceneLoader.cpp:364-820), analytic subset
+# --------------------------------------------------------------------------------------------------
+def load_json_scene(path_or_dict, aspect=1.0):
+    """Returns (Scene (built), Camera).  Supports materials, box/sphere/rect|plane objects, the five light
+    types and the camera block.  Meshes/textures/CSG raise NotImplementedError."""
+    d = path_or_dict
+    if not isinstance(d, dict):
+        with open(path_or_dict, "r") as f:
+            d = json.load(f)
+    scene = Scene()
+    materials = {}
+    for m in d.get("materials", []):
+        for key in ("baseColorTexture", "emissionTexture", "roughnessTexture", "metalnessTexture", "normalMap", "maskMap"):
+            if key in m:
+                raise NotImplementedError("textures are outside the hot-path scope (%s)" % key)
+        materials[m["name"]] = scene.add_material(
+            bsdf=m.get("bsdf", "diffuse"), base_color=m.get("baseColor", (0.7, 0.7, 0.7)), emission=m.get("emissionColor", (0.0, 0.0, 0.0)),
+            roughness=m.get("roughness", 0.1), metalness=m.get("metalness", 0.0), ior=m.get("IoR", 1.5), k=m.get("K", 4.0))
+
+    def xform(v):
+        t = v.get("transform", {})
+        return transform_from_euler(t.get("translation", (0.0, 0.0, 0.0)), t.get("orientation", (0.0, 0.0, 0.0)))
+
+    for o in d.get("objects", []):
+        mat = materials.get(o.get("material"), -1)
+        kind = o["type"]
+        if kind == "sphere":
+            scene.add_sphere(o["radius"], xform(o), mat)
+        elif kind == "box":
+            scene.add_box(o["size"], xform(o), mat)
+        elif kind in ("rect", "plane"):
+            scene.add_rect(o["size"], xform(o), mat, o.get("textureScale", (1.0, 1.0)))
+        else:
+            raise NotImplementedError("object type %r" % kind)
+
+    for l in d.get("lights", []):
+        kind = l["type"]
+        color = l["color"]
+        if kind == "area":
+            s = l["shape"]
+            st = s["type"]
+            if st == "sphere":
+                scene.add_area_light("sphere", [s["radius"]], color, xform(l))
+            elif st == "box":
+                scene.add_area_light("box", s["size"], color, xform(l))
+            elif st in ("rect", "plane"):
+                scene.add_area_light("rect", s["size"], color, xform(l))
+            else:
+                raise NotImplementedError("area light shape %r" % st)
+        elif kind == "point":
+            scene.add_point_light(color, xform(l))
+        elif kind == "spot":
+            scene.add_spot_light(color, np.float32(l.get("angle", 0.0)) / np.float32(180.0) * np.float32(3.14159265359), xform(l))
+        elif kind == "directional":
+            scene.add_directional_light(color, np.float32(l.get("angle", 0.0)) / np.float32(180.0) * np.float32(3.14159265359), xform(l))
+        elif kind == "background":
+            if "texture" in l:
+                raise NotImplementedError("environment maps are outside the hot-path scope")
+            scene.add_background_light(color)
+        else:
+            raise NotImplementedError("light type %r" % kind)
+    scene.build()
+
+    c = d.get("camera", {})
+    t = c.get("transform", {})
+    camera = Camera(t.get("translation", (0.0, 0.0, 0.0)), t.get("orientation", (0.0, 0.0, 0.0)), aspect, c.get("fieldOfView", 60.0))
+    if c.get("enableDOF", False):
+        camera.set_dof(True, c.get("focalPlaneDistance", 2.0), c.get("aperture", 0.1))
+    return scene, camera
+
+
+# Data/TestScenes/cornell_box.json of the reference, restated as a dict (BASELINE config 1)
+CORNELL_BOX = {
+    "materials": [
+        {"name": "white", "bsdf": "diffuse", "baseColor": [0.8, 0.8, 0.8]},
+        {"name": "red", "bsdf": "diffuse", "baseColor": [0.8, 0.1, 0.1]},
+        {"name": "green", "bsdf": "diffuse", "baseColor": [0.1, 0.2, 0.8]},
+        {"name": "glass", "bsdf": "dielectric", "baseColor": [1.0, 1.0, 1.0]},
+        {"name": "gold", "bsdf": "metal", "baseColor": [1.0, 0.6, 0.1]},
+        {"name": "silver", "bsdf": "metal", "baseColor": [0.98, 0.98, 0.98]},
+        {"name": "glossy", "bsdf": "roughMetal", "baseColor": [1.0, 1.0, 1.0], "roughness": 0.3},
+    ],
+    "objects": [
+        {"type": "box", "size": [5.0, 0.5, 5.0], "transform": {"translation": [0.0, 5.0, 0.0]}, "material": "white"},
+        {"type": "box", "size": [5.0, 0.5, 5.0], "transform": {"translation": [0.0, -5.0, 0.0]}, "material": "white"},
+        {"type": "box", "size": [0.5, 5.0, 5.0], "transform": {"translation": [5.0, 0.0, 0.0]}, "material": "green"},
+        {"type": "box", "size": [0.5, 5.0, 5.0], "transform": {"translation": [-5.0, 0.0, 0.0]}, "material": "red"},
+        {"type": "box", "size": [5.0, 5.0, 0.5], "transform": {"translation": [0.0, 0.0, -5.0]}, "material": "white"},
+        {"type": "box", "size": [1.5, 2.0, 1.5], "transform": {"translation": [-2.2, -3.5, -0.8], "orientation": [0.0, 0.74, 0.0]}, "material": "white"},
+        {"type": "box", "size": [1.5, 2.0, 1.5], "transform": {"translation": [2.0, -3.5, 1.0], "orientation": [0.0, 1.35, 0.0]}, "material": "white"},
+        {"type": "sphere", "radius": 1.5, "transform": {"translation": [-2.2, 0.002, -0.8]}, "material": "glass"},
+        {"type": "sphere", "radius": 1.5, "transform": {"translation": [2.0, 0.002, 1.0]}, "material": "silver"},
+    ],
+    "lights": [
+        {"type": "area", "color": [5.0, 5.0, 5.0], "transform": {"translation": [0.0, 4.45, 0.0], "orientation": [90.0, 0.0, 0.0]},
+         "shape": {"type": "plane", "size": [2.0, 2.0]}},
+    ],
+    "camera": {"transform": {"translation": [-0.1, 0.2, 12.0], "orientation": [0.01, 180.0, 0.0]}, "fieldOfView": 55.0},
+}
+
+
+def cornell_box(aspect):
+    """BASELINE config 1: the reference's Cornell box (7 boxes, glass + silver spheres, one rect light)."""
+    return load_json_scene(CORNELL_BOX, aspect)
+
+
+def sphere_area_light(aspect):
+    """BASELINE config 2: diffuse unit sphere at the origin under a 2x2 rect light (colour 5) at y = 4."""
+    scene = Scene()
+    mat = scene.add_material("diffuse", (0.8, 0.8, 0.8))
+    scene.add_sphere(1.0, None, mat)
+    scene.add_area_light("rect", [2.0, 2.0], (5.0, 5.0, 5.0), transform_from_euler((0.0, 4.0, 0.0), (90.0, 0.0, 0.0)))
+    scene.build()
+    camera = Camera((0.0, 0.0, 6.0), (0.0, 180.0, 0.0), aspect, 40.0)
+    return scene, camera
+
+
+def furnace(bsdf, base_color=(0.4, 0.6, 0.8), emission=(0.0, 0.0, 0.0), light_color=(1.0, 2.0, 3.0), ior=1.5, k=4.0, roughness=0.1):
+    """The reference's furnace set-up (Tests/RaytracingTests.cpp:317-523): unit sphere inside a uniform
+    background light, camera at z = -3 with a 10 degree field of view."""
+    scene = Scene()
+    mat = scene.add_material(bsdf, base_color, emission, roughness=roughness, ior=ior, k=k)
+    scene.add_background_light(light_color)
+    scene.add_sphere(1.0, None, mat)
+    scene.build()
+    camera = Camera((0.0, 0.0, -3.0), (0.0, 0.0, 0.0), 1.0, 10.0)
+    return scene, camera
+
+
+# --------------------------------------------------------------------------------------------------
+# procedural meshes
+# --------------------------------------------------------------------------------------------------
+class MeshBuilder:
+    """Accumulates indexed triangles with per-vertex normal / tangent / uv and per-triangle material."""
+
+    def __init__(self):
+        self.pos, self.nrm, self.tan, self.uv, self.idx, self.mat = [], [], [], [], [], []
+        self.nv = 0
+
+    def add_grid(self, origin, eu, ev, nu, nv, material, uv_scale=1.0):
+        """Tessellated parallelogram origin + s*eu + t*ev, s,t in [0,1], nu x nv quads.  Normal = eu x ev."""
+        origin, eu, ev = (np.asarray(a, dtype=np.float64) for a in (origin, eu, ev))
+        s = np.linspace(0.0, 1.0, nu + 1)
+        t = np.linspace(0.0, 1.0, nv + 1)
+        S, T = np.meshgrid(s, t, indexing="xy")
+        P = origin[None, None, :] + S[..., None] * eu[None, None, :] + T[..., None] * ev[None, None, :]
+        n = np.cross(eu, ev)
+        n /= np.linalg.norm(n)
+        tg = eu / np.linalg.norm(eu)
+        self._append(P.reshape(-1, 3), np.tile(n, ((nu + 1) * (nv + 1), 1)), np.tile(tg, ((nu + 1) * (nv + 1), 1)),
+                     np.stack([S, T], -1).reshape(-1, 2) * uv_scale, nu, nv, material)
+
+    def add_surface(self, P, N, T, UV, nu, nv, material):
+        """Generic (nv+1) x (nu+1) vertex grid."""
+        self._append(np.asarray(P, dtype=np.float64).reshape(-1, 3), np.asarray(N, dtype=np.float64).reshape(-1, 3),
+                     np.asarray(T, dtype=np.float64).reshape(-1, 3), np.asarray(UV, dtype=np.float64).reshape(-1, 2), nu, nv, material)
+
+    def _append(self, P, N, T, UV, nu, nv, material):
+        base = self.nv
+        j, i = np.meshgrid(np.arange(nv), np.arange(nu), indexing="ij")
+        a = base + j * (nu + 1) + i
+        b = a + 1
+        c = a + (nu + 1)
+        d = c + 1
+        tris = np.stack([np.stack([a, b, d], -1), np.stack([a, d, c], -1)], 2).reshape(-1, 3)
+        self.pos.append(P); self.nrm.append(N); self.tan.append(T); self.uv.append(UV)
+        self.idx.append(tris)
+        self.mat.append(np.full(tris.shape[0], material, dtype=np.uint32))
+        self.nv += P.shape[0]
+
+    def add_cylinder(self, center, radius, y0, y1, segments, rings, material, inward=False):
+        th = np.linspace(0.0, 2.0 * math.pi, segments + 1)
+        ys = np.linspace(y0, y1, rings + 1)
+        TH, Y = np.meshgrid(th, ys, indexing="xy")
+        # triangles are two-sided for the intersector; only the shading normal carries the orientation
+        x = center[0] + radius * np.cos(TH)
+        z = center[1] + radius * np.sin(TH)
+        P = np.stack([x, Y, z], -1)
+        N = np.stack([np.cos(TH), np.zeros_like(TH), np.sin(TH)], -1)
+        if inward:
+            N = -N
+        T = np.stack([-np.sin(TH), np.zeros_like(TH), np.cos(TH)], -1)
+        UV = np.stack([TH / (2.0 * math.pi), (Y - y0) / max(y1 - y0, 1e-6)], -1)
+        self.add_surface(P, N, T, UV, segments, rings, material)
+
+    def arrays(self):
+        pos = np.concatenate(self.pos).astype(np.float32)
+        nrm = np.concatenate(self.nrm)
+        tan = np.concatenate(self.tan)
+        # orthonormalise in double, then round once
+        nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+        tan = tan - nrm * np.sum(tan * nrm, axis=1, keepdims=True)
+        bad = np.linalg.norm(tan, axis=1) < 1e-8
+        if np.any(bad):
+            alt = np.where(np.abs(nrm[bad, 0:1]) < 0.9, np.array([[1.0, 0.0, 0.0]]), np.array([[0.0, 1.0, 0.0]]))
+            tan[bad] = alt - nrm[bad] * np.sum(alt * nrm[bad], axis=1, keepdims=True)
+        tan = tan / np.linalg.norm(tan, axis=1, keepdims=True)
+        return (pos, np.concatenate(self.idx).astype(np.uint32), nrm.astype(np.float32), tan.astype(np.float32),
+                np.concatenate(self.uv).astype(np.float32), np.concatenate(self.mat))
+
+
+SPONZA_MATERIALS = [
+    ("stone_floor", (0.55, 0.52, 0.48)), ("stone_wall", (0.62, 0.58, 0.50)), ("column", (0.70, 0.68, 0.62)),
+    ("arch", (0.60, 0.55, 0.45)), ("ceiling", (0.50, 0.47, 0.42)), ("drape_red", (0.65, 0.12, 0.10)),
+    ("drape_green", (0.12, 0.45, 0.18)), ("drape_blue", (0.12, 0.20, 0.60)),
+]
+
+
+def sponza_class_mesh(target_triangles=262144, seed=7):
+    """Procedural stand-in for crytek-sponza (the reference's Data/TestScenes/sponza.json points at
+    MODELS/crytek-sponza/sponza.obj, which is not shipped and cannot be downloaded): a 30 x 12 x 14 unit atrium
+    -- open roof, two storeys of 2 x 12 tessellated columns with arches, a gallery floor, draped cloth quads --
+    with ~target_triangles triangles and 8 diffuse materials.  Deterministic for a given (target, seed)."""
+    rng = np.random.RandomState(seed)
+    L, H, W = 30.0, 12.0, 14.0          # x in [-15, 15], y in [0, 12], z in [-7, 7]
+    hx, hz = L / 2, W / 2
+    aisle = 3.0                         # width of the side aisles behind the colonnades
+
+    def build(k):
+        """k scales every tessellation factor; returns the builder."""
+        mb = MeshBuilder()
+        q = lambda n: max(1, int(round(n * k)))
+        # floor (facing +y) and gallery floors of the upper storey over the aisles
+        mb.add_grid((-hx, 0.0, hz), (L, 0, 0), (0, 0, -W), q(60), q(28), 0, 8.0)
+        for zs in (-1.0, 1.0):
+            z0 = zs * hz
+            z1 = zs * (hz - aisle)
+            # gallery slab: top (+y) and bottom (-y)
+            if zs > 0:
+                mb.add_grid((-hx, 6.0, z0), (L, 0, 0), (0, 0, z1 - z0), q(60), q(6), 4, 8.0)
+                mb.add_grid((-hx, 5.7, z1), (L, 0, 0), (0, 0, z0 - z1), q(60), q(6), 4, 8.0)
+            else:
+                mb.add_grid((-hx, 6.0, z1), (L, 0, 0), (0, 0, z0 - z1), q(60), q(6), 4, 8.0)
+                mb.add_grid((-hx, 5.7, z0), (L, 0, 0), (0, 0, z1 - z0), q(60), q(6), 4, 8.0)
+        # long walls (normals pointing inwards)
+        mb.add_grid((-hx, 0.0, -hz), (L, 0, 0), (0, H, 0), q(60), q(24), 1, 6.0)          # z = -7, normal +z
+        mb.add_grid((hx, 0.0, hz), (-L, 0, 0), (0, H, 0), q(60), q(24), 1, 6.0)           # z = +7, normal -z
+        # end walls
+        mb.add_grid((-hx, 0.0, hz), (0, 0, -W), (0, H, 0), q(28), q(24), 1, 6.0)          # x = -15, normal +x
+        mb.add_grid((hx, 0.0, -hz), (0, 0, W), (0, H, 0), q(28), q(24), 1, 6.0)           # x = +15, normal -x
+        # roof over the aisles only: the nave is open to the sky
+        for zs in (-1.0, 1.0):
+            z_out = zs * hz
+            z_in = zs * (hz - aisle)
+            if zs > 0:
+                mb.add_grid((-hx, H, z_in), (L, 0, 0), (0, 0, z_out - z_in), q(60), q(6), 4, 8.0)
+            else:
+                mb.add_grid((-hx, H, z_out), (L, 0, 0), (0, 0, z_in - z_out), q(60), q(6), 4, 8.0)
+        # colonnades: 2 rows x 12 columns x 2 storeys, plus arches between neighbouring columns
+        xs = np.linspace(-hx + 1.5, hx - 1.5, 12)
+        for zs in (-1.0, 1.0):
+            zc = zs * (hz - aisle)
+            for storey, (y0, y1, r) in enumerate(((0.0, 5.7, 0.38), (6.0, 11.6, 0.30))):
+                for x in xs:
+                    mb.add_cylinder((x, zc), r, y0, y1 - 1.0, q(24), q(20), 2)
+                    # capital: a wider, short drum
+                    mb.add_cylinder((x, zc), r * 1.35, y1 - 1.0, y1 - 0.8, q(24), 1, 2)
+                # arches: half-tori swept between columns, approximated by a bent band
+                for xa, xb in zip(xs[:-1], xs[1:]):
+                    nu_, nv_ = q(20), q(6)
+                    u = np.linspace(0.0, math.pi, nu_ + 1)
+                    v = np.linspace(-0.25, 0.25, nv_ + 1)
+                    U, V = np.meshgrid(u, v, indexing="xy")
+                    cx, rad = 0.5 * (xa + xb), 0.5 * (xb - xa) - r
+                    X = cx - rad * np.cos(U)
+                    Y = (y1 - 1.0) + 0.8 * np.sin(U)
+                    Z = zc + V
+                    P = np.stack([X, Y, Z], -1)
+                    # underside of the arch faces down / inwards
+                    N = np.stack([np.cos(U) * 0.8, -np.sin(U) * rad, np.zeros_like(U)], -1)
+                    N = N / np.maximum(np.linalg.norm(N, axis=-1, keepdims=True), 1e-9)
+                    T = np.stack([np.zeros_like(U), np.zeros_like(U), np.ones_like(U)], -1)
+                    UVa = np.stack([U / math.pi, V * 2.0 + 0.5], -1)
+                    mb.add_surface(P, N, T, UVa, nu_, nv_, 3)
+        # draped cloths hanging between the upper columns across the nave: wavy quads
+        for d in range(9):
+            x = -hx + 3.0 + d * 3.0
+            nu_, nv_ = q(40), q(24)
+            s = np.linspace(0.0, 1.0, nu_ + 1)
+            t = np.linspace(0.0, 1.0, nv_ + 1)
+            S, T_ = np.meshgrid(s, t, indexing="xy")
+            phase = rng.uniform(0.0, 2.0 * math.pi)
+            Z = -(hz - aisle) * 0.8 + S * (hz - aisle) * 1.6
+            Y = 10.5 - 2.5 * T_ - 0.9 * np.sin(math.pi * S)
+            X = x + 0.25 * np.sin(6.0 * math.pi * S + phase) * (0.3 + T_)
+            P = np.stack([X, Y, Z], -1)
+            dXds = 0.25 * 6.0 * math.pi * np.cos(6.0 * math.pi * S + phase) * (0.3 + T_)
+            dYds = -0.9 * math.pi * np.cos(math.pi * S)
+            dZds = np.full_like(S, (hz - aisle) * 1.6)
+            dPdS = np.stack([dXds, dYds, dZds], -1)
+            dPdT = np.stack([0.25 * np.sin(6.0 * math.pi * S + phase), np.full_like(S, -2.5), np.zeros_like(S)], -1)
+            N = np.cross(dPdS, dPdT)
+            N = N / np.linalg.norm(N, axis=-1, keepdims=True)
+            mb.add_surface(P, N, dPdS, np.stack([S, T_], -1), nu_, nv_, 5 + d % 3)
+        return mb
+
+    # pick the tessellation scale that lands on the target triangle count (triangles ~ k^2)
+    k = 1.0
+    for _ in range(8):
+        n = sum(t.shape[0] for t in build(k).idx)
+        if abs(n - target_triangles) / target_triangles < 0.005:
+            break
+        k *= math.sqrt(target_triangles / n)
+    return build(k).arrays()
+
+
+def sponza_class(aspect, target_triangles=262144, seed=7):
+    """BASELINE config 3: Sponza-class mesh, background light (1, 1.5, 2) + delta directional light
+    (20000, 19000, 18000) pitched 80 degrees -- the lights of the reference's Data/TestScenes/sponza.json."""
+    pos, idx, nrm, tan, uv, mat = sponza_class_mesh(target_triangles, seed)
+    scene = Scene()
+    mats = [scene.add_material("diffuse", c) for _, c in SPONZA_MATERIALS]
+    scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    scene.add_background_light((1.0, 1.5, 2.0))
+    scene.add_directional_light((20000.0, 19000.0, 18000.0), np.float32(1.0) / np.float32(180.0) * np.float32(3.14159265359),
+                                transform_from_euler((0.0, 0.0, 0.0), (80.0, 20.0, 0.0)))
+    scene.build()
+    camera = Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+    return scene, camera
+
+
+def box_mesh(half=1.0):
+    """12-triangle box mesh with per-face normals / tangents / uvs (the fixture sketched, commented out, at
+    Tests/RaytracingTests.cpp:68-239)."""
+    mb = MeshBuilder()
+    h = half
+    faces = [((-h, -h, h), (2 * h, 0, 0), (0, 2 * h, 0)), ((h, -h, -h), (-2 * h, 0, 0), (0, 2 * h, 0)),
+             ((h, -h, h), (0, 0, -2 * h), (0, 2 * h, 0)), ((-h, -h, -h), (0, 0, 2 * h), (0, 2 * h, 0)),
+             ((-h, h, h), (2 * h, 0, 0), (0, 0, -2 * h)), ((-h, -h, -h), (2 * h, 0, 0), (0, 0, 2 * h))]
+    for f, (o, eu, ev) in enumerate(faces):
+        mb.add_grid(o, eu, ev, 1, 1, f % 2)
+    return mb.arrays()

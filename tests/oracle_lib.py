@@ -1,0 +1,73 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE: the product package
+raytracer_amd never imports this."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+
+_lib = None
+
+KAT = dict(SIN_LANE=1, SINCOS=2, FASTLOG=3, FASTACOS=4, FASTATAN2=5, FLOAT_NORMAL2=6, HEMISPHERE_COS=7, SPHERE=8, CIRCLE=9,
+           ORTHO_BASIS=10, FRESNEL_DIELECTRIC=11, FRESNEL_METAL=12, REFRACT3=13, REFLECT3=14, BOX_RAY=20, BOX_RAY_TWOSIDED=21,
+           TRIANGLE_RAY=22, MAKE_RAY=23, TRANSFORM_RAY=24, FAST_INVERSE=25, SHAPE_INTERSECT=30, SHAPE_SAMPLE=31, SHAPE_PDF=32,
+           SHAPE_EVAL=33, LIGHT_ILLUMINATE=40, LIGHT_RADIANCE=41, BSDF_SAMPLE=50, BSDF_EVALUATE=51, CAMERA_RAY=60)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_PATH):
+            raise RuntimeError("oracle not built: run `make -C oracle` (or __graft_entry__.build())")
+        _lib = C.CDLL(ORACLE_PATH)
+        _lib.rto_sizeof.restype = C.c_uint32
+    return _lib
+
+
+def render_pass(scene_desc_ptr, params, width, height, sum_buf, secondary=None, counters=None, shard=(0, 1), threads=1):
+    """One pass of the oracle into sum_buf (H, W, 3 float32, accumulated in place)."""
+    if counters is None:
+        counters = np.zeros(16, dtype=np.uint64)
+    r = lib().rto_render_pass(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(shard[0]), C.c_uint32(shard[1]),
+                              sum_buf.ctypes.data_as(C.POINTER(C.c_float)),
+                              secondary.ctypes.data_as(C.POINTER(C.c_float)) if secondary is not None else None,
+                              counters.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads))
+    if r != 0:
+        raise RuntimeError("rto_render_pass failed")
+    return counters
+
+
+def render_pixel(scene_desc_ptr, params, width, height, x, y):
+    out = (C.c_float * 4)()
+    lib().rto_render_pixel(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(x), C.c_uint32(y), out, None)
+    return np.array(out[:], dtype=np.float32)
+
+
+def kat(func, inputs, out_stride):
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    n, in_stride = inputs.shape
+    out = np.zeros((n, out_stride), dtype=np.float32)
+    r = lib().rto_kat(int(KAT[func] if isinstance(func, str) else func), inputs.ctypes.data_as(C.POINTER(C.c_float)), int(in_stride),
+                      out.ctypes.data_as(C.POINTER(C.c_float)), int(out_stride), int(n))
+    if r != 0:
+        raise RuntimeError("unknown KAT function %r" % (func,))
+    return out
+
+
+def sampler_ints(seed, blue_noise, use_blue_noise, x, y, count):
+    seed = np.ascontiguousarray(seed, dtype=np.uint32)
+    ints = np.zeros(count, dtype=np.uint32)
+    floats = np.zeros(count, dtype=np.float32)
+    bn = blue_noise.ctypes.data_as(C.POINTER(C.c_uint16)) if blue_noise is not None else None
+    lib().rto_kat_sampler(seed.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_uint32(len(seed)), bn, C.c_uint32(1 if use_blue_noise else 0),
+                          C.c_uint32(x), C.c_uint32(y), C.c_uint32(count), ints.ctypes.data_as(C.POINTER(C.c_uint32)),
+                          floats.ctypes.data_as(C.POINTER(C.c_float)))
+    return ints, floats
+
+
+def xoroshiro(s0, s1, count):
+    out = np.zeros(count, dtype=np.uint64)
+    lib().rto_kat_xoroshiro(C.c_uint64(s0), C.c_uint64(s1), C.c_uint32(count), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return out

@@ -1,0 +1,69 @@
+"""Pins the CPU oracle (oracle/rto_*.h) against golden vectors produced by the REFERENCE'S OWN functions
+(tests/golden/*.kat, see tests/golden/README.md).  Bit-exact everywhere except where the reference uses the
+vendor-specific _mm_rsqrt_ps approximation (FastNormalize3), which the oracle replaces by exact ops:
+those outputs must agree to 2^-11 relative."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import kat_io
+import oracle_lib
+
+KAT_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(kat_io.GOLDEN, "*.kat")) if not os.path.basename(p).startswith("host_"))
+RSQRT_TOLERANCE = 2.0 ** -11
+
+
+def test_fixture_inventory():
+    # every function group of SURVEY 8(a) rows X1/T3/T4/G1/I3/L1/L2/M3/C1 has a fixture
+    for prefix in ("math_", "geom_", "shape_", "light_", "bsdf_", "camera_"):
+        assert any(f.startswith(prefix) for f in KAT_FILES), prefix
+    assert len(KAT_FILES) >= 29
+
+
+@pytest.mark.parametrize("name", KAT_FILES)
+def test_oracle_matches_reference(built, name):
+    func, inputs, expected = kat_io.load_kat(name)
+    got = oracle_lib.kat(func, inputs, expected.shape[1])
+    bad = kat_io.bit_mismatch(expected, got)
+    if name == "shape_eval.kat":
+        # SphereShape::EvaluateIntersection ends with three FastNormalize3 (_mm_rsqrt_ps): tolerance there,
+        # bit-exact for boxes and rects (kinds 1, 2) and for the sphere's texture coordinates
+        kind = inputs[:, 0].view(np.uint32)
+        assert not bad[kind != 0].any()
+        assert not bad[kind == 0][:, 12:16].any()
+        e, g = expected[kind == 0][:, :12].astype(np.float64), got[kind == 0][:, :12].astype(np.float64)
+        assert np.all(np.abs(e - g) <= RSQRT_TOLERANCE * np.maximum(np.abs(e), 1e-3))
+        return
+    assert not bad.any(), "%d of %d values differ from the reference" % (int(bad.sum()), bad.size)
+
+
+def test_sampler_stream_bit_exact(built):
+    """GenericSampler::GetInt for dims 0..63 at 8 pixels, with and without blue-noise dithering."""
+    raw = np.fromfile(os.path.join(kat_io.GOLDEN, "sampler.bin"), dtype=np.uint32)
+    dims, num_pixels, count = (int(v) for v in raw[:3])
+    seed = raw[3:3 + dims].copy()
+    import raytracer_amd as ra
+    bn = ra.load_blue_noise()
+    off = 3 + dims
+    for use_blue in (0, 1):
+        for _ in range(num_pixels):
+            x, y = int(raw[off]), int(raw[off + 1])
+            expected = raw[off + 2:off + 2 + count]
+            off += 2 + count
+            ints, floats = oracle_lib.sampler_ints(seed, bn, use_blue, x, y, count)
+            assert np.array_equal(ints, expected), (use_blue, x, y)
+            # GetFloat = min(0.99999994, float(u) / 2^32)
+            ref = np.minimum(np.float32(0.999999940395), ints.astype(np.float32) / np.float32(4294967296.0))
+            assert np.array_equal(floats, ref)
+            assert floats.max() < 1.0
+
+
+def test_xoroshiro_bit_exact(built):
+    raw = np.fromfile(os.path.join(kat_io.GOLDEN, "random.bin"), dtype=np.uint8)
+    scalar = raw[:16].view(np.uint64)
+    count = int(raw[48:52].view(np.uint32)[0])
+    longs = raw[52:52 + 8 * count].view(np.uint64)
+    got = oracle_lib.xoroshiro(int(scalar[0]), int(scalar[1]), count)
+    assert np.array_equal(got, longs)
