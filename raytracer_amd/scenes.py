@@ -306,7 +306,10 @@ def sponza_class_mesh(target_triangles=262144, seed=7):
             dPdT = np.stack([0.25 * np.sin(6.0 * math.pi * S + phase), np.full_like(S, -2.5), np.zeros_like(S)], -1)
             N = np.cross(dPdS, dPdT)
             N = N / np.linalg.norm(N, axis=-1, keepdims=True)
+            # cloth is visible from both sides: the reference shades one-sided (the shading normal decides), so the
+            # back face is a second sheet 2 mm behind the first with the opposite normal
             mb.add_surface(P, N, dPdS, np.stack([S, T_], -1), nu_, nv_, 5 + d % 3)
+            mb.add_surface(P - 0.002 * N, -N, dPdS, np.stack([S, T_], -1), nu_, nv_, 5 + d % 3)
         return mb
 
     # pick the tessellation scale that lands on the target triangle count (triangles ~ k^2)

@@ -1,0 +1,177 @@
+"""GPU parity: the HIP wavefront path tracer (through the C-ABI, via the rt::Viewport mirror) against the CPU
+oracle on identical scenes and identical per-pass constants.
+
+Bar: BIT-EXACT float3 sum buffers and IDENTICAL ray counters.  Both sides evaluate the reference's arithmetic in
+the reference's operation order with IEEE ops (the two x86 approximate instructions the reference uses,
+_mm_rcp_ss and _mm_rsqrt_ps, are exact ops on both sides), so there is no tolerance to state.  Tolerance versus
+the REFERENCE itself: see tests/test_oracle_kat.py (2^-11 relative on the rsqrt-affected frames only)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_zoo
+import raytracer_amd as ra
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+COMPARED = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests", "numPassedRayBoxTests",
+            "numRayTriangleTests", "numPassedRayTriangleTests", "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
+            "numShadowRayTriangleTests")
+
+
+def run_both(scene, camera, w, h, passes, seed=99, threads=8, **vp_args):
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=seed, **vp_args)
+    vp.set_renderer(scene)
+    ref = np.zeros((h, w, 3), dtype=np.float32)
+    ref2 = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for _ in range(passes):
+        p = vp.next_pass_params(camera)
+        vp.render_pass_with(p)
+        oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=threads)
+    img, img2 = vp.sum_buffer(secondary=True)
+    return img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}
+
+
+def assert_identical(img, img2, counters, ref, ref2, ref_counters):
+    assert np.isfinite(ref).all()
+    nbad = int(np.count_nonzero(img.view(np.uint32) != ref.view(np.uint32)))
+    assert nbad == 0, "%d of %d sum-buffer values differ (max abs %.3e)" % (nbad, ref.size, float(np.abs(img - ref).max()))
+    assert np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
+    for n in COMPARED:
+        assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
+
+
+def test_cornell_box_bit_exact(built):
+    """BASELINE config 1 geometry (10 instances, top-level BVH, glass/metal/diffuse, rect light), depth 4."""
+    w, h = 160, 120
+    scene, camera = scenes.cornell_box(w / h)
+    out = run_both(scene, camera, w, h, passes=4, max_ray_depth=4)
+    assert_identical(*out)
+    assert out[2]["numRays"] > 4 * w * h * 2
+
+
+def test_sphere_area_light_bit_exact(built):
+    """BASELINE config 2 (single sphere + area light: no BVH, fp64 sphere intersection)."""
+    w, h = 192, 108
+    scene, camera = scenes.sphere_area_light(w / h)
+    assert_identical(*run_both(scene, camera, w, h, passes=4, max_ray_depth=4))
+
+
+def test_every_light_and_bsdf_all_strategy(built):
+    """All five light types, all nine BSDFs, LightSamplingStrategy::All with dimensions raised to 128."""
+    w, h = 128, 96
+    scene, camera = scene_zoo.all_lights_scene(w / h)
+    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=6, dimensions=128, light_sampling_all=True))
+
+
+def test_single_strategy_many_lights_and_dimension_overflow(built):
+    """Single strategy with 8 lights (per-pixel fallback generator picks the light) and only 16 Halton
+    dimensions (samples past them come from the fallback generator, GenericSampler.cpp:106-109)."""
+    w, h = 96, 64
+    scene, camera = scene_zoo.all_lights_scene(w / h)
+    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=5, dimensions=16, use_blue_noise=False))
+
+
+def test_mesh_two_level_bvh_bit_exact(built):
+    """Triangle mesh instance + analytic instances: mesh BVH traversal, Moller-Trumbore, barycentric frames."""
+    w, h = 160, 90
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
+    out = run_both(scene, camera, w, h, passes=2, max_ray_depth=8)
+    assert_identical(*out)
+    assert out[2]["numRayTriangleTests"] > 0 and out[2]["numMeshHits"] > 0
+
+
+def test_single_object_scene_bypasses_top_bvh(built):
+    """Sponza-class configuration: ONE object (Scene::Traverse bypasses the BVH, Scene.cpp:231-235), two global lights."""
+    w, h = 128, 72
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
+    assert scene.desc.contents.numObjects == 1
+    assert_identical(*run_both(scene, camera, w, h, passes=2, max_ray_depth=8))
+
+
+def test_depth_of_field(built):
+    w, h = 96, 72
+    scene, camera = scenes.cornell_box(w / h)
+    camera.set_dof(True, 11.0, 0.3)
+    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=3))
+
+
+def test_empty_scene_and_background_only(built):
+    """RenderingTest.EmptyScene / BackgroundLightOnly (Tests/RaytracingTests.cpp:263-315) with their tolerances."""
+    w = h = 32
+    scene = ra.Scene().build()
+    cam = ra.Camera((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 90.0)
+    img, _, counters, ref, _, _ = run_both(scene, cam, w, h, passes=1)
+    assert np.all(img == 0.0) and np.all(ref == 0.0)
+    scene = ra.Scene()
+    scene.add_background_light((1.0, 2.0, 3.0))
+    scene.build()
+    out = run_both(scene, cam, w, h, passes=1)
+    assert_identical(*out)
+    assert np.all(np.abs(out[0] - np.array([1.0, 2.0, 3.0], dtype=np.float32)) <= 0.01)
+
+
+@pytest.mark.parametrize("bsdf,passes,expected,tol,kwargs", [
+    ("diffuse", 100, (0.4, 1.2, 2.4), 0.05, {}),
+    ("null", 1, (3.0, 2.0, 1.0), 0.0, {"base_color": (0.0, 0.0, 0.0), "emission": (3.0, 2.0, 1.0)}),
+    ("metal", 20, (0.4, 1.2, 2.4), 0.05, {"ior": 0.0, "k": 100.0}),
+    ("dielectric", 1000, (1.0, 2.0, 3.0), 0.075, {"base_color": (1.0, 1.0, 1.0)}),
+])
+def test_reference_furnace_tests_on_gpu(built, bsdf, passes, expected, tol, kwargs):
+    """The reference's own RenderingTest.FurnaceTest_* (Tests/RaytracingTests.cpp:317-523): every pixel of the
+    sum buffer / numPasses within the reference's tolerance, 32x32 viewport, default RenderingParams."""
+    w = h = 32
+    scene, camera = scenes.furnace(bsdf, **kwargs)
+    vp = ra.Viewport(w, h, seed=2024)
+    vp.set_renderer(scene)
+    vp.render(camera, passes)
+    img = vp.sum_buffer() / np.float32(passes)
+    assert np.all(np.abs(img - np.array(expected, dtype=np.float32)) <= tol + 1e-6), float(np.abs(img - np.array(expected)).max())
+
+
+def test_tile_sharding_reproduces_single_gpu_image(built):
+    """64x64-tile interleaved ownership: the sum of the shard images equals the unsharded image bit for bit."""
+    w, h = 200, 136
+    scene, camera = scenes.cornell_box(w / h)
+    full = ra.Viewport(w, h, seed=5, max_ray_depth=4)
+    full.set_renderer(scene)
+    params = [full.next_pass_params(camera) for _ in range(2)]
+    for p in params:
+        full.render_pass_with(p)
+    whole = full.sum_buffer()
+    total = np.zeros_like(whole)
+    rays = 0
+    for rank in range(3):
+        vp = ra.Viewport(w, h, seed=5, max_ray_depth=4)
+        vp.set_renderer(scene)
+        vp.set_shard(rank, 3)
+        for p in params:
+            vp.render_pass_with(p)
+        part = vp.sum_buffer()
+        assert np.all((part == 0) | (total == 0))   # disjoint support
+        total += part
+        rays += vp.counters()["numRays"]
+    assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+    assert rays == full.counters()["numRays"]
+
+
+def test_c_abi_error_paths(built):
+    lib = ra.rtgpu_lib()
+    ctx = C.c_void_p()
+    assert lib.rtgpu_create(0, C.byref(ctx)) == 0
+    p = ra.RtPassParams()
+    assert lib.rtgpu_render_pass(ctx, C.byref(p)) == -5          # RTGPU_ERR_NOT_READY: no scene yet
+    assert b"upload_scene" in lib.rtgpu_last_error()
+    assert lib.rtgpu_resize(ctx, 0, 10) == -1                     # invalid size
+    d = ra.RtSceneDesc()
+    d.abiVersion = 999
+    assert lib.rtgpu_upload_scene(ctx, C.byref(d)) == -1
+    lib.rtgpu_destroy(ctx)
+    assert lib.rtgpu_create(99, C.byref(ctx)) == -1               # device index out of range
