@@ -13,11 +13,17 @@
 //
 // Path state lives in HBM as structure-of-arrays indexed by path slot, so a wave reads 64 consecutive
 // dwords per field; queues hold slot indices and are compacted with wave ballots (one atomic per wave).
+// The two traversal kernels are PERSISTENT: a fixed grid of waves pulls rays from the queue through an atomic
+// cursor and refills lanes whose ray has finished (rays of one wave take very different numbers of node
+// steps), with the per-lane node stack in LDS.  NEE rays go through their own dense queue; their results are
+// folded into the path radiance by the next kernel that touches the path (shade of the next bounce, or
+// accumulate), which preserves the reference's accumulation order.
 // Per-path arithmetic is kept in the reference's operation order (see rt_device_math.h), which makes the
 // result independent of the wavefront schedule and reproducible against the CPU oracle.
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include "rt_device_core.h"
+#include "rt_device_traverse.h"
 
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -184,23 +190,75 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, 
     }
 }
 
-// Scene::Traverse for every active path (Scene.cpp:219-243)
+// Wave-level work fetch for the persistent kernels: lanes without a ray claim consecutive queue indices with ONE
+// atomic per wave.  Returns the claimed index (>= count when the queue is exhausted) for lanes with want == true.
+RT_DEV uint32_t waveClaim(bool want, uint32_t* cursor, uint32_t& claimedEnd)
+{
+    const unsigned long long mask = __ballot(want);
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    claimedEnd = base + (uint32_t)__popcll(mask);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Scene::Traverse for every active path (Scene.cpp:219-243), persistent threads + LDS stack
+// Wave scheduling knobs of the persistent traversal kernels (wave-uniform, passed as kernel arguments)
+struct TravTuning
+{
+    uint32_t refillMinIdle;   // refill once this many lanes of the wave have no ray (or all of them)
+    uint32_t otherMinLanes;   // run the "other" phase (leaves, objects, finishing) once this many lanes wait for it
+};
+
+template <int kStack>
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(const RtSceneDesc scene, const Paths paths,
                                                             const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                            unsigned long long* counters)
+                                                            uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
 {
+    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
     const uint32_t count = *queueCount;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    TravState s; s.mode = TRAV_DONE;
+    uint32_t slot = 0;
+    bool have = false, exhausted = false;
+    for (;;)
     {
-        const uint32_t slot = queue[i];
-        const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
-        const Ray ray = loadPathRay(paths, slot, depth);
-        Hit hit; hit.objectId = RT_INVALID_OBJECT; hit.subObjectId = 0; hit.distance = __uint_as_float(0x7f800000u); hit.u = 0.0f; hit.v = 0.0f;
-        sceneTraverse(scene, ray, hit, cnt);
-        pu(paths, F_HIT_OBJ, slot) = hit.objectId; pu(paths, F_HIT_SUB, slot) = hit.subObjectId;
-        pf(paths, F_HIT_DIST, slot) = hit.distance; pf(paths, F_HIT_U, slot) = hit.u; pf(paths, F_HIT_V, slot) = hit.v;
+        const bool interior = have && travIsInterior(s);
+        const bool other = have && !interior;
+        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
+        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
+        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
+        {
+            uint32_t claimedEnd;
+            const uint32_t idx = waveClaim(!have, cursor, claimedEnd);
+            if (!have && idx < count)
+            {
+                slot = queue[idx];
+                const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
+                travBegin(s, scene, loadPathRay(paths, slot, depth), __uint_as_float(0x7f800000u));
+                have = true;
+            }
+            exhausted = claimedEnd >= count;
+            continue;
+        }
+        if ((mI | mO) == 0ull) break;
+        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
+        {
+            if (interior) travStepInterior<false>(s, scene, stack, cnt);
+        }
+        else if (other)
+        {
+            if (s.mode != TRAV_DONE) travStepOther<false>(s, scene, stack, cnt);
+            if (s.mode == TRAV_DONE)
+            {
+                pu(paths, F_HIT_OBJ, slot) = s.hit.objectId; pu(paths, F_HIT_SUB, slot) = s.hit.subObjectId;
+                pf(paths, F_HIT_DIST, slot) = s.hit.distance; pf(paths, F_HIT_U, slot) = s.hit.u; pf(paths, F_HIT_V, slot) = s.hit.v;
+                have = false;
+            }
+        }
     }
     flushCounters(cnt, counters);
 }
@@ -210,7 +268,7 @@ RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDi
 
 // PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
 // request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
-RT_DEV void prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
+RT_DEV bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
                                const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
                                const Paths& paths, uint32_t slot, uint32_t requestIndex)
 {
@@ -240,12 +298,37 @@ RT_DEV void prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sa
     psh(paths, requestIndex, 0, slot) = dir.x; psh(paths, requestIndex, 1, slot) = dir.y; psh(paths, requestIndex, 2, slot) = dir.z;
     psh(paths, requestIndex, 3, slot) = tmax;
     psh(paths, requestIndex, 4, slot) = contribution.x; psh(paths, requestIndex, 5, slot) = contribution.y; psh(paths, requestIndex, 6, slot) = contribution.z;
+    return tmax >= 0.0f;   // a shadow ray has to be traced for this request
+}
+
+// Folds the finished NEE requests of the path's previous vertex into its radiance:
+// accumulatedColor = sum of the unoccluded SampleLight() results in light order, times mLightSamplingWeight,
+// then resultColor.MulAndAccumulate(throughput, ...) (PathTracerMIS.cpp:141-151, 320).  k_trace_shadow marks
+// occluded requests with tmax < 0.
+RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, V4 lightSamplingWeight, V4& resultColor)
+{
+    const uint32_t n = pu(paths, F_SH_COUNT, slot);
+    if (n == 0) return;
+    pu(paths, F_SH_COUNT, slot) = 0;
+    V4 accumulated = zero4();
+    bool any = false;
+    for (uint32_t l = 0; l < n; ++l)
+    {
+        if (psh(paths, l, 3, slot) < 0.0f) continue;
+        accumulated = accumulated + V4(psh(paths, l, 4, slot), psh(paths, l, 5, slot), psh(paths, l, 6, slot), 0.0f);
+        any = true;
+    }
+    if (!any) return;
+    accumulated = accumulated * lightSamplingWeight;
+    const V4 tp(pf(paths, F_SH_TPX, slot), pf(paths, F_SH_TPY, slot), pf(paths, F_SH_TPZ, slot), 0.0f);
+    resultColor = mulAdd(tp, accumulated, resultColor);
 }
 
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395)
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass pass, const Paths paths,
                                                     const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                     uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                    uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
                                                     unsigned long long* counters)
 {
     Counters cnt; zeroCounters(cnt);
@@ -261,6 +344,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     {
         bool alive = false;
         uint32_t slot = 0;
+        unsigned long long rayMask = 0ull;   // NEE requests of this vertex that need a shadow ray (bit = request index)
         if (i < count)
         {
             slot = queueIn[i];
@@ -271,6 +355,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
             const Ray ray = loadPathRay(paths, slot, depth);
             V4 throughput(pf(paths, F_TPX, slot), pf(paths, F_TPY, slot), pf(paths, F_TPZ, slot), pf(paths, F_TPW, slot));
             V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
+            resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the previous vertex
             Hit hit;
             hit.objectId = pu(paths, F_HIT_OBJ, slot); hit.subObjectId = pu(paths, F_HIT_SUB, slot);
             hit.distance = pf(paths, F_HIT_DIST, slot); hit.u = pf(paths, F_HIT_U, slot); hit.v = pf(paths, F_HIT_V, slot);
@@ -349,13 +434,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                     {
                         uint32_t lightIndex = 0;
                         if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
-                        prepareLightSample(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0);
+                        if (prepareLightSample(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0)) rayMask = 1ull;
                         numRequests = 1;
                     }
                     else
                     {
                         for (uint32_t l = 0; l < scene.numLights; ++l)
-                            prepareLightSample(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
+                        {
+                            const bool ray = prepareLightSample(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
+                            if (ray)
+                            {
+                                if (l < 64u) rayMask |= 1ull << l;
+                                else shadowQueue[atomicAdd(shadowCount, 1u)] = l * paths.capacity + slot;   // more than 64 lights: per-lane append
+                            }
+                        }
                         numRequests = scene.numLights;
                     }
                     pu(paths, F_SH_COUNT, slot) = numRequests;
@@ -404,6 +496,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
             if (!alive) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
         }
 
+        // dense NEE ray queue: one wave-level compaction per request index in use
+        for (unsigned long long pending = rayMask; __any(pending != 0ull); )
+        {
+            // lowest request index any lane still has pending (wave-uniform)
+            uint32_t l = pending ? (uint32_t)(__ffsll((long long)pending) - 1) : 64u;
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)l, off); l = o < l ? o : l; }
+            const bool mine = ((pending >> l) & 1ull) != 0ull;
+            const unsigned long long m = __ballot(mine);
+            const uint32_t lane = threadIdx.x & 63u;
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if ((int)lane == leader) base = atomicAdd(shadowCount, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            if (mine) { shadowQueue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = l * paths.capacity + slot; pending &= ~(1ull << l); }
+        }
+
         // wave-level compaction of the survivors into the next queue: ballot + prefix popcount + one atomic per wave
         const unsigned long long ballot = __ballot(alive);
         if (ballot)
@@ -419,45 +527,59 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     flushCounters(cnt, counters);
 }
 
-// Occlusion of the NEE requests of one vertex + accumulation (PathTracerMIS.cpp:81-96,119,141-151,320)
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(const RtSceneDesc scene, const DevPass pass, const Paths paths,
-                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                           unsigned long long* counters)
+// Occlusion test of the queued NEE rays (PathTracerMIS.cpp:81-96): Scene::Traverse_Shadow, persistent threads.
+// An occluded request is marked by tmax = -1; the contribution is folded in by resolvePendingLightSamples.
+template <int kStack>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(const RtSceneDesc scene, const Paths paths,
+                                                           const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
+                                                           uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
 {
+    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
-    const uint32_t count = *queueCount;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    const uint32_t count = *shadowCount;
+    TravState s; s.mode = TRAV_DONE;
+    uint32_t slot = 0, light = 0;
+    bool have = false, exhausted = false;
+    for (;;)
     {
-        const uint32_t slot = queue[i];
-        const uint32_t n = pu(paths, F_SH_COUNT, slot);
-        if (n == 0) continue;
-        pu(paths, F_SH_COUNT, slot) = 0;
-        const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
-        V4 accumulated = zero4();
-        bool any = false;
-        for (uint32_t l = 0; l < n; ++l)
+        const bool interior = have && travIsInterior(s);
+        const bool other = have && !interior;
+        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
+        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
+        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
         {
-            const float tmax = psh(paths, l, 3, slot);
-            if (tmax < 0.0f) continue;   // SampleLight returned early: no shadow ray was cast
-            const V4 dir(psh(paths, l, 0, slot), psh(paths, l, 1, slot), psh(paths, l, 2, slot), 0.0f);
-            Ray shadowRay = makeRay(origin, dir);
-            shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
-            Hit hp; hp.objectId = RT_INVALID_OBJECT; hp.subObjectId = 0; hp.u = 0.0f; hp.v = 0.0f; hp.distance = tmax;
-            cnt.c[C_SHADOW]++;
-            if (sceneTraverseShadow(scene, shadowRay, hp, cnt)) continue;   // occluded
-            cnt.c[C_SHADOW_HIT]++;
-            accumulated = accumulated + V4(psh(paths, l, 4, slot), psh(paths, l, 5, slot), psh(paths, l, 6, slot), 0.0f);
-            any = true;
+            uint32_t claimedEnd;
+            const uint32_t idx = waveClaim(!have, cursor, claimedEnd);
+            if (!have && idx < count)
+            {
+                const uint32_t request = shadowQueue[idx];
+                light = request / paths.capacity; slot = request - light * paths.capacity;
+                const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
+                const V4 dir(psh(paths, light, 0, slot), psh(paths, light, 1, slot), psh(paths, light, 2, slot), 0.0f);
+                Ray shadowRay = makeRay(origin, dir);
+                shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
+                travBegin(s, scene, shadowRay, psh(paths, light, 3, slot));   // hitPoint.distance = illuminateResult.distance * 0.999f
+                cnt.c[C_SHADOW]++;
+                have = true;
+            }
+            exhausted = claimedEnd >= count;
+            continue;
         }
-        if (any)
+        if ((mI | mO) == 0ull) break;
+        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
         {
-            accumulated = accumulated * lightSamplingWeight;
-            const V4 tp(pf(paths, F_SH_TPX, slot), pf(paths, F_SH_TPY, slot), pf(paths, F_SH_TPZ, slot), 0.0f);
-            pf(paths, F_RX, slot) = __fmaf_rn(tp.x, accumulated.x, pf(paths, F_RX, slot));
-            pf(paths, F_RY, slot) = __fmaf_rn(tp.y, accumulated.y, pf(paths, F_RY, slot));
-            pf(paths, F_RZ, slot) = __fmaf_rn(tp.z, accumulated.z, pf(paths, F_RZ, slot));
+            if (interior) travStepInterior<true>(s, scene, stack, cnt);
+        }
+        else if (other)
+        {
+            if (s.mode != TRAV_DONE) travStepOther<true>(s, scene, stack, cnt);
+            if (s.mode == TRAV_DONE)
+            {
+                if (s.occluded) psh(paths, light, 3, slot) = -1.0f;
+                else cnt.c[C_SHADOW_HIT]++;
+                have = false;
+            }
         }
     }
     flushCounters(cnt, counters);
@@ -465,14 +587,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(const RtSceneDesc sce
 
 // Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y
 __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t numSlots, float* __restrict__ sum,
-                                                         float* __restrict__ secondary, uint32_t width, uint32_t evenPass)
+                                                         float* __restrict__ secondary, uint32_t width, uint32_t evenPass,
+                                                         const DevPass pass)
 {
+    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
     {
         const uint32_t pix = pu(paths, F_PIXEL, slot);
         const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
-        const float r = pf(paths, F_RX, slot), g = pf(paths, F_RY, slot), b = pf(paths, F_RZ, slot);
+        V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
+        resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the path's last vertex
+        const float r = resultColor.x, g = resultColor.y, b = resultColor.z;
         sum[idx + 0] = sum[idx + 0] + r; sum[idx + 1] = sum[idx + 1] + g; sum[idx + 2] = sum[idx + 2] + b;
         if (evenPass)
         {
@@ -524,8 +650,15 @@ struct RtgpuContext
     // paths
     Paths paths = { nullptr, 0, 0 };
     uint32_t* queues[2] = { nullptr, nullptr };
-    uint32_t* queueCounts = nullptr;   // [maxDepth + 3] one counter per bounce so that no reset races with a reader
+    uint32_t* shadowQueue = nullptr;   // capacity * maxLights NEE ray requests
+    // per-pass work counters, 4 planes of (maxDepth + 2) uint32, zeroed once per pass: path-queue counts,
+    // shadow-queue counts, closest-kernel cursors, shadow-kernel cursors (one of each per bounce, so that no
+    // reset ever races with a reader)
+    uint32_t* queueCounts = nullptr;
     uint32_t queueCountCapacity = 0;
+    uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
+    TravTuning tune = { 44u, 16u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
+    uint32_t travBlocksPerCU = 0;      // 0 = default
     unsigned long long* counters = nullptr;   // 16 x u64
 
     // per-pass seed ring
@@ -565,8 +698,9 @@ static void freePaths(RtgpuContext* c)
     if (c->paths.base) (void)hipFree(c->paths.base);
     if (c->queues[0]) (void)hipFree(c->queues[0]);
     if (c->queues[1]) (void)hipFree(c->queues[1]);
+    if (c->shadowQueue) (void)hipFree(c->shadowQueue);
     c->paths.base = nullptr; c->paths.capacity = 0; c->paths.maxLights = 0;
-    c->queues[0] = c->queues[1] = nullptr;
+    c->queues[0] = c->queues[1] = nullptr; c->shadowQueue = nullptr;
 }
 
 static int resolveTimed(RtgpuContext* c)
@@ -659,6 +793,12 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     for (int i = 0; i < RT_SEED_RING; ++i) { c->seedEvents[i] = nullptr; c->seedEventUsed[i] = false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, deviceIndex) == hipSuccess) c->numCUs = (uint32_t)prop.multiProcessorCount;
+    // scheduling knobs (performance only; results do not depend on them)
+    if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
+    if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
+    if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
+    if (c->tune.refillMinIdle < 1) c->tune.refillMinIdle = 1;
+    if (c->tune.otherMinLanes < 1) c->tune.otherMinLanes = 1;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
@@ -701,14 +841,21 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
 
     // validation: indices in range, stacks deep enough
     if (s->numObjects > 1 && s->numTopNodes == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene with more than one object needs a top-level BVH");
-    if (bvhDepth(s->topNodes, s->numTopNodes) > RT_TOP_STACK_SIZE) return fail(RTGPU_ERR_UNSUPPORTED, "top-level BVH deeper than the traversal stack");
+    const uint32_t topDepth = bvhDepth(s->topNodes, s->numTopNodes);
+    uint32_t maxMeshDepth = 0;
+    if (topDepth == 0xFFFFFFFFu) return fail(RTGPU_ERR_INVALID_ARGUMENT, "malformed top-level BVH");
     for (uint32_t i = 0; i < s->numMeshes; ++i)
     {
         const RtMesh& m = s->meshes[i];
         if ((uint64_t)m.firstNode + m.numNodes > s->numMeshNodes || (uint64_t)m.firstTriangle + m.numTriangles > s->numTriangles || (uint64_t)m.firstVertex + m.numVertices > s->numVertices)
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "mesh ranges out of bounds");
-        if (bvhDepth(s->meshNodes + m.firstNode, m.numNodes) > RT_MESH_STACK_SIZE) return fail(RTGPU_ERR_UNSUPPORTED, "mesh BVH deeper than the traversal stack");
+        const uint32_t md = bvhDepth(s->meshNodes + m.firstNode, m.numNodes);
+        if (md == 0xFFFFFFFFu) return fail(RTGPU_ERR_INVALID_ARGUMENT, "malformed mesh BVH");
+        if (md > maxMeshDepth) maxMeshDepth = md;
     }
+    if (topDepth + maxMeshDepth > 64) return fail(RTGPU_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack");
+    for (uint32_t i = 0; i < s->numTopNodes; ++i) if ((s->topNodes[i].leaves & 0x3FFFFFFFu) > RT_MAX_PACKED_LEAVES) return fail(RTGPU_ERR_UNSUPPORTED, "BVH leaves with more than 3 items are not supported");
+    for (uint32_t i = 0; i < s->numMeshNodes; ++i) if ((s->meshNodes[i].leaves & 0x3FFFFFFFu) > RT_MAX_PACKED_LEAVES) return fail(RTGPU_ERR_UNSUPPORTED, "BVH leaves with more than 3 items are not supported");
     for (uint32_t i = 0; i < s->numObjects; ++i)
     {
         const RtObject& o = s->objects[i];
@@ -741,6 +888,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
     c->sceneDev = d;
     c->numLights = s->numLights;
+    c->traversalStackNeed = topDepth + maxMeshDepth;
     c->sceneReady = true;
     return RTGPU_OK;
 }
@@ -837,14 +985,16 @@ static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
         HIP_TRY(hipMalloc((void**)&c->paths.base, floats * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&c->queues[0], cap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->queues[1], cap * sizeof(uint32_t)));
+        if ((unsigned long long)cap * maxLights >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x lights exceeds the NEE request index range");
+        HIP_TRY(hipMalloc((void**)&c->shadowQueue, cap * maxLights * sizeof(uint32_t)));
         c->paths.capacity = (uint32_t)cap; c->paths.maxLights = maxLights;
     }
-    if (c->queueCountCapacity < maxDepth + 3)
+    if (c->queueCountCapacity < maxDepth + 2)
     {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->queueCounts) (void)hipFree(c->queueCounts);
-        c->queueCountCapacity = maxDepth + 3;
-        HIP_TRY(hipMalloc((void**)&c->queueCounts, c->queueCountCapacity * sizeof(uint32_t)));
+        c->queueCountCapacity = maxDepth + 2;
+        HIP_TRY(hipMalloc((void**)&c->queueCounts, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t)));
     }
     return RTGPU_OK;
 }
@@ -895,32 +1045,43 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     const uint32_t maxBlocks = c->numCUs * 8u;
     const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), block(RT_BLOCK);
 
-    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, c->queueCountCapacity * sizeof(uint32_t), c->stream));
+    // persistent traversal grids: enough resident waves to cover the latency of dependent node fetches; surplus
+    // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
+    const bool smallStack = c->traversalStackNeed <= 32;
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (smallStack ? 5u : 2u)));
+    uint32_t* pathCounts = c->queueCounts;
+    uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
+    uint32_t* closestCursors = c->queueCounts + 2 * c->queueCountCapacity;
+    uint32_t* shadowCursors = c->queueCounts + 3 * c->queueCountCapacity;
+
+    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t), c->stream));
     {
         LaunchTimer t(c, KC_GENERATE);
-        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, c->slotPixel, c->numSlots, c->queues[0], c->queueCounts + 0, c->counters);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, c->slotPixel, c->numSlots, c->queues[0], pathCounts + 0, c->counters);
     }
     for (uint32_t depth = 0; depth <= p->maxRayDepth; ++depth)
     {
         uint32_t* qIn = c->queues[depth & 1u]; uint32_t* qOut = c->queues[(depth + 1u) & 1u];
-        uint32_t* cntIn = c->queueCounts + depth; uint32_t* cntOut = c->queueCounts + depth + 1;
+        uint32_t* cntIn = pathCounts + depth; uint32_t* cntOut = pathCounts + depth + 1;
         {
             LaunchTimer t(c, KC_TRACE_CLOSEST);
-            hipLaunchKernelGGL(k_trace_closest, grid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, c->counters);
+            if (smallStack) hipLaunchKernelGGL(k_trace_closest<32>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, closestCursors + depth, c->counters, c->tune);
+            else hipLaunchKernelGGL(k_trace_closest<64>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, closestCursors + depth, c->counters, c->tune);
         }
         {
             LaunchTimer t(c, KC_SHADE);
-            hipLaunchKernelGGL(k_shade, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, qOut, cntOut, c->counters);
+            hipLaunchKernelGGL(k_shade, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, qOut, cntOut, c->shadowQueue, shadowCounts + depth, c->counters);
         }
         if (c->numLights)
         {
             LaunchTimer t(c, KC_TRACE_SHADOW);
-            hipLaunchKernelGGL(k_trace_shadow, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, c->counters);
+            if (smallStack) hipLaunchKernelGGL(k_trace_shadow<32>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, c->shadowQueue, shadowCounts + depth, shadowCursors + depth, c->counters, c->tune);
+            else hipLaunchKernelGGL(k_trace_shadow<64>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, c->shadowQueue, shadowCounts + depth, shadowCursors + depth, c->counters, c->tune);
         }
     }
     {
         LaunchTimer t(c, KC_ACCUMULATE);
-        hipLaunchKernelGGL(k_accumulate, grid, block, 0, c->stream, c->paths, c->numSlots, c->sum, c->secondary, c->width, (p->passIndex % 2u) == 0u ? 1u : 0u);
+        hipLaunchKernelGGL(k_accumulate, grid, block, 0, c->stream, c->paths, c->numSlots, c->sum, c->secondary, c->width, (p->passIndex % 2u) == 0u ? 1u : 0u, pass);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->seedEvents[slot], c->stream));

@@ -1,0 +1,69 @@
+"""N > 1 path on CPU: two gloo ranks each render the tiles they own (with the CPU oracle standing in for the
+device pass -- same shard arithmetic, same per-pass constants from the same seed), the float3 sum buffers
+(disjoint support) are sum-reduced to rank 0 exactly like bench.py does over RCCL, and the result must equal the
+unsharded image bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import raytracer_amd as ra
+from raytracer_amd import scenes
+import oracle_lib
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+w, h = 200, 136
+scene, camera = scenes.cornell_box(w / h)
+bn = ra.load_blue_noise(); scene.desc.contents.blueNoise = bn.ctypes.data
+vp = ra.Viewport(w, h, seed=5, max_ray_depth=4)         # same seed on every rank => same per-pass constants
+img = np.zeros((h, w, 3), dtype=np.float32)
+cnt = np.zeros(16, dtype=np.uint64)
+for _ in range(2):
+    p = vp.next_pass_params(camera)
+    oracle_lib.render_pass(scene.desc, p, w, h, img, None, cnt, shard=(rank, world), threads=2)
+t = torch.from_numpy(img)
+dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+rays = torch.tensor([int(cnt[0])], dtype=torch.int64)
+dist.all_reduce(rays)
+if rank == 0:
+    np.save(out, np.concatenate([t.numpy().reshape(-1), np.array([float(rays.item())], dtype=np.float32)]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import raytracer_amd as ra
+    from raytracer_amd import scenes
+    import oracle_lib
+    w, h = 200, 136
+    scene, camera = scenes.cornell_box(w / h)
+    bn = ra.load_blue_noise()
+    scene.desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=5, max_ray_depth=4)
+    whole = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for _ in range(2):
+        oracle_lib.render_pass(scene.desc, vp.next_pass_params(camera), w, h, whole, None, cnt, threads=4)
+
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / "reduced.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29541", str(script), ROOT, out], env=env, timeout=600)
+    data = np.load(out)
+    reduced = data[:-1].reshape(h, w, 3)
+    assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))
+    assert int(data[-1]) == int(cnt[0])
