@@ -321,6 +321,12 @@ int rtgpu_get_device_sum(RtgpuContext* ctx, void** sumDevice, void** secondaryDe
  * difference two reads).  Synchronises. */
 int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
 
+/* Box / triangle test counters (numRayBoxTests ... numShadowRayTriangleTests).  In the reference they exist only
+ * under the compile-time switch RT_ENABLE_INTERSECTION_COUNTERS (Core/Config.h:4, off by default); here they are a
+ * run-time switch, ON by default.  numRays / numShadowRays / numShadowRaysHit / numPrimaryRays / hit counts are
+ * always maintained.  Synchronises. */
+int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
+
 /* --- measurement hooks (bench.py) ---------------------------------------------------------------
  * Per-kernel-class GPU time in milliseconds accumulated since rtgpu_reset, measured with HIP events
  * on the context's own stream when timing is enabled.  names[i] are static strings. */

@@ -305,6 +305,27 @@ RT_DEV void loadTriangle(const RtTriangle* t, V4& v0, V4& e1, V4& e2)
     v0 = V4(f[0], f[1], f[2], 0.0f); e1 = V4(f[3], f[4], f[5], 0.0f); e2 = V4(f[6], f[7], f[8], 0.0f);
 }
 
+// Slab test with hardware min/max (v_min_f32 / v_max_f32 / v_max3 / v_min3).  Valid ONLY for rays whose invDir and
+// originDivDir are finite: then fma(box, invDir, -originDivDir) can overflow to +-inf but never be NaN, and for
+// NaN-free inputs IEEE minNum/maxNum equal the _mm_min_ps/_mm_max_ps selects of intersectBoxRay bit for bit
+// (up to the sign of a zero, which no comparison downstream can observe).
+RT_DEV bool intersectBoxRayNoNaN(const Ray& ray, float minx, float miny, float minz, float maxx, float maxy, float maxz, float& outDistance)
+{
+    const float ax = __fmaf_rn(minx, ray.invDir.x, -ray.originDivDir.x), bx = __fmaf_rn(maxx, ray.invDir.x, -ray.originDivDir.x);
+    const float ay = __fmaf_rn(miny, ray.invDir.y, -ray.originDivDir.y), by = __fmaf_rn(maxy, ray.invDir.y, -ray.originDivDir.y);
+    const float az = __fmaf_rn(minz, ray.invDir.z, -ray.originDivDir.z), bz = __fmaf_rn(maxz, ray.invDir.z, -ray.originDivDir.z);
+    const float nearD = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float farD = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    outDistance = nearD;
+    return (farD >= nearD) && (farD >= 0.0f);
+}
+RT_DEV bool rayIsNaNFree(const Ray& r)
+{
+    const uint32_t inf = 0x7f800000u;
+    return ((__float_as_uint(r.invDir.x) & inf) != inf) && ((__float_as_uint(r.invDir.y) & inf) != inf) && ((__float_as_uint(r.invDir.z) & inf) != inf) &&
+           ((__float_as_uint(r.originDivDir.x) & inf) != inf) && ((__float_as_uint(r.originDivDir.y) & inf) != inf) && ((__float_as_uint(r.originDivDir.z) & inf) != inf);
+}
+
 // Tests both children of an interior node (Traversal_Single.h:44-63).  Returns the children as
 // (childIndex, leaves) words so that descending needs no further load.
 struct ChildTest { bool hitA, hitB; float distanceA, distanceB; uint32_t aChild, aLeaves, bChild, bLeaves; };
@@ -572,7 +593,10 @@ RT_DEV void meshEvaluateIntersection(const RtSceneDesc& d, const RtMesh& mesh, c
 }
 
 // Scene::EvaluateIntersection, Scene.cpp:305-365 (normal maps are outside the hot-path scope)
-RT_DEV void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
+// kLean: the uploaded scene contains only mesh shapes (no analytic shapes, no finite lights among the objects), so
+// the hit can only be a mesh triangle.
+template <bool kLean>
+__device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
 {
     const RtObject& obj = d.objects[hit.objectId];
     const M4 transform = loadM4(obj.transform);
@@ -580,7 +604,12 @@ RT_DEV void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, cons
     const V4 worldPosition = rayAt(ray, hit.distance);
     out.frame.r[3] = transformPoint(invTransform, worldPosition);
 
-    if (obj.objectKind == RT_OBJECT_LIGHT)       // LightSceneObject::EvaluateIntersection, SceneObject_Light.cpp:62-73
+    if (kLean)
+    {
+        out.material = obj.materialIndex;
+        meshEvaluateIntersection(d, d.meshes[obj.meshIndex], hit, out); cnt.c[C_MESH_HITS]++;
+    }
+    else if (obj.objectKind == RT_OBJECT_LIGHT)       // LightSceneObject::EvaluateIntersection, SceneObject_Light.cpp:62-73
     {
         const RtLight& L = d.lights[obj.lightIndex];
         shapeEvaluateIntersection(L.shapeKind, L.shapeParam, L.shapeParam2, out);
@@ -608,11 +637,14 @@ RT_DEV void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, cons
 struct IlluminateResult { V4 directionToLight; float distance, directPdfW, cosAtLight; };
 
 // ILight::Illuminate; returns radiance (4 lanes)
-RT_DEV V4 lightIlluminate(const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
+// kLean: the scene's lights are background and directional lights only
+template <bool kLean>
+__device__ __forceinline__ static V4 lightIlluminate(const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
 {
+    const uint32_t lightType = kLean ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
     out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
     const V4 color = load4(L.color);
-    switch (L.type)
+    switch (lightType)
     {
     case RT_LIGHT_AREA:          // AreaLight.cpp:55-107 (rendererSupportsSolidAngleSampling = true)
     {
@@ -679,9 +711,11 @@ RT_DEV V4 lightIlluminate(const RtLight& L, const Intersection& isect, const flo
 }
 
 // ILight::GetRadiance for a ray that hit / escaped; ray and hitPoint are in light space.
-RT_DEV V4 lightGetRadiance(const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
+template <bool kLean>
+__device__ __forceinline__ static V4 lightGetRadiance(const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
 {
-    switch (L.type)
+    const uint32_t lightType = kLean ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
+    switch (lightType)
     {
     case RT_LIGHT_AREA:          // AreaLight.cpp:109-147
         if (cosAtLight < RTD_EPSILON) return zero4();
@@ -1090,18 +1124,21 @@ RT_DEV void materialEvaluateShadingData(const RtMaterial& mat, ShadingData& sd)
     sd.mp.IoR = mat.IoR;
 }
 // Material::Evaluate, Material.cpp:160-180
-RT_DEV V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW)
+// kLean: every material of the scene uses the diffuse BSDF
+template <bool kLean>
+__device__ __forceinline__ static V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW)
 {
     const V4 incomingLocal = worldToLocal(sd.intersection, incomingDirWorldSpace);
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    return bsdfEvaluate(mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW);
+    return bsdfEvaluate(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW);
 }
 // Material::Sample, Material.cpp:182-232
-RT_DEV V4 materialSample(const RtMaterial& mat, const ShadingData& sd, const float u[3], V4& outIncomingDirWorldSpace, float& outPdfW, uint32_t& outEvent)
+template <bool kLean>
+__device__ __forceinline__ static V4 materialSample(const RtMaterial& mat, const ShadingData& sd, const float u[3], V4& outIncomingDirWorldSpace, float& outPdfW, uint32_t& outEvent)
 {
     BsdfSample s;
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    if (!bsdfSampleImpl(mat.bsdf, mat, sd.mp, u, outgoingLocal, s)) { outEvent = EV_NULL; return zero4(); }
+    if (!bsdfSampleImpl(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, u, outgoingLocal, s)) { outEvent = EV_NULL; return zero4(); }
     outIncomingDirWorldSpace = localToWorld(sd.intersection, s.incomingDir);
     outPdfW = s.pdf;
     outEvent = s.event;

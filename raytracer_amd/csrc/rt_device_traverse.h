@@ -9,10 +9,10 @@
 //   (a) refill lanes whose ray has finished with fresh rays from the queue (persistent threads),
 //   (b) keep its "nodes to visit" stack in LDS instead of scratch, and
 //   (c) run the two kinds of step as SEPARATE wave-wide phases: "interior" steps (two slab tests, ~90 % of all
-//       steps) and "other" steps (leaf triangles, per-object set-up, finishing).  Lanes that reach a leaf wait
-//       until enough lanes of the wave are at leaves too, instead of dragging the whole wave through the long
-//       triangle code on nearly every iteration (with 64 lanes and ~1 leaf per 16 steps, some lane is at a
-//       leaf 98 % of the time).
+//       steps, kept branch-light) and "other" steps (leaf triangles, per-object set-up, level exits, finishing).
+//       Lanes that reach a leaf wait until enough lanes of the wave are at leaves too, instead of dragging the
+//       whole wave through the long triangle code on nearly every iteration (with 64 lanes and ~1 leaf per 16
+//       steps, some lane is at a leaf 98 % of the time).
 //
 // Stack: one uint32 column per lane in LDS, shared by both levels -- the mesh level continues above the
 // entries the top level has pushed (meshBase remembers where the mesh's part starts).  An entry is the
@@ -33,22 +33,25 @@ enum TravMode : uint32_t
 
 #define RT_NODE_LEAVES_SHIFT 30u
 #define RT_NODE_CHILD_MASK 0x3FFFFFFFu
-#define RT_MAX_PACKED_LEAVES 3u   // numLeaves must fit two bits (the reference builds leaves of <= 2, BVHBuilder.h:16)
+#define RT_MAX_PACKED_LEAVES 3u    // numLeaves must fit two bits (the reference builds leaves of <= 2, BVHBuilder.h:16)
+#define RT_LEVEL_EXHAUSTED 0xFFFFFFFFu   // cur: the current level has no node left (its part of the stack is empty)
 
 RT_DEV uint32_t packNode(uint32_t childIndex, uint32_t leavesWord) { return childIndex | (leavesOf(leavesWord) << RT_NODE_LEAVES_SHIFT); }
 
 struct TravState
 {
     Ray ray;            // ray used for the tests of the current level (world ray, or the object's local ray)
-    Ray worldRay;       // saved world ray while inside a mesh
+    Ray worldRay;       // the world ray (object loop of top-level leaves, restored when a mesh is left)
     Hit hit;
     const RtNode* nodes;        // node array of the current level
     uint32_t mode;
-    uint32_t cur;               // packed current node
-    uint32_t stackSize, meshBase;
+    uint32_t cur;               // packed current node, or RT_LEVEL_EXHAUSTED
+    uint32_t stackSize, levelBase;   // levelBase: stack size at which the current level is exhausted
     uint32_t leafNext, leafEnd;
     uint32_t objectId;          // object whose mesh is being traversed
     uint32_t triBase;           // offset of the current mesh in triangles[]
+    bool nanFree;               // ray of the current level cannot produce NaNs in a slab test (rayIsNaNFree)
+    bool shadow;                // any-hit ray (Scene::Traverse_Shadow) instead of closest-hit (Scene::Traverse)
     bool occluded;              // shadow rays: result
 };
 
@@ -68,91 +71,104 @@ RT_DEV bool travIsInterior(const TravState& s)
 }
 
 // Scene::Traverse / Traverse_Shadow prologue (Scene.cpp:219-261): 0 objects, 1 object (BVH bypass), or the root.
-RT_DEV void travBegin(TravState& s, const RtSceneDesc& d, const Ray& worldRay, float maxDistance)
+RT_DEV void travBegin(TravState& s, const RtSceneDesc& d, const Ray& worldRay, float maxDistance, bool shadow)
 {
-    s.ray = worldRay; s.worldRay = worldRay;
+    s.ray = worldRay; s.worldRay = worldRay; s.shadow = shadow;
     s.hit.objectId = RT_INVALID_OBJECT; s.hit.subObjectId = 0; s.hit.distance = maxDistance; s.hit.u = 0.0f; s.hit.v = 0.0f;
-    s.stackSize = 0; s.meshBase = 0; s.leafNext = 0; s.leafEnd = 0; s.objectId = 0; s.triBase = 0;
-    s.cur = 0; s.occluded = false; s.nodes = d.topNodes;
+    s.stackSize = 0; s.levelBase = 0; s.leafNext = 0; s.leafEnd = 0; s.objectId = 0; s.triBase = 0;
+    s.cur = 0; s.occluded = false; s.nodes = d.topNodes; s.nanFree = rayIsNaNFree(worldRay);
     if (d.numObjects == 0) s.mode = TRAV_DONE;
     else if (d.numObjects == 1) { s.mode = TRAV_TOP_LEAF; s.leafNext = 0; s.leafEnd = 1; }
     else if (d.numTopNodes == 0) s.mode = TRAV_DONE;
     else { s.mode = TRAV_TOP_NODE; s.cur = packNode(d.topNodes[0].childIndex, d.topNodes[0].leaves); }
 }
 
-// next node of the current level, or leave the level when its part of the stack is empty
-RT_DEV void travPop(TravState& s, const RtSceneDesc& d, const LdsStack& stack)
-{
-    if (s.mode == TRAV_MESH)
-    {
-        if (s.stackSize == s.meshBase)
-        {
-            // GenericTraverse<MeshShape> returned: back to the object loop of the top-level leaf, in world space
-            s.ray = s.worldRay; s.nodes = d.topNodes;
-            s.mode = TRAV_TOP_LEAF;
-            return;
-        }
-        s.cur = stack.pop(s.stackSize);
-        return;
-    }
-    if (s.stackSize == 0) { s.mode = TRAV_DONE; return; }
-    s.cur = stack.pop(s.stackSize);
-    s.mode = TRAV_TOP_NODE;
-}
-
 // INTERIOR step: test both children, descend / push / pop (Traversal_Single.h:44-91 and :127-170).
-// Precondition: travIsInterior(s).
-template <bool kShadow>
-RT_DEV void travStepInterior(TravState& s, const RtSceneDesc& d, const LdsStack& stack, Counters& cnt)
+// Precondition: travIsInterior(s).  kExactMinMax selects the compare+select slab test that reproduces the
+// _mm_min_ps/_mm_max_ps NaN behaviour; the caller uses it whenever a lane of the wave is not nanFree.
+template <bool kCount, bool kExactMinMax>
+RT_DEV void travStepInterior(TravState& s, const LdsStack& stack, Counters& cnt)
 {
-    const uint32_t firstChild = s.cur & RT_NODE_CHILD_MASK;
-    const ChildTest t = testChildren<kShadow>(s.nodes, firstChild, s.ray, s.hit.distance, cnt);
-    const uint32_t a = packNode(t.aChild, t.aLeaves), b = packNode(t.bChild, t.bLeaves);
-    if (t.hitA && t.hitB)
+    const NodePair n = loadNodePair(s.nodes, s.cur & RT_NODE_CHILD_MASK);
+    float distanceA, distanceB;
+    bool hitA, hitB;
+    if (kExactMinMax)
     {
-        const bool swap = kShadow ? false : (t.distanceB < t.distanceA);   // closest: nearer child first; any-hit: A first
-        stack.push(s.stackSize, swap ? a : b);
-        s.cur = swap ? b : a;
-        return;
+        hitA = intersectBoxRay(s.ray, V4(n.a0.x, n.a0.y, n.a0.z, 0.0f), V4(n.a1.x, n.a1.y, n.a1.z, 0.0f), distanceA);
+        hitB = intersectBoxRay(s.ray, V4(n.b0.x, n.b0.y, n.b0.z, 0.0f), V4(n.b1.x, n.b1.y, n.b1.z, 0.0f), distanceB);
     }
-    if (t.hitA) { s.cur = a; return; }
-    if (t.hitB) { s.cur = b; return; }
-    travPop(s, d, stack);
+    else
+    {
+        hitA = intersectBoxRayNoNaN(s.ray, n.a0.x, n.a0.y, n.a0.z, n.a1.x, n.a1.y, n.a1.z, distanceA);
+        hitB = intersectBoxRayNoNaN(s.ray, n.b0.x, n.b0.y, n.b0.z, n.b1.x, n.b1.y, n.b1.z, distanceB);
+    }
+    hitA = hitA && (distanceA < s.hit.distance);   // box occlusion
+    hitB = hitB && (distanceB < s.hit.distance);
+    if (kCount)
+    {
+        cnt.c[C_BOX_SHADOW] += s.shadow ? 2u : 0u;
+        cnt.c[C_BOX] += s.shadow ? 0u : 2u;
+        cnt.c[C_BOX_PASS] += s.shadow ? 0u : ((hitA ? 1u : 0u) + (hitB ? 1u : 0u));
+    }
+    const uint32_t a = packNode(__float_as_uint(n.a0.w), __float_as_uint(n.a1.w));
+    const uint32_t b = packNode(__float_as_uint(n.b0.w), __float_as_uint(n.b1.w));
+    const bool both = hitA && hitB;
+    const bool swap = !s.shadow && both && (distanceB < distanceA);   // closest: nearer child first; any-hit: A first
+    if (both) stack.push(s.stackSize, swap ? a : b);
+    if (hitA || hitB) s.cur = (hitA && !swap) ? a : b;
+    else if (s.stackSize == s.levelBase) s.cur = RT_LEVEL_EXHAUSTED;        // handled by the "other" phase
+    else s.cur = stack.pop(s.stackSize);
 }
 
-// OTHER step: a mesh leaf, a top-level leaf header, or the next object of a top-level leaf.
+// next node of the current level after a leaf, or RT_LEVEL_EXHAUSTED
+RT_DEV void travNext(TravState& s, const LdsStack& stack)
+{
+    if (s.stackSize == s.levelBase) s.cur = RT_LEVEL_EXHAUSTED;
+    else s.cur = stack.pop(s.stackSize);
+}
+
+// OTHER step: a mesh leaf, a level exit, a top-level leaf header, or the next object of a top-level leaf.
 // Precondition: s.mode != TRAV_DONE && !travIsInterior(s).
-template <bool kShadow>
+template <bool kCount>
 RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& stack, Counters& cnt)
 {
     if (s.mode == TRAV_MESH)
     {
-        // MeshShape::Traverse_Leaf / Traverse_Leaf_Shadow
-        const uint32_t numLeaves = s.cur >> RT_NODE_LEAVES_SHIFT;
-        const uint32_t first = s.cur & RT_NODE_CHILD_MASK;
-        cnt.c[kShadow ? C_TRI_SHADOW : C_TRI] += numLeaves;
-        const RtTriangle* tris = d.triangles + s.triBase;
-        for (uint32_t i = 0; i < numLeaves; ++i)
+        if (s.cur != RT_LEVEL_EXHAUSTED)
         {
-            const uint32_t triangleIndex = first + i;
-            V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
-            float u, v, dist;
-            if (intersectTriangleRay(s.ray, v0, e1, e2, u, v, dist))
+            // MeshShape::Traverse_Leaf / Traverse_Leaf_Shadow
+            const uint32_t numLeaves = s.cur >> RT_NODE_LEAVES_SHIFT;
+            const uint32_t first = s.cur & RT_NODE_CHILD_MASK;
+            if (kCount) { cnt.c[C_TRI_SHADOW] += s.shadow ? numLeaves : 0u; cnt.c[C_TRI] += s.shadow ? 0u : numLeaves; }
+            const RtTriangle* tris = d.triangles + s.triBase;
+            for (uint32_t i = 0; i < numLeaves; ++i)
             {
-                if (dist < s.hit.distance)
+                const uint32_t triangleIndex = first + i;
+                V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
+                float u, v, dist;
+                if (intersectTriangleRay(s.ray, v0, e1, e2, u, v, dist))
                 {
-                    s.hit.distance = dist;
-                    if (kShadow) { s.occluded = true; s.mode = TRAV_DONE; return; }
-                    s.hit.subObjectId = triangleIndex; s.hit.objectId = s.objectId; s.hit.u = u; s.hit.v = v;
-                    cnt.c[C_TRI_PASS]++;
+                    if (dist < s.hit.distance)
+                    {
+                        s.hit.distance = dist;
+                        if (s.shadow) { s.occluded = true; s.mode = TRAV_DONE; return; }
+                        s.hit.subObjectId = triangleIndex; s.hit.objectId = s.objectId; s.hit.u = u; s.hit.v = v;
+                        if (kCount) cnt.c[C_TRI_PASS]++;
+                    }
                 }
             }
+            travNext(s, stack);
+            if (s.cur != RT_LEVEL_EXHAUSTED) return;
         }
-        travPop(s, d, stack);
+        // GenericTraverse<MeshShape> returned: back to the object loop of the top-level leaf, in world space
+        s.ray = s.worldRay; s.nanFree = rayIsNaNFree(s.worldRay);
+        s.nodes = d.topNodes; s.levelBase = 0;
+        s.mode = TRAV_TOP_LEAF;
         return;
     }
     if (s.mode == TRAV_TOP_NODE)
     {
+        if (s.cur == RT_LEVEL_EXHAUSTED) { s.mode = TRAV_DONE; return; }
         // Scene::Traverse_Leaf(_Shadow): objects [first, first + numLeaves)
         s.leafNext = s.cur & RT_NODE_CHILD_MASK; s.leafEnd = s.leafNext + (s.cur >> RT_NODE_LEAVES_SHIFT);
         s.mode = TRAV_TOP_LEAF;
@@ -161,7 +177,8 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
     if (s.leafNext >= s.leafEnd)
     {
         if (d.numObjects == 1) { s.mode = TRAV_DONE; return; }   // the bypass path has no stack
-        travPop(s, d, stack);
+        travNext(s, stack);
+        s.mode = (s.cur == RT_LEVEL_EXHAUSTED) ? TRAV_DONE : TRAV_TOP_NODE;
         return;
     }
     const uint32_t objectID = s.leafNext++;
@@ -172,7 +189,7 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
         float lightDistance;
         if (lightTestRayHit(d.lights[obj.lightIndex], lray, lightDistance))
         {
-            if (kShadow)
+            if (s.shadow)
             {
                 if (lightDistance < s.hit.distance) { s.hit.distance = lightDistance; s.occluded = true; s.mode = TRAV_DONE; }
             }
@@ -187,10 +204,10 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
     {
         const RtMesh& mesh = d.meshes[obj.meshIndex];
         if (mesh.numNodes == 0) return;
-        s.ray = lray;
+        s.ray = lray; s.nanFree = rayIsNaNFree(lray);
         s.objectId = objectID; s.triBase = mesh.firstTriangle;
         s.nodes = d.meshNodes + mesh.firstNode;
-        s.meshBase = s.stackSize;
+        s.levelBase = s.stackSize;
         s.cur = packNode(s.nodes[0].childIndex, s.nodes[0].leaves);
         s.mode = TRAV_MESH;
         return;
@@ -198,7 +215,7 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
     ShapeHit sh;
     if (shapeIntersect(obj.shapeKind, obj.shapeParam, lray, sh))
     {
-        if (kShadow)
+        if (s.shadow)
         {
             if (sh.farDist > 0.0f && sh.nearDist < s.hit.distance) { s.occluded = true; s.mode = TRAV_DONE; }
         }

@@ -138,15 +138,18 @@ RT_DEV Ray loadPathRay(const Paths& p, uint32_t slot, uint32_t depth)
 // =====================================================================================================
 
 // Viewport::RenderTile per-pixel prologue + Camera::GenerateRay (Viewport.cpp:305-331, Camera.cpp:81-118)
-__global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, const DevPass pass, const Paths paths,
-                                                       const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
+__global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass,
+                                                       const Paths paths, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
                                                        uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount,
                                                        unsigned long long* counters)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
     {
-        const uint32_t pix = slotPixel[slot];
+        // several passes ride in one batch: slot = passInBatch * slotsPerPass + pixelSlot
+        const uint32_t passInBatch = slot / slotsPerPass;
+        const DevPass& pass = passes[passInBatch];
+        const uint32_t pix = slotPixel[slot - passInBatch * slotsPerPass];
         const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
         const uint32_t realY = pass.height - 1u - y;
         // invSize = VECTOR_ONE2 / FromIntegers(w, h, 1, 1); coords = (FromIntegers(x, realY) + sampleOffset) * invSize
@@ -212,17 +215,25 @@ struct TravTuning
     uint32_t otherMinLanes;   // run the "other" phase (leaves, objects, finishing) once this many lanes wait for it
 };
 
-template <int kStack>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(const RtSceneDesc scene, const Paths paths,
-                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                            uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
+// ONE persistent traversal kernel per bounce: it serves the closest-hit rays of the paths alive at bounce k
+// (Scene::Traverse, Scene.cpp:219-243) AND the NEE shadow rays queued by the shade of bounce k-1
+// (Scene::Traverse_Shadow, Scene.cpp:245-261; PathTracerMIS.cpp:81-96).  The two sets are independent, and
+// serving them from one work cursor halves the number of launches whose tail (a few long rays keeping the
+// grid alive) would otherwise be paid twice.  An occluded NEE request is marked by tmax = -1; the contribution
+// is folded in later by resolvePendingLightSamples.
+template <int kStack, bool kCount>
+__global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, const Paths paths,
+                                                    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                    const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
+                                                    uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
     const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
-    const uint32_t count = *queueCount;
-    TravState s; s.mode = TRAV_DONE;
-    uint32_t slot = 0;
+    const uint32_t numClosest = queueCount ? *queueCount : 0u;
+    const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
+    TravState s; s.mode = TRAV_DONE; s.shadow = false;
+    uint32_t slot = 0, light = 0;
     bool have = false, exhausted = false;
     for (;;)
     {
@@ -236,9 +247,23 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(const RtSceneDesc sc
             const uint32_t idx = waveClaim(!have, cursor, claimedEnd);
             if (!have && idx < count)
             {
-                slot = queue[idx];
-                const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
-                travBegin(s, scene, loadPathRay(paths, slot, depth), __uint_as_float(0x7f800000u));
+                if (idx < numClosest)
+                {
+                    slot = queue[idx];
+                    const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
+                    travBegin(s, scene, loadPathRay(paths, slot, depth), __uint_as_float(0x7f800000u), false);
+                }
+                else
+                {
+                    const uint32_t request = shadowQueue[idx - numClosest];
+                    light = request / paths.capacity; slot = request - light * paths.capacity;
+                    const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
+                    const V4 dir(psh(paths, light, 0, slot), psh(paths, light, 1, slot), psh(paths, light, 2, slot), 0.0f);
+                    Ray shadowRay = makeRay(origin, dir);
+                    shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
+                    travBegin(s, scene, shadowRay, psh(paths, light, 3, slot), true);   // hitPoint.distance = illuminateResult.distance * 0.999f
+                    cnt.c[C_SHADOW]++;
+                }
                 have = true;
             }
             exhausted = claimedEnd >= count;
@@ -247,15 +272,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_closest(const RtSceneDesc sc
         if ((mI | mO) == 0ull) break;
         if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
         {
-            if (interior) travStepInterior<false>(s, scene, stack, cnt);
+            // hardware min/max unless some lane's ray could produce a NaN in a slab test (axis-parallel rays)
+            if (__all(!interior || s.nanFree)) { if (interior) travStepInterior<kCount, false>(s, stack, cnt); }
+            else if (interior) travStepInterior<kCount, true>(s, stack, cnt);
         }
         else if (other)
         {
-            if (s.mode != TRAV_DONE) travStepOther<false>(s, scene, stack, cnt);
+            if (s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt);
             if (s.mode == TRAV_DONE)
             {
-                pu(paths, F_HIT_OBJ, slot) = s.hit.objectId; pu(paths, F_HIT_SUB, slot) = s.hit.subObjectId;
-                pf(paths, F_HIT_DIST, slot) = s.hit.distance; pf(paths, F_HIT_U, slot) = s.hit.u; pf(paths, F_HIT_V, slot) = s.hit.v;
+                if (s.shadow)
+                {
+                    if (s.occluded) psh(paths, light, 3, slot) = -1.0f;
+                    else cnt.c[C_SHADOW_HIT]++;
+                }
+                else
+                {
+                    pu(paths, F_HIT_OBJ, slot) = s.hit.objectId; pu(paths, F_HIT_SUB, slot) = s.hit.subObjectId;
+                    pf(paths, F_HIT_DIST, slot) = s.hit.distance; pf(paths, F_HIT_U, slot) = s.hit.u; pf(paths, F_HIT_V, slot) = s.hit.v;
+                }
                 have = false;
             }
         }
@@ -268,18 +303,19 @@ RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDi
 
 // PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
 // request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
-RT_DEV bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
+template <bool kLean>
+__device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
                                const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
                                const Paths& paths, uint32_t slot, uint32_t requestIndex)
 {
     float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
     float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
     IlluminateResult ir;
-    const V4 radiance = lightIlluminate(light, sd.intersection, u, ir);
+    const V4 radiance = lightIlluminate<kLean>(light, sd.intersection, u, ir);
     if (!almostZero4(radiance))
     {
         float bsdfPdfW = 0.0f;
-        const V4 factor = materialEvaluate(mat, sd, neg(ir.directionToLight), bsdfPdfW);
+        const V4 factor = materialEvaluate<kLean>(mat, sd, neg(ir.directionToLight), bsdfPdfW);
         if (!almostZero4(factor))
         {
             float weight = 1.0f;
@@ -325,7 +361,8 @@ RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, V4 lig
 }
 
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395)
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass pass, const Paths paths,
+template <bool kLean>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
                                                     const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                     uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                     uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -334,6 +371,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     Counters cnt; zeroCounters(cnt);
     const uint32_t count = *countIn;
     const uint32_t stride = gridDim.x * blockDim.x;
+    // the structural parameters are identical for all passes of a batch (the host flushes when they change);
+    // seeds, camera, anti-aliasing offset and rng keys are per pass
+    const DevPass pass = passes[0];
     const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
     // GetLightPickingProbability, PathTracerMIS.cpp:157-172
     const float lightPickProbability = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1.0f / (float)scene.numLights : 1.0f;
@@ -371,7 +411,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         const RtLight& light = scene.lights[scene.globalLights[g]];
                         const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
                         float directPdfW = 0.0f;
-                        const V4 lightContribution = lightGetRadiance(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+                        const V4 lightContribution = lightGetRadiance<kLean>(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
                         if (!almostZero4(lightContribution))
                         {
                             float misWeight = 1.0f;
@@ -386,9 +426,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
 
                 ShadingData sd;
                 sd.intersection.material = RT_NO_MATERIAL;
-                if (hit.distance < FLT_MAX) sceneEvaluateIntersection(scene, ray, hit, sd.intersection, cnt);
+                if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
 
-                if (hit.subObjectId == RT_LIGHT_OBJECT)
+                if (!kLean && hit.subObjectId == RT_LIGHT_OBJECT)
                 {
                     // EvaluateLight, PathTracerMIS.cpp:174-212
                     const RtObject& obj = scene.objects[hit.objectId];
@@ -398,7 +438,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                     const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
                     const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
                     float directPdfA = 0.0f;
-                    V4 lightContribution = lightGetRadiance(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+                    V4 lightContribution = lightGetRadiance<false>(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
                     if (!almostZero4(lightContribution))
                     {
                         float misWeight = 1.0f;
@@ -425,6 +465,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                 resultColor = mulAdd(throughput, sd.mp.emission * bsdfSamplingWeight, resultColor);
 
                 Sampler sampler; loadSampler(sampler, paths, slot, pass, scene.blueNoise);
+                sampler.seed = passes[slot / slotsPerPass].seed;
 
                 // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
                 uint32_t numRequests = 0;
@@ -434,14 +475,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                     {
                         uint32_t lightIndex = 0;
                         if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
-                        if (prepareLightSample(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0)) rayMask = 1ull;
+                        if (prepareLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0)) rayMask = 1ull;
                         numRequests = 1;
                     }
                     else
                     {
                         for (uint32_t l = 0; l < scene.numLights; ++l)
                         {
-                            const bool ray = prepareLightSample(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
+                            const bool ray = prepareLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
                             if (ray)
                             {
                                 if (l < 64u) rayMask |= 1ull << l;
@@ -472,7 +513,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                 {
                     float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
                     float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
-                    const V4 bsdfValue = materialSample(mat, sd, u, incomingDirWorldSpace, pdf, event);
+                    const V4 bsdfValue = materialSample<kLean>(mat, sd, u, incomingDirWorldSpace, pdf, event);
                     if (event == EV_NULL) cont = false;
                     else
                     {
@@ -527,83 +568,30 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     flushCounters(cnt, counters);
 }
 
-// Occlusion test of the queued NEE rays (PathTracerMIS.cpp:81-96): Scene::Traverse_Shadow, persistent threads.
-// An occluded request is marked by tmax = -1; the contribution is folded in by resolvePendingLightSamples.
-template <int kStack>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace_shadow(const RtSceneDesc scene, const Paths paths,
-                                                           const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
-                                                           uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
+// Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y.  The passes of a
+// batch are added per pixel IN PASS ORDER, so the float sum is the one the reference builds pass after pass; the
+// secondary sum receives the even passes (Viewport.cpp:303).
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t slotsPerPass, uint32_t numPasses, float* __restrict__ sum,
+                                                         float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes)
 {
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
-    const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
-    Counters cnt; zeroCounters(cnt);
-    const uint32_t count = *shadowCount;
-    TravState s; s.mode = TRAV_DONE;
-    uint32_t slot = 0, light = 0;
-    bool have = false, exhausted = false;
-    for (;;)
-    {
-        const bool interior = have && travIsInterior(s);
-        const bool other = have && !interior;
-        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
-        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
-        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
-        {
-            uint32_t claimedEnd;
-            const uint32_t idx = waveClaim(!have, cursor, claimedEnd);
-            if (!have && idx < count)
-            {
-                const uint32_t request = shadowQueue[idx];
-                light = request / paths.capacity; slot = request - light * paths.capacity;
-                const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
-                const V4 dir(psh(paths, light, 0, slot), psh(paths, light, 1, slot), psh(paths, light, 2, slot), 0.0f);
-                Ray shadowRay = makeRay(origin, dir);
-                shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
-                travBegin(s, scene, shadowRay, psh(paths, light, 3, slot));   // hitPoint.distance = illuminateResult.distance * 0.999f
-                cnt.c[C_SHADOW]++;
-                have = true;
-            }
-            exhausted = claimedEnd >= count;
-            continue;
-        }
-        if ((mI | mO) == 0ull) break;
-        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
-        {
-            if (interior) travStepInterior<true>(s, scene, stack, cnt);
-        }
-        else if (other)
-        {
-            if (s.mode != TRAV_DONE) travStepOther<true>(s, scene, stack, cnt);
-            if (s.mode == TRAV_DONE)
-            {
-                if (s.occluded) psh(paths, light, 3, slot) = -1.0f;
-                else cnt.c[C_SHADOW_HIT]++;
-                have = false;
-            }
-        }
-    }
-    flushCounters(cnt, counters);
-}
-
-// Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t numSlots, float* __restrict__ sum,
-                                                         float* __restrict__ secondary, uint32_t width, uint32_t evenPass,
-                                                         const DevPass pass)
-{
-    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight);
+    const V4 lightSamplingWeight = load4(passes[0].lightSamplingWeight);
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < slotsPerPass; pixelSlot += stride)
     {
-        const uint32_t pix = pu(paths, F_PIXEL, slot);
+        const uint32_t pix = pu(paths, F_PIXEL, pixelSlot);
         const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
-        V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
-        resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the path's last vertex
-        const float r = resultColor.x, g = resultColor.y, b = resultColor.z;
-        sum[idx + 0] = sum[idx + 0] + r; sum[idx + 1] = sum[idx + 1] + g; sum[idx + 2] = sum[idx + 2] + b;
-        if (evenPass)
+        float sr = sum[idx + 0], sg = sum[idx + 1], sb = sum[idx + 2];
+        float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
+        for (uint32_t b = 0; b < numPasses; ++b)
         {
-            secondary[idx + 0] = secondary[idx + 0] + r; secondary[idx + 1] = secondary[idx + 1] + g; secondary[idx + 2] = secondary[idx + 2] + b;
+            const uint32_t slot = b * slotsPerPass + pixelSlot;
+            V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
+            resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the path's last vertex
+            sr = sr + resultColor.x; sg = sg + resultColor.y; sb = sb + resultColor.z;
+            if ((passes[b].passIndex % 2u) == 0u) { tr = tr + resultColor.x; tg = tg + resultColor.y; tb = tb + resultColor.z; }
         }
+        sum[idx + 0] = sr; sum[idx + 1] = sg; sum[idx + 2] = sb;
+        secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
 }
 
@@ -622,10 +610,12 @@ static int fail(int code, const std::string& msg) { gLastError = msg; return cod
                         std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
-enum KernelClass { KC_GENERATE = 0, KC_TRACE_CLOSEST, KC_SHADE, KC_TRACE_SHADOW, KC_ACCUMULATE, KC_COUNT };
-static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace_closest", "shade", "trace_shadow", "accumulate", "", "", "" };
+enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_COUNT };
+static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "", "", "", "" };
 
 #define RT_SEED_RING 32
+
+struct CtxPending { DevPass pass; std::vector<uint32_t> seeds; };
 
 struct RtgpuContext
 {
@@ -650,7 +640,7 @@ struct RtgpuContext
     // paths
     Paths paths = { nullptr, 0, 0 };
     uint32_t* queues[2] = { nullptr, nullptr };
-    uint32_t* shadowQueue = nullptr;   // capacity * maxLights NEE ray requests
+    uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
     // per-pass work counters, 4 planes of (maxDepth + 2) uint32, zeroed once per pass: path-queue counts,
     // shadow-queue counts, closest-kernel cursors, shadow-kernel cursors (one of each per bounce, so that no
     // reset ever races with a reader)
@@ -659,7 +649,16 @@ struct RtgpuContext
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
     TravTuning tune = { 44u, 16u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
+    bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
+    bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
     unsigned long long* counters = nullptr;   // 16 x u64
+
+    // passes queued by rtgpu_render_pass and not yet submitted: up to passBatch of them ride through ONE launch
+    // sequence (their paths are simply more slots), which amortises the per-launch tail of the persistent kernels
+    std::vector<CtxPending> pending;
+    uint32_t passBatch = 8;
+    DevPass* passRingDev = nullptr;
+    DevPass* passRingHost = nullptr;    // pinned
 
     // per-pass seed ring
     uint32_t* seedRingDev = nullptr;
@@ -698,9 +697,10 @@ static void freePaths(RtgpuContext* c)
     if (c->paths.base) (void)hipFree(c->paths.base);
     if (c->queues[0]) (void)hipFree(c->queues[0]);
     if (c->queues[1]) (void)hipFree(c->queues[1]);
-    if (c->shadowQueue) (void)hipFree(c->shadowQueue);
+    if (c->shadowQueues[0]) (void)hipFree(c->shadowQueues[0]);
+    if (c->shadowQueues[1]) (void)hipFree(c->shadowQueues[1]);
     c->paths.base = nullptr; c->paths.capacity = 0; c->paths.maxLights = 0;
-    c->queues[0] = c->queues[1] = nullptr; c->shadowQueue = nullptr;
+    c->queues[0] = c->queues[1] = nullptr; c->shadowQueues[0] = c->shadowQueues[1] = nullptr;
 }
 
 static int resolveTimed(RtgpuContext* c)
@@ -737,6 +737,8 @@ struct LaunchTimer
         if (c->timing) { (void)hipEventRecord(b, c->stream); c->pendingTimed.push_back({ kc, a, b }); }
     }
 };
+
+static int flushPending(RtgpuContext* c);
 
 template <typename T>
 static int uploadArray(RtgpuContext* c, const T* host, size_t count, const T** outDev)
@@ -797,6 +799,9 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
+    if (const char* e = getenv("RTGPU_PASS_BATCH")) c->passBatch = (uint32_t)atoi(e);
+    if (c->passBatch < 1) c->passBatch = 1;
+    if (c->passBatch > RT_SEED_RING / 2) c->passBatch = RT_SEED_RING / 2;
     if (c->tune.refillMinIdle < 1) c->tune.refillMinIdle = 1;
     if (c->tune.otherMinLanes < 1) c->tune.otherMinLanes = 1;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -804,6 +809,8 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&c->seedRingDev, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->seedRingHost, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->passRingDev, (size_t)RT_SEED_RING * sizeof(DevPass));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->passRingHost, (size_t)RT_SEED_RING * sizeof(DevPass), hipHostMallocDefault);
     for (int i = 0; i < RT_SEED_RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->seedEvents[i], hipEventDisableTiming);
     if (e != hipSuccess)
     {
@@ -825,6 +832,8 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
     if (c->counters) (void)hipFree(c->counters);
     if (c->seedRingDev) (void)hipFree(c->seedRingDev);
     if (c->seedRingHost) (void)hipHostFree(c->seedRingHost);
+    if (c->passRingDev) (void)hipFree(c->passRingDev);
+    if (c->passRingHost) (void)hipHostFree(c->passRingHost);
     for (int i = 0; i < RT_SEED_RING; ++i) if (c->seedEvents[i]) (void)hipEventDestroy(c->seedEvents[i]);
     for (auto& t : c->pendingTimed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
@@ -837,6 +846,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if (!c || !s) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
     if (s->abiVersion != RTGPU_ABI_VERSION) return fail(RTGPU_ERR_INVALID_ARGUMENT, "RtSceneDesc::abiVersion mismatch");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     // validation: indices in range, stacks deep enough
@@ -889,6 +899,11 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     c->sceneDev = d;
     c->numLights = s->numLights;
     c->traversalStackNeed = topDepth + maxMeshDepth;
+    bool lean = getenv("RTGPU_NO_LEAN") == nullptr;
+    for (uint32_t i = 0; i < s->numObjects && lean; ++i) lean = s->objects[i].objectKind == RT_OBJECT_SHAPE && s->objects[i].shapeKind == RT_SHAPE_MESH;
+    for (uint32_t i = 0; i < s->numMaterials && lean; ++i) lean = s->materials[i].bsdf == RT_BSDF_DIFFUSE;
+    for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].type == RT_LIGHT_BACKGROUND || s->lights[i].type == RT_LIGHT_DIRECTIONAL;
+    c->leanScene = lean;
     c->sceneReady = true;
     return RTGPU_OK;
 }
@@ -941,6 +956,7 @@ RTGPU_API int rtgpu_resize(RtgpuContext* c, uint32_t width, uint32_t height)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (width == 0 || height == 0 || width > 65536u || height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid viewport size");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->width = width; c->height = height;
     return rebuildFilm(c);
@@ -951,6 +967,7 @@ RTGPU_API int rtgpu_set_shard(RtgpuContext* c, RtgpuShard shard)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (shard.worldSize == 0 || shard.rank >= shard.worldSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid shard");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->shard = shard;
     return rebuildFilm(c);
@@ -960,6 +977,7 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     HIP_TRY(hipSetDevice(c->device));
+    { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->sum)
     {
@@ -976,17 +994,20 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
 static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    if (!c->paths.base || c->paths.capacity < c->numSlots || c->paths.maxLights < maxLights)
+    const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * c->passBatch;
+    if (!c->paths.base || c->paths.capacity < wanted || c->paths.maxLights < maxLights)
     {
         HIP_TRY(hipStreamSynchronize(c->stream));
         freePaths(c);
-        const size_t cap = c->numSlots ? c->numSlots : 1;
+        if (wanted >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
+        const size_t cap = wanted;
         const size_t floats = ((size_t)F_NUM_BASE + (size_t)maxLights * RT_SHADOW_STRIDE) * cap;
         HIP_TRY(hipMalloc((void**)&c->paths.base, floats * sizeof(float)));
         HIP_TRY(hipMalloc((void**)&c->queues[0], cap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->queues[1], cap * sizeof(uint32_t)));
         if ((unsigned long long)cap * maxLights >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x lights exceeds the NEE request index range");
-        HIP_TRY(hipMalloc((void**)&c->shadowQueue, cap * maxLights * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->shadowQueues[0], cap * maxLights * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->shadowQueues[1], cap * maxLights * sizeof(uint32_t)));
         c->paths.capacity = (uint32_t)cap; c->paths.maxLights = maxLights;
     }
     if (c->queueCountCapacity < maxDepth + 2)
@@ -995,6 +1016,98 @@ static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
         if (c->queueCounts) (void)hipFree(c->queueCounts);
         c->queueCountCapacity = maxDepth + 2;
         HIP_TRY(hipMalloc((void**)&c->queueCounts, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t)));
+    }
+    return RTGPU_OK;
+}
+
+// Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.
+static int flushPending(RtgpuContext* c)
+{
+    if (c->pending.empty()) return RTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t numPasses = (uint32_t)c->pending.size();
+    const DevPass& first = c->pending[0].pass;
+    const uint32_t maxLights = first.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
+    int r = ensurePaths(c, maxLights, first.maxRayDepth);
+    if (r) { c->pending.clear(); return r; }
+
+    // contiguous ring slots for the batch (seeds + pass constants); wait until their previous users have finished
+    if (c->seedCursor + numPasses > RT_SEED_RING) c->seedCursor = 0;
+    const uint32_t firstSlot = c->seedCursor; c->seedCursor = (c->seedCursor + numPasses) % RT_SEED_RING;
+    for (uint32_t i = 0; i < numPasses; ++i)
+    {
+        const uint32_t slot = firstSlot + i;
+        if (c->seedEventUsed[slot]) HIP_TRY(hipEventSynchronize(c->seedEvents[slot]));
+        uint32_t* seedHost = c->seedRingHost + (size_t)slot * RTGPU_MAX_DIMENSIONS;
+        uint32_t* seedDev = c->seedRingDev + (size_t)slot * RTGPU_MAX_DIMENSIONS;
+        CtxPending& pd = c->pending[i];
+        if (!pd.seeds.empty())
+        {
+            memcpy(seedHost, pd.seeds.data(), pd.seeds.size() * sizeof(uint32_t));
+            HIP_TRY(hipMemcpyAsync(seedDev, seedHost, pd.seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        }
+        pd.pass.seed = seedDev;
+        c->passRingHost[slot] = pd.pass;
+    }
+    HIP_TRY(hipMemcpyAsync(c->passRingDev + firstSlot, c->passRingHost + firstSlot, numPasses * sizeof(DevPass), hipMemcpyHostToDevice, c->stream));
+    const DevPass* passesDev = c->passRingDev + firstSlot;
+
+    const uint32_t totalSlots = c->numSlots * numPasses;
+    const uint32_t maxBlocks = c->numCUs * 8u;
+    const uint32_t blocksNeeded = (totalSlots + RT_BLOCK - 1) / RT_BLOCK;
+    const uint32_t pixelBlocks = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
+    const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), pixelGrid(pixelBlocks < maxBlocks ? pixelBlocks : maxBlocks), block(RT_BLOCK);
+
+    // persistent traversal grids: enough resident waves to cover the latency of dependent node fetches; surplus
+    // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
+    const bool smallStack = c->traversalStackNeed <= 32;
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (smallStack ? 5u : 2u)));
+    uint32_t* pathCounts = c->queueCounts;
+    uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
+    uint32_t* cursors = c->queueCounts + 2 * c->queueCountCapacity;
+    const uint32_t maxRayDepth = first.maxRayDepth;
+
+    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t), c->stream));
+    {
+        LaunchTimer t(c, KC_GENERATE);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, passesDev, c->numSlots, c->paths, c->slotPixel, totalSlots, c->queues[0], pathCounts + 0, c->counters);
+    }
+#define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, c->stream, c->sceneDev, c->paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
+    // bounce k: trace {closest rays of bounce k, NEE rays of bounce k-1} -> shade k; one last trace for the NEE rays of
+    // the final bounce
+    for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
+    {
+        const bool haveClosest = depth <= maxRayDepth;
+        const bool haveShadow = depth > 0 && c->numLights != 0;
+        if (haveClosest || haveShadow)
+        {
+            const uint32_t* tq = haveClosest ? c->queues[depth & 1u] : nullptr;
+            const uint32_t* tqc = haveClosest ? pathCounts + depth : nullptr;
+            const uint32_t* tsq = haveShadow ? c->shadowQueues[(depth - 1u) & 1u] : nullptr;
+            const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
+            const uint32_t launchIndex = depth;
+            LaunchTimer t(c, KC_TRACE);
+            if (smallStack) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
+            else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
+        }
+        if (haveClosest)
+        {
+            LaunchTimer t(c, KC_SHADE);
+#define RT_LAUNCH_SHADE(L) hipLaunchKernelGGL((k_shade<L>), grid, block, 0, c->stream, c->sceneDev, passesDev, c->numSlots, c->paths, c->queues[depth & 1u], pathCounts + depth, \
+                                             c->queues[(depth + 1u) & 1u], pathCounts + depth + 1, c->shadowQueues[depth & 1u], shadowCounts + depth, c->counters)
+            if (c->leanScene) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
+        }
+    }
+    {
+        LaunchTimer t(c, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, c->stream, c->paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
+    }
+    c->pending.clear();
+    HIP_TRY(hipGetLastError());
+    for (uint32_t i = 0; i < numPasses; ++i)
+    {
+        HIP_TRY(hipEventRecord(c->seedEvents[firstSlot + i], c->stream));
+        c->seedEventUsed[firstSlot + i] = true;
     }
     return RTGPU_OK;
 }
@@ -1008,27 +1121,13 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions > 0 && !p->seed) return fail(RTGPU_ERR_INVALID_ARGUMENT, "seed is NULL");
     if (p->maxRayDepth >= 255u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxRayDepth must be < 255");
     if (p->camera.dofEnable && p->camera.bokehShape != 0) return fail(RTGPU_ERR_UNSUPPORTED, "only circular bokeh is implemented");
-    HIP_TRY(hipSetDevice(c->device));
     if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
 
-    const uint32_t maxLights = p->lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
-    int r = ensurePaths(c, maxLights, p->maxRayDepth); if (r) return r;
-
-    // stage the seeds in the ring slot (wait until the pass that last used the slot has consumed it)
-    const uint32_t slot = c->seedCursor; c->seedCursor = (c->seedCursor + 1) % RT_SEED_RING;
-    if (c->seedEventUsed[slot]) HIP_TRY(hipEventSynchronize(c->seedEvents[slot]));
-    uint32_t* seedHost = c->seedRingHost + (size_t)slot * RTGPU_MAX_DIMENSIONS;
-    uint32_t* seedDev = c->seedRingDev + (size_t)slot * RTGPU_MAX_DIMENSIONS;
-    if (p->numDimensions)
-    {
-        memcpy(seedHost, p->seed, p->numDimensions * sizeof(uint32_t));
-        HIP_TRY(hipMemcpyAsync(seedDev, seedHost, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    }
-
-    DevPass pass;
+    CtxPending pd;
+    DevPass& pass = pd.pass;
     memset(&pass, 0, sizeof(pass));
     pass.camera = p->camera;
-    pass.seed = seedDev;
+    pass.seed = nullptr;   // assigned when the batch is submitted
     pass.numDimensions = p->numDimensions;
     pass.blueNoiseLayers = (c->sceneDev.blueNoise && p->useBlueNoise) ? 4u : 0u;   // GenericSampler.cpp:69-73
     pass.sampleOffset[0] = p->sampleOffset[0]; pass.sampleOffset[1] = p->sampleOffset[1];
@@ -1040,52 +1139,19 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     memcpy(pass.bsdfSamplingWeight, p->bsdfSamplingWeight, 16);
     pass.rngKey[0] = p->rngKey[0]; pass.rngKey[1] = p->rngKey[1];
     pass.width = c->width; pass.height = c->height;
+    pd.seeds.assign(p->seed, p->seed + p->numDimensions);   // the caller's array may be reused right away
 
-    const uint32_t blocksNeeded = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
-    const uint32_t maxBlocks = c->numCUs * 8u;
-    const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), block(RT_BLOCK);
-
-    // persistent traversal grids: enough resident waves to cover the latency of dependent node fetches; surplus
-    // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
-    const bool smallStack = c->traversalStackNeed <= 32;
-    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (smallStack ? 5u : 2u)));
-    uint32_t* pathCounts = c->queueCounts;
-    uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
-    uint32_t* closestCursors = c->queueCounts + 2 * c->queueCountCapacity;
-    uint32_t* shadowCursors = c->queueCounts + 3 * c->queueCountCapacity;
-
-    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t), c->stream));
+    // all passes of a batch share the structural parameters; a change submits what is queued first
+    if (!c->pending.empty())
     {
-        LaunchTimer t(c, KC_GENERATE);
-        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, c->slotPixel, c->numSlots, c->queues[0], pathCounts + 0, c->counters);
+        const DevPass& f = c->pending[0].pass;
+        const bool same = f.numDimensions == pass.numDimensions && f.blueNoiseLayers == pass.blueNoiseLayers && f.maxRayDepth == pass.maxRayDepth &&
+                          f.minRussianRouletteDepth == pass.minRussianRouletteDepth && f.lightSamplingStrategy == pass.lightSamplingStrategy &&
+                          memcmp(f.lightSamplingWeight, pass.lightSamplingWeight, 16) == 0 && memcmp(f.bsdfSamplingWeight, pass.bsdfSamplingWeight, 16) == 0;
+        if (!same) { int r = flushPending(c); if (r) return r; }
     }
-    for (uint32_t depth = 0; depth <= p->maxRayDepth; ++depth)
-    {
-        uint32_t* qIn = c->queues[depth & 1u]; uint32_t* qOut = c->queues[(depth + 1u) & 1u];
-        uint32_t* cntIn = pathCounts + depth; uint32_t* cntOut = pathCounts + depth + 1;
-        {
-            LaunchTimer t(c, KC_TRACE_CLOSEST);
-            if (smallStack) hipLaunchKernelGGL(k_trace_closest<32>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, closestCursors + depth, c->counters, c->tune);
-            else hipLaunchKernelGGL(k_trace_closest<64>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, qIn, cntIn, closestCursors + depth, c->counters, c->tune);
-        }
-        {
-            LaunchTimer t(c, KC_SHADE);
-            hipLaunchKernelGGL(k_shade, grid, block, 0, c->stream, c->sceneDev, pass, c->paths, qIn, cntIn, qOut, cntOut, c->shadowQueue, shadowCounts + depth, c->counters);
-        }
-        if (c->numLights)
-        {
-            LaunchTimer t(c, KC_TRACE_SHADOW);
-            if (smallStack) hipLaunchKernelGGL(k_trace_shadow<32>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, c->shadowQueue, shadowCounts + depth, shadowCursors + depth, c->counters, c->tune);
-            else hipLaunchKernelGGL(k_trace_shadow<64>, travGrid, block, 0, c->stream, c->sceneDev, c->paths, c->shadowQueue, shadowCounts + depth, shadowCursors + depth, c->counters, c->tune);
-        }
-    }
-    {
-        LaunchTimer t(c, KC_ACCUMULATE);
-        hipLaunchKernelGGL(k_accumulate, grid, block, 0, c->stream, c->paths, c->numSlots, c->sum, c->secondary, c->width, (p->passIndex % 2u) == 0u ? 1u : 0u, pass);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->seedEvents[slot], c->stream));
-    c->seedEventUsed[slot] = true;
+    c->pending.push_back(std::move(pd));
+    if (c->pending.size() >= c->passBatch) return flushPending(c);
     return RTGPU_OK;
 }
 
@@ -1093,6 +1159,7 @@ RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     HIP_TRY(hipSetDevice(c->device));
+    { int r = flushPending(c); if (r) return r; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return resolveTimed(c);
 }
@@ -1130,6 +1197,14 @@ RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
     out->numRayTriangleTests = host[C_TRI]; out->numPassedRayTriangleTests = host[C_TRI_PASS];
     out->numMeshHits = host[C_MESH_HITS]; out->numAnalyticHits = host[C_ANALYTIC_HITS];
     out->numShadowRayBoxTests = host[C_BOX_SHADOW]; out->numShadowRayTriangleTests = host[C_TRI_SHADOW];
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    c->countIntersections = enable != 0;
     return RTGPU_OK;
 }
 

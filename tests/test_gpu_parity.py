@@ -96,6 +96,43 @@ def test_single_object_scene_bypasses_top_bvh(built):
     assert_identical(*run_both(scene, camera, w, h, passes=2, max_ray_depth=8))
 
 
+def test_lean_and_generic_shade_variants_agree(built, monkeypatch):
+    """Scenes with only meshes / diffuse materials / background + directional lights run a feature-specialised shade
+    kernel; it must produce exactly what the generic kernel produces (RTGPU_NO_LEAN forces the generic one)."""
+    w, h = 128, 72
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
+    images = []
+    for no_lean in (False, True):
+        if no_lean:
+            monkeypatch.setenv("RTGPU_NO_LEAN", "1")
+        else:
+            monkeypatch.delenv("RTGPU_NO_LEAN", raising=False)
+        vp = ra.Viewport(w, h, seed=11, max_ray_depth=8)
+        vp.set_renderer(scene)
+        vp.render(camera, 3)
+        images.append((vp.sum_buffer(), vp.counters()))
+    assert np.array_equal(images[0][0].view(np.uint32), images[1][0].view(np.uint32))
+    assert images[0][1] == images[1][1]
+
+
+def test_pass_batching_is_invisible(built, monkeypatch):
+    """Up to RTGPU_PASS_BATCH passes share one launch sequence; per-pixel accumulation stays in pass order, so any
+    batch size gives the same bits (5 passes: full batches + a partial one)."""
+    w, h = 96, 72
+    scene, camera = scenes.cornell_box(w / h)
+    results = []
+    for batch in ("1", "2", "8"):
+        monkeypatch.setenv("RTGPU_PASS_BATCH", batch)
+        vp = ra.Viewport(w, h, seed=21, max_ray_depth=4)
+        vp.set_renderer(scene)
+        vp.render(camera, 5)
+        results.append((vp.sum_buffer(secondary=True), vp.counters()))
+    for r in results[1:]:
+        assert np.array_equal(r[0][0].view(np.uint32), results[0][0][0].view(np.uint32))
+        assert np.array_equal(r[0][1].view(np.uint32), results[0][0][1].view(np.uint32))
+        assert r[1] == results[0][1]
+
+
 def test_depth_of_field(built):
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
