@@ -192,7 +192,7 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(dom)
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch_upper")
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

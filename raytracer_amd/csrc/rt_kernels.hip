@@ -193,22 +193,35 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, 
     }
 }
 
-// Wave-level work fetch for the persistent kernels: lanes without a ray claim consecutive queue indices with ONE
-// atomic per wave.  Returns the claimed index (>= count when the queue is exhausted) for lanes with want == true.
-RT_DEV uint32_t waveClaim(bool want, uint32_t* cursor, uint32_t& claimedEnd)
+// Work distribution of the persistent traversal kernel.  A wave owns a CHUNK of consecutive queue indices obtained
+// with one global atomic and hands them to its idle lanes locally; only when the chunk is used up does it touch
+// the global cursor again (a single word sustains only ~88 returning atomics per microsecond).
+struct WaveChunk { uint32_t next, end; };
+
+// Gives idle lanes (want == true) indices from the wave's chunk; returns 0xFFFFFFFF for lanes that got none.
+RT_DEV uint32_t waveTake(bool want, WaveChunk& chunk)
 {
     const unsigned long long mask = __ballot(want);
     const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    claimedEnd = base + (uint32_t)__popcll(mask);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const uint32_t available = chunk.end - chunk.next;
+    const uint32_t idx = (want && rank < available) ? chunk.next + rank : 0xFFFFFFFFu;
+    const uint32_t taken = (uint32_t)__popcll(mask) < available ? (uint32_t)__popcll(mask) : available;
+    chunk.next += taken;
+    return idx;
 }
 
-// Scene::Traverse for every active path (Scene.cpp:219-243), persistent threads + LDS stack
-// Wave scheduling knobs of the persistent traversal kernels (wave-uniform, passed as kernel arguments)
+RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSize, uint32_t count)
+{
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(cursor, chunkSize);
+    base = __shfl(base, 0);
+    chunk.next = base < count ? base : count;
+    chunk.end = base + chunkSize < count ? base + chunkSize : count;
+    if (chunk.end < chunk.next) chunk.end = chunk.next;
+}
+
+// Wave scheduling knobs of the persistent traversal kernel (wave-uniform, passed as kernel arguments)
 struct TravTuning
 {
     uint32_t refillMinIdle;   // refill once this many lanes of the wave have no ray (or all of them)
@@ -235,6 +248,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
     TravState s; s.mode = TRAV_DONE; s.shadow = false;
     uint32_t slot = 0, light = 0;
     bool have = false, exhausted = false;
+    // chunk size: large enough to make global atomics rare, small enough to keep the tail of the launch balanced
+    uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
+    chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
+    WaveChunk chunk = { 0u, 0u };
     for (;;)
     {
         const bool interior = have && travIsInterior(s);
@@ -243,9 +260,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
         const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
         if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
         {
-            uint32_t claimedEnd;
-            const uint32_t idx = waveClaim(!have, cursor, claimedEnd);
-            if (!have && idx < count)
+            if (chunk.next >= chunk.end)
+            {
+                waveClaimChunk(chunk, cursor, chunkSize, count);
+                if (chunk.next >= chunk.end) { exhausted = true; continue; }
+            }
+            const uint32_t idx = waveTake(!have, chunk);
+            if (idx != 0xFFFFFFFFu)
             {
                 if (idx < numClosest)
                 {
@@ -266,15 +287,36 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                 }
                 have = true;
             }
-            exhausted = claimedEnd >= count;
             continue;
         }
         if ((mI | mO) == 0ull) break;
         if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
         {
-            // hardware min/max unless some lane's ray could produce a NaN in a slab test (axis-parallel rays)
-            if (__all(!interior || s.nanFree)) { if (interior) travStepInterior<kCount, false>(s, stack, cnt); }
-            else if (interior) travStepInterior<kCount, true>(s, stack, cnt);
+            // INTERIOR PHASE as a tight inner loop: only (cur, stackSize) change per step, everything else of the lane
+            // state is loop invariant, so the wave keeps stepping without re-evaluating the refill logic until enough
+            // lanes wait at leaves / level exits.  Hardware min/max unless some lane's ray could produce a NaN in a
+            // slab test (axis-parallel rays).
+            bool in = interior;
+            if (__all(!have || s.nanFree))
+            {
+                for (;;)
+                {
+                    if (in) travStepInterior<kCount, false>(s, stack, cnt);
+                    in = have && travIsInterior(s);
+                    const unsigned long long m = __ballot(in);
+                    if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
+                }
+            }
+            else
+            {
+                for (;;)
+                {
+                    if (in) travStepInterior<kCount, true>(s, stack, cnt);
+                    in = have && travIsInterior(s);
+                    const unsigned long long m = __ballot(in);
+                    if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
+                }
+            }
         }
         else if (other)
         {
@@ -360,6 +402,25 @@ RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, V4 lig
     resultColor = mulAdd(tp, accumulated, resultColor);
 }
 
+#define RT_APPEND_BUFFER 2048u
+
+// Publishes a block's LDS append buffer with ONE global atomic and coalesced stores.  Called by all threads of
+// the block at a block-uniform point (after a __syncthreads()).
+RT_DEV void flushAppendBuffer(const uint32_t* buf, uint32_t& count, uint32_t& base, uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount)
+{
+    const uint32_t n = count;
+    if (n != 0)
+    {
+        if (threadIdx.x == 0) base = atomicAdd(queueCount, n);
+        __syncthreads();
+        const uint32_t b = base;
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) queue[b + k] = buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) count = 0;
+    }
+    __syncthreads();
+}
+
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395)
 template <bool kLean>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
@@ -368,6 +429,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                                                     uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
                                                     unsigned long long* counters)
 {
+    __shared__ uint32_t sPathBuf[RT_APPEND_BUFFER], sShadowBuf[RT_APPEND_BUFFER];
+    __shared__ uint32_t sPathCount, sShadowCount, sPathBase, sShadowBase;
+    if (threadIdx.x == 0) { sPathCount = 0; sShadowCount = 0; }
+    __syncthreads();
     Counters cnt; zeroCounters(cnt);
     const uint32_t count = *countIn;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -377,6 +442,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
     // GetLightPickingProbability, PathTracerMIS.cpp:157-172
     const float lightPickProbability = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1.0f / (float)scene.numLights : 1.0f;
+    const uint32_t maxRequestsPerVertex = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1u : (scene.numLights < 8u ? scene.numLights : 8u);
 
     // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
     const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
@@ -485,7 +551,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                             const bool ray = prepareLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
                             if (ray)
                             {
-                                if (l < 64u) rayMask |= 1ull << l;
+                                if (l < 8u) rayMask |= 1ull << l;
                                 else shadowQueue[atomicAdd(shadowCount, 1u)] = l * paths.capacity + slot;   // more than 64 lights: per-lane append
                             }
                         }
@@ -537,33 +603,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
             if (!alive) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
         }
 
-        // dense NEE ray queue: one wave-level compaction per request index in use
-        for (unsigned long long pending = rayMask; __any(pending != 0ull); )
+        // Queue appends go through per-block LDS buffers: a returning atomic on ONE global word sustains only ~88
+        // operations per microsecond on this chip, so per-wave appends (hundreds of thousands per launch) would
+        // dominate the kernel; a block publishes ~RT_APPEND_BUFFER entries per global atomic instead.
+        for (unsigned long long pending = rayMask; pending != 0ull; pending &= pending - 1ull)
         {
-            // lowest request index any lane still has pending (wave-uniform)
-            uint32_t l = pending ? (uint32_t)(__ffsll((long long)pending) - 1) : 64u;
-            for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)l, off); l = o < l ? o : l; }
-            const bool mine = ((pending >> l) & 1ull) != 0ull;
-            const unsigned long long m = __ballot(mine);
-            const uint32_t lane = threadIdx.x & 63u;
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if ((int)lane == leader) base = atomicAdd(shadowCount, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
-            if (mine) { shadowQueue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = l * paths.capacity + slot; pending &= ~(1ull << l); }
+            const uint32_t l = (uint32_t)(__ffsll((long long)pending) - 1);
+            sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * paths.capacity + slot;
         }
-
-        // wave-level compaction of the survivors into the next queue: ballot + prefix popcount + one atomic per wave
-        const unsigned long long ballot = __ballot(alive);
-        if (ballot)
-        {
-            const uint32_t lane = threadIdx.x & 63u;
-            const uint32_t prefix = __popcll(ballot & ((1ull << lane) - 1ull));
-            uint32_t base = 0;
-            if (lane == (uint32_t)(__ffsll((long long)ballot) - 1)) base = atomicAdd(countOut, (uint32_t)__popcll(ballot));
-            base = __shfl(base, __ffsll((long long)ballot) - 1);
-            if (alive) queueOut[base + prefix] = slot;
-        }
+        if (alive) sPathBuf[atomicAdd(&sPathCount, 1u)] = slot;
+        __syncthreads();
+        // flush when the next iteration could overflow a buffer (wave-uniform decision on block-shared counters)
+        const bool last = (i - threadIdx.x) + stride >= rounded;
+        if (last || sPathCount + RT_BLOCK > RT_APPEND_BUFFER) flushAppendBuffer(sPathBuf, sPathCount, sPathBase, queueOut, countOut);
+        if (last || sShadowCount + RT_BLOCK * maxRequestsPerVertex > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
     }
     flushCounters(cnt, counters);
 }
@@ -647,7 +700,7 @@ struct RtgpuContext
     uint32_t* queueCounts = nullptr;
     uint32_t queueCountCapacity = 0;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
-    TravTuning tune = { 44u, 16u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
+    TravTuning tune = { 28u, 32u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
     bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
