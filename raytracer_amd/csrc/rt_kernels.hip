@@ -1113,8 +1113,9 @@ static int flushPending(RtgpuContext* c)
 
     // persistent traversal grids: enough resident waves to cover the latency of dependent node fetches; surplus
     // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
-    const bool smallStack = c->traversalStackNeed <= 32;
-    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (smallStack ? 5u : 2u)));
+    // LDS stack capacity in entries per lane: 24 (6 blocks per CU), 32 (4-5) or 64 (2); the scene's BVH depth decides
+    const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 6u : (stackClass == 32u ? 5u : 2u))));
     uint32_t* pathCounts = c->queueCounts;
     uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
     uint32_t* cursors = c->queueCounts + 2 * c->queueCountCapacity;
@@ -1140,7 +1141,8 @@ static int flushPending(RtgpuContext* c)
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
             LaunchTimer t(c, KC_TRACE);
-            if (smallStack) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
+            if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
+            else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
             else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
         }
         if (haveClosest)
