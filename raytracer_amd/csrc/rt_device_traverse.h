@@ -161,10 +161,10 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
             if (s.cur != RT_LEVEL_EXHAUSTED) return;
         }
         // GenericTraverse<MeshShape> returned: back to the object loop of the top-level leaf, in world space
+        // (falls through to the next object of the leaf: one "other" step less per mesh visit)
         s.ray = s.worldRay; s.nanFree = rayIsNaNFree(s.worldRay);
         s.nodes = d.topNodes; s.levelBase = 0;
         s.mode = TRAV_TOP_LEAF;
-        return;
     }
     if (s.mode == TRAV_TOP_NODE)
     {

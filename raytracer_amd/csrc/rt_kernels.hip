@@ -286,6 +286,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                     cnt.c[C_SHADOW]++;
                 }
                 have = true;
+                // single-object scenes start at the object loop (BVH bypass): enter the object right away instead of
+                // queueing for the "other" phase
+                if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt);
             }
             continue;
         }
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                 for (;;)
                 {
                     if (in) travStepInterior<kCount, false>(s, stack, cnt);
-                    in = have && travIsInterior(s);
+                    in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
                 }
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                 for (;;)
                 {
                     if (in) travStepInterior<kCount, true>(s, stack, cnt);
-                    in = have && travIsInterior(s);
+                    in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
                 }

@@ -221,7 +221,7 @@ SPONZA_MATERIALS = [
 ]
 
 
-def sponza_class_mesh(target_triangles=262144, seed=7):
+def sponza_class_mesh(target_triangles=262144, seed=7, refine=False):
     """Procedural stand-in for crytek-sponza (the reference's Data/TestScenes/sponza.json points at
     MODELS/crytek-sponza/sponza.obj, which is not shipped and cannot be downloaded): a 30 x 12 x 14 unit atrium
     -- open roof, two storeys of 2 x 12 tessellated columns with arches, a gallery floor, draped cloth quads --
@@ -231,12 +231,12 @@ def sponza_class_mesh(target_triangles=262144, seed=7):
     hx, hz = L / 2, W / 2
     aisle = 3.0                         # width of the side aisles behind the colonnades
 
-    def build(k):
-        """k scales every tessellation factor; returns the builder."""
+    def build(k, kf=1.0):
+        """k scales every tessellation factor (kf: the floor grid's on top of it); returns the builder."""
         mb = MeshBuilder()
         q = lambda n: max(1, int(round(n * k)))
         # floor (facing +y) and gallery floors of the upper storey over the aisles
-        mb.add_grid((-hx, 0.0, hz), (L, 0, 0), (0, 0, -W), q(60), q(28), 0, 8.0)
+        mb.add_grid((-hx, 0.0, hz), (L, 0, 0), (0, 0, -W), q(60 * kf), q(28 * kf), 0, 8.0)
         for zs in (-1.0, 1.0):
             z0 = zs * hz
             z1 = zs * (hz - aisle)
@@ -319,13 +319,21 @@ def sponza_class_mesh(target_triangles=262144, seed=7):
         if abs(n - target_triangles) / target_triangles < 0.005:
             break
         k *= math.sqrt(target_triangles / n)
-    return build(k).arrays()
+    if not refine:
+        return build(k).arrays()
+    # Every tessellation factor is rounded to an integer, so the count moves in coarse steps with k.  Take the scale
+    # whose count is closest to the target, then trim with the floor grid alone, whose steps are a few hundred
+    # triangles (BASELINE config 3 asks for 262 144 +- 1 %).
+    count = lambda kk, kf: sum(t.shape[0] for t in build(kk, kf).idx)
+    k = min((k * (1.0 + 0.0025 * j) for j in range(-24, 25)), key=lambda kk: abs(count(kk, 1.0) - target_triangles))
+    kf = min((0.7 + 0.005 * j for j in range(0, 141)), key=lambda f: abs(count(k, f) - target_triangles))
+    return build(k, kf).arrays()
 
 
 def sponza_class(aspect, target_triangles=262144, seed=7):
     """BASELINE config 3: Sponza-class mesh, background light (1, 1.5, 2) + delta directional light
     (20000, 19000, 18000) pitched 80 degrees -- the lights of the reference's Data/TestScenes/sponza.json."""
-    pos, idx, nrm, tan, uv, mat = sponza_class_mesh(target_triangles, seed)
+    pos, idx, nrm, tan, uv, mat = sponza_class_mesh(target_triangles, seed, refine=True)
     scene = Scene()
     mats = [scene.add_material("diffuse", c) for _, c in SPONZA_MATERIALS]
     scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
