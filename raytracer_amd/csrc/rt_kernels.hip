@@ -37,38 +37,40 @@ using namespace rtd;
 // =====================================================================================================
 // Device-side data
 // =====================================================================================================
-enum PathField : uint32_t
+// Path state lives in HBM as 16-byte RECORDS, one array per record kind (record-major, slot-minor): a lane moves a
+// whole record with one dwordx4 access, a wave's accesses to consecutive slots coalesce into 1 KB, and a path
+// vertex touches 7-9 arrays (and as many DRAM pages / TLB entries) instead of 34 scalar planes.
+enum PathRecord : uint32_t
 {
-    F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ,          // ray: origin BEFORE the 1e-3 offset, direction as passed to Ray()
-    F_TPX, F_TPY, F_TPZ, F_TPW,                  // throughput (4 lanes: RayColor::AlmostZero tests all four)
-    F_RX, F_RY, F_RZ,                            // accumulated radiance of this path
-    F_PIXEL,                                     // x | y << 16
-    F_SALT, F_GENERATED,                         // GenericSampler state
-    F_RNG0L, F_RNG0H, F_RNG1L, F_RNG1H,          // per-pixel xoroshiro128+ state
-    F_FLAGS,                                     // depth (bits 0-7) | lastSpecular << 8
-    F_LASTPDFW,
-    F_HIT_OBJ, F_HIT_SUB, F_HIT_DIST, F_HIT_U, F_HIT_V,
-    F_SH_COUNT,                                  // number of NEE requests pending for this vertex
-    F_SH_PX, F_SH_PY, F_SH_PZ,                   // shading point (shadow ray origin before the 1e-4 offset)
-    F_SH_TPX, F_SH_TPY, F_SH_TPZ,                // throughput at the vertex (the NEE fma uses it)
-    F_NUM_BASE
+    R_ORIGIN,    // ray origin xyz BEFORE the 1e-3 offset | flags: depth (bits 0-7), lastSpecular << 8
+    R_DIR,       // ray direction xyz as passed to Ray()   | lastPdfW
+    R_TP,        // throughput (4 lanes: RayColor::AlmostZero tests all four)
+    R_RESULT,    // accumulated radiance rgb of this path  | pixel: x | y << 16
+    R_HIT,       // objectId, subObjectId, distance, u
+    R_SAMPLER,   // hit v | GenericSampler salt, generated | number of NEE requests pending for this vertex
+    R_RNG,       // per-pixel xoroshiro128+ state (2 x 64 bit)
+    R_SH_P,      // shading point xyz (shadow ray origin before the 1e-4 offset)
+    R_SH_TP,     // throughput at the vertex (the NEE fma uses it)
+    R_NUM_BASE
 };
-// per NEE request (RT_SHADOW_STRIDE floats each, light-major): direction xyz, tmax (<0 = no ray), contribution rgb
-#define RT_SHADOW_STRIDE 7
+// per NEE request two records, light-major: {direction xyz, tmax (< 0: no ray / occluded)}, {contribution rgb, -}
+#define RT_SHADOW_RECORDS 2
 
 struct Paths
 {
-    float* base;        // F_NUM_BASE * capacity floats, then maxLights * RT_SHADOW_STRIDE * capacity
+    float4* base;       // (R_NUM_BASE + maxLights * RT_SHADOW_RECORDS) * capacity records
     uint32_t capacity;
     uint32_t maxLights; // NEE requests per vertex (1 for LightSamplingStrategy::Single)
 };
 
-RT_DEV float& pf(const Paths& p, uint32_t field, uint32_t slot) { return p.base[(size_t)field * p.capacity + slot]; }
-RT_DEV uint32_t& pu(const Paths& p, uint32_t field, uint32_t slot) { return reinterpret_cast<uint32_t*>(p.base)[(size_t)field * p.capacity + slot]; }
-RT_DEV float& psh(const Paths& p, uint32_t light, uint32_t k, uint32_t slot)
+RT_DEV float4& prec(const Paths& p, uint32_t record, uint32_t slot) { return p.base[(size_t)record * p.capacity + slot]; }
+RT_DEV float4& pshadow(const Paths& p, uint32_t light, uint32_t k, uint32_t slot)
 {
-    return p.base[((size_t)F_NUM_BASE + (size_t)light * RT_SHADOW_STRIDE + k) * p.capacity + slot];
+    return p.base[((size_t)R_NUM_BASE + (size_t)light * RT_SHADOW_RECORDS + k) * p.capacity + slot];
 }
+RT_DEV float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+RT_DEV float fbits(uint32_t u) { return __uint_as_float(u); }
+RT_DEV uint32_t ubits(float f) { return __float_as_uint(f); }
 
 struct DevPass
 {
@@ -105,30 +107,29 @@ RT_DEV void zeroCounters(Counters& c) {
     for (int k = 0; k < RT_NUM_COUNTERS; ++k) c.c[k] = 0;
 }
 
-RT_DEV void loadSampler(Sampler& s, const Paths& p, uint32_t slot, const DevPass& pass, const uint16_t* blueNoise)
+// GenericSampler + per-pixel RNG state of a path (R_SAMPLER.yz, R_RNG); `sampler` is the record already loaded
+RT_DEV void loadSampler(Sampler& s, const Paths& p, uint32_t slot, uint32_t pix, const float4& sampler, const DevPass& pass, const uint16_t* blueNoise)
 {
-    const uint32_t pix = pu(p, F_PIXEL, slot);
     s.seed = pass.seed; s.numDims = pass.numDimensions; s.blueNoiseLayers = pass.blueNoiseLayers; s.blueNoise = blueNoise;
     s.bx = (pix & 0xFFFFu) & 127u; s.by = (pix >> 16) & 127u;
-    s.salt = pu(p, F_SALT, slot); s.generated = pu(p, F_GENERATED, slot);
-    s.fallback.s[0] = (uint64_t)pu(p, F_RNG0L, slot) | ((uint64_t)pu(p, F_RNG0H, slot) << 32);
-    s.fallback.s[1] = (uint64_t)pu(p, F_RNG1L, slot) | ((uint64_t)pu(p, F_RNG1H, slot) << 32);
+    s.salt = ubits(sampler.y); s.generated = ubits(sampler.z);
+    const float4 rng = prec(p, R_RNG, slot);
+    s.fallback.s[0] = (uint64_t)ubits(rng.x) | ((uint64_t)ubits(rng.y) << 32);
+    s.fallback.s[1] = (uint64_t)ubits(rng.z) | ((uint64_t)ubits(rng.w) << 32);
 }
-RT_DEV void storeSampler(const Sampler& s, const Paths& p, uint32_t slot)
+RT_DEV void storeSampler(const Sampler& s, const Paths& p, uint32_t slot, float hitV, uint32_t pendingRequests)
 {
-    pu(p, F_SALT, slot) = s.salt; pu(p, F_GENERATED, slot) = s.generated;
-    pu(p, F_RNG0L, slot) = (uint32_t)s.fallback.s[0]; pu(p, F_RNG0H, slot) = (uint32_t)(s.fallback.s[0] >> 32);
-    pu(p, F_RNG1L, slot) = (uint32_t)s.fallback.s[1]; pu(p, F_RNG1H, slot) = (uint32_t)(s.fallback.s[1] >> 32);
+    prec(p, R_SAMPLER, slot) = f4(hitV, fbits(s.salt), fbits(s.generated), fbits(pendingRequests));
+    prec(p, R_RNG, slot) = f4(fbits((uint32_t)s.fallback.s[0]), fbits((uint32_t)(s.fallback.s[0] >> 32)),
+                              fbits((uint32_t)s.fallback.s[1]), fbits((uint32_t)(s.fallback.s[1] >> 32)));
 }
 
 // The path's current ray exactly as the reference holds it: Ray(origin, direction) -- which normalises and
 // computes invDir / originDivDir from the UN-offset origin -- and then origin += dir * 0.001f for
 // secondary rays, leaving originDivDir stale (PathTracerMIS.cpp:392-393).
-RT_DEV Ray loadPathRay(const Paths& p, uint32_t slot, uint32_t depth)
+RT_DEV Ray makePathRay(const float4& origin, const float4& dir, uint32_t depth)
 {
-    const V4 o(pf(p, F_OX, slot), pf(p, F_OY, slot), pf(p, F_OZ, slot), 0.0f);
-    const V4 d(pf(p, F_DX, slot), pf(p, F_DY, slot), pf(p, F_DZ, slot), 0.0f);
-    Ray ray = makeRay(o, d);
+    Ray ray = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));
     if (depth > 0) ray.origin = ray.origin + ray.dir * 0.001f;
     return ray;
 }
@@ -175,15 +176,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, 
             direction = focusPoint - origin;
         }
 
-        pf(paths, F_OX, slot) = origin.x; pf(paths, F_OY, slot) = origin.y; pf(paths, F_OZ, slot) = origin.z;
-        pf(paths, F_DX, slot) = direction.x; pf(paths, F_DY, slot) = direction.y; pf(paths, F_DZ, slot) = direction.z;
-        pf(paths, F_TPX, slot) = 1.0f; pf(paths, F_TPY, slot) = 1.0f; pf(paths, F_TPZ, slot) = 1.0f; pf(paths, F_TPW, slot) = 1.0f;
-        pf(paths, F_RX, slot) = 0.0f; pf(paths, F_RY, slot) = 0.0f; pf(paths, F_RZ, slot) = 0.0f;
-        pu(paths, F_PIXEL, slot) = pix;
-        pu(paths, F_FLAGS, slot) = 0x100u;   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
-        pf(paths, F_LASTPDFW, slot) = 1.0f;
-        pu(paths, F_SH_COUNT, slot) = 0;
-        storeSampler(sampler, paths, slot);
+        prec(paths, R_ORIGIN, slot) = f4(origin.x, origin.y, origin.z, fbits(0x100u));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
+        prec(paths, R_DIR, slot) = f4(direction.x, direction.y, direction.z, 1.0f);        // lastPdfW = 1
+        prec(paths, R_TP, slot) = f4(1.0f, 1.0f, 1.0f, 1.0f);
+        prec(paths, R_RESULT, slot) = f4(0.0f, 0.0f, 0.0f, fbits(pix));
+        storeSampler(sampler, paths, slot, 0.0f, 0u);
         queue[slot] = slot;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -271,18 +268,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                 if (idx < numClosest)
                 {
                     slot = queue[idx];
-                    const uint32_t depth = pu(paths, F_FLAGS, slot) & 0xFFu;
-                    travBegin(s, scene, loadPathRay(paths, slot, depth), __uint_as_float(0x7f800000u), false);
+                    const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
+                    travBegin(s, scene, makePathRay(origin, dir, ubits(origin.w) & 0xFFu), __uint_as_float(0x7f800000u), false);
                 }
                 else
                 {
                     const uint32_t request = shadowQueue[idx - numClosest];
                     light = request / paths.capacity; slot = request - light * paths.capacity;
-                    const V4 origin(pf(paths, F_SH_PX, slot), pf(paths, F_SH_PY, slot), pf(paths, F_SH_PZ, slot), 0.0f);
-                    const V4 dir(psh(paths, light, 0, slot), psh(paths, light, 1, slot), psh(paths, light, 2, slot), 0.0f);
-                    Ray shadowRay = makeRay(origin, dir);
+                    const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
+                    Ray shadowRay = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
                     shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
-                    travBegin(s, scene, shadowRay, psh(paths, light, 3, slot), true);   // hitPoint.distance = illuminateResult.distance * 0.999f
+                    travBegin(s, scene, shadowRay, dirTmax.w, true);   // hitPoint.distance = illuminateResult.distance * 0.999f
                     cnt.c[C_SHADOW]++;
                 }
                 have = true;
@@ -328,13 +324,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
             {
                 if (s.shadow)
                 {
-                    if (s.occluded) psh(paths, light, 3, slot) = -1.0f;
+                    if (s.occluded) pshadow(paths, light, 0, slot).w = -1.0f;
                     else cnt.c[C_SHADOW_HIT]++;
                 }
                 else
                 {
-                    pu(paths, F_HIT_OBJ, slot) = s.hit.objectId; pu(paths, F_HIT_SUB, slot) = s.hit.subObjectId;
-                    pf(paths, F_HIT_DIST, slot) = s.hit.distance; pf(paths, F_HIT_U, slot) = s.hit.u; pf(paths, F_HIT_V, slot) = s.hit.v;
+                    prec(paths, R_HIT, slot) = f4(fbits(s.hit.objectId), fbits(s.hit.subObjectId), s.hit.distance, s.hit.u);
+                    prec(paths, R_SAMPLER, slot).x = s.hit.v;
                 }
                 have = false;
             }
@@ -376,9 +372,8 @@ __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& sce
             tmax = ir.distance * 0.999f;
         }
     }
-    psh(paths, requestIndex, 0, slot) = dir.x; psh(paths, requestIndex, 1, slot) = dir.y; psh(paths, requestIndex, 2, slot) = dir.z;
-    psh(paths, requestIndex, 3, slot) = tmax;
-    psh(paths, requestIndex, 4, slot) = contribution.x; psh(paths, requestIndex, 5, slot) = contribution.y; psh(paths, requestIndex, 6, slot) = contribution.z;
+    pshadow(paths, requestIndex, 0, slot) = f4(dir.x, dir.y, dir.z, tmax);
+    pshadow(paths, requestIndex, 1, slot) = f4(contribution.x, contribution.y, contribution.z, 0.0f);
     return tmax >= 0.0f;   // a shadow ray has to be traced for this request
 }
 
@@ -386,23 +381,22 @@ __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& sce
 // accumulatedColor = sum of the unoccluded SampleLight() results in light order, times mLightSamplingWeight,
 // then resultColor.MulAndAccumulate(throughput, ...) (PathTracerMIS.cpp:141-151, 320).  k_trace_shadow marks
 // occluded requests with tmax < 0.
-RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, V4 lightSamplingWeight, V4& resultColor)
+RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, uint32_t numRequests, V4 lightSamplingWeight, V4& resultColor)
 {
-    const uint32_t n = pu(paths, F_SH_COUNT, slot);
-    if (n == 0) return;
-    pu(paths, F_SH_COUNT, slot) = 0;
+    if (numRequests == 0) return;
     V4 accumulated = zero4();
     bool any = false;
-    for (uint32_t l = 0; l < n; ++l)
+    for (uint32_t l = 0; l < numRequests; ++l)
     {
-        if (psh(paths, l, 3, slot) < 0.0f) continue;
-        accumulated = accumulated + V4(psh(paths, l, 4, slot), psh(paths, l, 5, slot), psh(paths, l, 6, slot), 0.0f);
+        if (pshadow(paths, l, 0, slot).w < 0.0f) continue;
+        const float4 c = pshadow(paths, l, 1, slot);
+        accumulated = accumulated + V4(c.x, c.y, c.z, 0.0f);
         any = true;
     }
     if (!any) return;
     accumulated = accumulated * lightSamplingWeight;
-    const V4 tp(pf(paths, F_SH_TPX, slot), pf(paths, F_SH_TPY, slot), pf(paths, F_SH_TPZ, slot), 0.0f);
-    resultColor = mulAdd(tp, accumulated, resultColor);
+    const float4 tp = prec(paths, R_SH_TP, slot);
+    resultColor = mulAdd(V4(tp.x, tp.y, tp.z, 0.0f), accumulated, resultColor);
 }
 
 #define RT_APPEND_BUFFER 2048u
@@ -457,17 +451,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
         if (i < count)
         {
             slot = queueIn[i];
-            const uint32_t flags = pu(paths, F_FLAGS, slot);
+            const float4 rOrigin = prec(paths, R_ORIGIN, slot), rDir = prec(paths, R_DIR, slot), rTp = prec(paths, R_TP, slot);
+            const float4 rResult = prec(paths, R_RESULT, slot), rHit = prec(paths, R_HIT, slot), rSampler = prec(paths, R_SAMPLER, slot);
+            const uint32_t flags = ubits(rOrigin.w);
             uint32_t depth = flags & 0xFFu;
             const bool lastSpecular = (flags & 0x100u) != 0;
-            const float lastPdfW = pf(paths, F_LASTPDFW, slot);
-            const Ray ray = loadPathRay(paths, slot, depth);
-            V4 throughput(pf(paths, F_TPX, slot), pf(paths, F_TPY, slot), pf(paths, F_TPZ, slot), pf(paths, F_TPW, slot));
-            V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
-            resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the previous vertex
+            const float lastPdfW = rDir.w;
+            const uint32_t pix = ubits(rResult.w);
+            const Ray ray = makePathRay(rOrigin, rDir, depth);
+            V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+            resolvePendingLightSamples(paths, slot, ubits(rSampler.w), lightSamplingWeight, resultColor);   // NEE of the previous vertex
             Hit hit;
-            hit.objectId = pu(paths, F_HIT_OBJ, slot); hit.subObjectId = pu(paths, F_HIT_SUB, slot);
-            hit.distance = pf(paths, F_HIT_DIST, slot); hit.u = pf(paths, F_HIT_U, slot); hit.v = pf(paths, F_HIT_V, slot);
+            hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+            bool samplerStored = false;
 
             do
             {
@@ -533,7 +530,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                 // emission, PathTracerMIS.cpp:309-317
                 resultColor = mulAdd(throughput, sd.mp.emission * bsdfSamplingWeight, resultColor);
 
-                Sampler sampler; loadSampler(sampler, paths, slot, pass, scene.blueNoise);
+                Sampler sampler; loadSampler(sampler, paths, slot, pix, rSampler, pass, scene.blueNoise);
                 sampler.seed = passes[slot / slotsPerPass].seed;
 
                 // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
@@ -560,9 +557,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         }
                         numRequests = scene.numLights;
                     }
-                    pu(paths, F_SH_COUNT, slot) = numRequests;
-                    pf(paths, F_SH_PX, slot) = sd.intersection.frame.r[3].x; pf(paths, F_SH_PY, slot) = sd.intersection.frame.r[3].y; pf(paths, F_SH_PZ, slot) = sd.intersection.frame.r[3].z;
-                    pf(paths, F_SH_TPX, slot) = throughput.x; pf(paths, F_SH_TPY, slot) = throughput.y; pf(paths, F_SH_TPZ, slot) = throughput.z;
+                    prec(paths, R_SH_P, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                    prec(paths, R_SH_TP, slot) = f4(throughput.x, throughput.y, throughput.z, 0.0f);
                 }
 
                 bool cont = true;
@@ -590,19 +586,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         if (almostZero4(throughput)) cont = false;
                         else
                         {
-                            pf(paths, F_OX, slot) = sd.intersection.frame.r[3].x; pf(paths, F_OY, slot) = sd.intersection.frame.r[3].y; pf(paths, F_OZ, slot) = sd.intersection.frame.r[3].z;
-                            pf(paths, F_DX, slot) = incomingDirWorldSpace.x; pf(paths, F_DY, slot) = incomingDirWorldSpace.y; pf(paths, F_DZ, slot) = incomingDirWorldSpace.z;
-                            pf(paths, F_TPX, slot) = throughput.x; pf(paths, F_TPY, slot) = throughput.y; pf(paths, F_TPZ, slot) = throughput.z; pf(paths, F_TPW, slot) = throughput.w;
-                            pf(paths, F_LASTPDFW, slot) = pdf;
-                            pu(paths, F_FLAGS, slot) = (depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u);
+                            prec(paths, R_ORIGIN, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
+                                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u)));
+                            prec(paths, R_DIR, slot) = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
+                            prec(paths, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
                             alive = true;
                         }
                     }
                 }
-                storeSampler(sampler, paths, slot);
+                storeSampler(sampler, paths, slot, hit.v, numRequests);
+                samplerStored = true;
             } while (false);
 
-            pf(paths, F_RX, slot) = resultColor.x; pf(paths, F_RY, slot) = resultColor.y; pf(paths, F_RZ, slot) = resultColor.z;
+            if (!samplerStored && ubits(rSampler.w) != 0u) prec(paths, R_SAMPLER, slot).w = fbits(0u);   // the resolved requests are spent
+            prec(paths, R_RESULT, slot) = f4(resultColor.x, resultColor.y, resultColor.z, rResult.w);
             if (!alive) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
         }
 
@@ -634,15 +631,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < slotsPerPass; pixelSlot += stride)
     {
-        const uint32_t pix = pu(paths, F_PIXEL, pixelSlot);
+        const uint32_t pix = ubits(prec(paths, R_RESULT, pixelSlot).w);
         const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
         float sr = sum[idx + 0], sg = sum[idx + 1], sb = sum[idx + 2];
         float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
         for (uint32_t b = 0; b < numPasses; ++b)
         {
             const uint32_t slot = b * slotsPerPass + pixelSlot;
-            V4 resultColor(pf(paths, F_RX, slot), pf(paths, F_RY, slot), pf(paths, F_RZ, slot), 0.0f);
-            resolvePendingLightSamples(paths, slot, lightSamplingWeight, resultColor);   // NEE of the path's last vertex
+            const float4 rResult = prec(paths, R_RESULT, slot);
+            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+            resolvePendingLightSamples(paths, slot, ubits(prec(paths, R_SAMPLER, slot).w), lightSamplingWeight, resultColor);   // NEE of the path's last vertex
             sr = sr + resultColor.x; sg = sg + resultColor.y; sb = sb + resultColor.z;
             if ((passes[b].passIndex % 2u) == 0u) { tr = tr + resultColor.x; tg = tg + resultColor.y; tb = tb + resultColor.z; }
         }
@@ -1057,8 +1055,8 @@ static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
         freePaths(c);
         if (wanted >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
         const size_t cap = wanted;
-        const size_t floats = ((size_t)F_NUM_BASE + (size_t)maxLights * RT_SHADOW_STRIDE) * cap;
-        HIP_TRY(hipMalloc((void**)&c->paths.base, floats * sizeof(float)));
+        const size_t records = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * cap;
+        HIP_TRY(hipMalloc((void**)&c->paths.base, records * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&c->queues[0], cap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&c->queues[1], cap * sizeof(uint32_t)));
         if ((unsigned long long)cap * maxLights >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x lights exceeds the NEE request index range");
