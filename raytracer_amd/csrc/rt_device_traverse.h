@@ -40,9 +40,11 @@ RT_DEV uint32_t packNode(uint32_t childIndex, uint32_t leavesWord) { return chil
 
 struct TravState
 {
-    Ray ray;            // ray used for the tests of the current level (world ray, or the object's local ray)
-    Ray worldRay;       // the world ray (object loop of top-level leaves, restored when a mesh is left)
-    Hit hit;
+    Ray ray;            // ray used for the tests of the current level: the world ray, or the mesh's local ray.  The world
+                        // ray is NOT kept while a mesh is traversed (12 registers per lane that would cost a whole wave
+                        // of occupancy); the caller rebuilds it from the path state when the mesh is left
+    float hitDistance;  // running closest distance (the rest of the reference's HitPoint is written through to the
+                        // path state by the caller's onHit at every accepted hit, not carried in registers)
     const RtNode* nodes;        // node array of the current level
     uint32_t mode;
     uint32_t cur;               // packed current node, or RT_LEVEL_EXHAUSTED
@@ -73,8 +75,8 @@ RT_DEV bool travIsInterior(const TravState& s)
 // Scene::Traverse / Traverse_Shadow prologue (Scene.cpp:219-261): 0 objects, 1 object (BVH bypass), or the root.
 RT_DEV void travBegin(TravState& s, const RtSceneDesc& d, const Ray& worldRay, float maxDistance, bool shadow)
 {
-    s.ray = worldRay; s.worldRay = worldRay; s.shadow = shadow;
-    s.hit.objectId = RT_INVALID_OBJECT; s.hit.subObjectId = 0; s.hit.distance = maxDistance; s.hit.u = 0.0f; s.hit.v = 0.0f;
+    s.ray = worldRay; s.shadow = shadow;
+    s.hitDistance = maxDistance;
     s.stackSize = 0; s.levelBase = 0; s.leafNext = 0; s.leafEnd = 0; s.objectId = 0; s.triBase = 0;
     s.cur = 0; s.occluded = false; s.nodes = d.topNodes; s.nanFree = rayIsNaNFree(worldRay);
     if (d.numObjects == 0) s.mode = TRAV_DONE;
@@ -102,8 +104,8 @@ RT_DEV void travStepInterior(TravState& s, const LdsStack& stack, Counters& cnt)
         hitA = intersectBoxRayNoNaN(s.ray, n.a0.x, n.a0.y, n.a0.z, n.a1.x, n.a1.y, n.a1.z, distanceA);
         hitB = intersectBoxRayNoNaN(s.ray, n.b0.x, n.b0.y, n.b0.z, n.b1.x, n.b1.y, n.b1.z, distanceB);
     }
-    hitA = hitA && (distanceA < s.hit.distance);   // box occlusion
-    hitB = hitB && (distanceB < s.hit.distance);
+    hitA = hitA && (distanceA < s.hitDistance);   // box occlusion
+    hitB = hitB && (distanceB < s.hitDistance);
     if (kCount)
     {
         cnt.c[C_BOX_SHADOW] += s.shadow ? 2u : 0u;
@@ -128,9 +130,10 @@ RT_DEV void travNext(TravState& s, const LdsStack& stack)
 }
 
 // OTHER step: a mesh leaf, a level exit, a top-level leaf header, or the next object of a top-level leaf.
-// Precondition: s.mode != TRAV_DONE && !travIsInterior(s).
-template <bool kCount>
-RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& stack, Counters& cnt)
+// Precondition: s.mode != TRAV_DONE && !travIsInterior(s).  reloadWorldRay() returns the ray travBegin was given;
+// onHit(objectId, subObjectId, distance, u, v) records a new closest hit (closest-hit rays only).
+template <bool kCount, typename ReloadWorldRay, typename OnHit>
+RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& stack, Counters& cnt, ReloadWorldRay reloadWorldRay, OnHit onHit)
 {
     if (s.mode == TRAV_MESH)
     {
@@ -148,11 +151,11 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
                 float u, v, dist;
                 if (intersectTriangleRay(s.ray, v0, e1, e2, u, v, dist))
                 {
-                    if (dist < s.hit.distance)
+                    if (dist < s.hitDistance)
                     {
-                        s.hit.distance = dist;
+                        s.hitDistance = dist;
                         if (s.shadow) { s.occluded = true; s.mode = TRAV_DONE; return; }
-                        s.hit.subObjectId = triangleIndex; s.hit.objectId = s.objectId; s.hit.u = u; s.hit.v = v;
+                        onHit(s.objectId, triangleIndex, dist, u, v);
                         if (kCount) cnt.c[C_TRI_PASS]++;
                     }
                 }
@@ -162,9 +165,10 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
         }
         // GenericTraverse<MeshShape> returned: back to the object loop of the top-level leaf, in world space
         // (falls through to the next object of the leaf: one "other" step less per mesh visit)
-        s.ray = s.worldRay; s.nanFree = rayIsNaNFree(s.worldRay);
         s.nodes = d.topNodes; s.levelBase = 0;
         s.mode = TRAV_TOP_LEAF;
+        if (d.numObjects == 1) { s.mode = TRAV_DONE; return; }   // the bypass path: that was the only object
+        s.ray = reloadWorldRay(); s.nanFree = rayIsNaNFree(s.ray);
     }
     if (s.mode == TRAV_TOP_NODE)
     {
@@ -183,7 +187,7 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
     }
     const uint32_t objectID = s.leafNext++;
     const RtObject& obj = d.objects[objectID];
-    const Ray lray = transformRayUnsafe(loadM4(obj.invTransform), s.worldRay);
+    const Ray lray = transformRayUnsafe(loadM4(obj.invTransform), s.ray);   // s.ray is the world ray here
     if (obj.objectKind == RT_OBJECT_LIGHT)
     {
         float lightDistance;
@@ -191,11 +195,11 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
         {
             if (s.shadow)
             {
-                if (lightDistance < s.hit.distance) { s.hit.distance = lightDistance; s.occluded = true; s.mode = TRAV_DONE; }
+                if (lightDistance < s.hitDistance) { s.hitDistance = lightDistance; s.occluded = true; s.mode = TRAV_DONE; }
             }
-            else if (lightDistance > 0.0f && lightDistance < s.hit.distance)
+            else if (lightDistance > 0.0f && lightDistance < s.hitDistance)
             {
-                s.hit.distance = lightDistance; s.hit.objectId = objectID; s.hit.subObjectId = RT_LIGHT_OBJECT;
+                s.hitDistance = lightDistance; onHit(objectID, RT_LIGHT_OBJECT, lightDistance, 0.0f, 0.0f);   // u, v: mesh hits only
             }
         }
         return;
@@ -217,10 +221,10 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
     {
         if (s.shadow)
         {
-            if (sh.farDist > 0.0f && sh.nearDist < s.hit.distance) { s.occluded = true; s.mode = TRAV_DONE; }
+            if (sh.farDist > 0.0f && sh.nearDist < s.hitDistance) { s.occluded = true; s.mode = TRAV_DONE; }
         }
-        else if (sh.nearDist > 0.0f && sh.nearDist < s.hit.distance) { s.hit.distance = sh.nearDist; s.hit.objectId = objectID; s.hit.subObjectId = sh.subObjectId; }
-        else if (sh.farDist > 0.0f && sh.farDist < s.hit.distance) { s.hit.distance = sh.farDist; s.hit.objectId = objectID; s.hit.subObjectId = sh.subObjectId; }
+        else if (sh.nearDist > 0.0f && sh.nearDist < s.hitDistance) { s.hitDistance = sh.nearDist; onHit(objectID, sh.subObjectId, sh.nearDist, 0.0f, 0.0f); }
+        else if (sh.farDist > 0.0f && sh.farDist < s.hitDistance) { s.hitDistance = sh.farDist; onHit(objectID, sh.subObjectId, sh.farDist, 0.0f, 0.0f); }
     }
 }
 

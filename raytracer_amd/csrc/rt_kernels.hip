@@ -231,8 +231,11 @@ struct TravTuning
 // serving them from one work cursor halves the number of launches whose tail (a few long rays keeping the
 // grid alive) would otherwise be paid twice.  An occluded NEE request is marked by tmax = -1; the contribution
 // is folded in later by resolvePendingLightSamples.
+// Occupancy: 5 waves per SIMD (<= 96 VGPRs; the register allocator gets there without spilling once the world ray and
+// the hit record are not carried) x 24.6 KB of LDS stack per block = 5 blocks per CU.  The interior loop waits ~800 ns
+// per dependent node fetch, so every extra wave is throughput.
 template <int kStack, bool kCount>
-__global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, const Paths paths,
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace(const RtSceneDesc scene, const Paths paths,
                                                     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                     const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                     uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
@@ -249,6 +252,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
     uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
     chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
     WaveChunk chunk = { 0u, 0u };
+    // the world ray of the lane's current request, rebuilt from the path state exactly as at refill time
+    auto loadWorldRay = [&]() -> Ray
+    {
+        if (s.shadow)
+        {
+            const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
+            Ray shadowRay = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
+            shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;   // PathTracerMIS.cpp:86
+            return shadowRay;
+        }
+        const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
+        return makePathRay(origin, dir, ubits(origin.w) & 0xFFu);
+    };
+    // HitPoint of a closest-hit ray, written through at every accepted hit (T6: objectId, subObjectId, distance, u, v)
+    auto onHit = [&](uint32_t objectId, uint32_t subObjectId, float distance, float u, float v)
+    {
+        prec(paths, R_HIT, slot) = f4(fbits(objectId), fbits(subObjectId), distance, u);
+        prec(paths, R_SAMPLER, slot).x = v;
+    };
     for (;;)
     {
         const bool interior = have && travIsInterior(s);
@@ -265,26 +287,21 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
             const uint32_t idx = waveTake(!have, chunk);
             if (idx != 0xFFFFFFFFu)
             {
-                if (idx < numClosest)
-                {
-                    slot = queue[idx];
-                    const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
-                    travBegin(s, scene, makePathRay(origin, dir, ubits(origin.w) & 0xFFu), __uint_as_float(0x7f800000u), false);
-                }
+                float maxDistance = __uint_as_float(0x7f800000u);
+                s.shadow = idx >= numClosest;
+                if (!s.shadow) slot = queue[idx];
                 else
                 {
                     const uint32_t request = shadowQueue[idx - numClosest];
                     light = request / paths.capacity; slot = request - light * paths.capacity;
-                    const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
-                    Ray shadowRay = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
-                    shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;
-                    travBegin(s, scene, shadowRay, dirTmax.w, true);   // hitPoint.distance = illuminateResult.distance * 0.999f
+                    maxDistance = pshadow(paths, light, 0, slot).w;   // hitPoint.distance = illuminateResult.distance * 0.999f
                     cnt.c[C_SHADOW]++;
                 }
+                travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
                 have = true;
                 // single-object scenes start at the object loop (BVH bypass): enter the object right away instead of
                 // queueing for the "other" phase
-                if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt);
+                if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
             }
             continue;
         }
@@ -319,7 +336,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
         }
         else if (other)
         {
-            if (s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt);
+            if (s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
             if (s.mode == TRAV_DONE)
             {
                 if (s.shadow)
@@ -329,8 +346,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace(const RtSceneDesc scene, con
                 }
                 else
                 {
-                    prec(paths, R_HIT, slot) = f4(fbits(s.hit.objectId), fbits(s.hit.subObjectId), s.hit.distance, s.hit.u);
-                    prec(paths, R_SAMPLER, slot).x = s.hit.v;
+                    // nothing was hit: HitPoint stays {RT_INVALID_OBJECT, distance = FLT_MAX-ish infinity} (HitPoint.h:14-51)
+                    if (s.hitDistance == __uint_as_float(0x7f800000u)) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), s.hitDistance, 0.0f);
                 }
                 have = false;
             }
@@ -1116,7 +1133,7 @@ static int flushPending(RtgpuContext* c)
     // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
     // LDS stack capacity in entries per lane: 24 (6 blocks per CU), 32 (4-5) or 64 (2); the scene's BVH depth decides
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
-    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 6u : (stackClass == 32u ? 5u : 2u))));
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u))));
     uint32_t* pathCounts = c->queueCounts;
     uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
     uint32_t* cursors = c->queueCounts + 2 * c->queueCountCapacity;
