@@ -327,9 +327,18 @@ int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
  * always maintained.  Synchronises. */
 int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
 
+/* Batch lanes (1..4, default 3).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
+ * alternating HIP streams with their own path-state arenas, so the drain of one batch's traversal launches (a few
+ * very long rays) overlaps with the next batch's kernels.  The film is still summed in pass order.  Performance
+ * only: results do not depend on it.  1 = strictly serial kernels (what per-kernel timing wants).  Synchronises.
+ * Replaces the thread-pool width of the reference (RenderingParams::numThreads, Viewport.cpp:44-50). */
+int rtgpu_set_concurrency(RtgpuContext* ctx, uint32_t lanes);
+
 /* --- measurement hooks (bench.py) ---------------------------------------------------------------
  * Per-kernel-class GPU time in milliseconds accumulated since rtgpu_reset, measured with HIP events
- * on the context's own stream when timing is enabled.  names[i] are static strings. */
+ * on the stream each kernel is launched on when timing is enabled (with more than one batch lane the kernels of
+ * different batches overlap, so the classes' times can add up to more than the wall time).  names[i] are static
+ * strings. */
 #define RTGPU_NUM_KERNEL_CLASSES 8
 int rtgpu_enable_timing(RtgpuContext* ctx, int enable);
 int rtgpu_get_kernel_times(RtgpuContext* ctx, double ms[RTGPU_NUM_KERNEL_CLASSES],

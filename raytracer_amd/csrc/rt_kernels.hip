@@ -688,10 +688,23 @@ static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "genera
 
 struct CtxPending { DevPass pass; std::vector<uint32_t> seeds; };
 
+#define RT_MAX_LANES 4
+struct BatchLane
+{
+    hipStream_t stream = nullptr;
+    Paths paths = { nullptr, 0, 0 };
+    uint32_t* queues[2] = { nullptr, nullptr };
+    uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
+    // per-batch work counters, 4 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
+    // shadow-queue counts, traversal cursors (one of each per bounce, so that no reset ever races with a reader)
+    uint32_t* queueCounts = nullptr;
+    uint32_t queueCountCapacity = 0;
+    hipEvent_t accumulated = nullptr;   // recorded after the lane's k_accumulate
+};
+
 struct RtgpuContext
 {
     int device = 0;
-    hipStream_t stream = nullptr;
     uint32_t numCUs = 256;
 
     // scene (device copies); sceneDev holds DEVICE pointers
@@ -708,15 +721,15 @@ struct RtgpuContext
     uint32_t* slotPixel = nullptr;
     uint32_t numSlots = 0;
 
-    // paths
-    Paths paths = { nullptr, 0, 0 };
-    uint32_t* queues[2] = { nullptr, nullptr };
-    uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
-    // per-pass work counters, 4 planes of (maxDepth + 2) uint32, zeroed once per pass: path-queue counts,
-    // shadow-queue counts, closest-kernel cursors, shadow-kernel cursors (one of each per bounce, so that no
-    // reset ever races with a reader)
-    uint32_t* queueCounts = nullptr;
-    uint32_t queueCountCapacity = 0;
+    // Batch lanes.  Every batch of passes runs on ONE lane = its own stream, path-state arena, queues and work
+    // counters; consecutive batches alternate lanes, so the drain of a persistent traversal launch (a handful of
+    // rays with thousands of steps keep a few waves busy for milliseconds -- an axis-parallel NEE ray that grazes
+    // a plane of box faces can take 30 000) overlaps with the next batch's kernels instead of idling the chip.
+    // Only k_accumulate is ordered across lanes (an event): the film is summed in pass order.
+    BatchLane lanes[RT_MAX_LANES];
+    uint32_t numLanes = 3;
+    uint32_t nextLane = 0;
+    int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
     TravTuning tune = { 28u, 32u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
@@ -763,15 +776,23 @@ static void freeFilm(RtgpuContext* c)
     c->sum = c->secondary = nullptr; c->slotPixel = nullptr; c->numSlots = 0;
 }
 
-static void freePaths(RtgpuContext* c)
+static void freePaths(BatchLane& l)
 {
-    if (c->paths.base) (void)hipFree(c->paths.base);
-    if (c->queues[0]) (void)hipFree(c->queues[0]);
-    if (c->queues[1]) (void)hipFree(c->queues[1]);
-    if (c->shadowQueues[0]) (void)hipFree(c->shadowQueues[0]);
-    if (c->shadowQueues[1]) (void)hipFree(c->shadowQueues[1]);
-    c->paths.base = nullptr; c->paths.capacity = 0; c->paths.maxLights = 0;
-    c->queues[0] = c->queues[1] = nullptr; c->shadowQueues[0] = c->shadowQueues[1] = nullptr;
+    if (l.paths.base) (void)hipFree(l.paths.base);
+    if (l.queues[0]) (void)hipFree(l.queues[0]);
+    if (l.queues[1]) (void)hipFree(l.queues[1]);
+    if (l.shadowQueues[0]) (void)hipFree(l.shadowQueues[0]);
+    if (l.shadowQueues[1]) (void)hipFree(l.shadowQueues[1]);
+    l.paths.base = nullptr; l.paths.capacity = 0; l.paths.maxLights = 0;
+    l.queues[0] = l.queues[1] = nullptr; l.shadowQueues[0] = l.shadowQueues[1] = nullptr;
+}
+
+static hipError_t syncLanes(RtgpuContext* c)
+{
+    hipError_t first = hipSuccess;
+    for (uint32_t i = 0; i < RT_MAX_LANES; ++i)
+        if (c->lanes[i].stream) { const hipError_t e = hipStreamSynchronize(c->lanes[i].stream); if (first == hipSuccess) first = e; }
+    return first;
 }
 
 static int resolveTimed(RtgpuContext* c)
@@ -798,14 +819,14 @@ static hipEvent_t acquireEvent(RtgpuContext* c)
 
 struct LaunchTimer
 {
-    RtgpuContext* c; int kc; hipEvent_t a = nullptr, b = nullptr;
-    LaunchTimer(RtgpuContext* ctx, int k) : c(ctx), kc(k)
+    RtgpuContext* c; hipStream_t stream; int kc; hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(RtgpuContext* ctx, hipStream_t st, int k) : c(ctx), stream(st), kc(k)
     {
-        if (c->timing) { a = acquireEvent(c); b = acquireEvent(c); (void)hipEventRecord(a, c->stream); }
+        if (c->timing) { a = acquireEvent(c); b = acquireEvent(c); (void)hipEventRecord(a, stream); }
     }
     ~LaunchTimer()
     {
-        if (c->timing) { (void)hipEventRecord(b, c->stream); c->pendingTimed.push_back({ kc, a, b }); }
+        if (c->timing) { (void)hipEventRecord(b, stream); c->pendingTimed.push_back({ kc, a, b }); }
     }
 };
 
@@ -873,9 +894,17 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_PASS_BATCH")) c->passBatch = (uint32_t)atoi(e);
     if (c->passBatch < 1) c->passBatch = 1;
     if (c->passBatch > RT_SEED_RING / 2) c->passBatch = RT_SEED_RING / 2;
+    if (const char* e = getenv("RTGPU_LANES")) c->numLanes = (uint32_t)atoi(e);
+    if (c->numLanes < 1) c->numLanes = 1;
+    if (c->numLanes > RT_MAX_LANES) c->numLanes = RT_MAX_LANES;
     if (c->tune.refillMinIdle < 1) c->tune.refillMinIdle = 1;
     if (c->tune.otherMinLanes < 1) c->tune.otherMinLanes = 1;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < RT_MAX_LANES && e == hipSuccess; ++i)
+    {
+        e = hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lanes[i].accumulated, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMalloc((void**)&c->seedRingDev, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t));
@@ -886,7 +915,7 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (e != hipSuccess)
     {
         const std::string msg = std::string("context creation failed: ") + hipGetErrorString(e);
-        delete c;
+        rtgpu_destroy(c);
         return fail(RTGPU_ERR_DEVICE, msg);
     }
     *outCtx = c;
@@ -897,9 +926,14 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    freeScene(c); freeFilm(c); freePaths(c);
-    if (c->queueCounts) (void)hipFree(c->queueCounts);
+    (void)syncLanes(c);
+    freeScene(c); freeFilm(c);
+    for (uint32_t i = 0; i < RT_MAX_LANES; ++i)
+    {
+        freePaths(c->lanes[i]);
+        if (c->lanes[i].queueCounts) (void)hipFree(c->lanes[i].queueCounts);
+        if (c->lanes[i].accumulated) (void)hipEventDestroy(c->lanes[i].accumulated);
+    }
     if (c->counters) (void)hipFree(c->counters);
     if (c->seedRingDev) (void)hipFree(c->seedRingDev);
     if (c->seedRingHost) (void)hipHostFree(c->seedRingHost);
@@ -908,7 +942,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
     for (int i = 0; i < RT_SEED_RING; ++i) if (c->seedEvents[i]) (void)hipEventDestroy(c->seedEvents[i]);
     for (auto& t : c->pendingTimed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (uint32_t i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamDestroy(c->lanes[i].stream);
     delete c;
 }
 
@@ -918,7 +952,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if (s->abiVersion != RTGPU_ABI_VERSION) return fail(RTGPU_ERR_INVALID_ARGUMENT, "RtSceneDesc::abiVersion mismatch");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(syncLanes(c));
 
     // validation: indices in range, stacks deep enough
     if (s->numObjects > 1 && s->numTopNodes == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene with more than one object needs a top-level BVH");
@@ -1028,7 +1062,7 @@ RTGPU_API int rtgpu_resize(RtgpuContext* c, uint32_t width, uint32_t height)
     if (width == 0 || height == 0 || width > 65536u || height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid viewport size");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(syncLanes(c));
     c->width = width; c->height = height;
     return rebuildFilm(c);
 }
@@ -1039,7 +1073,7 @@ RTGPU_API int rtgpu_set_shard(RtgpuContext* c, RtgpuShard shard)
     if (shard.worldSize == 0 || shard.rank >= shard.worldSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid shard");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(syncLanes(c));
     c->shard = shard;
     return rebuildFilm(c);
 }
@@ -1049,7 +1083,7 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(syncLanes(c));
     if (c->sum)
     {
         const size_t n = (size_t)c->width * c->height * 3;
@@ -1062,31 +1096,31 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
     return RTGPU_OK;
 }
 
-static int ensurePaths(RtgpuContext* c, uint32_t maxLights, uint32_t maxDepth)
+static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
     const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * c->passBatch;
-    if (!c->paths.base || c->paths.capacity < wanted || c->paths.maxLights < maxLights)
+    if (!l.paths.base || l.paths.capacity < wanted || l.paths.maxLights < maxLights)
     {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        freePaths(c);
+        HIP_TRY(hipStreamSynchronize(l.stream));
+        freePaths(l);
         if (wanted >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
         const size_t cap = wanted;
         const size_t records = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * cap;
-        HIP_TRY(hipMalloc((void**)&c->paths.base, records * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&c->queues[0], cap * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->queues[1], cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.paths.base, records * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&l.queues[0], cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.queues[1], cap * sizeof(uint32_t)));
         if ((unsigned long long)cap * maxLights >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x lights exceeds the NEE request index range");
-        HIP_TRY(hipMalloc((void**)&c->shadowQueues[0], cap * maxLights * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&c->shadowQueues[1], cap * maxLights * sizeof(uint32_t)));
-        c->paths.capacity = (uint32_t)cap; c->paths.maxLights = maxLights;
+        HIP_TRY(hipMalloc((void**)&l.shadowQueues[0], cap * maxLights * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.shadowQueues[1], cap * maxLights * sizeof(uint32_t)));
+        l.paths.capacity = (uint32_t)cap; l.paths.maxLights = maxLights;
     }
-    if (c->queueCountCapacity < maxDepth + 2)
+    if (l.queueCountCapacity < maxDepth + 2)
     {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->queueCounts) (void)hipFree(c->queueCounts);
-        c->queueCountCapacity = maxDepth + 2;
-        HIP_TRY(hipMalloc((void**)&c->queueCounts, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t)));
+        HIP_TRY(hipStreamSynchronize(l.stream));
+        if (l.queueCounts) (void)hipFree(l.queueCounts);
+        l.queueCountCapacity = maxDepth + 2;
+        HIP_TRY(hipMalloc((void**)&l.queueCounts, (size_t)4 * l.queueCountCapacity * sizeof(uint32_t)));
     }
     return RTGPU_OK;
 }
@@ -1099,7 +1133,10 @@ static int flushPending(RtgpuContext* c)
     const uint32_t numPasses = (uint32_t)c->pending.size();
     const DevPass& first = c->pending[0].pass;
     const uint32_t maxLights = first.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
-    int r = ensurePaths(c, maxLights, first.maxRayDepth);
+    BatchLane& l = c->lanes[c->nextLane];
+    const int laneIndex = (int)c->nextLane;
+    c->nextLane = (c->nextLane + 1u) % c->numLanes;
+    int r = ensurePaths(c, l, maxLights, first.maxRayDepth);
     if (r) { c->pending.clear(); return r; }
 
     // contiguous ring slots for the batch (seeds + pass constants); wait until their previous users have finished
@@ -1115,12 +1152,12 @@ static int flushPending(RtgpuContext* c)
         if (!pd.seeds.empty())
         {
             memcpy(seedHost, pd.seeds.data(), pd.seeds.size() * sizeof(uint32_t));
-            HIP_TRY(hipMemcpyAsync(seedDev, seedHost, pd.seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(seedDev, seedHost, pd.seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, l.stream));
         }
         pd.pass.seed = seedDev;
         c->passRingHost[slot] = pd.pass;
     }
-    HIP_TRY(hipMemcpyAsync(c->passRingDev + firstSlot, c->passRingHost + firstSlot, numPasses * sizeof(DevPass), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->passRingDev + firstSlot, c->passRingHost + firstSlot, numPasses * sizeof(DevPass), hipMemcpyHostToDevice, l.stream));
     const DevPass* passesDev = c->passRingDev + firstSlot;
 
     const uint32_t totalSlots = c->numSlots * numPasses;
@@ -1134,17 +1171,17 @@ static int flushPending(RtgpuContext* c)
     // LDS stack capacity in entries per lane: 24 (6 blocks per CU), 32 (4-5) or 64 (2); the scene's BVH depth decides
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
     const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u))));
-    uint32_t* pathCounts = c->queueCounts;
-    uint32_t* shadowCounts = c->queueCounts + c->queueCountCapacity;
-    uint32_t* cursors = c->queueCounts + 2 * c->queueCountCapacity;
+    uint32_t* pathCounts = l.queueCounts;
+    uint32_t* shadowCounts = l.queueCounts + l.queueCountCapacity;
+    uint32_t* cursors = l.queueCounts + 2 * l.queueCountCapacity;
     const uint32_t maxRayDepth = first.maxRayDepth;
 
-    HIP_TRY(hipMemsetAsync(c->queueCounts, 0, (size_t)4 * c->queueCountCapacity * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(l.queueCounts, 0, (size_t)4 * l.queueCountCapacity * sizeof(uint32_t), l.stream));
     {
-        LaunchTimer t(c, KC_GENERATE);
-        hipLaunchKernelGGL(k_generate, grid, block, 0, c->stream, c->sceneDev, passesDev, c->numSlots, c->paths, c->slotPixel, totalSlots, c->queues[0], pathCounts + 0, c->counters);
+        LaunchTimer t(c, l.stream, KC_GENERATE);
+        hipLaunchKernelGGL(k_generate, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, l.queues[0], pathCounts + 0, c->counters);
     }
-#define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, c->stream, c->sceneDev, c->paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
+#define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
     // bounce k: trace {closest rays of bounce k, NEE rays of bounce k-1} -> shade k; one last trace for the NEE rays of
     // the final bounce
     for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
@@ -1153,33 +1190,37 @@ static int flushPending(RtgpuContext* c)
         const bool haveShadow = depth > 0 && c->numLights != 0;
         if (haveClosest || haveShadow)
         {
-            const uint32_t* tq = haveClosest ? c->queues[depth & 1u] : nullptr;
+            const uint32_t* tq = haveClosest ? l.queues[depth & 1u] : nullptr;
             const uint32_t* tqc = haveClosest ? pathCounts + depth : nullptr;
-            const uint32_t* tsq = haveShadow ? c->shadowQueues[(depth - 1u) & 1u] : nullptr;
+            const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
-            LaunchTimer t(c, KC_TRACE);
+            LaunchTimer t(c, l.stream, KC_TRACE);
             if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
             else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
             else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
         }
         if (haveClosest)
         {
-            LaunchTimer t(c, KC_SHADE);
-#define RT_LAUNCH_SHADE(L) hipLaunchKernelGGL((k_shade<L>), grid, block, 0, c->stream, c->sceneDev, passesDev, c->numSlots, c->paths, c->queues[depth & 1u], pathCounts + depth, \
-                                             c->queues[(depth + 1u) & 1u], pathCounts + depth + 1, c->shadowQueues[depth & 1u], shadowCounts + depth, c->counters)
+            LaunchTimer t(c, l.stream, KC_SHADE);
+#define RT_LAUNCH_SHADE(L) hipLaunchKernelGGL((k_shade<L>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth, \
+                                             l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters)
             if (c->leanScene) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
         }
     }
+    // the film is summed in pass order: this batch's accumulate runs after the previous batch's
+    if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
     {
-        LaunchTimer t(c, KC_ACCUMULATE);
-        hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, c->stream, c->paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
+        LaunchTimer t(c, l.stream, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, l.stream, l.paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
     }
+    HIP_TRY(hipEventRecord(l.accumulated, l.stream));
+    c->lastAccumulateLane = laneIndex;
     c->pending.clear();
     HIP_TRY(hipGetLastError());
     for (uint32_t i = 0; i < numPasses; ++i)
     {
-        HIP_TRY(hipEventRecord(c->seedEvents[firstSlot + i], c->stream));
+        HIP_TRY(hipEventRecord(c->seedEvents[firstSlot + i], l.stream));
         c->seedEventUsed[firstSlot + i] = true;
     }
     return RTGPU_OK;
@@ -1233,7 +1274,7 @@ RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     HIP_TRY(hipSetDevice(c->device));
     { int r = flushPending(c); if (r) return r; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(syncLanes(c));
     return resolveTimed(c);
 }
 
@@ -1278,6 +1319,15 @@ RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     int r = rtgpu_synchronize(c); if (r) return r;
     c->countIntersections = enable != 0;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (lanes < 1 || lanes > RT_MAX_LANES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "lanes must be 1..4");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    c->numLanes = lanes; c->nextLane = 0;
     return RTGPU_OK;
 }
 

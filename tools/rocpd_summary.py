@@ -35,5 +35,21 @@ def main(path):
             print("%-44s %-16s %7d %18.1f %18.1f" % (name.split("(")[0][:44], counter, n, s, s / max(1, n)))
 
 
+def timeline(path):
+    """Every kernel launch in start order: offset from the first launch, duration, gap to the previous kernel's end."""
+    db = sqlite3.connect(path)
+    rows = db.cursor().execute("select name, start, end from kernels order by start").fetchall()
+    if not rows:
+        return
+    t0, prev_end = rows[0][1], rows[0][1]
+    print("# %s\n%-40s %12s %12s %10s" % (path, "kernel", "start_ms", "duration_us", "gap_us"))
+    for name, start, end in rows:
+        print("%-40s %12.3f %12.1f %10.1f" % (name.split("(")[0][:40], (start - t0) / 1e6, (end - start) / 1e3, (start - prev_end) / 1e3))
+        prev_end = end
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[1] == "--timeline":
+        timeline(sys.argv[2])
+    else:
+        main(sys.argv[1])
