@@ -327,7 +327,7 @@ int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
  * always maintained.  Synchronises. */
 int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
 
-/* Batch lanes (1..4, default 3).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
+/* Batch lanes (1..6, default 3).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
  * alternating HIP streams with their own path-state arenas, so the drain of one batch's traversal launches (a few
  * very long rays) overlaps with the next batch's kernels.  The film is still summed in pass order.  Performance
  * only: results do not depend on it.  1 = strictly serial kernels (what per-kernel timing wants).  Synchronises.

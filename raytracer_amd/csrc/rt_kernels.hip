@@ -218,6 +218,8 @@ RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSiz
     if (chunk.end < chunk.next) chunk.end = chunk.next;
 }
 
+#define RT_SPLIT_AFTER 32u   // drain iterations of a wave before its shadow rays start sharing subtrees
+
 // Wave scheduling knobs of the persistent traversal kernel (wave-uniform, passed as kernel arguments)
 struct TravTuning
 {
@@ -271,37 +273,88 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         prec(paths, R_HIT, slot) = f4(fbits(objectId), fbits(subObjectId), distance, u);
         prec(paths, R_SAMPLER, slot).x = v;
     };
+    // Drain-phase work sharing for any-hit rays.  When the queue is used up, a launch lasts as long as its longest
+    // ray, and some NEE rays are very long: a direction that is exactly a coordinate axis makes two of the three slab
+    // tests meaningless in the reference's box * invDir - origin * invDir formulation (inf - inf), and such a ray
+    // walks every node whose remaining slab it overlaps -- tens of thousands of steps, alone in its wave.  Occlusion
+    // is an OR over subtrees, so the deferred subtrees on a shadow ray's stack can be searched by other lanes: a
+    // lane with nothing to do takes the OLDEST deferred node (the largest subtree) of a busy shadow ray in its wave
+    // and searches it as a ray of its own with the same request id; whoever finds an occluder marks the request.
+    // Closest-hit rays are never split (their box culling and tie-breaking depend on the visiting order), and the
+    // counting variant does not split at all, so the intersection counters stay those of the serial traversal.
+    const bool splitShadowRays = !kCount && scene.numObjects == 1u;   // bypass scenes: a mesh level is all a ray has
+    uint32_t drainIterations = 0;
     for (;;)
     {
         const bool interior = have && travIsInterior(s);
         const bool other = have && !interior;
         const unsigned long long mI = __ballot(interior), mO = __ballot(other);
         const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
-        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
+        // Idle lanes get work from the queue (refill) or, once the queue is used up, from a busy shadow ray of the wave
+        const bool refill = !exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle);
+        unsigned long long mDonors = 0ull;
+        const bool canDonate = have && s.shadow && s.mode == TRAV_MESH && s.stackSize > s.levelBase;
+        if (splitShadowRays && exhausted && nIdle != 0u && ++drainIterations > RT_SPLIT_AFTER) mDonors = __ballot(canDonate);
+        if (refill || mDonors != 0ull)
         {
-            if (chunk.next >= chunk.end)
+            uint32_t request = 0xFFFFFFFFu, donated = 0u;
+            bool shadowRequest = true;
+            if (refill)
             {
-                waveClaimChunk(chunk, cursor, chunkSize, count);
-                if (chunk.next >= chunk.end) { exhausted = true; continue; }
+                if (chunk.next >= chunk.end)
+                {
+                    waveClaimChunk(chunk, cursor, chunkSize, count);
+                    if (chunk.next >= chunk.end) { exhausted = true; continue; }
+                }
+                const uint32_t idx = waveTake(!have, chunk);
+                if (idx != 0xFFFFFFFFu)
+                {
+                    shadowRequest = idx >= numClosest;
+                    request = shadowRequest ? shadowQueue[idx - numClosest] : queue[idx];
+                    if (shadowRequest) cnt.c[C_SHADOW]++;
+                }
             }
-            const uint32_t idx = waveTake(!have, chunk);
-            if (idx != 0xFFFFFFFFu)
+            else
+            {
+                // the k-th idle lane takes the OLDEST deferred node (stack bottom of the level) of the k-th donor
+                const unsigned long long mIdle = __ballot(!have);
+                const uint32_t lane = threadIdx.x & 63u;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t nDonors = (uint32_t)__popcll(mDonors), nTakers = (uint32_t)__popcll(mIdle);
+                const uint32_t pairs = nDonors < nTakers ? nDonors : nTakers;
+                const bool donate = canDonate && (uint32_t)__popcll(mDonors & below) < pairs;
+                const uint32_t takerRank = (uint32_t)__popcll(mIdle & below);
+                const bool take = !have && takerRank < pairs;
+                uint32_t src = lane;
+                if (take)
+                {
+                    unsigned long long m = mDonors;
+                    for (uint32_t k = 0; k < takerRank; ++k) m &= m - 1ull;
+                    src = (uint32_t)__ffsll((long long)m) - 1u;
+                }
+                uint32_t entry = 0u;
+                if (donate) { entry = stack.base[s.levelBase * stack.stride]; s.levelBase++; }
+                const uint32_t donorRequest = (uint32_t)__shfl((int)(light * paths.capacity + slot), (int)src);
+                donated = (uint32_t)__shfl((int)entry, (int)src);
+                if (take) request = donorRequest;
+            }
+            if (request != 0xFFFFFFFFu)
             {
                 float maxDistance = __uint_as_float(0x7f800000u);
-                s.shadow = idx >= numClosest;
-                if (!s.shadow) slot = queue[idx];
+                s.shadow = shadowRequest;
+                if (!shadowRequest) slot = request;
                 else
                 {
-                    const uint32_t request = shadowQueue[idx - numClosest];
                     light = request / paths.capacity; slot = request - light * paths.capacity;
                     maxDistance = pshadow(paths, light, 0, slot).w;   // hitPoint.distance = illuminateResult.distance * 0.999f
-                    cnt.c[C_SHADOW]++;
                 }
                 travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
                 have = true;
                 // single-object scenes start at the object loop (BVH bypass): enter the object right away instead of
                 // queueing for the "other" phase
                 if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
+                // a taken subtree: same ray, same mesh, but only the donated node instead of the root
+                if (!refill && s.mode == TRAV_MESH) s.cur = donated;
             }
             continue;
         }
@@ -341,8 +394,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             {
                 if (s.shadow)
                 {
-                    if (s.occluded) pshadow(paths, light, 0, slot).w = -1.0f;
-                    else cnt.c[C_SHADOW_HIT]++;
+                    if (s.occluded) pshadow(paths, light, 0, slot).w = -1.0f;   // unoccluded requests are tallied when they are resolved
                 }
                 else
                 {
@@ -398,17 +450,18 @@ __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& sce
 // accumulatedColor = sum of the unoccluded SampleLight() results in light order, times mLightSamplingWeight,
 // then resultColor.MulAndAccumulate(throughput, ...) (PathTracerMIS.cpp:141-151, 320).  k_trace_shadow marks
 // occluded requests with tmax < 0.
-RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, uint32_t numRequests, V4 lightSamplingWeight, V4& resultColor)
+RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, uint32_t numRequests, V4 lightSamplingWeight, V4& resultColor, Counters& cnt)
 {
     if (numRequests == 0) return;
     V4 accumulated = zero4();
     bool any = false;
     for (uint32_t l = 0; l < numRequests; ++l)
     {
-        if (pshadow(paths, l, 0, slot).w < 0.0f) continue;
+        if (pshadow(paths, l, 0, slot).w < 0.0f) continue;   // no shadow ray was needed, or k_trace found an occluder
         const float4 c = pshadow(paths, l, 1, slot);
         accumulated = accumulated + V4(c.x, c.y, c.z, 0.0f);
         any = true;
+        cnt.c[C_SHADOW_HIT]++;   // counters.numShadowRaysHit: the shadow ray reached the light (PathTracerMIS.cpp:96-99)
     }
     if (!any) return;
     accumulated = accumulated * lightSamplingWeight;
@@ -478,7 +531,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
             const Ray ray = makePathRay(rOrigin, rDir, depth);
             V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
             V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-            resolvePendingLightSamples(paths, slot, ubits(rSampler.w), lightSamplingWeight, resultColor);   // NEE of the previous vertex
+            resolvePendingLightSamples(paths, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
             Hit hit;
             hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
             bool samplerStored = false;
@@ -642,8 +695,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
 // batch are added per pixel IN PASS ORDER, so the float sum is the one the reference builds pass after pass; the
 // secondary sum receives the even passes (Viewport.cpp:303).
 __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t slotsPerPass, uint32_t numPasses, float* __restrict__ sum,
-                                                         float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes)
+                                                         float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes,
+                                                         unsigned long long* counters)
 {
+    Counters cnt; zeroCounters(cnt);
     const V4 lightSamplingWeight = load4(passes[0].lightSamplingWeight);
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < slotsPerPass; pixelSlot += stride)
@@ -657,13 +712,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
             const uint32_t slot = b * slotsPerPass + pixelSlot;
             const float4 rResult = prec(paths, R_RESULT, slot);
             V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-            resolvePendingLightSamples(paths, slot, ubits(prec(paths, R_SAMPLER, slot).w), lightSamplingWeight, resultColor);   // NEE of the path's last vertex
+            resolvePendingLightSamples(paths, slot, ubits(prec(paths, R_SAMPLER, slot).w), lightSamplingWeight, resultColor, cnt);   // NEE of the path's last vertex
             sr = sr + resultColor.x; sg = sg + resultColor.y; sb = sb + resultColor.z;
             if ((passes[b].passIndex % 2u) == 0u) { tr = tr + resultColor.x; tg = tg + resultColor.y; tb = tb + resultColor.z; }
         }
         sum[idx + 0] = sr; sum[idx + 1] = sg; sum[idx + 2] = sb;
         secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
+    flushCounters(cnt, counters);
 }
 
 // =====================================================================================================
@@ -684,11 +740,11 @@ static int fail(int code, const std::string& msg) { gLastError = msg; return cod
 enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_COUNT };
 static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "", "", "", "" };
 
-#define RT_SEED_RING 32
+#define RT_SEED_RING 64
 
 struct CtxPending { DevPass pass; std::vector<uint32_t> seeds; };
 
-#define RT_MAX_LANES 4
+#define RT_MAX_LANES 6
 struct BatchLane
 {
     hipStream_t stream = nullptr;
@@ -1136,7 +1192,9 @@ static int flushPending(RtgpuContext* c)
     BatchLane& l = c->lanes[c->nextLane];
     const int laneIndex = (int)c->nextLane;
     c->nextLane = (c->nextLane + 1u) % c->numLanes;
-    int r = ensurePaths(c, l, maxLights, first.maxRayDepth);
+    // all lanes get their arenas with the first batch: a 3 GB hipMalloc costs tens of milliseconds
+    int r = RTGPU_OK;
+    for (uint32_t i = 0; i < c->numLanes && r == RTGPU_OK; ++i) r = ensurePaths(c, c->lanes[i], maxLights, first.maxRayDepth);
     if (r) { c->pending.clear(); return r; }
 
     // contiguous ring slots for the batch (seeds + pass constants); wait until their previous users have finished
@@ -1212,7 +1270,7 @@ static int flushPending(RtgpuContext* c)
     if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
     {
         LaunchTimer t(c, l.stream, KC_ACCUMULATE);
-        hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, l.stream, l.paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
+        hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, l.stream, l.paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev, c->counters);
     }
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
@@ -1325,7 +1383,7 @@ RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
 RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
-    if (lanes < 1 || lanes > RT_MAX_LANES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "lanes must be 1..4");
+    if (lanes < 1 || lanes > RT_MAX_LANES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "lanes must be 1..6");
     int r = rtgpu_synchronize(c); if (r) return r;
     c->numLanes = lanes; c->nextLane = 0;
     return RTGPU_OK;

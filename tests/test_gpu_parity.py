@@ -135,12 +135,12 @@ def test_pass_batching_is_invisible(built, monkeypatch):
 
 def test_batch_lanes_are_invisible(built, monkeypatch):
     """Consecutive batches run on alternating streams with their own path arenas (rtgpu_set_concurrency); the film is
-    still summed in pass order, so 1..4 lanes give the same bits.  7 passes at batch size 2 = 4 batches in flight."""
+    still summed in pass order, so 1..6 lanes give the same bits.  7 passes at batch size 2 = 4 batches in flight."""
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
     monkeypatch.setenv("RTGPU_PASS_BATCH", "2")
     results = []
-    for lanes in (1, 2, 3, 4):
+    for lanes in (1, 2, 3, 6):
         vp = ra.Viewport(w, h, seed=33, max_ray_depth=4)
         vp.set_renderer(scene)
         assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), lanes) == 0
@@ -150,7 +150,7 @@ def test_batch_lanes_are_invisible(built, monkeypatch):
         assert np.array_equal(r[0][0].view(np.uint32), results[0][0][0].view(np.uint32))
         assert np.array_equal(r[0][1].view(np.uint32), results[0][0][1].view(np.uint32))
         assert r[1] == results[0][1]
-    assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), 5) == -1   # RTGPU_ERR_INVALID_ARGUMENT
+    assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), 7) == -1   # RTGPU_ERR_INVALID_ARGUMENT
 
 
 def test_depth_of_field(built):
