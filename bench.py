@@ -87,9 +87,17 @@ def main():
         entry.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one rank per GPU; BENCH_DIST_BACKEND=gloo with ranks sharing a device exists only to exercise the N>1 code path
+    # on a 1-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     import raytracer_amd as ra
 
