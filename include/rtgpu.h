@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 1u
+#define RTGPU_ABI_VERSION 2u
 
 typedef enum RtgpuStatus
 {
@@ -151,7 +151,9 @@ typedef struct RtLight
     uint32_t shapeKind;      /* area lights: RT_SHAPE_SPHERE / BOX / RECT */
     uint32_t isDelta;        /* directional / spot: mIsDelta (cos > 0.9999, Light.h:25) */
     float    cosAngle;       /* directional / spot: cosf(angle) computed by the host */
-    float    _pad[3];
+    uint32_t texture;        /* background light: BackgroundLight::mTexture (environment map, BackgroundLight.cpp:45-61)
+                              * as an index into RtSceneDesc::textures, or RT_NO_TEXTURE */
+    float    _pad[2];
     float    shapeParam[4];
     float    shapeParam2[4];
 } RtLight;
@@ -169,7 +171,51 @@ typedef enum RtBsdf /* string names of Material::SetBsdf, Core/Material/Material
     RT_BSDF_ROUGH_PLASTIC = 8
 } RtBsdf;
 
-/* 64 bytes; scalar part of rt::Material after Compile() (Core/Material/Material.cpp:105-117). */
+#define RT_NO_TEXTURE 0xFFFFFFFFu
+
+/* ITexture implementations that can sit on the shading path (Core/Textures/). */
+typedef enum RtTextureKind
+{
+    RT_TEXTURE_BITMAP = 0,        /* BitmapTexture  (BitmapTexture.cpp:32-93) */
+    RT_TEXTURE_CHECKERBOARD = 1,  /* CheckerboardTexture (CheckerboardTexture.cpp:31-40): colorA / colorB */
+    RT_TEXTURE_CONST = 2          /* ConstTexture: colorA */
+} RtTextureKind;
+
+/* Texel formats: the values of rt::Bitmap::Format (Core/Utils/Bitmap.h:15-41).  The ones listed are decoded on the
+ * device exactly as Bitmap::GetPixelBlock does (Bitmap.cpp:520-832); palette, B5G6R5, R11G11B10, R9G9B9E5 and the
+ * block-compressed formats are rejected by rtgpu_upload_scene with RTGPU_ERR_UNSUPPORTED. */
+typedef enum RtBitmapFormat
+{
+    RT_FORMAT_R8_UNORM = 1, RT_FORMAT_R8G8_UNORM = 2, RT_FORMAT_B8G8R8_UNORM = 3, RT_FORMAT_B8G8R8A8_UNORM = 4,
+    RT_FORMAT_R8G8B8A8_UNORM = 5, RT_FORMAT_R16_UNORM = 8, RT_FORMAT_R16G16_UNORM = 9, RT_FORMAT_R16G16B16A16_UNORM = 10,
+    RT_FORMAT_R32_FLOAT = 11, RT_FORMAT_R32G32_FLOAT = 12, RT_FORMAT_R32G32B32_FLOAT = 13, RT_FORMAT_R32G32B32A32_FLOAT = 14,
+    RT_FORMAT_R16_HALF = 16, RT_FORMAT_R16G16_HALF = 17, RT_FORMAT_R16G16B16_HALF = 18, RT_FORMAT_R16G16B16A16_HALF = 19
+} RtBitmapFormat;
+
+typedef enum RtTextureFilter /* BitmapTextureFilter, Core/Textures/BitmapTexture.h */
+{
+    RT_FILTER_NEAREST = 0, RT_FILTER_BILINEAR = 1, RT_FILTER_BILINEAR_SMOOTHSTEP = 2
+} RtTextureFilter;
+
+/* 80 bytes */
+typedef struct RtTexture
+{
+    uint32_t kind;          /* RtTextureKind */
+    uint32_t format;        /* RtBitmapFormat */
+    uint32_t width, height;
+    uint32_t stride;        /* bytes per row, Bitmap::mStride */
+    uint32_t linearSpace;   /* Bitmap::mLinearSpace; 0 => Convert_sRGB_To_Linear on every fetched texel (all four lanes) */
+    uint32_t filter;        /* RtTextureFilter */
+    uint32_t _pad;
+    uint64_t dataOffset;    /* byte offset of the first row in RtSceneDesc::texelData (rows are `stride` apart) */
+    uint64_t _pad2;
+    float    colorA[4];     /* checkerboard / const */
+    float    colorB[4];
+} RtTexture;
+
+/* 80 bytes; rt::Material after Compile() (Core/Material/Material.cpp:105-117): scalar parameters, the textures of the
+ * four MaterialParameters (value = baseValue * texture->Evaluate(uv), MaterialParameter.h:22-32) and the normal map
+ * (Material::GetNormalVector, Material.cpp:120-138; applied in Scene::EvaluateIntersection, Scene.cpp:327-337). */
 typedef struct RtMaterial
 {
     float    emission[4];   /* all four lanes significant */
@@ -179,7 +225,13 @@ typedef struct RtMaterial
     float    IoR;
     float    K;
     uint32_t bsdf;          /* RtBsdf */
-    uint32_t _pad[3];
+    uint32_t baseColorTexture;   /* indices into RtSceneDesc::textures, or RT_NO_TEXTURE */
+    uint32_t emissionTexture;
+    uint32_t roughnessTexture;
+    uint32_t metalnessTexture;
+    uint32_t normalMapTexture;
+    float    normalMapStrength;
+    uint32_t _pad;
 } RtMaterial;
 
 typedef struct RtSceneDesc
@@ -194,7 +246,8 @@ typedef struct RtSceneDesc
     uint32_t numMeshNodes;
     uint32_t numTriangles;
     uint32_t numVertices;
-    uint32_t _pad[2];
+    uint32_t numTextures;
+    uint32_t _pad;
 
     const RtNode*          topNodes;       /* [numTopNodes]  Scene::mTraceableObjectsBVH */
     const RtObject*        objects;        /* [numObjects]   */
@@ -209,6 +262,9 @@ typedef struct RtSceneDesc
     /* 128*128*4 uint16 = 131072 bytes, contents of Data/BlueNoise128_RGBA16.dat
      * (Core/Sampling/GenericSampler.cpp:13-52).  NULL => blue-noise dithering silently off (:72). */
     const uint16_t*        blueNoise;
+    const RtTexture*       textures;       /* [numTextures] */
+    const uint8_t*         texelData;      /* [texelBytes] rows of all bitmap textures (RtTexture::dataOffset points into it) */
+    uint64_t               texelBytes;
 } RtSceneDesc;
 
 /* ---------------------------------------------------------------------------------------------
@@ -333,6 +389,11 @@ int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
  * only: results do not depend on it.  1 = strictly serial kernels (what per-kernel timing wants).  Synchronises.
  * Replaces the thread-pool width of the reference (RenderingParams::numThreads, Viewport.cpp:44-50). */
 int rtgpu_set_concurrency(RtgpuContext* ctx, uint32_t lanes);
+
+/* Evaluates textures of the uploaded scene on the device: out[4*i..] = ITexture::Evaluate(textures[textureIndex[i]],
+ * (uv[2*i], uv[2*i+1])).  Host pointers; synchronous.  Exists so that the device decode of every texel format can be
+ * checked against the reference's vectors directly (tests/golden/texture_kat.bin). */
+int rtgpu_evaluate_textures(RtgpuContext* ctx, uint32_t count, const uint32_t* textureIndex, const float* uv, float* out);
 
 /* --- measurement hooks (bench.py) ---------------------------------------------------------------
  * Per-kernel-class GPU time in milliseconds accumulated since rtgpu_reset, measured with HIP events

@@ -59,6 +59,10 @@
 #include "Scene/Object/SceneObject_Light.h"
 #include "Scene/Camera.h"
 #include "Material/Material.h"
+#include "Textures/BitmapTexture.h"
+#include "Textures/CheckerboardTexture.h"
+#include "Utils/Bitmap.h"
+#include "Math/Half.h"
 #include "Material/BSDF/BSDF.h"
 #include "Material/BSDF/Microfacet.h"
 #include "Rendering/Context.h"
@@ -378,6 +382,7 @@ static void fillLight(RtLight& L, const ILight& light, const Matrix4& xf, uint32
     L.type = (uint32_t)light.GetType();
     L.flags = (uint32_t)light.GetFlags();
     L.shapeKind = shapeKind;
+    L.texture = RT_NO_TEXTURE;
     memcpy(L.shapeParam, p, 16); memcpy(L.shapeParam2, p2, 16);
 }
 
@@ -489,7 +494,7 @@ static void genBsdf()
         // --- Sample
         {
             const Float3 u(g.unit(), g.unit(), g.unit());
-            float* in = ks.addIn(); memcpy(in, &M, sizeof(M)); put4(in + 16, outgoing); in[20] = u.x; in[21] = u.y; in[22] = u.z;
+            float* in = ks.addIn(); memcpy(in, &M, 64); put4(in + 16, outgoing); in[20] = u.x; in[21] = u.y; in[22] = u.z;
             BSDF::SamplingContext sc = { mat, mp, u, outgoing, wavelength };
             const bool ok = mat.GetBSDF()->Sample(sc);
             float* out = ks.addOut(); out[0] = bitsf(ok ? 1u : 0u);
@@ -499,7 +504,7 @@ static void genBsdf()
         {
             Vector4 incoming = g.dir();
             if (i % 4 != 0) incoming.z = -Abs(incoming.z);   // mostly arriving from above (NdotL = -incoming.z > 0)
-            float* in = ke.addIn(); memcpy(in, &M, sizeof(M)); put4(in + 16, outgoing); put4(in + 20, incoming);
+            float* in = ke.addIn(); memcpy(in, &M, 64); put4(in + 16, outgoing); put4(in + 20, incoming);
             const BSDF::EvaluationContext ec = { mat, mp, wavelength, outgoing, incoming };
             float pdf = 0.0f;
             const RayColor c = mat.GetBSDF()->Evaluate(ec, &pdf);
@@ -760,6 +765,152 @@ static void genMesh()
     writeRaw("mesh_kat.bin", blob.data(), blob.size() * 4);
 }
 
+
+// =====================================================================================================
+// Textures on the shading path: BitmapTexture::Evaluate over every format the device decodes, both colour spaces,
+// the three filters; CheckerboardTexture; Material::EvaluateShadingData / GetNormalVector with textures;
+// BackgroundLight with an environment map.  File "texture_kat.bin":
+//   u32 magic 'TEX1', numTextures, numEval, numMaterial, numBackground; u64 texelBytes
+//   RtTexture[numTextures]; texel blob;
+//   eval records:       u32 texture, f32 u, v, f32 out[4]
+//   material records:   RtMaterial (80 B), f32 u, v, f32 baseColor[4], emission[4], roughness, metalness, normal[4]
+//   background records: RtLight, f32 dir[4], f32 color[4]
+static void genTextures()
+{
+    Lcg g(70);
+    std::vector<RtTexture> descs;
+    std::vector<uint8_t> blob;
+    std::vector<std::shared_ptr<ITexture>> textures;
+    struct Fmt { Bitmap::Format f; uint32_t bytes; int kind; };   // kind: 0 = unorm bytes, 1 = float, 2 = half
+    const Fmt fmts[] = {
+        { Bitmap::Format::R8_UNorm, 1, 0 }, { Bitmap::Format::R8G8_UNorm, 2, 0 }, { Bitmap::Format::B8G8R8_UNorm, 3, 0 },
+        { Bitmap::Format::B8G8R8A8_UNorm, 4, 0 }, { Bitmap::Format::R8G8B8A8_UNorm, 4, 0 }, { Bitmap::Format::R16_UNorm, 2, 0 },
+        { Bitmap::Format::R16G16_UNorm, 4, 0 }, { Bitmap::Format::R16G16B16A16_UNorm, 8, 0 }, { Bitmap::Format::R32_Float, 4, 1 },
+        { Bitmap::Format::R32G32_Float, 8, 1 }, { Bitmap::Format::R32G32B32_Float, 12, 1 }, { Bitmap::Format::R32G32B32A32_Float, 16, 1 },
+        { Bitmap::Format::R16_Half, 2, 2 }, { Bitmap::Format::R16G16_Half, 4, 2 }, { Bitmap::Format::R16G16B16_Half, 6, 2 },
+        { Bitmap::Format::R16G16B16A16_Half, 8, 2 } };
+    const uint32_t sizes[][2] = { { 7, 5 }, { 16, 16 }, { 1, 1 }, { 33, 2 }, { 2, 19 }, { 64, 32 } };
+    int combo = 0;
+    for (const Fmt& fm : fmts)
+        for (int variant = 0; variant < 3; ++variant, ++combo)
+        {
+            const uint32_t w = sizes[combo % 6][0], h = sizes[combo % 6][1];
+            std::vector<uint8_t> data((size_t)w * h * fm.bytes);
+            if (fm.kind == 0) for (auto& b : data) b = (uint8_t)g.u32();
+            else if (fm.kind == 1) { float* f = (float*)data.data(); for (size_t k = 0; k < data.size() / 4; ++k) f[k] = g.range(0.0f, 2.0f); }
+            else { Half* hp = (Half*)data.data(); for (size_t k = 0; k < data.size() / 2; ++k) hp[k] = Half(k % 37 == 0 ? 1.0e-6f : g.range(0.0f, 2.0f)); }
+            Bitmap::InitData init;
+            init.width = w; init.height = h; init.format = fm.f; init.data = data.data();
+            init.linearSpace = (variant != 1);
+            BitmapPtr bitmap = std::make_shared<Bitmap>("kat");
+            if (!bitmap->Init(init)) { fprintf(stderr, "Bitmap::Init failed\n"); exit(1); }
+            auto tex = std::make_shared<BitmapTexture>(bitmap);
+            tex->mFilter = (BitmapTextureFilter)((combo + variant) % 3);
+            RtTexture t; memset(&t, 0, sizeof(t));
+            t.kind = RT_TEXTURE_BITMAP; t.format = (uint32_t)fm.f; t.width = w; t.height = h; t.stride = bitmap->mStride;
+            t.linearSpace = init.linearSpace ? 1u : 0u; t.filter = (uint32_t)tex->mFilter;
+            while (blob.size() % 16) blob.push_back(0);
+            t.dataOffset = blob.size();
+            blob.insert(blob.end(), bitmap->mData, bitmap->mData + (size_t)bitmap->mStride * h);
+            descs.push_back(t); textures.push_back(tex);
+        }
+    for (int k = 0; k < 2; ++k)
+    {
+        Vector4 a(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), 0.0f), b(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), 1.0f);
+        textures.push_back(std::make_shared<CheckerboardTexture>(a, b));
+        RtTexture t; memset(&t, 0, sizeof(t)); t.kind = RT_TEXTURE_CHECKERBOARD; memcpy(t.colorA, &a, 16); memcpy(t.colorB, &b, 16);
+        descs.push_back(t);
+    }
+    for (int k = 0; k < 32; ++k) blob.push_back(0);   // the reference's loads read up to 16 bytes past a texel
+
+    std::vector<uint32_t> out;
+    auto pushf = [&](float f) { out.push_back(fbits(f)); };
+    auto push4 = [&](const Vector4& v) { pushf(v.x); pushf(v.y); pushf(v.z); pushf(v.w); };
+    const uint32_t numTextures = (uint32_t)descs.size();
+    // --- Evaluate
+    const float special[] = { 0.0f, 1.0f, -1.0f, 0.5f, 2.0f, -0.0f, 0.99999994f, -1.0e-8f, 1.0e-8f, 0.25f, 0.75f, -2.5f, 3.0f };
+    uint32_t numEval = 0;
+    std::vector<uint32_t> evalRecords;
+    for (uint32_t ti = 0; ti < numTextures; ++ti)
+        for (int k = 0; k < 96; ++k)
+        {
+            float u = g.range(-3.0f, 3.0f), v = g.range(-3.0f, 3.0f);
+            if (k < 13) { u = special[k]; v = special[(k * 5 + 3) % 13]; }
+            else if (k < 26) { v = special[k - 13]; }
+            else if (k < 40) { u = (float)((k - 26) % 8) / (float)descs[ti].width + (k % 2 ? 0.0f : 1.0e-7f); }   // texel edges
+            const Vector4 c = textures[ti]->Evaluate(Vector4(u, v, 0.0f, 0.0f));
+            out.push_back(ti); pushf(u); pushf(v); push4(c);
+            ++numEval;
+        }
+    // --- Material::EvaluateShadingData + GetNormalVector
+    const uint32_t numMaterial = 256;
+    Wavelength wavelength;
+    for (uint32_t i = 0; i < numMaterial; ++i)
+    {
+        MaterialPtr mat = Material::Create();
+        mat->SetBsdf("roughPlastic");
+        mat->baseColor = Vector4(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), 0.0f);
+        mat->emission = Vector4(g.range(0.0f, 3.0f), g.range(0.0f, 3.0f), g.range(0.0f, 3.0f), 0.0f);
+        mat->roughness = g.range(0.05f, 1.0f);
+        mat->metalness = g.range(0.0f, 1.0f);
+        mat->normalMapStrength = (i % 5 == 0) ? 1.0f : g.range(0.0f, 1.5f);
+        RtMaterial M; memset(&M, 0, sizeof(M));
+        M.baseColorTexture = M.emissionTexture = M.roughnessTexture = M.metalnessTexture = M.normalMapTexture = RT_NO_TEXTURE;
+        auto pick = [&]() { return g.u32() % numTextures; };
+        if (i % 2 == 0) { M.baseColorTexture = pick(); mat->baseColor.texture = textures[M.baseColorTexture]; }
+        if (i % 3 == 0) { M.emissionTexture = pick(); mat->emission.texture = textures[M.emissionTexture]; }
+        if (i % 4 != 1) { M.roughnessTexture = pick(); mat->roughness.texture = textures[M.roughnessTexture]; }
+        if (i % 4 != 2) { M.metalnessTexture = pick(); mat->metalness.texture = textures[M.metalnessTexture]; }
+        M.normalMapTexture = pick(); mat->normalMap = textures[M.normalMapTexture];
+        mat->Compile();
+        memcpy(M.emission, &mat->emission.baseValue, 16); memcpy(M.baseColor, &mat->baseColor.baseValue, 16);
+        M.roughness = mat->roughness.baseValue; M.metalness = mat->metalness.baseValue; M.IoR = mat->IoR; M.K = mat->K; M.bsdf = RT_BSDF_ROUGH_PLASTIC;
+        M.normalMapStrength = mat->normalMapStrength;
+        const float u = g.range(-2.0f, 2.0f), v = g.range(-2.0f, 2.0f);
+        ShadingData sd;
+        sd.intersection.texCoord = Vector4(u, v, 0.0f, 0.0f);
+        mat->EvaluateShadingData(wavelength, sd);
+        const Vector4 n = mat->GetNormalVector(sd.intersection.texCoord);
+        uint32_t mw[sizeof(M) / 4]; memcpy(mw, &M, sizeof(M));
+        for (size_t k = 0; k < sizeof(M) / 4; ++k) out.push_back(mw[k]);
+        pushf(u); pushf(v); push4(sd.materialParams.baseColor.value); push4(sd.materialParams.emissionColor.value);
+        pushf(sd.materialParams.roughness); pushf(sd.materialParams.metalness); push4(n);
+    }
+    // --- BackgroundLight::GetBackgroundColor with an environment map (through GetRadiance)
+    const uint32_t numBackground = 256;
+    RenderingContext* ctx = new RenderingContext();
+    for (uint32_t i = 0; i < numBackground; ++i)
+    {
+        const Vector4 color(g.range(0.0f, 4.0f), g.range(0.0f, 4.0f), g.range(0.0f, 4.0f), 0.0f);
+        BackgroundLight light(color);
+        const uint32_t ti = g.u32() % numTextures;
+        light.mTexture = textures[ti];
+        const float p[4] = { 0, 0, 0, 0 };
+        RtLight L; fillLight(L, light, Matrix4::Identity(), 0, p, p);
+        L.texture = ti;
+        Vector4 dir = g.dir();
+        if (i % 17 == 0) dir = Vector4(0.0f, 1.0f, 0.0f, 0.0f);
+        if (i % 19 == 0) dir = Vector4(0.0f, 0.0f, -1.0f, 0.0f);
+        const Ray ray(Vector4::Zero(), dir);
+        const ILight::RadianceParam param = { *ctx, ray, Vector4::Zero(), 1.0f };
+        float pdf = 0.0f;
+        const RayColor rad = light.GetRadiance(param, &pdf, nullptr);
+        uint32_t lw[sizeof(L) / 4]; memcpy(lw, &L, sizeof(L));
+        for (size_t k = 0; k < sizeof(L) / 4; ++k) out.push_back(lw[k]);
+        push4(ray.dir); push4(rad.value);
+    }
+    std::vector<uint8_t> file;
+    auto putU32 = [&](uint32_t v) { const uint8_t* b = (const uint8_t*)&v; file.insert(file.end(), b, b + 4); };
+    putU32(0x31584554u); putU32(numTextures); putU32(numEval); putU32(numMaterial); putU32(numBackground);
+    putU32(0);
+    const uint64_t texelBytes = blob.size();
+    file.insert(file.end(), (const uint8_t*)&texelBytes, (const uint8_t*)&texelBytes + 8);
+    file.insert(file.end(), (const uint8_t*)descs.data(), (const uint8_t*)descs.data() + descs.size() * sizeof(RtTexture));
+    file.insert(file.end(), blob.begin(), blob.end());
+    file.insert(file.end(), (const uint8_t*)out.data(), (const uint8_t*)out.data() + out.size() * 4);
+    writeRaw("texture_kat.bin", file.data(), file.size());
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -773,6 +924,7 @@ int main(int argc, char** argv)
     genIntegers();
     genHost();
     genMesh();
+    genTextures();
     printf("done\n");
     return 0;
 }

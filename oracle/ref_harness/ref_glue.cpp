@@ -4,7 +4,9 @@
 // includes <Windows.h> unconditionally, line 8), so the four allocation entry points it would define are
 // provided below over posix_memalign/free.  No arithmetic on the hot path depends on them.  They are
 // declared (not defined) in the reference's own header Core/Utils/Memory.h:15-29, which is what is
-// included here.
+// included here.  Likewise Core/Utils/MemoryHelpers.cpp (needs <intrin.h>) would define LargeMemCopy, which
+// Bitmap::Copy references; the KAT generator never copies a bitmap, so the symbol only has to exist for the
+// linker -- it aborts if it is ever called.
 #include <stdlib.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -15,6 +17,7 @@
 
 #include "PCH.h"
 #include "Utils/Memory.h"
+#include "Utils/MemoryHelpers.h"
 
 namespace rt {
 
@@ -34,5 +37,7 @@ void DefaultAllocator::Free(void* ptr) { free(ptr); }
 void* SystemAllocator::Allocate(size_t size, size_t alignment) { return DefaultAllocator::Allocate(size, std::max<size_t>(alignment, 64)); }
 
 void SystemAllocator::Free(void* ptr) { free(ptr); }
+
+void LargeMemCopy(void* __restrict, const void* __restrict, size_t) { abort(); }   // link-only, see the header comment
 
 } // namespace rt

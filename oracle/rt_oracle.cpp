@@ -128,6 +128,15 @@ static inline float bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 static void putV4(float* o, V4 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 
+// the BSDF fixtures carry the scalar part of RtMaterial (through `bsdf`, 52 bytes) in 16 float slots
+static RtMaterial katMaterial(const float* in)
+{
+    RtMaterial m; memset(&m, 0, sizeof(m));
+    memcpy(&m, in, 52);
+    m.baseColorTexture = m.emissionTexture = m.roughnessTexture = m.metalnessTexture = m.normalMapTexture = RT_NO_TEXTURE;
+    return m;
+}
+
 int rto_kat(int func, const float* in, int inStride, float* out, int outStride, int n)
 {
     for (int r = 0; r < n; ++r)
@@ -211,7 +220,7 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             RtLight L; memcpy(&L, i, sizeof(RtLight));
             Intersection is; is.frame = loadM4(i + LW); is.texCoord = zero4(); is.material = 0;
             IlluminateResult ir;
-            const V4 rad = lightIlluminate(L, is, i + LW + 16, ir);
+            const V4 rad = lightIlluminate(nullptr, L, is, i + LW + 16, ir);
             putV4(o, rad); putV4(o + 4, ir.directionToLight); o[8] = ir.distance; o[9] = ir.directPdfW; o[10] = ir.cosAtLight; break;
         }
         case KAT_LIGHT_RADIANCE:  // in: RtLight, ray origin[4], dir[4] (light space), hitPoint[4], cosAtLight
@@ -220,13 +229,13 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             RtLight L; memcpy(&L, i, sizeof(RtLight));
             Ray ray; ray.origin = load4(i + LW); ray.dir = load4(i + LW + 4); ray.invDir = zero4(); ray.originDivDir = zero4();
             float pdf = 0.0f;
-            const V4 rad = lightGetRadiance(L, ray, load4(i + LW + 8), i[LW + 12], pdf);
+            const V4 rad = lightGetRadiance(nullptr, L, ray, load4(i + LW + 8), i[LW + 12], pdf);
             putV4(o, rad); o[4] = pdf; break;
         }
-        case KAT_BSDF_SAMPLE:     // in: RtMaterial (16 floats), outgoingDir[4] (local), u[3]
+        case KAT_BSDF_SAMPLE:     // in: the first 64 bytes of RtMaterial (16 floats; no textures), outgoingDir[4] (local), u[3]
         {
-            RtMaterial m; memcpy(&m, i, sizeof(RtMaterial));
-            ShadingData sd; materialEvaluateShadingData(m, sd);
+            RtMaterial m = katMaterial(i);
+            ShadingData sd; sd.intersection.texCoord = zero4(); materialEvaluateShadingData(nullptr, m, sd);
             BsdfSample s;
             const bool ok = bsdfSampleImpl(m.bsdf, m, sd.mp, i + 20, load4(i + 16), s);
             o[0] = bitsf(ok ? 1u : 0u);
@@ -236,8 +245,8 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
         }
         case KAT_BSDF_EVALUATE:   // in: RtMaterial, outgoingDir[4], incomingDir[4] (local)
         {
-            RtMaterial m; memcpy(&m, i, sizeof(RtMaterial));
-            ShadingData sd; materialEvaluateShadingData(m, sd);
+            RtMaterial m = katMaterial(i);
+            ShadingData sd; sd.intersection.texCoord = zero4(); materialEvaluateShadingData(nullptr, m, sd);
             float pdf = 0.0f;
             const V4 c = bsdfEvaluate(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), pdf);
             putV4(o, c); o[4] = almostZero4(c) ? 0.0f : pdf; break;
@@ -344,6 +353,34 @@ int rto_kat_mesh(const RtSceneDesc* scene, uint32_t meshIndex, const float* rays
     return 0;
 }
 
+// ---- textures on the shading path (tests/golden/texture_kat.bin) -------------------------------------------------
+// ITexture::Evaluate of textures[index] at (u, v)
+void rto_texture_evaluate(const RtTexture* textures, const uint8_t* texels, uint32_t index, float u, float v, float out[4])
+{
+    RtSceneDesc d; memset(&d, 0, sizeof(d)); d.textures = textures; d.texelData = texels;
+    const V4 c = textureEvaluate(&d, index, V4(u, v, 0.0f, 0.0f));
+    out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+}
+// Material::EvaluateShadingData + GetNormalVector: out = baseColor[4], emission[4], roughness, metalness, normal[4]
+void rto_material_shading(const RtTexture* textures, const uint8_t* texels, const RtMaterial* mat, float u, float v, float out[14])
+{
+    RtSceneDesc d; memset(&d, 0, sizeof(d)); d.textures = textures; d.texelData = texels;
+    ShadingData sd; sd.intersection.texCoord = V4(u, v, 0.0f, 0.0f);
+    materialEvaluateShadingData(&d, *mat, sd);
+    putV4(out, sd.mp.baseColor); putV4(out + 4, sd.mp.emission); out[8] = sd.mp.roughness; out[9] = sd.mp.metalness;
+    V4 n(0.0f, 0.0f, 1.0f, 0.0f);
+    if (mat->normalMapTexture != RT_NO_TEXTURE) n = materialGetNormalVector(&d, *mat, sd.intersection.texCoord);
+    putV4(out + 10, n);
+}
+// BackgroundLight::GetRadiance with an environment map
+void rto_background_radiance(const RtTexture* textures, const uint8_t* texels, const RtLight* light, const float dir[4], float out[4])
+{
+    RtSceneDesc d; memset(&d, 0, sizeof(d)); d.textures = textures; d.texelData = texels;
+    Ray ray; ray.origin = zero4(); ray.dir = load4(dir); ray.invDir = zero4(); ray.originDivDir = zero4();
+    float pdf = 0.0f;
+    putV4(out, lightGetRadiance(&d, *light, ray, zero4(), 1.0f, pdf));
+}
+
 uint32_t rto_sizeof(int what)
 {
     switch (what)
@@ -354,6 +391,7 @@ uint32_t rto_sizeof(int what)
     case 3: return (uint32_t)sizeof(RtLight);
     case 4: return (uint32_t)sizeof(RtMaterial);
     case 5: return (uint32_t)sizeof(RtCamera);
+    case 6: return (uint32_t)sizeof(RtTexture);
     default: return 0;
     }
 }

@@ -528,7 +528,118 @@ static inline void meshEvaluateIntersection(const RtSceneDesc* d, const RtMesh& 
     out.frame.r[2] = normalized3(normal);
 }
 
-// Scene::EvaluateIntersection, Scene.cpp:305-365 (normal maps are outside the hot-path scope)
+// =====================================================================================================
+// Textures -- Core/Textures/BitmapTexture.cpp, CheckerboardTexture.cpp, Core/Utils/Bitmap.cpp, Core/Color/ColorHelpers.h
+// =====================================================================================================
+// Half::ToFloat, Core/Math/HalfImpl.h:69-107
+static inline float halfToFloat(uint16_t value)
+{
+    uint32_t mantissa = (uint32_t)(value & 0x03FF);
+    uint32_t exponent = (value & 0x7C00);
+    if (exponent == 0x7C00) exponent = 0x8f;
+    else if (exponent != 0) exponent = (uint32_t)(((int)value >> 10) & 0x1F);
+    else if (mantissa != 0)
+    {
+        exponent = 1;
+        do { exponent--; mantissa <<= 1; } while ((mantissa & 0x0400) == 0);
+        mantissa &= 0x03FF;
+    }
+    else exponent = (uint32_t)(-112);
+    const uint32_t bits = (((uint32_t)value & 0x8000u) << 16) | ((exponent + 112u) << 23) | (mantissa << 13);
+    float f; memcpy(&f, &bits, 4); return f;
+}
+// Convert_sRGB_To_Linear on all four lanes, ColorHelpers.h:15-27
+static inline V4 srgbToLinear(V4 c)
+{
+    V4 r = mulAdd(c, splat(0.305306011f), splat(0.682171111f));
+    r = mulAdd(c, r, splat(0.012522878f));
+    return r * c;
+}
+static inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
+static inline float rdf(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
+// One texel as Bitmap::GetPixel / GetPixelBlock decode it (Bitmap.cpp:335-517, 520-832; loads: Math/Vector4Load.h).
+// Every UNorm load is float(integer) * RN(1 / max): the SSE paths scale by powers of two around that, exactly.
+static inline V4 bitmapTexel(const RtTexture& t, const uint8_t* texels, uint32_t x, uint32_t y)
+{
+    const uint8_t* row = texels + t.dataOffset + (size_t)t.stride * y;
+    const float s8 = 1.0f / 255.0f, s16 = 1.0f / 65535.0f;
+    V4 c = zero4();
+    switch (t.format)
+    {
+    case RT_FORMAT_R8_UNORM:       c = splat((float)(int32_t)row[x] * s8); break;
+    case RT_FORMAT_R8G8_UNORM:     c = V4((float)(int32_t)row[2 * x] * s8, (float)(int32_t)row[2 * x + 1] * s8, 0.0f, 0.0f); break;
+    case RT_FORMAT_B8G8R8_UNORM:   c = V4((float)(int32_t)row[3 * x + 2] * s8, (float)(int32_t)row[3 * x + 1] * s8, (float)(int32_t)row[3 * x] * s8, 0.0f); break;
+    case RT_FORMAT_B8G8R8A8_UNORM: c = V4((float)(int32_t)row[4 * x + 2] * s8, (float)(int32_t)row[4 * x + 1] * s8, (float)(int32_t)row[4 * x] * s8, (float)(int32_t)row[4 * x + 3] * s8); break;
+    case RT_FORMAT_R8G8B8A8_UNORM: c = V4((float)(int32_t)row[4 * x] * s8, (float)(int32_t)row[4 * x + 1] * s8, (float)(int32_t)row[4 * x + 2] * s8, (float)(int32_t)row[4 * x + 3] * s8); break;
+    case RT_FORMAT_R16_UNORM:      c = splat((float)(int32_t)rd16(row + 2 * x) * s16); break;
+    case RT_FORMAT_R16G16_UNORM:   c = V4((float)(int32_t)rd16(row + 4 * x) * s16, (float)(int32_t)rd16(row + 4 * x + 2) * s16, 0.0f, 0.0f); break;
+    case RT_FORMAT_R16G16B16A16_UNORM:
+        c = V4((float)(int32_t)rd16(row + 8 * x) * s16, (float)(int32_t)rd16(row + 8 * x + 2) * s16, (float)(int32_t)rd16(row + 8 * x + 4) * s16, (float)(int32_t)rd16(row + 8 * x + 6) * s16); break;
+    case RT_FORMAT_R32_FLOAT:          c = splat(rdf(row + 4 * x)); break;
+    case RT_FORMAT_R32G32_FLOAT:       c = V4(rdf(row + 8 * x), rdf(row + 8 * x + 4), 0.0f, 0.0f); break;
+    case RT_FORMAT_R32G32B32_FLOAT:    c = V4(rdf(row + 12 * x), rdf(row + 12 * x + 4), rdf(row + 12 * x + 8), 0.0f); break;
+    case RT_FORMAT_R32G32B32A32_FLOAT: c = V4(rdf(row + 16 * x), rdf(row + 16 * x + 4), rdf(row + 16 * x + 8), rdf(row + 16 * x + 12)); break;
+    case RT_FORMAT_R16_HALF:           c = splat(halfToFloat(rd16(row + 2 * x))); break;
+    case RT_FORMAT_R16G16_HALF:        c = V4(halfToFloat(rd16(row + 4 * x)), halfToFloat(rd16(row + 4 * x + 2)), 0.0f, 0.0f); break;
+    case RT_FORMAT_R16G16B16_HALF:     c = V4(halfToFloat(rd16(row + 6 * x)), halfToFloat(rd16(row + 6 * x + 2)), halfToFloat(rd16(row + 6 * x + 4)), 0.0f); break;
+    case RT_FORMAT_R16G16B16A16_HALF:  c = V4(halfToFloat(rd16(row + 8 * x)), halfToFloat(rd16(row + 8 * x + 2)), halfToFloat(rd16(row + 8 * x + 4)), halfToFloat(rd16(row + 8 * x + 6))); break;
+    default: break;
+    }
+    if (!t.linearSpace) c = srgbToLinear(c);
+    return c;
+}
+static inline float smoothStep(float x) { return x * x * (3.0f - x * 2.0f); }   // Math.h:176-179
+// Vector4::Lerp(v1, v2, w) = MulAndAdd(v2 - v1, w, v1), Vector4Impl.h:58-61
+static inline V4 lerp4(V4 v1, V4 v2, V4 w) { return mulAdd(v2 - v1, w, v1); }
+// BitmapTexture::Evaluate, BitmapTexture.cpp:32-93
+static inline V4 bitmapTextureEvaluate(const RtTexture& t, const uint8_t* texels, V4 coords)
+{
+    const int32_t sw = (int32_t)t.width, sh = (int32_t)t.height;
+    const float wx = coords.x - floorf(coords.x), wy = coords.y - floorf(coords.y);   // Vector4::Mod1
+    const float scx = wx * (float)sw, scy = wy * (float)sh;                             // * mFloatSize
+    const float fx = floorf(scx), fy = floorf(scy);
+    const int32_t ix = (int32_t)lrintf(fx), iy = (int32_t)lrintf(fy);                   // VectorInt4::Convert (cvtps2dq)
+    int32_t tx = ix, ty = iy;
+    if (!(ix < sw)) tx -= sw;                                                           // texelCoords -= AndNot(intCoords < size, size)
+    if (!(iy < sh)) ty -= sh;
+    if (ix < 0) tx += sw;                                                               // texelCoords += size & (intCoords < 0)
+    if (iy < 0) ty += sh;
+    if (t.filter == RT_FILTER_NEAREST) return bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)ty);
+    int32_t tz = tx + 1, tw = ty + 1;
+    if (!(tz < sw)) tz -= sw;                                                           // wrap secondary coordinates
+    if (!(tw < sh)) tw -= sh;
+    // GetPixelBlock: colors[0] = (x, y), [1] = (z, y), [2] = (x, w), [3] = (z, w)
+    const V4 c0 = bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)ty), c1 = bitmapTexel(t, texels, (uint32_t)tz, (uint32_t)ty);
+    const V4 c2 = bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)tw), c3 = bitmapTexel(t, texels, (uint32_t)tz, (uint32_t)tw);
+    float weightX = scx - (float)ix, weightY = scy - (float)iy;                         // scaledCoords - intCoords.ConvertToFloat()
+    if (t.filter == RT_FILTER_BILINEAR_SMOOTHSTEP) { weightX = smoothStep(weightX); weightY = smoothStep(weightY); }
+    const V4 value0 = lerp4(c0, c2, splat(weightY));
+    const V4 value1 = lerp4(c1, c3, splat(weightY));
+    return lerp4(value0, value1, splat(weightX));
+}
+// ITexture::Evaluate dispatch
+static inline V4 textureEvaluate(const RtSceneDesc* d, uint32_t index, V4 coords)
+{
+    const RtTexture& t = d->textures[index];
+    if (t.kind == RT_TEXTURE_CHECKERBOARD)      // CheckerboardTexture.cpp:31-40
+    {
+        const float wx = coords.x - floorf(coords.x), wy = coords.y - floorf(coords.y);
+        const bool cond = (wx > 0.5f) != (wy > 0.5f);
+        return cond ? load4(t.colorA) : load4(t.colorB);
+    }
+    if (t.kind == RT_TEXTURE_CONST) return load4(t.colorA);
+    return bitmapTextureEvaluate(t, d->texelData, coords);
+}
+// Material::GetNormalVector, Material.cpp:120-138 (normalMap != NULL)
+static inline V4 materialGetNormalVector(const RtSceneDesc* d, const RtMaterial& mat, V4 uv)
+{
+    V4 normal = textureEvaluate(d, mat.normalMapTexture, uv);
+    normal = mulSub(normal, 2.0f, splat(1.0f));                    // UnipolarToBipolar
+    normal.z = sqrtf(Max(0.0f, 1.0f - dot2(normal, normal)));      // reconstruct Z
+    return lerp4(V4(0.0f, 0.0f, 1.0f, 0.0f), normal, splat(mat.normalMapStrength));
+}
+
+// Scene::EvaluateIntersection, Scene.cpp:305-365
 static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
 {
     const RtObject& obj = d->objects[hit.objectId];
@@ -551,7 +662,16 @@ static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ra
     }
 
     V4 localSpaceTangent = out.frame.r[0];
-    const V4 localSpaceNormal = out.frame.r[2];
+    V4 localSpaceNormal = out.frame.r[2];
+    const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
+    if (out.material != RT_NO_MATERIAL && d->materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
+    {
+        const V4 localNormal = materialGetNormalVector(d, d->materials[out.material], out.texCoord);
+        V4 newNormal = localSpaceTangent * localNormal.x;
+        newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
+        newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
+        localSpaceNormal = fastNormalized3(newNormal);
+    }
     localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
     out.frame.r[2] = transformVector(transform, localSpaceNormal);
     out.frame.r[0] = transformVector(transform, localSpaceTangent);
@@ -565,7 +685,14 @@ static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ra
 struct IlluminateResult { V4 directionToLight; float distance, directPdfW, cosAtLight; };
 
 // ILight::Illuminate; returns radiance (4 lanes)
-static inline V4 lightIlluminate(const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
+// BackgroundLight::GetBackgroundColor, BackgroundLight.cpp:45-61
+static inline V4 backgroundColor(const RtSceneDesc* d, const RtLight& L, V4 dir)
+{
+    V4 color = load4(L.color);
+    if (L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluate(d, L.texture, cartesianToSpherical(dir)));
+    return color;
+}
+static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
 {
     out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
     const V4 color = load4(L.color);
@@ -588,7 +715,7 @@ static inline V4 lightIlluminate(const RtLight& L, const Intersection& isect, co
         out.directPdfW = uniformHemispherePdf();
         out.distance = FLT_MAX;
         out.cosAtLight = 1.0f;
-        return color;
+        return backgroundColor(d, L, out.directionToLight);
     }
     case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:48-92
     {
@@ -636,7 +763,7 @@ static inline V4 lightIlluminate(const RtLight& L, const Intersection& isect, co
 }
 
 // ILight::GetRadiance for a ray that hit / escaped; ray and hitPoint are in light space.
-static inline V4 lightGetRadiance(const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
+static inline V4 lightGetRadiance(const RtSceneDesc* d, const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
 {
     switch (L.type)
     {
@@ -646,7 +773,7 @@ static inline V4 lightGetRadiance(const RtLight& L, const Ray& lray, V4 hitPoint
         return load4(L.color);
     case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:78-92
         outDirectPdfA = uniformHemispherePdf();
-        return load4(L.color);
+        return backgroundColor(d, L, lray.dir);
     case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:94-121
         if (L.isDelta) return zero4();
         if (dot3(lray.dir, V4(0, 0, 1, 0)) > -L.cosAngle) return zero4();
@@ -1037,13 +1164,19 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
 
 struct ShadingData { Intersection intersection; V4 outgoingDirWorldSpace; MatParams mp; };   // ShadingData.h:21-30
 
-// Material::EvaluateShadingData (no textures), Material.cpp:151-158
-static inline void materialEvaluateShadingData(const RtMaterial& mat, ShadingData& sd)
+// Material::EvaluateShadingData, Material.cpp:151-158; MaterialParameter<T>::Evaluate, MaterialParameter.h:22-32:
+// value = baseValue * texture->Evaluate(uv) (Vector4 parameters: all four lanes; float parameters: lane x)
+static inline void materialEvaluateShadingData(const RtSceneDesc* d, const RtMaterial& mat, ShadingData& sd)
 {
+    const V4 uv = sd.intersection.texCoord;
     sd.mp.baseColor = load4(mat.baseColor);
+    if (mat.baseColorTexture != RT_NO_TEXTURE) sd.mp.baseColor = sd.mp.baseColor * textureEvaluate(d, mat.baseColorTexture, uv);
     sd.mp.emission = load4(mat.emission);
+    if (mat.emissionTexture != RT_NO_TEXTURE) sd.mp.emission = sd.mp.emission * textureEvaluate(d, mat.emissionTexture, uv);
     sd.mp.roughness = mat.roughness;
+    if (mat.roughnessTexture != RT_NO_TEXTURE) sd.mp.roughness = (splat(mat.roughness) * textureEvaluate(d, mat.roughnessTexture, uv)).x;
     sd.mp.metalness = mat.metalness;
+    if (mat.metalnessTexture != RT_NO_TEXTURE) sd.mp.metalness = (splat(mat.metalness) * textureEvaluate(d, mat.metalnessTexture, uv)).x;
     sd.mp.IoR = mat.IoR;
 }
 // Material::Evaluate, Material.cpp:160-180
@@ -1106,7 +1239,7 @@ static inline V4 sampleLight(RenderCtx& ctx, const RtLight& light, const Shading
 {
     float u[3]; u[0] = ctx.sampler.getFloat(); u[1] = ctx.sampler.getFloat(); u[2] = ctx.sampler.getFloat();
     IlluminateResult ir;
-    const V4 radiance = lightIlluminate(light, sd.intersection, u, ir);
+    const V4 radiance = lightIlluminate(ctx.scene, light, sd.intersection, u, ir);
     if (almostZero4(radiance)) return zero4();
     float bsdfPdfW = 0.0f;
     const RtMaterial& mat = ctx.scene->materials[sd.intersection.material];
@@ -1165,7 +1298,7 @@ static inline V4 evaluateLight(RenderCtx& ctx, const RtObject& obj, const Ray& r
     const V4 lightSpaceHitPoint = transformPoint(worldToLight, isect.frame.r[3]);
     const float cosAtLight = -dot3(isect.frame.r[2], ray.dir);
     float directPdfA = 0.0f;
-    V4 lightContribution = lightGetRadiance(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+    V4 lightContribution = lightGetRadiance(ctx.scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
     if (almostZero4(lightContribution)) return zero4();
     float misWeight = 1.0f;
     if (ps.depth > 0 && !ps.lastSpecular)
@@ -1187,7 +1320,7 @@ static inline V4 evaluateGlobalLights(RenderCtx& ctx, const Ray& ray, const Path
         const M4 worldToLight = loadM4(light.invTransform);
         const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
         float directPdfW = 0.0f;
-        const V4 lightContribution = lightGetRadiance(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+        const V4 lightContribution = lightGetRadiance(ctx.scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
         if (!almostZero4(lightContribution))
         {
             float misWeight = 1.0f;
@@ -1235,7 +1368,7 @@ static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
 
         shadingData.outgoingDirWorldSpace = neg(ray.dir);
         const RtMaterial& mat = scene->materials[shadingData.intersection.material];
-        materialEvaluateShadingData(mat, shadingData);
+        materialEvaluateShadingData(scene, mat, shadingData);
 
         {
             V4 emissionColor = shadingData.mp.emission;

@@ -81,23 +81,35 @@ class RtObject(C.Structure):
 
 class RtLight(C.Structure):
     _fields_ = [("transform", C.c_float * 16), ("invTransform", C.c_float * 16), ("color", C.c_float * 4), ("type", C.c_uint32),
-                ("flags", C.c_uint32), ("shapeKind", C.c_uint32), ("isDelta", C.c_uint32), ("cosAngle", C.c_float), ("_pad", C.c_float * 3),
+                ("flags", C.c_uint32), ("shapeKind", C.c_uint32), ("isDelta", C.c_uint32), ("cosAngle", C.c_float), ("texture", C.c_uint32), ("_pad", C.c_float * 2),
                 ("shapeParam", C.c_float * 4), ("shapeParam2", C.c_float * 4)]
+
+
+RT_NO_TEXTURE = 0xFFFFFFFF
+
+
+class RtTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("format", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("stride", C.c_uint32),
+                ("linearSpace", C.c_uint32), ("filter", C.c_uint32), ("_pad", C.c_uint32), ("dataOffset", C.c_uint64),
+                ("_pad2", C.c_uint64), ("colorA", C.c_float * 4), ("colorB", C.c_float * 4)]
 
 
 class RtMaterial(C.Structure):
     _fields_ = [("emission", C.c_float * 4), ("baseColor", C.c_float * 4), ("roughness", C.c_float), ("metalness", C.c_float),
-                ("IoR", C.c_float), ("K", C.c_float), ("bsdf", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+                ("IoR", C.c_float), ("K", C.c_float), ("bsdf", C.c_uint32), ("baseColorTexture", C.c_uint32),
+                ("emissionTexture", C.c_uint32), ("roughnessTexture", C.c_uint32), ("metalnessTexture", C.c_uint32),
+                ("normalMapTexture", C.c_uint32), ("normalMapStrength", C.c_float), ("_pad", C.c_uint32)]
 
 
 class RtSceneDesc(C.Structure):
     _fields_ = [("abiVersion", C.c_uint32), ("numObjects", C.c_uint32), ("numTopNodes", C.c_uint32), ("numLights", C.c_uint32),
                 ("numGlobalLights", C.c_uint32), ("numMaterials", C.c_uint32), ("numMeshes", C.c_uint32), ("numMeshNodes", C.c_uint32),
-                ("numTriangles", C.c_uint32), ("numVertices", C.c_uint32), ("_pad", C.c_uint32 * 2),
+                ("numTriangles", C.c_uint32), ("numVertices", C.c_uint32), ("numTextures", C.c_uint32), ("_pad", C.c_uint32),
                 ("topNodes", C.POINTER(RtNode)), ("objects", C.POINTER(RtObject)), ("lights", C.POINTER(RtLight)),
                 ("globalLights", C.POINTER(C.c_uint32)), ("materials", C.POINTER(RtMaterial)), ("meshes", C.POINTER(RtMesh)),
                 ("meshNodes", C.POINTER(RtNode)), ("triangles", C.c_void_p), ("vertexIndices", C.c_void_p),
-                ("vertexShading", C.c_void_p), ("blueNoise", C.c_void_p)]
+                ("vertexShading", C.c_void_p), ("blueNoise", C.c_void_p), ("textures", C.POINTER(RtTexture)), ("texelData", C.c_void_p),
+                ("texelBytes", C.c_uint64)]
 
 
 class RtCamera(C.Structure):
@@ -220,8 +232,40 @@ class Scene:
         if host_lib().rth_add_light_area(self._h, kind, _f(p, 4), _color(color), transform or _IDENTITY) != 0:
             raise ValueError("bad area light")
 
-    def add_background_light(self, color):
-        host_lib().rth_add_light_background(self._h, _color(color))
+    def add_background_light(self, color, texture=None):
+        if texture is None:
+            host_lib().rth_add_light_background(self._h, _color(color))
+        elif host_lib().rth_add_light_background_textured(self._h, _color(color), int(texture)) != 0:
+            raise ValueError("bad environment map texture")
+
+    # ---- textures (ITexture of the reference; evaluated on the device) --------------------------------------------
+    FORMATS = dict(R8_UNorm=1, R8G8_UNorm=2, B8G8R8_UNorm=3, B8G8R8A8_UNorm=4, R8G8B8A8_UNorm=5, R16_UNorm=8, R16G16_UNorm=9,
+                   R16G16B16A16_UNorm=10, R32_Float=11, R32G32_Float=12, R32G32B32_Float=13, R32G32B32A32_Float=14, R16_Half=16,
+                   R16G16_Half=17, R16G16B16_Half=18, R16G16B16A16_Half=19)
+    FILTERS = dict(nearest=0, bilinear=1, smoothstep=2)
+
+    def add_bitmap_texture(self, pixels, fmt, linear_space=True, filter="smoothstep"):
+        """pixels: C-contiguous numpy array of shape (height, width[, channels]) whose dtype/channels match `fmt`
+        (uint8, uint16, float16 or float32); rows are tightly packed."""
+        a = np.ascontiguousarray(pixels)
+        h, w = a.shape[0], a.shape[1]
+        tid = host_lib().rth_texture_bitmap(self._h, C.c_uint32(w), C.c_uint32(h), C.c_uint32(self.FORMATS[fmt]), a.ctypes.data_as(C.c_void_p),
+                                            C.c_uint32(a.strides[0]), 1 if linear_space else 0, self.FILTERS[filter])
+        if tid < 0:
+            raise ValueError("bad bitmap texture")
+        return tid
+
+    def add_checkerboard_texture(self, color_a, color_b):
+        return host_lib().rth_texture_checkerboard(self._h, _color(color_a), _color(color_b))
+
+    def add_const_texture(self, color):
+        return host_lib().rth_texture_const(self._h, _color(color))
+
+    def set_material_texture(self, material, slot, texture, strength=1.0):
+        """slot: 'baseColor' | 'emission' | 'roughness' | 'metalness' | 'normal' (strength = normalMapStrength)"""
+        slots = dict(baseColor=0, emission=1, roughness=2, metalness=3, normal=4)
+        if host_lib().rth_material_set_texture(self._h, int(material), slots[slot], int(texture), C.c_float(strength)) != 0:
+            raise ValueError("bad material / texture id")
 
     def add_directional_light(self, color, angle_rad=0.2, transform=None):
         host_lib().rth_add_light_directional(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)

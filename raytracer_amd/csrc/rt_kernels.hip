@@ -42,7 +42,7 @@ using namespace rtd;
 // vertex touches 7-9 arrays (and as many DRAM pages / TLB entries) instead of 34 scalar planes.
 enum PathRecord : uint32_t
 {
-    R_ORIGIN,    // ray origin xyz BEFORE the 1e-3 offset | flags: depth (bits 0-7), lastSpecular << 8
+    R_ORIGIN,    // ray origin xyz BEFORE the 1e-3 offset | flags: depth (bits 0-7), lastSpecular << 8, (previous vertex's material + 1) << 9
     R_DIR,       // ray direction xyz as passed to Ray()   | lastPdfW
     R_TP,        // throughput (4 lanes: RayColor::AlmostZero tests all four)
     R_RESULT,    // accumulated radiance rgb of this path  | pixel: x | y << 16
@@ -421,7 +421,7 @@ __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& sce
     float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
     float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
     IlluminateResult ir;
-    const V4 radiance = lightIlluminate<kLean>(light, sd.intersection, u, ir);
+    const V4 radiance = lightIlluminate<kLean>(scene, light, sd.intersection, u, ir);
     if (!almostZero4(radiance))
     {
         float bsdfPdfW = 0.0f;
@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         const RtLight& light = scene.lights[scene.globalLights[g]];
                         const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
                         float directPdfW = 0.0f;
-                        const V4 lightContribution = lightGetRadiance<kLean>(light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+                        const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
                         if (!almostZero4(lightContribution))
                         {
                             float misWeight = 1.0f;
@@ -561,7 +561,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                 }
 
                 ShadingData sd;
-                sd.intersection.material = RT_NO_MATERIAL;
+                // The reference keeps ONE ShadingData for the whole path (PathTracerMIS.cpp:258) and LightSceneObject::
+                // EvaluateIntersection does not touch `material` (SceneObject_Light.cpp:62-73): when a path hits an area light,
+                // IntersectionData::material is still the PREVIOUS vertex's, and its normal map (if any) is applied to the
+                // light's frame (Scene.cpp:327).  The previous material rides in the flags word: (index + 1) << 9.
+                sd.intersection.material = (flags >> 9) - 1u;   // 0 -> RT_NO_MATERIAL
                 if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
 
                 if (!kLean && hit.subObjectId == RT_LIGHT_OBJECT)
@@ -574,7 +578,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                     const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
                     const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
                     float directPdfA = 0.0f;
-                    V4 lightContribution = lightGetRadiance<false>(light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+                    V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
                     if (!almostZero4(lightContribution))
                     {
                         float misWeight = 1.0f;
@@ -595,7 +599,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
 
                 sd.outgoingDirWorldSpace = neg(ray.dir);
                 const RtMaterial& mat = scene.materials[sd.intersection.material];
-                materialEvaluateShadingData(mat, sd);
+                materialEvaluateShadingData<kLean>(scene, mat, sd);
 
                 // emission, PathTracerMIS.cpp:309-317
                 resultColor = mulAdd(throughput, sd.mp.emission * bsdfSamplingWeight, resultColor);
@@ -657,7 +661,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         else
                         {
                             prec(paths, R_ORIGIN, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
-                                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u)));
+                                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
                             prec(paths, R_DIR, slot) = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
                             prec(paths, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
                             alive = true;
@@ -720,6 +724,16 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
         secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
     flushCounters(cnt, counters);
+}
+
+// ITexture::Evaluate for a list of (texture, uv) pairs -- rtgpu_evaluate_textures
+__global__ void __launch_bounds__(RT_BLOCK) k_evaluate_textures(const RtSceneDesc scene, uint32_t count, const uint32_t* __restrict__ textureIndex,
+                                                                const float* __restrict__ uv, float* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const V4 c = textureEvaluate(scene, textureIndex[i], V4(uv[2 * i], uv[2 * i + 1], 0.0f, 0.0f));
+    out[4 * i + 0] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
 }
 
 // =====================================================================================================
@@ -1042,6 +1056,40 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         if (s->vertexIndices[i].materialIndex != RT_NO_MATERIAL && s->vertexIndices[i].materialIndex >= s->numMaterials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "triangle material index out of range");
     for (uint32_t i = 0; i < s->numGlobalLights; ++i) if (s->globalLights[i] >= s->numLights) return fail(RTGPU_ERR_INVALID_ARGUMENT, "global light index out of range");
     for (uint32_t i = 0; i < s->numMaterials; ++i) if (s->materials[i].bsdf > RT_BSDF_ROUGH_PLASTIC) return fail(RTGPU_ERR_UNSUPPORTED, "unknown BSDF kind");
+    if (s->numMaterials >= (1u << 22)) return fail(RTGPU_ERR_UNSUPPORTED, "more than 4M materials");   // the path flags hold a material index in 23 bits
+    // textures: formats the device decodes, rows inside the texel blob (plus the 16 bytes the reference's loads over-read)
+    for (uint32_t i = 0; i < s->numTextures; ++i)
+    {
+        const RtTexture& t = s->textures[i];
+        if (t.kind == RT_TEXTURE_CHECKERBOARD || t.kind == RT_TEXTURE_CONST) continue;
+        if (t.kind != RT_TEXTURE_BITMAP) return fail(RTGPU_ERR_UNSUPPORTED, "unknown texture kind");
+        uint32_t texelSize = 0;
+        switch (t.format)
+        {
+        case RT_FORMAT_R8_UNORM: texelSize = 1; break;
+        case RT_FORMAT_R8G8_UNORM: case RT_FORMAT_R16_UNORM: case RT_FORMAT_R16_HALF: texelSize = 2; break;
+        case RT_FORMAT_B8G8R8_UNORM: texelSize = 3; break;
+        case RT_FORMAT_B8G8R8A8_UNORM: case RT_FORMAT_R8G8B8A8_UNORM: case RT_FORMAT_R16G16_UNORM: case RT_FORMAT_R32_FLOAT: case RT_FORMAT_R16G16_HALF: texelSize = 4; break;
+        case RT_FORMAT_R16G16B16_HALF: texelSize = 6; break;
+        case RT_FORMAT_R16G16B16A16_UNORM: case RT_FORMAT_R32G32_FLOAT: case RT_FORMAT_R16G16B16A16_HALF: texelSize = 8; break;
+        case RT_FORMAT_R32G32B32_FLOAT: texelSize = 12; break;
+        case RT_FORMAT_R32G32B32A32_FLOAT: texelSize = 16; break;
+        default: return fail(RTGPU_ERR_UNSUPPORTED, "bitmap format is not decoded on the device (palette, B5G6R5, R11G11B10, R9G9B9E5, BC1/4/5)");
+        }
+        if (t.width == 0 || t.height == 0 || t.width > 65536u || t.height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid texture size");
+        if (t.stride < t.width * texelSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture stride smaller than a row");
+        if (t.filter > RT_FILTER_BILINEAR_SMOOTHSTEP) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown texture filter");
+        if (!s->texelData || t.dataOffset + (uint64_t)t.stride * (t.height - 1u) + (uint64_t)t.width * texelSize > s->texelBytes)
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture rows outside texelData");
+    }
+    auto textureOk = [&](uint32_t index) { return index == RT_NO_TEXTURE || index < s->numTextures; };
+    for (uint32_t i = 0; i < s->numMaterials; ++i)
+    {
+        const RtMaterial& m = s->materials[i];
+        if (!textureOk(m.baseColorTexture) || !textureOk(m.emissionTexture) || !textureOk(m.roughnessTexture) || !textureOk(m.metalnessTexture) || !textureOk(m.normalMapTexture))
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
+    }
+    for (uint32_t i = 0; i < s->numLights; ++i) if (!textureOk(s->lights[i].texture)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "light texture index out of range");
 
     freeScene(c);
     RtSceneDesc d = *s;
@@ -1057,6 +1105,8 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->vertexIndices, s->numTriangles, &d.vertexIndices))) return r;
     if ((r = uploadArray(c, s->vertexShading, s->numVertices, &d.vertexShading))) return r;
     if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
+    if ((r = uploadArray(c, s->textures, s->numTextures, &d.textures))) return r;
+    if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
     c->sceneDev = d;
     c->numLights = s->numLights;
     c->traversalStackNeed = topDepth + maxMeshDepth;
@@ -1064,6 +1114,9 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     for (uint32_t i = 0; i < s->numObjects && lean; ++i) lean = s->objects[i].objectKind == RT_OBJECT_SHAPE && s->objects[i].shapeKind == RT_SHAPE_MESH;
     for (uint32_t i = 0; i < s->numMaterials && lean; ++i) lean = s->materials[i].bsdf == RT_BSDF_DIFFUSE;
     for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].type == RT_LIGHT_BACKGROUND || s->lights[i].type == RT_LIGHT_DIRECTIONAL;
+    for (uint32_t i = 0; i < s->numMaterials && lean; ++i)
+        lean = (s->materials[i].baseColorTexture & s->materials[i].emissionTexture & s->materials[i].roughnessTexture & s->materials[i].metalnessTexture & s->materials[i].normalMapTexture) == RT_NO_TEXTURE;
+    for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].texture == RT_NO_TEXTURE;
     c->leanScene = lean;
     c->sceneReady = true;
     return RTGPU_OK;
@@ -1377,6 +1430,32 @@ RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     int r = rtgpu_synchronize(c); if (r) return r;
     c->countIntersections = enable != 0;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_evaluate_textures(RtgpuContext* c, uint32_t count, const uint32_t* textureIndex, const float* uv, float* out)
+{
+    if (!c || (count && (!textureIndex || !uv || !out))) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->sceneReady) return fail(RTGPU_ERR_NOT_READY, "rtgpu_upload_scene has not been called");
+    if (count == 0) return RTGPU_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; ++i) if (textureIndex[i] >= c->sceneDev.numTextures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture index out of range");
+    uint32_t* dIndex = nullptr; float* dUv = nullptr; float* dOut = nullptr;
+    hipError_t e = hipMalloc((void**)&dIndex, count * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&dUv, (size_t)count * 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dOut, (size_t)count * 4 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(dIndex, textureIndex, count * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dUv, uv, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(k_evaluate_textures, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->lanes[0].stream, c->sceneDev, count, dIndex, dUv, dOut);
+        e = hipStreamSynchronize(c->lanes[0].stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)count * 4 * sizeof(float), hipMemcpyDeviceToHost);
+    if (dIndex) (void)hipFree(dIndex);
+    if (dUv) (void)hipFree(dUv);
+    if (dOut) (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_evaluate_textures: ") + hipGetErrorString(e));
     return RTGPU_OK;
 }
 

@@ -1,9 +1,10 @@
 // Simple PBR material (host-side description).  Mirrors the public fields and SetBsdf/Compile of the
 // reference's rt::Material (Core/Material/Material.h:25-117); the BSDF itself runs on the device, the
-// host only records which of the nine kinds is selected.  Textures are outside the hot-path scope.
+// host only records which of the nine kinds is selected and which textures modulate the parameters.
 #pragma once
 
 #include "../Math/Math.h"
+#include "../Textures/Texture.h"
 
 namespace rt {
 
@@ -11,6 +12,7 @@ template <typename T>
 struct MaterialParameter
 {
     T baseValue = T(1.0f);
+    TexturePtr texture = nullptr;   // value = baseValue * texture->Evaluate(uv), MaterialParameter.h:22-32 (on the device)
     MaterialParameter() = default;
     MaterialParameter(const T v) : baseValue(v) {}
     MaterialParameter& operator=(const T v) { baseValue = v; return *this; }
@@ -35,6 +37,8 @@ public:
     MaterialParameter<float> metalness = 0.0f;
     float IoR = 1.5f;
     float K = 4.0f;
+    TexturePtr normalMap = nullptr;    // Material::GetNormalVector, Material.cpp:120-138
+    float normalMapStrength = 1.0f;
 
     // one of: null, diffuse, roughDiffuse, dielectric, roughDielectric, metal, roughMetal, plastic, roughPlastic
     void SetBsdf(const std::string& bsdfName);

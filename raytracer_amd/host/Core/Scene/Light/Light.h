@@ -4,6 +4,7 @@
 
 #include "../../Math/Math.h"
 #include "../../Shapes/Shape.h"
+#include "../../Textures/Texture.h"
 
 namespace rt {
 
@@ -43,6 +44,7 @@ class RAYLIB_API BackgroundLight : public ILight
 public:
     BackgroundLight() = default;
     explicit BackgroundLight(const math::Vector4& color) : ILight(color) {}
+    TexturePtr mTexture = nullptr;   // environment map, BackgroundLight.cpp:45-61 (public member in the reference too)
     Type GetType() const override { return Type::Background; }
     const math::Box GetBoundingBox() const override { return math::Box::Full(); }
     Flags GetFlags() const override { return Flag_None; }

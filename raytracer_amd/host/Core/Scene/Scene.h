@@ -50,6 +50,8 @@ private:
     std::vector<RtTriangle> mFlatTriangles;
     std::vector<RtVertexIndices> mFlatVertexIndices;
     std::vector<RtVertexShading> mFlatVertexShading;
+    std::vector<RtTexture> mFlatTextures;
+    std::vector<uint8> mFlatTexels;
     RtSceneDesc mDesc;
     uint64 mBuildId = 0;
 };

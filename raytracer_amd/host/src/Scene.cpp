@@ -262,6 +262,8 @@ static void CopyNodes(const BVH& bvh, std::vector<RtNode>& out)
 static void FillMaterial(const Material& m, RtMaterial& out)
 {
     memset(&out, 0, sizeof(out));
+    out.baseColorTexture = out.emissionTexture = out.roughnessTexture = out.metalnessTexture = out.normalMapTexture = RT_NO_TEXTURE;
+    out.normalMapStrength = m.normalMapStrength;
     memcpy(out.emission, &m.emission.baseValue, 16);
     memcpy(out.baseColor, &m.baseColor.baseValue, 16);
     out.roughness = m.roughness.baseValue;
@@ -276,12 +278,31 @@ bool Scene::Flatten()
     mFlatTopNodes.clear(); mFlatMeshNodes.clear(); mFlatObjects.clear(); mFlatLights.clear(); mFlatGlobalLights.clear();
     mFlatMaterials.clear(); mFlatMeshes.clear(); mFlatTriangles.clear(); mFlatVertexIndices.clear(); mFlatVertexShading.clear();
 
+    mFlatTextures.clear(); mFlatTexels.clear();
+    bool texturesOk = true;
+    std::map<const ITexture*, uint32> textureIds;
+    auto internTexture = [&](const TexturePtr& t) -> uint32 {
+        if (!t) return RT_NO_TEXTURE;
+        auto it = textureIds.find(t.get());
+        if (it != textureIds.end()) return it->second;
+        RtTexture flat;
+        if (!t->Describe(flat, mFlatTexels)) { texturesOk = false; return RT_NO_TEXTURE; }
+        const uint32 id = (uint32)mFlatTextures.size();
+        mFlatTextures.push_back(flat);
+        textureIds[t.get()] = id;
+        return id;
+    };
     std::map<const Material*, uint32> materialIds;
     auto internMaterial = [&](const Material* m) -> uint32 {
         auto it = materialIds.find(m);
         if (it != materialIds.end()) return it->second;
         const uint32 id = (uint32)mFlatMaterials.size();
         RtMaterial flat; FillMaterial(*m, flat);
+        flat.baseColorTexture = internTexture(m->baseColor.texture);
+        flat.emissionTexture = internTexture(m->emission.texture);
+        flat.roughnessTexture = internTexture(m->roughness.texture);
+        flat.metalnessTexture = internTexture(m->metalness.texture);
+        flat.normalMapTexture = internTexture(m->normalMap);
         mFlatMaterials.push_back(flat);
         materialIds[m] = id;
         return id;
@@ -330,6 +351,8 @@ bool Scene::Flatten()
         memcpy(L.color, &light.GetColor(), 16);
         L.type = (uint32)light.GetType();
         L.flags = (uint32)light.GetFlags();
+        L.texture = RT_NO_TEXTURE;
+        if (light.GetType() == ILight::Type::Background) L.texture = internTexture(static_cast<const BackgroundLight&>(light).mTexture);
         if (light.GetType() == ILight::Type::Area)
         {
             const AreaLight& al = static_cast<const AreaLight&>(light);
@@ -393,6 +416,11 @@ bool Scene::Flatten()
     mDesc.numMeshNodes = (uint32)mFlatMeshNodes.size();
     mDesc.numTriangles = (uint32)mFlatTriangles.size();
     mDesc.numVertices = (uint32)mFlatVertexShading.size();
+    mDesc.numTextures = (uint32)mFlatTextures.size();
+    mDesc.textures = mFlatTextures.data();
+    mDesc.texelData = mFlatTexels.data();
+    mDesc.texelBytes = mFlatTexels.size();
+    if (!texturesOk) return false;
     mDesc.topNodes = mFlatTopNodes.data();
     mDesc.objects = mFlatObjects.data();
     mDesc.lights = mFlatLights.data();

@@ -1,6 +1,10 @@
 // Camera, Bitmap, Viewport and the renderer factory.  Host side.
 #include "../Core/Rendering/Viewport.h"
 #include "../Core/Rendering/PathTracerMIS.h"
+#include "../Core/Textures/BitmapTexture.h"
+#include "../Core/Textures/CheckerboardTexture.h"
+#include "../Core/Textures/ConstTexture.h"
+#include "../../../include/rtgpu.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -64,27 +68,101 @@ bool Camera::GetDesc(RtCamera& out) const
 // ---------------------------------------------------------------------------------------------------
 // Bitmap
 // ---------------------------------------------------------------------------------------------------
-bool Bitmap::Init(uint32 width, uint32 height)
+uint32 Bitmap::BitsPerPixel(Format format)   // Bitmap::BitsPerPixel, Core/Utils/Bitmap.cpp:34-66 (formats the device decodes)
 {
-    mWidth = width; mHeight = height;
-    mData.assign((size_t)width * height * 3, 0.0f);
+    switch (format)
+    {
+    case Format::R8_UNorm: return 8;
+    case Format::R8G8_UNorm: case Format::R16_UNorm: case Format::R16_Half: return 16;
+    case Format::B8G8R8_UNorm: return 24;
+    case Format::B8G8R8A8_UNorm: case Format::R8G8B8A8_UNorm: case Format::R16G16_UNorm: case Format::R32_Float: case Format::R16G16_Half: return 32;
+    case Format::R16G16B16_Half: return 48;
+    case Format::R16G16B16A16_UNorm: case Format::R32G32_Float: case Format::R16G16B16A16_Half: return 64;
+    case Format::R32G32B32_Float: return 96;
+    case Format::R32G32B32A32_Float: return 128;
+    default: return 0;
+    }
+}
+
+bool Bitmap::Init(const InitData& initData)
+{
+    const uint32 bits = BitsPerPixel(initData.format);
+    if (bits == 0 || initData.width == 0 || initData.height == 0)
+    {
+        fprintf(stderr, "[rt] ERROR: Invalid bitmap format\n");
+        return false;
+    }
+    const uint32 tight = initData.width * (bits / 8u);
+    mStride = initData.stride > tight ? initData.stride : tight;   // Max(stride, ComputeDataStride), Bitmap.cpp:245
+    mWidth = initData.width; mHeight = initData.height; mFormat = initData.format; mLinearSpace = initData.linearSpace;
+    mData.assign((size_t)mStride * mHeight, 0);
+    if (initData.data) memcpy(mData.data(), initData.data, mData.size());
     return true;
 }
 
-void Bitmap::Clear() { std::fill(mData.begin(), mData.end(), 0.0f); }
+bool Bitmap::Init(uint32 width, uint32 height)
+{
+    InitData init;
+    init.width = width; init.height = height; init.format = Format::R32G32B32_Float;
+    if (width == 0 || height == 0) { mWidth = width; mHeight = height; mStride = width * 12u; mFormat = init.format; mData.clear(); return true; }
+    return Init(init);
+}
+
+void Bitmap::Clear() { std::fill(mData.begin(), mData.end(), (uint8)0); }
 
 const Vector4 Bitmap::GetPixel(uint32 x, uint32 y, const bool) const
 {
-    const float* p = mData.data() + 3 * ((size_t)y * mWidth + x);
+    if (mFormat != Format::R32G32B32_Float) return Vector4::Zero();
+    const float* p = reinterpret_cast<const float*>(mData.data() + (size_t)mStride * y) + 3 * (size_t)x;
     return Vector4(p[0], p[1], p[2], 0.0f);
 }
 
 bool Bitmap::Scale(const Vector4& factor)
 {
-    for (size_t i = 0; i < (size_t)mWidth * mHeight; ++i)
+    if (mFormat != Format::R32G32B32_Float) return false;
+    for (uint32 y = 0; y < mHeight; ++y)
     {
-        mData[3 * i + 0] *= factor.x; mData[3 * i + 1] *= factor.y; mData[3 * i + 2] *= factor.z;
+        float* row = reinterpret_cast<float*>(mData.data() + (size_t)mStride * y);
+        for (uint32 x = 0; x < mWidth; ++x) { row[3 * x + 0] *= factor.x; row[3 * x + 1] *= factor.y; row[3 * x + 2] *= factor.z; }
     }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Textures: device descriptors
+// ---------------------------------------------------------------------------------------------------
+bool BitmapTexture::Describe(RtTexture& out, std::vector<uint8>& texels) const
+{
+    memset(&out, 0, sizeof(out));
+    if (!mBitmap || Bitmap::BitsPerPixel(mBitmap->GetFormat()) == 0)
+    {
+        fprintf(stderr, "[rt] ERROR: bitmap texture '%s' has no pixels in a format the device decodes\n", GetName());
+        return false;
+    }
+    out.kind = RT_TEXTURE_BITMAP;
+    out.format = (uint32)mBitmap->GetFormat();
+    out.width = mBitmap->GetWidth(); out.height = mBitmap->GetHeight(); out.stride = mBitmap->GetStride();
+    out.linearSpace = mBitmap->IsLinearSpace() ? 1u : 0u;
+    out.filter = (uint32)mFilter;
+    while (texels.size() % 16u) texels.push_back(0);
+    out.dataOffset = texels.size();
+    texels.insert(texels.end(), mBitmap->GetBytes(), mBitmap->GetBytes() + mBitmap->GetDataSize());
+    return true;
+}
+
+bool CheckerboardTexture::Describe(RtTexture& out, std::vector<uint8>&) const
+{
+    memset(&out, 0, sizeof(out));
+    out.kind = RT_TEXTURE_CHECKERBOARD;
+    memcpy(out.colorA, &mColorA, 16); memcpy(out.colorB, &mColorB, 16);
+    return true;
+}
+
+bool ConstTexture::Describe(RtTexture& out, std::vector<uint8>&) const
+{
+    memset(&out, 0, sizeof(out));
+    out.kind = RT_TEXTURE_CONST;
+    memcpy(out.colorA, &mColor, 16);
     return true;
 }
 
@@ -94,7 +172,7 @@ bool Bitmap::SaveRaw(const char* path) const
     if (!f) return false;
     const uint32 header[3] = { 0x33465452u /* "RTF3" */, mWidth, mHeight };
     bool ok = fwrite(header, sizeof(header), 1, f) == 1;
-    ok = ok && (mData.empty() || fwrite(mData.data(), mData.size() * sizeof(float), 1, f) == 1);
+    ok = ok && mFormat == Format::R32G32B32_Float && (mData.empty() || fwrite(mData.data(), mData.size(), 1, f) == 1);
     fclose(f);
     return ok;
 }

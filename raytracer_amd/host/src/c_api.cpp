@@ -4,6 +4,9 @@
 #include "../Core/Rendering/Viewport.h"
 #include "../Core/Rendering/PathTracerMIS.h"
 #include "../Core/BVH/BVHBuilder.h"
+#include "../Core/Textures/BitmapTexture.h"
+#include "../Core/Textures/CheckerboardTexture.h"
+#include "../Core/Textures/ConstTexture.h"
 
 #include <stdio.h>
 
@@ -16,6 +19,7 @@ struct SceneHandle
 {
     Scene scene;
     std::vector<MaterialPtr> materials;
+    std::vector<TexturePtr> textures;
 };
 
 struct ViewportHandle
@@ -79,6 +83,52 @@ RTH_API int rth_material_create(void* sh, const char* bsdf, const float baseColo
     m->Compile();
     s->materials.push_back(m);
     return (int)s->materials.size() - 1;
+}
+
+// ---- textures ---------------------------------------------------------------------------------------
+// format = rt::Bitmap::Format value; data: height rows of `stride` bytes (0 = tight); returns a texture id
+RTH_API int rth_texture_bitmap(void* sh, uint32_t width, uint32_t height, uint32_t format, const void* data, uint32_t stride, int linearSpace, int filter)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    Bitmap::InitData init;
+    init.width = width; init.height = height; init.format = (Bitmap::Format)format; init.data = data; init.stride = stride;
+    init.linearSpace = linearSpace != 0;
+    BitmapPtr bitmap = std::make_shared<Bitmap>("texture");
+    if (!bitmap->Init(init)) return -1;
+    auto tex = std::make_shared<BitmapTexture>(bitmap);
+    tex->SetFilter((BitmapTextureFilter)filter);
+    s->textures.push_back(tex);
+    return (int)s->textures.size() - 1;
+}
+RTH_API int rth_texture_checkerboard(void* sh, const float colorA[4], const float colorB[4])
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    s->textures.push_back(std::make_shared<CheckerboardTexture>(LoadColor(colorA), LoadColor(colorB)));
+    return (int)s->textures.size() - 1;
+}
+RTH_API int rth_texture_const(void* sh, const float color[4])
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    s->textures.push_back(std::make_shared<ConstTexture>(LoadColor(color)));
+    return (int)s->textures.size() - 1;
+}
+// slot: 0 baseColor, 1 emission, 2 roughness, 3 metalness, 4 normal map (strength = normalMapStrength)
+RTH_API int rth_material_set_texture(void* sh, int material, int slot, int texture, float strength)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    MaterialPtr m = GetMaterial(s, material);
+    if (!m || texture < 0 || texture >= (int)s->textures.size()) return -1;
+    const TexturePtr& t = s->textures[(size_t)texture];
+    switch (slot)
+    {
+    case 0: m->baseColor.texture = t; break;
+    case 1: m->emission.texture = t; break;
+    case 2: m->roughness.texture = t; break;
+    case 3: m->metalness.texture = t; break;
+    case 4: m->normalMap = t; m->normalMapStrength = strength; break;
+    default: return -1;
+    }
+    return 0;
 }
 
 static int AddShape(SceneHandle* s, const ShapePtr& shape, const float* transform, int material)
@@ -158,6 +208,14 @@ RTH_API int rth_add_light_area(void* sh, int shapeKind, const float p[4], const 
 RTH_API int rth_add_light_background(void* sh, const float color[4])
 {
     return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<BackgroundLight>(LoadColor(color)), nullptr);
+}
+RTH_API int rth_add_light_background_textured(void* sh, const float color[4], int texture)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    if (texture < 0 || texture >= (int)s->textures.size()) return -1;
+    auto light = std::make_unique<BackgroundLight>(LoadColor(color));
+    light->mTexture = s->textures[(size_t)texture];
+    return AddLight(s, std::move(light), nullptr);
 }
 RTH_API int rth_add_light_directional(void* sh, const float color[4], float angleRad, const float transform[16])
 {

@@ -17,3 +17,31 @@ def bit_mismatch(expected, got):
     """Boolean mask of values that differ bitwise (NaN == NaN counts as equal)."""
     e, g = np.ascontiguousarray(expected, dtype=np.float32), np.ascontiguousarray(got, dtype=np.float32)
     return ~((e.view(np.uint32) == g.view(np.uint32)) | (np.isnan(e) & np.isnan(g)))
+
+
+def load_texture_kat():
+    """tests/golden/texture_kat.bin (layout: oracle/ref_harness/kat_gen.cpp genTextures).  Returns a dict with the
+    RtTexture array, the texel blob (uint8) and the three record tables as structured numpy arrays."""
+    import ctypes as C
+    import raytracer_amd as ra
+    raw = np.fromfile(os.path.join(GOLDEN, "texture_kat.bin"), dtype=np.uint8)
+    magic, num_tex, num_eval, num_mat, num_bg, _ = (int(v) for v in raw[:24].view(np.uint32))
+    assert magic == 0x31584554
+    texel_bytes = int(raw[24:32].view(np.uint64)[0])
+    off = 32
+    tex_size = C.sizeof(ra.RtTexture)
+    textures = (ra.RtTexture * num_tex).from_buffer_copy(raw[off:off + num_tex * tex_size].tobytes())
+    off += num_tex * tex_size
+    texels = raw[off:off + texel_bytes].copy()
+    off += texel_bytes
+    ev = np.dtype([("texture", np.uint32), ("uv", np.float32, 2), ("out", np.float32, 4)])
+    evals = raw[off:off + num_eval * ev.itemsize].view(ev)
+    off += num_eval * ev.itemsize
+    mt = np.dtype([("material", np.uint8, C.sizeof(ra.RtMaterial)), ("uv", np.float32, 2), ("out", np.float32, 14)])
+    mats = raw[off:off + num_mat * mt.itemsize].view(mt)
+    off += num_mat * mt.itemsize
+    bg = np.dtype([("light", np.uint8, C.sizeof(ra.RtLight)), ("dir", np.float32, 4), ("out", np.float32, 4)])
+    bgs = raw[off:off + num_bg * bg.itemsize].view(bg)
+    off += num_bg * bg.itemsize
+    assert off == raw.size
+    return dict(textures=textures, texels=texels, evals=evals, materials=mats, backgrounds=bgs)

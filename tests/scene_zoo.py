@@ -54,3 +54,62 @@ def mesh_scene(aspect, triangles=20000, with_analytic=True):
     s.build()
     cam = ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
     return s, cam
+
+
+def textured_scene(aspect, triangles=6000, seed=11, skip=()):
+    """Textures on every slot of the shading path: a mesh whose 8 materials carry bitmap base-colour / roughness /
+    metalness / emission textures in different texel formats, colour spaces and filters, normal maps (bitmap and
+    checkerboard), analytic shapes with checkerboard / const textures, and an HDR environment map on the background
+    light (BackgroundLight::mTexture)."""
+    rng = np.random.RandomState(seed)
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(triangles, seed=5)
+    s = ra.Scene()
+
+    def rgba8(h, w):
+        return rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+
+    t_albedo = s.add_bitmap_texture(rgba8(32, 48), "B8G8R8A8_UNorm", linear_space=False, filter="smoothstep")
+    t_albedo2 = s.add_bitmap_texture(rng.randint(0, 256, size=(7, 5, 3)).astype(np.uint8), "B8G8R8_UNorm", linear_space=False, filter="bilinear")
+    t_rough = s.add_bitmap_texture(rng.randint(0, 256, size=(16, 16)).astype(np.uint8), "R8_UNorm", filter="nearest")
+    t_metal = s.add_bitmap_texture(rng.randint(0, 65536, size=(9, 13)).astype(np.uint16), "R16_UNorm", filter="bilinear")
+    t_emit = s.add_bitmap_texture(rng.uniform(0.0, 1.0, size=(8, 8, 3)).astype(np.float32), "R32G32B32_Float", filter="smoothstep")
+    nm = rng.uniform(0.35, 0.65, size=(24, 24, 4)).astype(np.float32)
+    t_normal = s.add_bitmap_texture(nm, "R32G32B32A32_Float", filter="smoothstep")
+    t_normal_h = s.add_bitmap_texture(rng.uniform(0.3, 0.7, size=(12, 10, 2)).astype(np.float16), "R16G16_Half", filter="bilinear")
+    t_check = s.add_checkerboard_texture((0.9, 0.2, 0.1), (0.1, 0.3, 0.9, 1.0))
+    t_const = s.add_const_texture((0.5, 0.75, 1.0, 0.0))
+    env = rng.uniform(0.0, 3.0, size=(16, 32, 4)).astype(np.float16)
+    t_env = s.add_bitmap_texture(env, "R16G16B16A16_Half", filter="smoothstep")
+
+    kinds = ["diffuse", "roughDiffuse", "roughPlastic", "roughMetal", "diffuse", "plastic", "roughDielectric", "diffuse"]
+    mats = []
+    for i, (_, c) in enumerate(scenes.SPONZA_MATERIALS):
+        m = s.add_material(kinds[i], c, roughness=0.4, metalness=0.3 if i == 3 else 0.0,
+                           emission=(0.6, 0.5, 0.4) if i == 5 else (0.0, 0.0, 0.0))
+        mats.append(m)
+    if 0 not in skip: s.set_material_texture(mats[0], "baseColor", t_albedo)
+    if 1 not in skip: s.set_material_texture(mats[0], "normal", t_normal, 0.8)
+    if 2 not in skip: s.set_material_texture(mats[1], "baseColor", t_albedo2)
+    if 3 not in skip: s.set_material_texture(mats[1], "roughness", t_rough)
+    if 4 not in skip: s.set_material_texture(mats[2], "roughness", t_rough)
+    if 5 not in skip: s.set_material_texture(mats[2], "baseColor", t_check)
+    if 6 not in skip: s.set_material_texture(mats[3], "metalness", t_metal)
+    if 7 not in skip: s.set_material_texture(mats[3], "normal", t_normal_h, 1.0)
+    if 8 not in skip: s.set_material_texture(mats[4], "normal", t_check, 0.5)
+    if 9 not in skip: s.set_material_texture(mats[5], "emission", t_emit)
+    if 10 not in skip: s.set_material_texture(mats[6], "roughness", t_metal)
+    if 11 not in skip: s.set_material_texture(mats[7], "baseColor", t_const)
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+
+    ball = s.add_material("roughPlastic", (0.8, 0.8, 0.8), roughness=0.3)
+    if 12 not in skip: s.set_material_texture(ball, "baseColor", t_check)
+    if 13 not in skip: s.set_material_texture(ball, "normal", t_normal, 1.0)
+    s.add_sphere(1.2, ra.transform_from_euler((-4.0, 1.2, 0.5)), ball)
+    crate = s.add_material("diffuse", (1.0, 1.0, 1.0))
+    if 14 not in skip: s.set_material_texture(crate, "baseColor", t_albedo)
+    s.add_box((0.8, 1.5, 0.8), ra.transform_from_euler((3.0, 1.5, -1.0), (0.0, 30.0, 0.0)), crate)
+    s.add_area_light("rect", [1.5, 1.5], (30.0, 28.0, 25.0), ra.transform_from_euler((0.0, 11.0, 0.0), (90.0, 0.0, 0.0)))
+    s.add_background_light((1.0, 1.2, 1.5), texture=None if 'env' in skip else t_env)
+    s.build()
+    cam = ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+    return s, cam

@@ -24,16 +24,16 @@ def test_every_declared_symbol_is_exported(built):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), "librtgpu.so does not export %s" % n
-    assert lib.rtgpu_abi_version() == 1
+    assert lib.rtgpu_abi_version() == 2
 
 
 def test_struct_layouts_agree(built):
     import raytracer_amd as ra
     import oracle_lib
     o = oracle_lib.lib()
-    for what, ty in enumerate((ra.RtSceneDesc, ra.RtPassParams, ra.RtObject, ra.RtLight, ra.RtMaterial, ra.RtCamera)):
+    for what, ty in enumerate((ra.RtSceneDesc, ra.RtPassParams, ra.RtObject, ra.RtLight, ra.RtMaterial, ra.RtCamera, ra.RtTexture)):
         assert o.rto_sizeof(what) == C.sizeof(ty), ty.__name__
-    assert C.sizeof(ra.RtNode) == 32 and C.sizeof(ra.RtMaterial) == 64 and C.sizeof(ra.RtCounters) == 128
+    assert C.sizeof(ra.RtNode) == 32 and C.sizeof(ra.RtMaterial) == 80 and C.sizeof(ra.RtTexture) == 80 and C.sizeof(ra.RtCounters) == 128
 
 
 def test_no_gpu_means_loud_failure_not_fallback(built):

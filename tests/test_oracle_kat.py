@@ -67,3 +67,34 @@ def test_xoroshiro_bit_exact(built):
     longs = raw[52:52 + 8 * count].view(np.uint64)
     got = oracle_lib.xoroshiro(int(scalar[0]), int(scalar[1]), count)
     assert np.array_equal(got, longs)
+
+
+def test_textures_on_the_shading_path_bit_exact(built):
+    """BitmapTexture::Evaluate (16 formats x sRGB/linear x 3 filters, wrap/edge coordinates), CheckerboardTexture,
+    Material::EvaluateShadingData + GetNormalVector with textured parameters, BackgroundLight with an environment
+    map: all produced by the reference (texture_kat.bin); the oracle must reproduce every float bit for bit."""
+    import ctypes as C
+    import raytracer_amd as ra
+    k = kat_io.load_texture_kat()
+    o = oracle_lib.lib()
+    texels = k["texels"].ctypes.data_as(C.c_void_p)
+    out4 = (C.c_float * 4)()
+    formats = set()
+    for rec in k["evals"]:
+        o.rto_texture_evaluate(k["textures"], texels, C.c_uint32(int(rec["texture"])), C.c_float(rec["uv"][0]), C.c_float(rec["uv"][1]), out4)
+        got = np.array(out4[:], dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), rec["out"].view(np.uint32)), (int(rec["texture"]), rec["uv"], got, rec["out"])
+        formats.add((k["textures"][int(rec["texture"])].kind, k["textures"][int(rec["texture"])].format))
+    assert len(formats) == 17   # 16 bitmap formats + checkerboard
+    out14 = (C.c_float * 14)()
+    for rec in k["materials"]:
+        mat = ra.RtMaterial.from_buffer_copy(rec["material"].tobytes())
+        o.rto_material_shading(k["textures"], texels, C.byref(mat), C.c_float(rec["uv"][0]), C.c_float(rec["uv"][1]), out14)
+        got = np.array(out14[:], dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), rec["out"].view(np.uint32)), (got, rec["out"])
+    for rec in k["backgrounds"]:
+        light = ra.RtLight.from_buffer_copy(rec["light"].tobytes())
+        d = (C.c_float * 4)(*rec["dir"])
+        o.rto_background_radiance(k["textures"], texels, C.byref(light), d, out4)
+        got = np.array(out4[:], dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), rec["out"].view(np.uint32)), (rec["dir"], got, rec["out"])
