@@ -107,6 +107,9 @@ def main():
     vp.set_renderer(scene, device=local_rank)
     if world > 1:
         vp.set_shard(rank, world)
+    elif os.environ.get("BENCH_EMULATE_SHARD"):
+        # tuning aid on a 1-GPU box: render only the tiles rank 0 of N would own ("value" is then that rank's share)
+        vp.set_shard(0, int(os.environ["BENCH_EMULATE_SHARD"]))
     lib = ra.rtgpu_lib()
     ctx = vp.device_context()
 
@@ -156,6 +159,8 @@ def main():
         v.set_renderer(scene, device=local_rank)
         if world > 1:
             v.set_shard(rank, world)
+        elif os.environ.get("BENCH_EMULATE_SHARD"):
+            v.set_shard(0, int(os.environ["BENCH_EMULATE_SHARD"]))
         vctx = v.device_context()
         lib.rtgpu_set_concurrency(vctx, lanes)
         lib.rtgpu_set_intersection_counters(vctx, 1 if intersection_counters else 0)
