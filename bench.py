@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--triangles", type=int, default=262144)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "cornell", "sphere"])
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "sponza-textured", "cornell", "sphere"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -46,8 +46,8 @@ def parse_args():
 
 def build_scene(args, aspect):
     from raytracer_amd import scenes
-    if args.workload == "sponza":
-        return scenes.sponza_class(aspect, args.triangles)
+    if args.workload in ("sponza", "sponza-textured"):
+        return scenes.sponza_class(aspect, args.triangles, textured=args.workload == "sponza-textured")
     if args.workload == "cornell":
         return scenes.cornell_box(aspect)
     return scenes.sphere_area_light(aspect)
@@ -204,7 +204,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::Single" %
                        ("procedural Sponza-class mesh (%d triangles, 8 diffuse materials)" % scene.desc.contents.numTriangles
-                        if args.workload == "sponza" else args.workload, args.depth, w, h),
+                        if args.workload.startswith("sponza") else args.workload, args.depth, w, h)
+                       + (" + albedo / normal maps on all materials, HDR environment map" if args.workload == "sponza-textured" else ""),
                        "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world},
             "counters": {k: delta[k] for k in ("numRays", "numPrimaryRays", "numShadowRays", "numRayBoxTests", "numRayTriangleTests",
                                                "numShadowRayBoxTests", "numShadowRayTriangleTests", "numMeshHits", "numAnalyticHits")},

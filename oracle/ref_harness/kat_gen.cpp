@@ -911,6 +911,63 @@ static void genTextures()
     writeRaw("texture_kat.bin", file.data(), file.size());
 }
 
+// =====================================================================================================
+// OBJ ingestion: the reference's helpers::LoadMesh (Demo/MeshLoader.cpp + the vendored tinyobjloader 1.4.0) on
+// tests/golden/obj/fixture.obj.  File "obj_mesh_kat.bin" (uint32 words):
+//   numNodes, numTriangles, numMaterials; nodes (8 words each); per triangle: 9 floats {v0, edge1, edge2},
+//   i0, i1, i2, materialIndex, then 3 x {normal xyz, tangent xyz, uv} of its vertices;
+//   per material: baseColor xyz, emission xyz, roughness, hasBaseColorTexture, texture width, texture height
+namespace helpers
+{
+using MaterialsMap = std::map<std::string, rt::MaterialPtr>;
+rt::MeshShapePtr LoadMesh(const std::string& filePath, MaterialsMap& outMaterials, const float scale);
+}
+
+static void genObjMesh()
+{
+    helpers::MaterialsMap materialsMap;
+    MeshShapePtr meshPtr = helpers::LoadMesh(gOutDir + "/obj/fixture.obj", materialsMap, 1.25f);
+    if (!meshPtr) { fprintf(stderr, "helpers::LoadMesh failed\n"); exit(1); }
+    MeshShape& mesh = *meshPtr;
+    std::vector<uint32_t> blob;
+    const BVH& bvh = mesh.mBVH;
+    const uint32_t nt = mesh.mVertexBuffer.GetNumTriangles();
+    const uint32_t nmat = (uint32_t)mesh.mVertexBuffer.mMaterials.Size();
+    blob.push_back(bvh.GetNumNodes()); blob.push_back(nt); blob.push_back(nmat);
+    for (uint32_t i = 0; i < bvh.GetNumNodes(); ++i)
+    {
+        const BVH::Node& nd = bvh.GetNodes()[i];
+        blob.push_back(fbits(nd.min.x)); blob.push_back(fbits(nd.min.y)); blob.push_back(fbits(nd.min.z)); blob.push_back(nd.childIndex);
+        blob.push_back(fbits(nd.max.x)); blob.push_back(fbits(nd.max.y)); blob.push_back(fbits(nd.max.z));
+        blob.push_back(nd.numLeaves | ((nd.numLeaves == 0 ? nd.splitAxis : 0u) << 30));
+    }
+    for (uint32_t i = 0; i < nt; ++i)
+    {
+        const ProcessedTriangle& t = mesh.mVertexBuffer.GetTriangle(i);
+        const float v[9] = { t.v0.x, t.v0.y, t.v0.z, t.edge1.x, t.edge1.y, t.edge1.z, t.edge2.x, t.edge2.y, t.edge2.z };
+        for (float x : v) blob.push_back(fbits(x));
+        VertexIndices vi; mesh.mVertexBuffer.GetVertexIndices(i, vi);
+        blob.push_back(vi.i0); blob.push_back(vi.i1); blob.push_back(vi.i2); blob.push_back(vi.materialIndex);
+        VertexShadingData a, b, c; mesh.mVertexBuffer.GetShadingData(vi, a, b, c);
+        for (const VertexShadingData* s : { &a, &b, &c })
+        {
+            blob.push_back(fbits(s->normal.x)); blob.push_back(fbits(s->normal.y)); blob.push_back(fbits(s->normal.z));
+            blob.push_back(fbits(s->tangent.x)); blob.push_back(fbits(s->tangent.y)); blob.push_back(fbits(s->tangent.z));
+            blob.push_back(fbits(s->texCoord.x)); blob.push_back(fbits(s->texCoord.y));
+        }
+    }
+    for (uint32_t i = 0; i < nmat; ++i)
+    {
+        const Material& m = *mesh.mVertexBuffer.mMaterials[i];
+        blob.push_back(fbits(m.baseColor.baseValue.x)); blob.push_back(fbits(m.baseColor.baseValue.y)); blob.push_back(fbits(m.baseColor.baseValue.z));
+        blob.push_back(fbits(m.emission.baseValue.x)); blob.push_back(fbits(m.emission.baseValue.y)); blob.push_back(fbits(m.emission.baseValue.z));
+        blob.push_back(fbits(m.roughness.baseValue));
+        const BitmapTexture* tex = dynamic_cast<const BitmapTexture*>(m.baseColor.texture.get());
+        blob.push_back(tex ? 1u : 0u); blob.push_back(tex ? tex->mBitmap->GetWidth() : 0u); blob.push_back(tex ? tex->mBitmap->GetHeight() : 0u);
+    }
+    writeRaw("obj_mesh_kat.bin", blob.data(), blob.size() * 4);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -925,6 +982,7 @@ int main(int argc, char** argv)
     genHost();
     genMesh();
     genTextures();
+    genObjMesh();
     printf("done\n");
     return 0;
 }

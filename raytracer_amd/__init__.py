@@ -238,6 +238,14 @@ class Scene:
         elif host_lib().rth_add_light_background_textured(self._h, _color(color), int(texture)) != 0:
             raise ValueError("bad environment map texture")
 
+    # ---- ingestion (helpers::LoadScene / LoadMesh of the reference's Demo, in the C++ host mirror) ------------------
+    def load_json(self, path, data_path="", camera=None):
+        """helpers::LoadScene: adds the objects / lights of a JSON scene file (and sets `camera`, a Camera, if given).
+        data_path is prepended to the mesh / texture paths of the file (Options::dataPath)."""
+        if host_lib().rth_load_scene(self._h, camera._h if camera is not None else None, str(path).encode(), str(data_path).encode()) != 0:
+            raise ValueError("LoadScene failed: %s" % path)
+        return self
+
     # ---- textures (ITexture of the reference; evaluated on the device) --------------------------------------------
     FORMATS = dict(R8_UNorm=1, R8G8_UNorm=2, B8G8R8_UNorm=3, B8G8R8A8_UNorm=4, R8G8B8A8_UNorm=5, R16_UNorm=8, R16G16_UNorm=9,
                    R16G16B16A16_UNorm=10, R32_Float=11, R32G32_Float=12, R32G32B32_Float=13, R32G32B32A32_Float=14, R16_Half=16,

@@ -96,4 +96,6 @@ private:
     std::vector<MaterialPtr> mMaterials;
 };
 
+using MeshShapePtr = std::shared_ptr<MeshShape>;
+
 } // namespace rt

@@ -36,6 +36,9 @@ public:
     static uint32 BitsPerPixel(Format format);   // 0 for formats this build cannot hold
     bool Init(const InitData& initData);
     bool Init(uint32 width, uint32 height);      // R32G32B32_Float, zeroed (the Viewport's sum buffers)
+    // Uncompressed 24-bit and palette-less 8-bit BMP files, rows as stored, sRGB (Bitmap::LoadBMP, Core/Utils/BitmapBMP.cpp:47-134);
+    // the reference's other loaders (DDS, EXR, palettes) are outside the hot-path scope
+    bool Load(const char* path);
     void Clear();
     const char* GetDebugName() const { return mDebugName.c_str(); }
     uint32 GetWidth() const { return mWidth; }

@@ -1,0 +1,12 @@
+// The slice of the Demo's global options that the loaders read (reference: Demo/Demo.h -- Options::dataPath is
+// prepended to every mesh / texture path of a scene file, SceneLoader.cpp:237, 311, 447).
+#pragma once
+
+#include <string>
+
+struct Options
+{
+    std::string dataPath;
+};
+
+extern Options gOptions;

@@ -100,6 +100,36 @@ bool Bitmap::Init(const InitData& initData)
     return true;
 }
 
+bool Bitmap::Load(const char* path)
+{
+    FILE* file = fopen(path, "rb");
+    if (!file) { fprintf(stderr, "[rt] ERROR: Failed to load source image from file '%s'\n", path); return false; }
+#pragma pack(push, 2)
+    struct FileHeader { uint16 bfType; uint32 bfSize; uint16 bfReserved1, bfReserved2; uint32 bfOffBits; } fileHeader;
+    struct InfoHeader { uint32 biSize; int32 biWidth, biHeight; uint16 biPlanes, biBitCount; uint32 biCompression, biSizeImage; int32 biXPelsPerMeter, biYPelsPerMeter; uint32 biClrUsed, biClrImportant; } infoHeader;
+#pragma pack(pop)
+    bool ok = fread(&fileHeader, sizeof(fileHeader), 1, file) == 1 && fileHeader.bfType == 0x4D42 && fread(&infoHeader, sizeof(infoHeader), 1, file) == 1;
+    if (ok && (infoHeader.biPlanes != 1 || infoHeader.biCompression != 0)) { fprintf(stderr, "[rt] ERROR: Unsupported BMP format: '%s'\n", path); ok = false; }
+    InitData init;
+    if (ok)
+    {
+        if (infoHeader.biBitCount == 24) init.format = Format::B8G8R8_UNorm;
+        else if (infoHeader.biBitCount == 8 && infoHeader.biClrUsed == 0) init.format = Format::R8_UNorm;
+        else { fprintf(stderr, "[rt] ERROR: Unsupported BMP bit depth (%u): '%s'\n", (uint32)infoHeader.biBitCount, path); ok = false; }
+    }
+    if (ok && (infoHeader.biWidth <= 0 || infoHeader.biHeight <= 0)) { fprintf(stderr, "[rt] ERROR: Invalid image size: '%s'\n", path); ok = false; }
+    if (ok)
+    {
+        init.linearSpace = false;
+        init.width = (uint32)infoHeader.biWidth; init.height = (uint32)infoHeader.biHeight;
+        init.stride = ((uint32)infoHeader.biWidth * BitsPerPixel(init.format) / 8u + 3u) & ~3u;   // BMP rows are multiples of 4 bytes
+        ok = Init(init) && fseek(file, (long)fileHeader.bfOffBits, SEEK_SET) == 0 && fread(mData.data(), mData.size(), 1, file) == 1;
+        if (!ok) fprintf(stderr, "[rt] ERROR: Failed to read bitmap data from file '%s'\n", path);
+    }
+    fclose(file);
+    return ok;
+}
+
 bool Bitmap::Init(uint32 width, uint32 height)
 {
     InitData init;

@@ -7,6 +7,10 @@
 #include "../Core/Textures/BitmapTexture.h"
 #include "../Core/Textures/CheckerboardTexture.h"
 #include "../Core/Textures/ConstTexture.h"
+#include "../Demo/Demo.h"
+#include "../Demo/MeshLoader.h"
+#include "../Demo/ObjReader.h"
+#include "../Demo/SceneLoader.h"
 
 #include <stdio.h>
 
@@ -229,6 +233,33 @@ RTH_API int rth_add_light_spot(void* sh, const float color[4], float angleRad, c
 {
     return AddLight(static_cast<SceneHandle*>(sh), std::make_unique<SpotLight>(LoadColor(color), angleRad), transform);
 }
+
+// ---- ingestion (Demo/SceneLoader.cpp, Demo/MeshLoader.cpp) ---------------------------------------------------------
+// helpers::LoadScene(path) into this scene; camera may be NULL.  dataPath = Options::dataPath (prefix of mesh / texture paths)
+RTH_API int rth_load_scene(void* sh, void* camera, const char* path, const char* dataPath)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    gOptions.dataPath = dataPath ? dataPath : "";
+    Camera scratch;
+    return helpers::LoadScene(path, s->scene, camera ? *static_cast<Camera*>(camera) : scratch) ? 0 : -1;
+}
+// helpers::LoadMesh's vertex streams for the parity test: two calls, the first with NULL outputs returns the sizes
+RTH_API int rth_load_mesh_streams(const char* path, float scale, uint32_t* numVertices, uint32_t* numTriangles, uint32_t* numMaterials,
+                                  float* positions, float* normals, float* tangents, float* texCoords, uint32_t* indices, uint32_t* materialIndices)
+{
+    helpers::MaterialsMap materials;
+    helpers::MeshStreams m;
+    if (!helpers::LoadMeshStreams(path, materials, scale, m)) return -1;
+    *numVertices = (uint32_t)m.positions.size(); *numTriangles = (uint32_t)(m.vertexIndices.size() / 3); *numMaterials = (uint32_t)m.materials.size();
+    if (positions) memcpy(positions, m.positions.data(), m.positions.size() * 12);
+    if (normals) memcpy(normals, m.normals.data(), m.normals.size() * 12);
+    if (tangents) memcpy(tangents, m.tangents.data(), m.tangents.size() * 12);
+    if (texCoords) memcpy(texCoords, m.texCoords.data(), m.texCoords.size() * 8);
+    if (indices) memcpy(indices, m.vertexIndices.data(), m.vertexIndices.size() * 4);
+    if (materialIndices) memcpy(materialIndices, m.materialIndices.data(), m.materialIndices.size() * 4);
+    return 0;
+}
+RTH_API int rth_kat_parse_double(const char* text, double* out) { return helpers::obj::TryParseDouble(text, text + strlen(text), out) ? 0 : -1; }
 
 RTH_API int rth_scene_build(void* sh) { return static_cast<SceneHandle*>(sh)->scene.BuildBVH() ? 0 : -1; }
 RTH_API const RtSceneDesc* rth_scene_desc(void* sh) { return &static_cast<SceneHandle*>(sh)->scene.GetDesc(); }

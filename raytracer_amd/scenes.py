@@ -330,14 +330,27 @@ def sponza_class_mesh(target_triangles=262144, seed=7, refine=False):
     return build(k, kf).arrays()
 
 
-def sponza_class(aspect, target_triangles=262144, seed=7):
+def sponza_class(aspect, target_triangles=262144, seed=7, textured=False):
     """BASELINE config 3: Sponza-class mesh, background light (1, 1.5, 2) + delta directional light
     (20000, 19000, 18000) pitched 80 degrees -- the lights of the reference's Data/TestScenes/sponza.json."""
     pos, idx, nrm, tan, uv, mat = sponza_class_mesh(target_triangles, seed, refine=True)
     scene = Scene()
     mats = [scene.add_material("diffuse", c) for _, c in SPONZA_MATERIALS]
+    env = None
+    if textured:
+        # what the real (textured) Sponza adds to the shading path: an sRGB albedo map and a normal map on every
+        # material (512 x 512 BGRA8, bilinear-smoothstep) and an HDR environment map on the background light
+        rng = np.random.RandomState(seed + 1)
+        for i, m in enumerate(mats):
+            albedo = (128 + 127 * np.sin(np.arange(512)[:, None, None] * (0.05 + 0.01 * i) + np.arange(512)[None, :, None] * 0.07
+                                         + np.arange(4)[None, None, :])).astype(np.uint8)
+            scene.set_material_texture(m, "baseColor", scene.add_bitmap_texture(albedo, "B8G8R8A8_UNorm", linear_space=False))
+            bump = (127.5 + 20.0 * rng.standard_normal((512, 512, 4))).clip(0, 255).astype(np.uint8)
+            scene.set_material_texture(m, "normal", scene.add_bitmap_texture(bump, "B8G8R8A8_UNorm"), 1.0)
+        sky = rng.uniform(0.2, 1.5, size=(256, 512, 4)).astype(np.float16)
+        env = scene.add_bitmap_texture(sky, "R16G16B16A16_Half")
     scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
-    scene.add_background_light((1.0, 1.5, 2.0))
+    scene.add_background_light((1.0, 1.5, 2.0), texture=env)
     scene.add_directional_light((20000.0, 19000.0, 18000.0), np.float32(1.0) / np.float32(180.0) * np.float32(3.14159265359),
                                 transform_from_euler((0.0, 0.0, 0.0), (80.0, 20.0, 0.0)))
     scene.build()

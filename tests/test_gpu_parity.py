@@ -132,6 +132,25 @@ def test_textured_materials_normal_maps_and_environment_map(built):
     assert not np.array_equal(vp.sum_buffer(), out[0])
 
 
+def test_ingested_json_obj_scene_bit_exact(built):
+    """SURVEY 8(f) row 3 end to end: a JSON scene file (helpers::LoadScene) with an OBJ mesh + MTL materials + BMP texture
+    (helpers::LoadMesh), textured materials, three light types and a depth-of-field camera, rendered on the GPU and
+    by the oracle from the same flattened scene."""
+    import os
+    import kat_io
+    w, h = 160, 100
+    obj_dir = os.path.join(kat_io.GOLDEN, "obj")
+    camera = ra.Camera()
+    scene = ra.Scene().load_json(os.path.join(obj_dir, "scene.json"), data_path=obj_dir + "/", camera=camera)
+    scene.build()
+    camera.set_perspective(w / h, np.float32(48.0) / np.float32(180.0) * np.float32(3.14159265359))
+    d = scene.desc.contents
+    assert d.numMeshes == 1 and d.numTriangles > 200 and d.numTextures == 3 and d.numLights == 3   # checkerboard + the BMP twice (scene file, MTL)
+    out = run_both(scene, camera, w, h, passes=3, max_ray_depth=5)
+    assert_identical(*out)
+    assert out[2]["numMeshHits"] > 0 and out[2]["numAnalyticHits"] > 0
+
+
 def test_single_object_scene_bypasses_top_bvh(built):
     """Sponza-class configuration: ONE object (Scene::Traverse bypasses the BVH, Scene.cpp:231-235), two global lights."""
     w, h = 128, 72
