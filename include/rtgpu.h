@@ -390,6 +390,32 @@ int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
  * Replaces the thread-pool width of the reference (RenderingParams::numThreads, Viewport.cpp:44-50). */
 int rtgpu_set_concurrency(RtgpuContext* ctx, uint32_t lanes);
 
+/* ---------------------------------------------------------------------------------------------
+ * Post-processing of the sum buffer into the displayable front buffer: Viewport::PostProcessTile
+ * (Core/Rendering/Viewport.cpp:495-550) per pixel -- scale by 1 / numPasses, saturation, contrast as
+ * FastExp(FastLog(c) * contrast), exposure and colour filter, tone mapping (Core/Color/ColorHelpers.h:78-132),
+ * dithering, Vector4::ToBGR().  Bloom (bloomFactor > 0) needs the blurred image pyramid and is not implemented:
+ * RTGPU_ERR_UNSUPPORTED.  Dithering uses a per-pixel hash of (x, y, ditherSeed) instead of the reference's
+ * per-thread generator (which makes the reference's own front buffer thread-schedule dependent).
+ * --------------------------------------------------------------------------------------------- */
+typedef enum RtTonemapper { RT_TONEMAPPER_CLAMPED = 0, RT_TONEMAPPER_REINHARD = 1, RT_TONEMAPPER_HEJL_BURGESS_DAWSON = 2, RT_TONEMAPPER_ACES = 3 } RtTonemapper;
+
+typedef struct RtPostprocessParams   /* PostprocessParams, Core/Rendering/PostProcess.h:10-28 (defaults: PostProcess.cpp:6-14) */
+{
+    float    colorFilter[4];
+    float    exposure;            /* log2 scale: colorScale = colorFilter * 2^exposure (Viewport.cpp:455) */
+    float    contrast;
+    float    saturation;
+    float    ditheringStrength;
+    float    bloomFactor;         /* must be 0 */
+    uint32_t tonemapper;          /* RtTonemapper */
+    uint32_t numPasses;           /* pixelScaling = 1 / numPasses (1 + passesFinished at the time of the call, :502) */
+    uint32_t ditherSeed;
+} RtPostprocessParams;
+
+/* frontBufferBGRA: host, width * height uint32 (0x00RRGGBB), row y = sum-buffer row y.  Synchronises. */
+int rtgpu_postprocess(RtgpuContext* ctx, const RtPostprocessParams* params, uint32_t* frontBufferBGRA);
+
 /* Evaluates textures of the uploaded scene on the device: out[4*i..] = ITexture::Evaluate(textures[textureIndex[i]],
  * (uv[2*i], uv[2*i+1])).  Host pointers; synchronous.  Exists so that the device decode of every texel format can be
  * checked against the reference's vectors directly (tests/golden/texture_kat.bin). */

@@ -62,6 +62,8 @@
 #include "Textures/BitmapTexture.h"
 #include "Textures/CheckerboardTexture.h"
 #include "Utils/Bitmap.h"
+#include "Rendering/PostProcess.h"
+#include "Color/ColorHelpers.h"
 #include "Math/Half.h"
 #include "Material/BSDF/BSDF.h"
 #include "Material/BSDF/Microfacet.h"
@@ -968,6 +970,56 @@ static void genObjMesh()
     writeRaw("obj_mesh_kat.bin", blob.data(), blob.size() * 4);
 }
 
+// =====================================================================================================
+// Post-processing: the per-pixel body of Viewport::PostProcessTile (Viewport.cpp:506-547; Viewport.cpp itself cannot be
+// linked here) composed from the reference's own functions in the same order -- Vector4 ops, FastLog / FastExp
+// (Transcendental.cpp), ToneMap (ColorHelpers.h), Vector4::ToBGR -- without bloom and without dithering.
+// File "postprocess_kat.bin": u32 count; records: RtPostprocessParams, f32 raw[3], u32 bgr, f32 toneMapped[3].
+static void genPostprocess()
+{
+    Lcg g(110);
+    std::vector<uint32_t> out;
+    const uint32_t N = 4096;
+    out.push_back(N);
+    for (uint32_t i = 0; i < N; ++i)
+    {
+        RtPostprocessParams P; memset(&P, 0, sizeof(P));
+        PostprocessParams params;
+        if (i % 4 != 0)
+        {
+            params.colorFilter = Vector4(g.range(0.2f, 1.5f), g.range(0.2f, 1.5f), g.range(0.2f, 1.5f), 1.0f);
+            params.exposure = g.range(-3.0f, 3.0f); params.contrast = g.range(0.4f, 1.6f); params.saturation = g.range(0.0f, 1.5f);
+        }
+        params.tonemapper = (Tonemapper)(i % 4);
+        const uint32_t numPasses = 1u + (g.u32() % 300u);
+        memcpy(P.colorFilter, &params.colorFilter, 16);
+        P.exposure = params.exposure; P.contrast = params.contrast; P.saturation = params.saturation;
+        P.ditheringStrength = 0.0f; P.bloomFactor = 0.0f; P.tonemapper = (uint32_t)params.tonemapper; P.numPasses = numPasses;
+        float scale = 1.0f;
+        switch (i % 7) { case 0: scale = 0.0f; break; case 1: scale = 1.0e-4f; break; case 2: scale = 50.0f; break; case 3: scale = 1.0e4f; break; default: break; }
+        const Float3 raw(g.range(0.0f, 2.0f) * scale * numPasses, g.range(0.0f, 2.0f) * scale * numPasses, g.range(0.0f, 2.0f) * scale * numPasses);
+
+        // Viewport::PostProcessTile
+        const Vector4 colorScale = params.colorFilter * powf(2.0f, params.exposure);
+        const float pixelScaling = 1.0f / (float)numPasses;
+        Vector4 rgbColor(raw);   // Vector4_Load_Float3_Unsafe(mSum.GetPixelRef<Float3>(x, y)): the w lane (the next pixel) never reaches ToBGR
+        rgbColor *= pixelScaling;
+        const float grayscale = Vector4::Dot3(rgbColor, Vector4(0.2126f, 0.7152f, 0.0722f));
+        rgbColor = Vector4::Max(Vector4::Zero(), Vector4::Lerp(Vector4(grayscale), rgbColor, params.saturation));
+        rgbColor = FastExp(FastLog(rgbColor) * params.contrast);
+        rgbColor *= colorScale;
+        const Vector4 toneMapped = ToneMap(rgbColor, params.tonemapper);
+        const uint32_t bgr = toneMapped.ToBGR();
+
+        uint32_t pw[sizeof(P) / 4]; memcpy(pw, &P, sizeof(P));
+        for (uint32_t w : pw) out.push_back(w);
+        out.push_back(fbits(raw.x)); out.push_back(fbits(raw.y)); out.push_back(fbits(raw.z));
+        out.push_back(bgr & 0x00FFFFFFu);
+        out.push_back(fbits(toneMapped.x)); out.push_back(fbits(toneMapped.y)); out.push_back(fbits(toneMapped.z));
+    }
+    writeRaw("postprocess_kat.bin", out.data(), out.size() * 4);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -983,6 +1035,7 @@ int main(int argc, char** argv)
     genMesh();
     genTextures();
     genObjMesh();
+    genPostprocess();
     printf("done\n");
     return 0;
 }

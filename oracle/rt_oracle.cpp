@@ -381,6 +381,19 @@ void rto_background_radiance(const RtTexture* textures, const uint8_t* texels, c
     putV4(out, lightGetRadiance(&d, *light, ray, zero4(), 1.0f, pdf));
 }
 
+// Viewport::PostProcessTile over a whole float3 sum buffer -> 0x00RRGGBB front buffer
+void rto_postprocess(const float* sumRGB, uint32_t width, uint32_t height, const RtPostprocessParams* params, uint32_t* out)
+{
+    const float exposureScale = powf(2.0f, params->exposure);
+    const float colorScale[3] = { params->colorFilter[0] * exposureScale, params->colorFilter[1] * exposureScale, params->colorFilter[2] * exposureScale };
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            const float* px = sumRGB + 3 * ((size_t)y * width + x);
+            out[(size_t)y * width + x] = postProcessPixel(px[0], px[1], px[2], x, y, *params, colorScale);
+        }
+}
+
 uint32_t rto_sizeof(int what)
 {
     switch (what)

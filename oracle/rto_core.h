@@ -1406,4 +1406,110 @@ static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
     return resultColor;
 }
 
+
+// =====================================================================================================
+// Post-processing -- Viewport::PostProcessTile (Core/Rendering/Viewport.cpp:495-550), lane-wise over rgb(+w)
+// =====================================================================================================
+// FastLog(Vector4) -- the FMA form, Core/Math/Transcendental.cpp:215-233 (the scalar FastLog is NOT fused)
+static inline float fastLogVec(float x)
+{
+    int32_t xi; memcpy(&xi, &x, 4);
+    const int32_t e = (int32_t)((uint32_t)(xi - 0x3f2aaaab) & 0xff800000u);
+    const int32_t mi = xi - e; float m; memcpy(&m, &mi, 4);
+    const float i = (float)e * 1.19209290e-7f;
+    const float f = m - 1.0f;
+    const float s = f * f;
+    float r = fmaf(f, 0.230836749f, -0.279208571f);
+    const float t = fmaf(f, 0.331826031f, -0.498910338f);
+    r = fmaf(r, s, t);
+    r = fmaf(r, s, f);
+    return fmaf(i, 0.693147182f, r);
+}
+// FastExp(Vector4), Transcendental.cpp:147-165
+static inline float fastExpVec(float a)
+{
+    const float t = a * 1.442695041f;
+    const float fi = floorf(t);
+    const int32_t i = (int32_t)lrintf(fi);
+    const float f = t - fi;
+    float y = fmaf(f, 0.3371894346f, 0.657636276f);
+    y = fmaf(f, y, 1.00172476f);
+    int32_t yi; memcpy(&yi, &y, 4);
+    yi += (int32_t)((uint32_t)i << 23);
+    memcpy(&y, &yi, 4);
+    if ((0.0f - a) >= 87.0f) y = 0.0f;
+    if (a >= 87.0f) y = __builtin_inff();
+    return y;
+}
+// Convert_Linear_To_sRGB, Core/Color/ColorHelpers.h:29-43
+static inline float linearToSrgb(float c)
+{
+    const float s1 = sqrtf(c), s2 = sqrtf(s1), s3 = sqrtf(s2);
+    float r = 0.585122381f * s1;
+    r = fmaf(s2, 0.783140355f, r);
+    r = fmaf(s3, -0.368262736f, r);
+    return sseMin(1.0f, sseMax(0.0f, r));   // Saturate = Min(1, Max(0, v))
+}
+// Vector4::FastReciprocal (Vector4ImplSSE.h:380-386): _mm_rcp_ps refined by one Newton step; the approximate seed is
+// replaced by the correctly rounded 1 / v (vendor specific otherwise), the refinement is kept
+static inline float fastReciprocal(float v)
+{
+    const float rcp = 1.0f / v;
+    return fmaf(-(rcp * rcp), v, rcp + rcp);
+}
+// ToneMap, ColorHelpers.h:85-132
+static inline float toneMap(float c, uint32_t tonemapper)
+{
+    switch (tonemapper)
+    {
+    case RT_TONEMAPPER_CLAMPED: return linearToSrgb(c);
+    case RT_TONEMAPPER_REINHARD: return linearToSrgb(c / (1.0f + c));
+    case RT_TONEMAPPER_HEJL_BURGESS_DAWSON:
+    {
+        const float t0 = c * fmaf(c, 6.2f, 0.5f);
+        const float t1 = fmaf(c, 6.2f, 1.7f);
+        const float t2 = fmaf(c, t1, 0.06f);
+        return t0 * fastReciprocal(t2);
+    }
+    default:   // ACES
+    {
+        const float t0 = c * fmaf(c, 2.51f, 0.03f);
+        const float t1 = fmaf(c, 2.43f, 0.59f);
+        const float t2 = fmaf(c, t1, 0.14f);
+        return linearToSrgb(t0 * fastReciprocal(t2));
+    }
+    }
+}
+// per-pixel dithering noise in [-1, 1): a hash of (x, y, seed) -> mantissa trick of Random::GetVector4Bipolar (Random.cpp:128-139)
+static inline float ditherNoise(uint32_t x, uint32_t y, uint32_t channel, uint32_t seed)
+{
+    uint32_t h = x * 0x9E3779B1u ^ (y * 0x85EBCA77u + 0x7F4A7C15u) ^ (seed * 0xC2B2AE3Du + channel * 0x27D4EB2Fu);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    const uint32_t bits = (h & 0x007fffffu) | 0x40000000u;   // [2, 4)
+    float f; memcpy(&f, &bits, 4);
+    return f - 3.0f;
+}
+// one pixel: r, g, b = sum-buffer value; returns 0x00RRGGBB (Vector4::ToBGR, Vector4ImplSSE.h:89-110)
+static inline uint32_t postProcessPixel(float r, float g, float b, uint32_t x, uint32_t y, const RtPostprocessParams& p, const float colorScale[3])
+{
+    const float pixelScaling = 1.0f / (float)p.numPasses;
+    float c[3] = { r * pixelScaling, g * pixelScaling, b * pixelScaling };
+    // saturation: Max(0, Lerp(grayscale, rgb, saturation)), Lerp = MulAndAdd(v2 - v1, w, v1)
+    const float grayscale = (c[0] * 0.2126f + c[1] * 0.7152f) + (c[2] * 0.0722f + 0.0f);
+    uint32_t out = 0;
+    for (int k = 0; k < 3; ++k)
+    {
+        float v = sseMax(0.0f, fmaf(c[k] - grayscale, p.saturation, grayscale));
+        v = fastExpVec(fastLogVec(v) * p.contrast);                       // contrast
+        v = v * colorScale[k];                                            // exposure: colorScale = colorFilter * powf(2, exposure), computed on the host (Viewport.cpp:453)
+        v = toneMap(v, p.tonemapper);
+        if (p.ditheringStrength != 0.0f) v = fmaf(ditherNoise(x, y, (uint32_t)k, p.ditherSeed), p.ditheringStrength, v);
+        const float scaled = v * 255.0f;
+        int32_t q = (scaled != scaled) ? (int32_t)0x80000000 : (int32_t)scaled;   // cvttps2dq (NaN -> INT_MIN); values here are far from overflow
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        out |= (uint32_t)q << (16 - 8 * k);                              // r << 16 | g << 8 | b
+    }
+    return out;
+}
+
 } // namespace rto

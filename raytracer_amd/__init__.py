@@ -112,6 +112,12 @@ class RtSceneDesc(C.Structure):
                 ("texelBytes", C.c_uint64)]
 
 
+class RtPostprocessParams(C.Structure):
+    _fields_ = [("colorFilter", C.c_float * 4), ("exposure", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float),
+                ("ditheringStrength", C.c_float), ("bloomFactor", C.c_float), ("tonemapper", C.c_uint32), ("numPasses", C.c_uint32),
+                ("ditherSeed", C.c_uint32)]
+
+
 class RtCamera(C.Structure):
     _fields_ = [("localToWorld", C.c_float * 16), ("aspectRatio", C.c_float), ("tanHalfFoV", C.c_float), ("dofEnable", C.c_uint32),
                 ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2)]
@@ -381,6 +387,20 @@ class Viewport:
         """Submit one pass with explicit constants (used by the parity tests)."""
         if host_lib().rth_viewport_render_pass_with(self._h, C.byref(params)) != 0:
             raise RuntimeError("render pass failed: %s" % (rtgpu_lib().rtgpu_last_error() or b"").decode())
+
+    def front_buffer(self, exposure=0.0, contrast=0.8, saturation=0.98, dithering=0.005, tonemapper=3, color_filter=(1.0, 1.0, 1.0, 1.0),
+                     dither_seed=0):
+        """Viewport::PostProcessTile on the device (defaults = PostprocessParams(), Core/Rendering/PostProcess.cpp:6-14):
+        the (H, W) uint32 0x00RRGGBB front buffer of the passes rendered so far."""
+        p = RtPostprocessParams()
+        for k in range(4):
+            p.colorFilter[k] = color_filter[k]
+        p.exposure, p.contrast, p.saturation, p.ditheringStrength, p.bloomFactor = exposure, contrast, saturation, dithering, 0.0
+        p.tonemapper, p.numPasses, p.ditherSeed = int(tonemapper), max(1, self.passes_finished), int(dither_seed)
+        out = np.zeros((self.height, self.width), dtype=np.uint32)
+        if rtgpu_lib().rtgpu_postprocess(self.device_context(), C.byref(p), out.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError("postprocess failed: %s" % (rtgpu_lib().rtgpu_last_error() or b"").decode())
+        return out
 
     def device_context(self):
         return C.c_void_p(host_lib().rth_viewport_device_ctx(self._h))

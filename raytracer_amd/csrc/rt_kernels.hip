@@ -26,6 +26,7 @@
 #include "rt_device_traverse.h"
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -724,6 +725,17 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
         secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
     flushCounters(cnt, counters);
+}
+
+// Viewport::PostProcessTile (Viewport.cpp:495-550): sum buffer -> 0x00RRGGBB front buffer, one thread per pixel
+struct PostScale { float c[3]; };
+__global__ void __launch_bounds__(RT_BLOCK) k_postprocess(const float* __restrict__ sum, uint32_t* __restrict__ front, uint32_t width, uint32_t height,
+                                                          const RtPostprocessParams params, const PostScale colorScale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t y = i / width, x = i - y * width;
+    front[i] = postProcessPixel(sum[3 * (size_t)i + 0], sum[3 * (size_t)i + 1], sum[3 * (size_t)i + 2], x, y, params, colorScale.c);
 }
 
 // ITexture::Evaluate for a list of (texture, uv) pairs -- rtgpu_evaluate_textures
@@ -1434,6 +1446,27 @@ RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     int r = rtgpu_synchronize(c); if (r) return r;
     c->countIntersections = enable != 0;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, uint32_t* frontBufferBGRA)
+{
+    if (!c || !p || !frontBufferBGRA) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    if (p->bloomFactor > 0.0f) return fail(RTGPU_ERR_UNSUPPORTED, "bloom is not implemented");
+    if (p->tonemapper > RT_TONEMAPPER_ACES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown tonemapper");
+    if (p->numPasses == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numPasses must be > 0");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    const size_t pixels = (size_t)c->width * c->height;
+    uint32_t* dFront = nullptr;
+    HIP_TRY(hipMalloc((void**)&dFront, pixels * sizeof(uint32_t)));
+    const float exposureScale = powf(2.0f, p->exposure);   // colorScale on the host like the reference (Viewport.cpp:453)
+    const PostScale scale = { { p->colorFilter[0] * exposureScale, p->colorFilter[1] * exposureScale, p->colorFilter[2] * exposureScale } };
+    hipLaunchKernelGGL(k_postprocess, dim3((uint32_t)((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->lanes[0].stream, c->sum, dFront, c->width, c->height, *p, scale);
+    hipError_t e = hipStreamSynchronize(c->lanes[0].stream);
+    if (e == hipSuccess) e = hipMemcpy(frontBufferBGRA, dFront, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(dFront);
+    if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_postprocess: ") + hipGetErrorString(e));
     return RTGPU_OK;
 }
 

@@ -18,6 +18,7 @@ public:
     bool RenderPass(const RtPassParams& params) override;
     bool ReadSum(float* sumRGB, float* secondaryRGB) override;
     bool GetCounters(RayTracingCounters& outTotals) override;
+    bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) override;
 
     // for debugging (the reference's UI pokes these: Demo/Demo_UserInterface.cpp:467-469)
     math::Vector4 mLightSamplingWeight;

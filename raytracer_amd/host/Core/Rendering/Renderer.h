@@ -9,6 +9,7 @@
 #include "../Scene/Scene.h"
 #include "../Scene/Camera.h"
 #include "../Utils/Bitmap.h"
+#include "PostProcess.h"
 
 namespace rt {
 
@@ -25,6 +26,8 @@ public:
     virtual bool RenderPass(const RtPassParams& params) = 0;                 // asynchronous
     virtual bool ReadSum(float* sumRGB, float* secondaryRGB) = 0;            // synchronises
     virtual bool GetCounters(RayTracingCounters& outTotals) = 0;             // totals since Reset; synchronises
+    // Viewport::PostProcessTile over the whole sum buffer -> 0x00RRGGBB pixels; synchronises
+    virtual bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) = 0;
 
 protected:
     const Scene& mScene;

@@ -1,7 +1,8 @@
 // Viewport: progressive accumulation driver (reference: Core/Rendering/Viewport.h:37-58).
 // Render() performs the pass prologue of Viewport::Render (Core/Rendering/Viewport.cpp:200-242) on the
 // host -- Halton seeds, anti-aliasing offset -- then hands ONE pass to the renderer instead of fanning
-// 32x32 tiles out to a thread pool.  Post-processing / adaptive rendering are outside the hot-path scope.
+// 32x32 tiles out to a thread pool.  GetFrontBuffer() runs Viewport::PostProcessTile (Viewport.cpp:495-550) on the device for the
+// whole image; bloom and adaptive rendering are not implemented.
 #pragma once
 
 #include "Renderer.h"
@@ -34,6 +35,10 @@ public:
     // Synchronises with the device and returns the accumulated (not tone-mapped) image.
     const Bitmap& GetSumBuffer();
     const Bitmap& GetSecondarySumBuffer();
+    // tone-mapped B8G8R8A8 image of the passes finished so far (reference: Viewport::GetFrontBuffer, Viewport.h:47)
+    const Bitmap& GetFrontBuffer();
+    bool SetPostprocessParams(const PostprocessParams& params);
+    const PostprocessParams& GetPostprocessParams() const { return mPostprocessParams; }
     uint32 GetWidth() const { return mWidth; }
     uint32 GetHeight() const { return mHeight; }
     const RenderingProgress& GetProgress() const { return mProgress; }
@@ -56,7 +61,8 @@ private:
     HaltonSequence mHaltonSequence;
     RenderingParams mParams;
     RenderingProgress mProgress;
-    Bitmap mSum, mSecondarySum;
+    Bitmap mSum, mSecondarySum, mFrontBuffer;
+    PostprocessParams mPostprocessParams;
     uint32 mWidth = 0, mHeight = 0;
     bool mSumDirty = false;
     std::vector<uint32> mSeedStorage;

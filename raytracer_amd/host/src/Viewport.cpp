@@ -326,6 +326,22 @@ const Bitmap& Viewport::GetSumBuffer()
     return mSum;
 }
 
+bool Viewport::SetPostprocessParams(const PostprocessParams& params)
+{
+    if (params.bloomFactor > 0.0f) { fprintf(stderr, "[rt] ERROR: bloom is not supported by the device path\n"); return false; }
+    mPostprocessParams = params;
+    return true;
+}
+
+const Bitmap& Viewport::GetFrontBuffer()
+{
+    Bitmap::InitData init;
+    init.width = mWidth; init.height = mHeight; init.format = Bitmap::Format::B8G8R8A8_UNorm; init.linearSpace = false;
+    if (mWidth && mHeight && (mFrontBuffer.GetWidth() != mWidth || mFrontBuffer.GetHeight() != mHeight || mFrontBuffer.GetFormat() != init.format)) mFrontBuffer.Init(init);
+    if (mRenderer && mWidth && mHeight) mRenderer->PostProcess(mPostprocessParams, mProgress.passesFinished, reinterpret_cast<uint32*>(mFrontBuffer.GetBytes()));
+    return mFrontBuffer;
+}
+
 const Bitmap& Viewport::GetSecondarySumBuffer()
 {
     GetSumBuffer();
@@ -457,6 +473,21 @@ bool PathTracerMIS::RenderPass(const RtPassParams& params)
 }
 
 bool PathTracerMIS::ReadSum(float* sumRGB, float* secondaryRGB) { return mCtx && rtgpu_read_sum(mCtx, sumRGB, secondaryRGB) == RTGPU_OK; }
+
+bool PathTracerMIS::PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA)
+{
+    RtPostprocessParams p; memset(&p, 0, sizeof(p));
+    memcpy(p.colorFilter, &params.colorFilter, 16);
+    p.exposure = params.exposure; p.contrast = params.contrast; p.saturation = params.saturation;
+    p.ditheringStrength = params.ditheringStrength; p.bloomFactor = params.bloomFactor;
+    p.tonemapper = (uint32)params.tonemapper; p.numPasses = numPasses ? numPasses : 1u; p.ditherSeed = numPasses;
+    if (!mCtx || rtgpu_postprocess(mCtx, &p, outBGRA) != RTGPU_OK)
+    {
+        fprintf(stderr, "[rt] ERROR: post-processing failed: %s\n", rtgpu_last_error());
+        return false;
+    }
+    return true;
+}
 
 bool PathTracerMIS::GetCounters(RayTracingCounters& out)
 {

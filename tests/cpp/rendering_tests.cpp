@@ -108,6 +108,20 @@ static void Furnace(const char* test, const MaterialPtr& material, uint32 numPas
     Bitmap bitmap = f.mViewport->GetSumBuffer();
     bitmap.Scale(Vector4(1.0f / numPasses));
     ValidateBitmap(bitmap, expected, tolerance, test);
+
+    // the displayable image (Viewport::GetFrontBuffer): B8G8R8A8, uniform for a furnace scene up to dithering
+    PostprocessParams post;
+    post.ditheringStrength = 0.0f;
+    post.tonemapper = Tonemapper::Clamped;
+    if (!f.mViewport->SetPostprocessParams(post)) { printf("%s: SetPostprocessParams failed\n", test); gFailures++; }
+    const Bitmap& front = f.mViewport->GetFrontBuffer();
+    if (front.GetWidth() != ViewportSize || front.GetFormat() != Bitmap::Format::B8G8R8A8_UNorm) { printf("%s: bad front buffer\n", test); gFailures++; return; }
+    const uint32* px = reinterpret_cast<const uint32*>(front.GetBytes());
+    uint32 lo[3] = { 255, 255, 255 }, hi[3] = { 0, 0, 0 };
+    for (uint32 i = 0; i < ViewportSize * ViewportSize; ++i)
+        for (int c = 0; c < 3; ++c) { const uint32 v = (px[i] >> (8 * c)) & 255u; lo[c] = v < lo[c] ? v : lo[c]; hi[c] = v > hi[c] ? v : hi[c]; }
+    for (int c = 0; c < 3; ++c)
+        if (hi[c] - lo[c] > 40) { printf("%s: front buffer channel %d spreads %u..%u\n", test, c, lo[c], hi[c]); gFailures++; }
 }
 
 int main()

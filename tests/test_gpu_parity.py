@@ -216,6 +216,34 @@ def test_batch_lanes_are_invisible(built, monkeypatch):
     assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), 7) == -1   # RTGPU_ERR_INVALID_ARGUMENT
 
 
+def test_front_buffer_postprocess_matches_oracle(built):
+    """Viewport::PostProcessTile on the device (rtgpu_postprocess) against the oracle's restatement (itself pinned to the
+    reference's FastLog / FastExp / ToneMap / ToBGR by postprocess_kat.bin) on a rendered sum buffer: identical 8-bit
+    pixels for all four tone mappers, with and without dithering (same per-pixel hash on both sides)."""
+    w, h = 160, 120
+    scene, camera = scenes.cornell_box(w / h)
+    vp = ra.Viewport(w, h, seed=5, max_ray_depth=4)
+    vp.set_renderer(scene)
+    vp.render(camera, 6)
+    sum_buffer = np.ascontiguousarray(vp.sum_buffer())
+    o = oracle_lib.lib()
+    for tonemapper in (0, 1, 2, 3):
+        for dithering, exposure, contrast, saturation in ((0.0, 0.0, 0.8, 0.98), (0.005, 1.3, 1.1, 0.5)):
+            got = vp.front_buffer(exposure=exposure, contrast=contrast, saturation=saturation, dithering=dithering, tonemapper=tonemapper,
+                                  color_filter=(1.0, 0.9, 0.8, 1.0), dither_seed=17)
+            p = ra.RtPostprocessParams()
+            p.colorFilter[0], p.colorFilter[1], p.colorFilter[2], p.colorFilter[3] = 1.0, 0.9, 0.8, 1.0
+            p.exposure, p.contrast, p.saturation, p.ditheringStrength, p.bloomFactor = exposure, contrast, saturation, dithering, 0.0
+            p.tonemapper, p.numPasses, p.ditherSeed = tonemapper, 6, 17
+            ref = np.zeros((h, w), dtype=np.uint32)
+            o.rto_postprocess(sum_buffer.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), C.byref(p), ref.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(got, ref), (tonemapper, dithering, int((got != ref).sum()))
+            assert got.max() > 0x202020 and len(np.unique(got)) > 100
+    p.bloomFactor = 0.5
+    out = np.zeros((h, w), dtype=np.uint32)
+    assert ra.rtgpu_lib().rtgpu_postprocess(vp.device_context(), C.byref(p), out.ctypes.data_as(C.c_void_p)) == -6   # RTGPU_ERR_UNSUPPORTED
+
+
 def test_depth_of_field(built):
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
