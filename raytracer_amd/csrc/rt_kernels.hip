@@ -284,6 +284,23 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     // Closest-hit rays are never split (their box culling and tie-breaking depend on the visiting order), and the
     // counting variant does not split at all, so the intersection counters stay those of the serial traversal.
     const bool splitShadowRays = !kCount && scene.numObjects == 1u;   // bypass scenes: a mesh level is all a ray has
+    // Single-mesh scenes (Scene::Traverse's one-object bypass, Scene.cpp:231-235, into MeshShape::Traverse): everything a ray
+    // needs to enter the mesh is the same for all rays, so it is fetched ONCE per wave (uniform -> scalar registers) instead
+    // of through three dependent loads (object -> mesh -> root node) behind every refill.
+    bool bypassMesh = false;
+    M4 bypassInvTransform; const RtNode* bypassNodes = nullptr; uint32_t bypassTriBase = 0, bypassRoot = 0;
+    if (scene.numObjects == 1u && scene.objects[0].objectKind == RT_OBJECT_SHAPE && scene.objects[0].shapeKind == RT_SHAPE_MESH)
+    {
+        const RtMesh& mesh = scene.meshes[scene.objects[0].meshIndex];
+        if (mesh.numNodes != 0u)
+        {
+            bypassMesh = true;
+            bypassInvTransform = loadM4(scene.objects[0].invTransform);
+            bypassNodes = scene.meshNodes + mesh.firstNode;
+            bypassTriBase = mesh.firstTriangle;
+            bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
+        }
+    }
     uint32_t drainIterations = 0;
     for (;;)
     {
@@ -349,11 +366,23 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     light = request / paths.capacity; slot = request - light * paths.capacity;
                     maxDistance = pshadow(paths, light, 0, slot).w;   // hitPoint.distance = illuminateResult.distance * 0.999f
                 }
-                travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
                 have = true;
-                // single-object scenes start at the object loop (BVH bypass): enter the object right away instead of
-                // queueing for the "other" phase
-                if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
+                if (bypassMesh)
+                {
+                    // = travBegin + the object step of travStepOther for the one mesh object
+                    s.ray = transformRayUnsafe(bypassInvTransform, loadWorldRay());
+                    s.nanFree = rayIsNaNFree(s.ray);
+                    s.hitDistance = maxDistance;
+                    s.stackSize = 0; s.levelBase = 0; s.leafNext = 1; s.leafEnd = 1; s.objectId = 0; s.triBase = bypassTriBase;
+                    s.occluded = false; s.nodes = bypassNodes; s.cur = bypassRoot; s.mode = TRAV_MESH;
+                }
+                else
+                {
+                    travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
+                    // other single-object scenes start at the object loop (BVH bypass): enter the object right away instead
+                    // of queueing for the "other" phase
+                    if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
+                }
                 // a taken subtree: same ray, same mesh, but only the donated node instead of the root
                 if (!refill && s.mode == TRAV_MESH) s.cur = donated;
             }
