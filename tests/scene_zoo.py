@@ -113,3 +113,22 @@ def textured_scene(aspect, triangles=6000, seed=11, skip=()):
     s.build()
     cam = ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
     return s, cam
+
+
+def many_lights_scene(aspect, num_point_lights=14):
+    """More than 8 lights (under LightSamplingStrategy::All the NEE requests past the eighth take the per-lane append
+    path of k_shade), some of them black (zero radiance: no shadow ray), a one-triangle mesh and a mesh-free object."""
+    s = ra.Scene()
+    grey = s.add_material("roughDiffuse", (0.7, 0.7, 0.7), roughness=0.4)
+    s.add_rect((6.0, 6.0), ra.transform_from_euler((0.0, -1.0, 0.0), (-90.0, 0.0, 0.0)), grey)
+    s.add_sphere(0.8, ra.transform_from_euler((0.0, -0.2, 0.0)), s.add_material("plastic", (0.9, 0.3, 0.2)))
+    pos = np.array([[-2.0, -0.9, 1.0], [2.0, -0.9, 1.0], [0.0, 1.5, -1.5]], dtype=np.float32)
+    s.add_mesh(pos, np.array([[0, 1, 2]], dtype=np.uint32), None, None, None, None, [], default_material=grey)
+    for i in range(num_point_lights):
+        a = 2.0 * np.pi * i / num_point_lights
+        color = (0.0, 0.0, 0.0) if i % 5 == 4 else (3.0 + i, 4.0, 12.0 - 0.5 * i)
+        s.add_point_light(color, ra.transform_from_euler((3.0 * np.cos(a), 2.0 + 0.1 * i, 3.0 * np.sin(a))))
+    s.add_area_light("sphere", [0.3], (5.0, 5.0, 4.0), ra.transform_from_euler((0.0, 3.0, 0.0)))
+    s.add_background_light((0.05, 0.06, 0.08))
+    s.build()
+    return s, ra.Camera((0.0, 1.5, 7.0), (8.0, 180.0, 0.0), aspect, 50.0)

@@ -244,6 +244,37 @@ def test_front_buffer_postprocess_matches_oracle(built):
     assert ra.rtgpu_lib().rtgpu_postprocess(vp.device_context(), C.byref(p), out.ctypes.data_as(C.c_void_p)) == -6   # RTGPU_ERR_UNSUPPORTED
 
 
+def test_many_lights_all_strategy_and_degenerate_sizes(built):
+    """Edge cases: 16 lights under LightSamplingStrategy::All (requests past the eighth use the per-lane queue append, black
+    lights produce no shadow ray), a one-triangle mesh without normals / tangents / uvs, a 1 x 1 viewport, a viewport that is
+    not a multiple of the 64-pixel tiles or the 8 x 8 blocks, maxRayDepth = 0 (direct light only) and Russian roulette
+    from the first bounce."""
+    for (w, h, depth, rr) in ((67, 41, 5, 0), (1, 1, 3, 1), (96, 64, 0, 1)):
+        scene, camera = scene_zoo.many_lights_scene(w / h)
+        assert scene.desc.contents.numLights == 16
+        out = run_both(scene, camera, w, h, passes=2, max_ray_depth=depth, min_russian_roulette_depth=rr, dimensions=256, light_sampling_all=True)
+        assert_identical(*out)
+        assert out[2]["numShadowRays"] > 0
+
+
+def test_reset_restarts_the_accumulation(built):
+    """rtgpu_reset (Viewport::Reset) zeroes sums and counters; the passes rendered afterwards with the same constants give
+    the bits a fresh viewport gives."""
+    w, h = 96, 72
+    scene, camera = scenes.cornell_box(w / h)
+    vp = ra.Viewport(w, h, seed=3, max_ray_depth=4)
+    vp.set_renderer(scene)
+    params = [vp.next_pass_params(camera) for _ in range(3)]
+    for p in params:
+        vp.render_pass_with(p)
+    first = vp.sum_buffer().copy(); c_first = vp.counters()
+    ra.host_lib().rth_viewport_reset(vp._h)
+    assert not vp.sum_buffer().any() and vp.counters()["numRays"] == 0
+    for p in params:
+        vp.render_pass_with(p)
+    assert np.array_equal(vp.sum_buffer().view(np.uint32), first.view(np.uint32)) and vp.counters() == c_first
+
+
 def test_depth_of_field(built):
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
