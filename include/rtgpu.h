@@ -178,18 +178,24 @@ typedef enum RtTextureKind
 {
     RT_TEXTURE_BITMAP = 0,        /* BitmapTexture  (BitmapTexture.cpp:32-93) */
     RT_TEXTURE_CHECKERBOARD = 1,  /* CheckerboardTexture (CheckerboardTexture.cpp:31-40): colorA / colorB */
-    RT_TEXTURE_CONST = 2          /* ConstTexture: colorA */
+    RT_TEXTURE_CONST = 2,         /* ConstTexture: colorA */
+    RT_TEXTURE_NOISE = 3,         /* NoiseTexture (NoiseTexture.cpp:58-164): simplex noise octaves, Lerp(colorA, colorB, value) */
+    RT_TEXTURE_MIX = 4            /* MixTexture (MixTexture.cpp:23-30): Lerp(textures[mixA], textures[mixB], textures[mixWeight]);
+                                   * a mix may reference mixes one level deep (rtgpu_upload_scene rejects deeper nesting) */
 } RtTextureKind;
 
-/* Texel formats: the values of rt::Bitmap::Format (Core/Utils/Bitmap.h:15-41).  The ones listed are decoded on the
- * device exactly as Bitmap::GetPixelBlock does (Bitmap.cpp:520-832); palette, B5G6R5, R11G11B10, R9G9B9E5 and the
- * block-compressed formats are rejected by rtgpu_upload_scene with RTGPU_ERR_UNSUPPORTED. */
+/* Texel formats: the values of rt::Bitmap::Format (Core/Utils/Bitmap.h:15-41), every one decoded on the device exactly
+ * as Bitmap::GetPixel / GetPixelBlock do (Bitmap.cpp:335-832, Math/Packed.h, Utils/BlockCompression.cpp).  The
+ * block-compressed formats address whole 4 x 4 blocks (width / 4 blocks per row, like the reference). */
 typedef enum RtBitmapFormat
 {
     RT_FORMAT_R8_UNORM = 1, RT_FORMAT_R8G8_UNORM = 2, RT_FORMAT_B8G8R8_UNORM = 3, RT_FORMAT_B8G8R8A8_UNORM = 4,
-    RT_FORMAT_R8G8B8A8_UNORM = 5, RT_FORMAT_R16_UNORM = 8, RT_FORMAT_R16G16_UNORM = 9, RT_FORMAT_R16G16B16A16_UNORM = 10,
+    RT_FORMAT_R8G8B8A8_UNORM = 5, RT_FORMAT_B8G8R8A8_UNORM_PALETTE = 6, RT_FORMAT_B5G6R5_UNORM = 7,
+    RT_FORMAT_R16_UNORM = 8, RT_FORMAT_R16G16_UNORM = 9, RT_FORMAT_R16G16B16A16_UNORM = 10,
     RT_FORMAT_R32_FLOAT = 11, RT_FORMAT_R32G32_FLOAT = 12, RT_FORMAT_R32G32B32_FLOAT = 13, RT_FORMAT_R32G32B32A32_FLOAT = 14,
-    RT_FORMAT_R16_HALF = 16, RT_FORMAT_R16G16_HALF = 17, RT_FORMAT_R16G16B16_HALF = 18, RT_FORMAT_R16G16B16A16_HALF = 19
+    RT_FORMAT_R11G11B10_FLOAT = 15,
+    RT_FORMAT_R16_HALF = 16, RT_FORMAT_R16G16_HALF = 17, RT_FORMAT_R16G16B16_HALF = 18, RT_FORMAT_R16G16B16A16_HALF = 19,
+    RT_FORMAT_R9G9B9E5_SHAREDEXP = 20, RT_FORMAT_BC1 = 21, RT_FORMAT_BC4 = 22, RT_FORMAT_BC5 = 23
 } RtBitmapFormat;
 
 typedef enum RtTextureFilter /* BitmapTextureFilter, Core/Textures/BitmapTexture.h */
@@ -197,20 +203,22 @@ typedef enum RtTextureFilter /* BitmapTextureFilter, Core/Textures/BitmapTexture
     RT_FILTER_NEAREST = 0, RT_FILTER_BILINEAR = 1, RT_FILTER_BILINEAR_SMOOTHSTEP = 2
 } RtTextureFilter;
 
-/* 80 bytes */
+/* 96 bytes */
 typedef struct RtTexture
 {
     uint32_t kind;          /* RtTextureKind */
     uint32_t format;        /* RtBitmapFormat */
     uint32_t width, height;
-    uint32_t stride;        /* bytes per row, Bitmap::mStride */
+    uint32_t stride;        /* bytes per row, Bitmap::mStride (unused by the block-compressed formats) */
     uint32_t linearSpace;   /* Bitmap::mLinearSpace; 0 => Convert_sRGB_To_Linear on every fetched texel (all four lanes) */
     uint32_t filter;        /* RtTextureFilter */
-    uint32_t _pad;
-    uint64_t dataOffset;    /* byte offset of the first row in RtSceneDesc::texelData (rows are `stride` apart) */
-    uint64_t _pad2;
-    float    colorA[4];     /* checkerboard / const */
+    uint32_t numOctaves;    /* noise */
+    uint64_t dataOffset;    /* byte offset of the first row (or block) in RtSceneDesc::texelData */
+    uint64_t paletteOffset; /* palette format: byte offset of the B8G8R8A8 palette entries in texelData */
+    float    colorA[4];     /* checkerboard / const / noise */
     float    colorB[4];
+    uint32_t mixA, mixB, mixWeight;   /* mix: indices into RtSceneDesc::textures */
+    uint32_t _pad;
 } RtTexture;
 
 /* 80 bytes; rt::Material after Compile() (Core/Material/Material.cpp:105-117): scalar parameters, the textures of the

@@ -61,6 +61,8 @@
 #include "Material/Material.h"
 #include "Textures/BitmapTexture.h"
 #include "Textures/CheckerboardTexture.h"
+#include "Textures/NoiseTexture.h"
+#include "Textures/MixTexture.h"
 #include "Utils/Bitmap.h"
 #include "Rendering/PostProcess.h"
 #include "Color/ColorHelpers.h"
@@ -790,22 +792,41 @@ static void genTextures()
         { Bitmap::Format::R16G16_UNorm, 4, 0 }, { Bitmap::Format::R16G16B16A16_UNorm, 8, 0 }, { Bitmap::Format::R32_Float, 4, 1 },
         { Bitmap::Format::R32G32_Float, 8, 1 }, { Bitmap::Format::R32G32B32_Float, 12, 1 }, { Bitmap::Format::R32G32B32A32_Float, 16, 1 },
         { Bitmap::Format::R16_Half, 2, 2 }, { Bitmap::Format::R16G16_Half, 4, 2 }, { Bitmap::Format::R16G16B16_Half, 6, 2 },
-        { Bitmap::Format::R16G16B16A16_Half, 8, 2 } };
+        { Bitmap::Format::R16G16B16A16_Half, 8, 2 },
+        // kind 3: any bytes, 32-bit texel (R11G11B10 with exponents kept in 1..30, R9G9B9E5); 4: palette indices; 5: B5G6R5;
+        // 6: block compressed (8 bytes per 4x4 block), 7: BC5 (16 bytes per block)
+        { Bitmap::Format::R11G11B10_Float, 4, 3 }, { Bitmap::Format::R9G9B9E5_SharedExp, 4, 3 }, { Bitmap::Format::B8G8R8A8_UNorm_Palette, 1, 4 },
+        { Bitmap::Format::B5G6R5_UNorm, 2, 5 }, { Bitmap::Format::BC1, 0, 6 }, { Bitmap::Format::BC4, 0, 6 }, { Bitmap::Format::BC5, 0, 7 } };
     const uint32_t sizes[][2] = { { 7, 5 }, { 16, 16 }, { 1, 1 }, { 33, 2 }, { 2, 19 }, { 64, 32 } };
     int combo = 0;
     for (const Fmt& fm : fmts)
         for (int variant = 0; variant < 3; ++variant, ++combo)
         {
-            const uint32_t w = sizes[combo % 6][0], h = sizes[combo % 6][1];
-            std::vector<uint8_t> data((size_t)w * h * fm.bytes);
-            if (fm.kind == 0) for (auto& b : data) b = (uint8_t)g.u32();
+            uint32_t w = sizes[combo % 6][0], h = sizes[combo % 6][1];
+            if (fm.kind >= 6) { w = ((w + 3u) / 4u) * 4u; h = ((h + 3u) / 4u) * 4u; }   // whole 4x4 blocks
+            std::vector<uint8_t> data(fm.kind == 6 ? (size_t)w * h / 2 : (fm.kind == 7 ? (size_t)w * h : (size_t)w * h * fm.bytes));
+            if (fm.kind == 0 || fm.kind >= 3) for (auto& b : data) b = (uint8_t)g.u32();
+            if (fm.f == Bitmap::Format::R11G11B10_Float)   // keep the three 5-bit exponents in 1..30 (no INF / NaN / denormal patterns)
+            {
+                uint32_t* p32 = (uint32_t*)data.data();
+                for (size_t k = 0; k < data.size() / 4; ++k)
+                {
+                    uint32_t v = p32[k];
+                    auto fix = [&](uint32_t shift) { uint32_t e = (v >> shift) & 0x1Fu; e = 1u + e % 30u; v = (v & ~(0x1Fu << shift)) | (e << shift); };
+                    fix(6); fix(17); fix(27);
+                    p32[k] = v;
+                }
+            }
+            if (false) for (auto& b : data) b = (uint8_t)g.u32();
             else if (fm.kind == 1) { float* f = (float*)data.data(); for (size_t k = 0; k < data.size() / 4; ++k) f[k] = g.range(0.0f, 2.0f); }
             else { Half* hp = (Half*)data.data(); for (size_t k = 0; k < data.size() / 2; ++k) hp[k] = Half(k % 37 == 0 ? 1.0e-6f : g.range(0.0f, 2.0f)); }
             Bitmap::InitData init;
             init.width = w; init.height = h; init.format = fm.f; init.data = data.data();
             init.linearSpace = (variant != 1);
+            if (fm.kind == 4) init.paletteSize = 256;
             BitmapPtr bitmap = std::make_shared<Bitmap>("kat");
             if (!bitmap->Init(init)) { fprintf(stderr, "Bitmap::Init failed\n"); exit(1); }
+            if (fm.kind == 4) for (uint32_t k = 0; k < 1024; ++k) bitmap->mPalette[k] = (uint8_t)g.u32();
             auto tex = std::make_shared<BitmapTexture>(bitmap);
             tex->mFilter = (BitmapTextureFilter)((combo + variant) % 3);
             RtTexture t; memset(&t, 0, sizeof(t));
@@ -814,6 +835,12 @@ static void genTextures()
             while (blob.size() % 16) blob.push_back(0);
             t.dataOffset = blob.size();
             blob.insert(blob.end(), bitmap->mData, bitmap->mData + (size_t)bitmap->mStride * h);
+            if (fm.kind == 4)
+            {
+                while (blob.size() % 16) blob.push_back(0);
+                t.paletteOffset = blob.size();
+                blob.insert(blob.end(), bitmap->mPalette, bitmap->mPalette + 1024);
+            }
             descs.push_back(t); textures.push_back(tex);
         }
     for (int k = 0; k < 2; ++k)
@@ -822,6 +849,24 @@ static void genTextures()
         textures.push_back(std::make_shared<CheckerboardTexture>(a, b));
         RtTexture t; memset(&t, 0, sizeof(t)); t.kind = RT_TEXTURE_CHECKERBOARD; memcpy(t.colorA, &a, 16); memcpy(t.colorB, &b, 16);
         descs.push_back(t);
+    }
+    // noise (1, 3, 6 octaves) and mix textures (leaf children, then a mix of mixes)
+    for (uint32_t octaves : { 1u, 3u, 6u })
+    {
+        Vector4 a(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), 0.0f), b(g.range(0.0f, 2.0f), g.range(0.0f, 2.0f), g.range(0.0f, 2.0f), 1.0f);
+        textures.push_back(std::make_shared<NoiseTexture>(a, b, octaves));
+        RtTexture t; memset(&t, 0, sizeof(t)); t.kind = RT_TEXTURE_NOISE; t.numOctaves = octaves; memcpy(t.colorA, &a, 16); memcpy(t.colorB, &b, 16);
+        descs.push_back(t);
+    }
+    {
+        const uint32_t n = (uint32_t)descs.size();
+        const uint32_t triples[3][3] = { { 3, n - 1, n - 4 }, { n - 5, 10, n - 2 }, { n, n + 1, 4 } };   // the third mixes the first two
+        for (int k = 0; k < 3; ++k)
+        {
+            textures.push_back(std::make_shared<MixTexture>(textures[triples[k][0]], textures[triples[k][1]], textures[triples[k][2]]));
+            RtTexture t; memset(&t, 0, sizeof(t)); t.kind = RT_TEXTURE_MIX; t.mixA = triples[k][0]; t.mixB = triples[k][1]; t.mixWeight = triples[k][2];
+            descs.push_back(t);
+        }
     }
     for (int k = 0; k < 32; ++k) blob.push_back(0);   // the reference's loads read up to 16 bytes past a texel
 
@@ -839,7 +884,7 @@ static void genTextures()
             float u = g.range(-3.0f, 3.0f), v = g.range(-3.0f, 3.0f);
             if (k < 13) { u = special[k]; v = special[(k * 5 + 3) % 13]; }
             else if (k < 26) { v = special[k - 13]; }
-            else if (k < 40) { u = (float)((k - 26) % 8) / (float)descs[ti].width + (k % 2 ? 0.0f : 1.0e-7f); }   // texel edges
+            else if (k < 40) { u = (float)((k - 26) % 8) / (float)(descs[ti].width ? descs[ti].width : 16u) + (k % 2 ? 0.0f : 1.0e-7f); }   // texel edges
             const Vector4 c = textures[ti]->Evaluate(Vector4(u, v, 0.0f, 0.0f));
             out.push_back(ti); pushf(u); pushf(v); push4(c);
             ++numEval;

@@ -557,6 +557,20 @@ static inline V4 srgbToLinear(V4 c)
 }
 static inline uint16_t rd16(const uint8_t* p) { uint16_t v; memcpy(&v, p, 2); return v; }
 static inline float rdf(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
+// helper::DecodeBC_Grayscale, Utils/BlockCompression.cpp:81-109
+static inline float bcGrayscale(const uint8_t* blockData, uint32_t x, uint32_t y)
+{
+    const float intColor0 = (float)blockData[0], intColor1 = (float)blockData[1];
+    const float color0 = intColor0 / 255.0f, color1 = intColor1 / 255.0f;
+    uint64_t code; memcpy(&code, blockData + 2, 8);
+    const uint32_t index = (uint32_t)((code >> (uint64_t)(3u * (4u * y + x))) % 8u);
+    if (index == 0u) return color0;
+    if (index == 1u) return color1;
+    if (intColor0 > intColor1) return (color0 * (float)(8u - index) + color1 * (float)(index - 1u)) / 7.0f;
+    if (index == 6u) return 0.0f;
+    if (index == 7u) return 1.0f;
+    return (color0 * (float)(6u - index) + color1 * (float)(index - 1u)) / 5.0f;
+}
 // One texel as Bitmap::GetPixel / GetPixelBlock decode it (Bitmap.cpp:335-517, 520-832; loads: Math/Vector4Load.h).
 // Every UNorm load is float(integer) * RN(1 / max): the SSE paths scale by powers of two around that, exactly.
 static inline V4 bitmapTexel(const RtTexture& t, const uint8_t* texels, uint32_t x, uint32_t y)
@@ -583,6 +597,54 @@ static inline V4 bitmapTexel(const RtTexture& t, const uint8_t* texels, uint32_t
     case RT_FORMAT_R16G16_HALF:        c = V4(halfToFloat(rd16(row + 4 * x)), halfToFloat(rd16(row + 4 * x + 2)), 0.0f, 0.0f); break;
     case RT_FORMAT_R16G16B16_HALF:     c = V4(halfToFloat(rd16(row + 6 * x)), halfToFloat(rd16(row + 6 * x + 2)), halfToFloat(rd16(row + 6 * x + 4)), 0.0f); break;
     case RT_FORMAT_R16G16B16A16_HALF:  c = V4(halfToFloat(rd16(row + 8 * x)), halfToFloat(rd16(row + 8 * x + 2)), halfToFloat(rd16(row + 8 * x + 4)), halfToFloat(rd16(row + 8 * x + 6))); break;
+    case RT_FORMAT_B8G8R8A8_UNORM_PALETTE:   // palette entries are B8G8R8A8, Bitmap.cpp:380-386
+    {
+        const uint8_t* e = texels + t.paletteOffset + 4u * (size_t)row[x];
+        c = V4((float)(int32_t)e[2] * s8, (float)(int32_t)e[1] * s8, (float)(int32_t)e[0] * s8, (float)(int32_t)e[3] * s8); break;
+    }
+    case RT_FORMAT_B5G6R5_UNORM:             // Vector4_Load_B5G6R5_Norm, Vector4Load.h:52-58
+    {
+        const uint32_t v = rd16(row + 2 * x);
+        c = V4((float)(int32_t)(v >> 11) * (1.0f / 31.0f), (float)(int32_t)((v >> 5) & 0x3Fu) * (1.0f / 63.0f), (float)(int32_t)(v & 0x1Fu) * (1.0f / 31.0f), 0.0f); break;
+    }
+    case RT_FORMAT_R11G11B10_FLOAT:          // PackedFloat3::ToVector, Math/Packed.h:160-167 (bit-casts, no INF / NaN / denormal handling)
+    {
+        uint32_t v; memcpy(&v, row + 4 * x, 4);
+        const uint32_t xm = v & 0x3Fu, xe = (v >> 6) & 0x1Fu, ym = (v >> 11) & 0x3Fu, ye = (v >> 17) & 0x1Fu, zm = (v >> 22) & 0x1Fu, ze = (v >> 27) & 0x1Fu;
+        const uint32_t bx = ((xe + 112u) << 23) | (xm << 17), by = ((ye + 112u) << 23) | (ym << 17), bz = ((ze + 112u) << 23) | (zm << 17);
+        float fx, fy, fz; memcpy(&fx, &bx, 4); memcpy(&fy, &by, 4); memcpy(&fz, &bz, 4);
+        c = V4(fx, fy, fz, 0.0f); break;
+    }
+    case RT_FORMAT_R9G9B9E5_SHAREDEXP:       // SharedExpFloat3::ToVector, Math/Packed.h:126-131
+    {
+        uint32_t v; memcpy(&v, row + 4 * x, 4);
+        const uint32_t sb = 0x33800000u + ((v >> 27) << 23);
+        float scale; memcpy(&scale, &sb, 4);
+        c = V4(scale * (float)(int32_t)(v & 0x1FFu), scale * (float)(int32_t)((v >> 9) & 0x1FFu), scale * (float)(int32_t)((v >> 18) & 0x1FFu), scale * 0.0f); break;
+    }
+    case RT_FORMAT_BC1:                      // DecodeBC1, Utils/BlockCompression.cpp:49-76
+    {
+        const uint8_t* block = texels + t.dataOffset + 8u * ((size_t)(t.width / 4u) * (y / 4u) + (x / 4u));
+        const uint32_t c0 = rd16(block), c1 = rd16(block + 2);
+        uint32_t code; memcpy(&code, block + 4, 4);
+        const uint32_t index = (code >> (2u * (4u * (y % 4u) + (x % 4u)))) % 4u;
+        const float w = index == 0u ? 0.0f : (index == 1u ? 1.0f : (index == 2u ? 1.0f / 3.0f : 2.0f / 3.0f));
+        // base colours stay in their 5/6/5 bit positions until the final scale; Lerp = MulAndAdd(v2 - v1, w, v1)
+        const float r0 = (float)(int32_t)(c0 & 0xF800u), g0 = (float)(int32_t)(c0 & 0x07E0u), b0 = (float)(int32_t)(c0 & 0x001Fu);
+        const float r1 = (float)(int32_t)(c1 & 0xF800u), g1 = (float)(int32_t)(c1 & 0x07E0u), b1 = (float)(int32_t)(c1 & 0x001Fu);
+        c = V4(fmaf(r1 - r0, w, r0) * (1.0f / 2048.0f / 31.0f), fmaf(g1 - g0, w, g0) * (1.0f / 32.0f / 63.0f), fmaf(b1 - b0, w, b0) * (1.0f / 31.0f), fmaf(0.0f, w, 0.0f) * 0.0f); break;
+    }
+    case RT_FORMAT_BC4:                      // DecodeBC4, BlockCompression.cpp:113-126
+    {
+        const float v = bcGrayscale(texels + t.dataOffset + 8u * ((size_t)(t.width / 4u) * (y / 4u) + (x / 4u)), x % 4u, y % 4u);
+        c = V4(v, v, v, 1.0f); break;
+    }
+    case RT_FORMAT_BC5:                      // DecodeBC5, BlockCompression.cpp:128-146 (green first, as the reference returns it)
+    {
+        const uint8_t* block = texels + t.dataOffset + 16u * ((size_t)(t.width / 4u) * (y / 4u) + (x / 4u));
+        const float red = bcGrayscale(block, x % 4u, y % 4u), green = bcGrayscale(block + 8, x % 4u, y % 4u);
+        c = V4(green, red, 0.0f, 1.0f); break;
+    }
     default: break;
     }
     if (!t.linearSpace) c = srgbToLinear(c);
@@ -617,10 +679,50 @@ static inline V4 bitmapTextureEvaluate(const RtTexture& t, const uint8_t* texels
     const V4 value1 = lerp4(c1, c3, splat(weightY));
     return lerp4(value0, value1, splat(weightX));
 }
-// ITexture::Evaluate dispatch
-static inline V4 textureEvaluate(const RtSceneDesc* d, uint32_t index, V4 coords)
+// NoiseTexture (Core/Textures/NoiseTexture.cpp): 2D simplex noise after github.com/SRombauts/SimplexNoise; the table is
+// Ken Perlin's reference permutation
+static const uint8_t kNoisePermutation[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10, 23, 190, 6, 148,
+    247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87, 174, 20, 125, 136, 171, 168, 68, 175,
+    74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211, 133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54,
+    65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208, 89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64,
+    52, 217, 226, 250, 124, 123, 5, 202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213,
+    119, 248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232, 178, 185, 112, 104,
+    218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249, 14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157,
+    184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205, 93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180 };
+static inline int32_t noiseHash(int32_t i) { return kNoisePermutation[(uint8_t)i]; }
+static inline float noiseGradient(int32_t hash, float x, float y)   // NoiseTexture.cpp:34-40
 {
-    const RtTexture& t = d->textures[index];
+    const int32_t h = hash & 0x3F;
+    const float u = h < 4 ? x : y, v = h < 4 ? y : x;
+    return ((h & 1) ? -u : u) + ((h & 2) ? -2.0f * v : 2.0f * v);
+}
+static inline int32_t floorInt(float fp) { const int32_t i = (int32_t)fp; return fp < (float)i ? (i - 1) : i; }   // Math.h:100-104
+static inline float noiseEvaluateInternal(float cx, float cy)   // NoiseTexture::EvaluateInternal, :58-147
+{
+    const float F2 = 0.366025403f, G2 = 0.211324865f;
+    const float s = (cx + cy) * F2;
+    const float xs = cx + s, ys = cy + s;
+    const int32_t i = floorInt(xs), j = floorInt(ys);
+    const float t = (float)(i + j) * G2;
+    const float X0 = (float)i - t, Y0 = (float)j - t;
+    const float x0 = cx - X0, y0 = cy - Y0;
+    const int32_t i1 = x0 > y0 ? 1 : 0, j1 = x0 > y0 ? 0 : 1;
+    const float x1 = x0 - (float)i1 + G2, y1 = y0 - (float)j1 + G2;
+    const float x2 = x0 - 1.0f + 2.0f * G2, y2 = y0 - 1.0f + 2.0f * G2;
+    const int32_t gi0 = noiseHash(i + noiseHash(j)), gi1 = noiseHash(i + i1 + noiseHash(j + j1)), gi2 = noiseHash(i + 1 + noiseHash(j + 1));
+    float n0, n1, n2;
+    float t0 = 0.5f - x0 * x0 - y0 * y0;
+    if (t0 < 0.0f) n0 = 0.0f; else { t0 *= t0; n0 = t0 * t0 * noiseGradient(gi0, x0, y0); }
+    float t1 = 0.5f - x1 * x1 - y1 * y1;
+    if (t1 < 0.0f) n1 = 0.0f; else { t1 *= t1; n1 = t1 * t1 * noiseGradient(gi1, x1, y1); }
+    float t2 = 0.5f - x2 * x2 - y2 * y2;
+    if (t2 < 0.0f) n2 = 0.0f; else { t2 *= t2; n2 = t2 * t2 * noiseGradient(gi2, x2, y2); }
+    return Clamp(0.5f + 22.615325f * (n0 + n1 + n2), 0.0f, 1.0f);
+}
+// every ITexture but MixTexture
+static inline V4 textureEvaluateLeaf(const RtSceneDesc* d, const RtTexture& t, V4 coords)
+{
     if (t.kind == RT_TEXTURE_CHECKERBOARD)      // CheckerboardTexture.cpp:31-40
     {
         const float wx = coords.x - floorf(coords.x), wy = coords.y - floorf(coords.y);
@@ -628,7 +730,32 @@ static inline V4 textureEvaluate(const RtSceneDesc* d, uint32_t index, V4 coords
         return cond ? load4(t.colorA) : load4(t.colorB);
     }
     if (t.kind == RT_TEXTURE_CONST) return load4(t.colorA);
+    if (t.kind == RT_TEXTURE_NOISE)             // NoiseTexture::Evaluate, NoiseTexture.cpp:149-164
+    {
+        float value = 0.0f, octaveValueScale = 0.5f, octaveCoordScale = 1.0f;
+        for (uint32_t i = 0; i < t.numOctaves; ++i)
+        {
+            value += octaveValueScale * noiseEvaluateInternal(coords.x * octaveCoordScale, coords.y * octaveCoordScale);
+            octaveValueScale *= 0.5f; octaveCoordScale *= 2.0f;
+        }
+        return lerp4(load4(t.colorA), load4(t.colorB), splat(value));
+    }
     return bitmapTextureEvaluate(t, d->texelData, coords);
+}
+// MixTexture::Evaluate (MixTexture.cpp:23-30) = Lerp(A(uv), B(uv), weight(uv)), all four lanes.  Mixes nest one level deep.
+static inline V4 textureEvaluateInner(const RtSceneDesc* d, uint32_t index, V4 coords)
+{
+    const RtTexture& t = d->textures[index];
+    if (t.kind != RT_TEXTURE_MIX) return textureEvaluateLeaf(d, t, coords);
+    return lerp4(textureEvaluateLeaf(d, d->textures[t.mixA], coords), textureEvaluateLeaf(d, d->textures[t.mixB], coords),
+                 textureEvaluateLeaf(d, d->textures[t.mixWeight], coords));
+}
+// ITexture::Evaluate dispatch
+static inline V4 textureEvaluate(const RtSceneDesc* d, uint32_t index, V4 coords)
+{
+    const RtTexture& t = d->textures[index];
+    if (t.kind != RT_TEXTURE_MIX) return textureEvaluateLeaf(d, t, coords);
+    return lerp4(textureEvaluateInner(d, t.mixA, coords), textureEvaluateInner(d, t.mixB, coords), textureEvaluateInner(d, t.mixWeight, coords));
 }
 // Material::GetNormalVector, Material.cpp:120-138 (normalMap != NULL)
 static inline V4 materialGetNormalVector(const RtSceneDesc* d, const RtMaterial& mat, V4 uv)

@@ -90,8 +90,9 @@ RT_NO_TEXTURE = 0xFFFFFFFF
 
 class RtTexture(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("format", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("stride", C.c_uint32),
-                ("linearSpace", C.c_uint32), ("filter", C.c_uint32), ("_pad", C.c_uint32), ("dataOffset", C.c_uint64),
-                ("_pad2", C.c_uint64), ("colorA", C.c_float * 4), ("colorB", C.c_float * 4)]
+                ("linearSpace", C.c_uint32), ("filter", C.c_uint32), ("numOctaves", C.c_uint32), ("dataOffset", C.c_uint64),
+                ("paletteOffset", C.c_uint64), ("colorA", C.c_float * 4), ("colorB", C.c_float * 4), ("mixA", C.c_uint32),
+                ("mixB", C.c_uint32), ("mixWeight", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class RtMaterial(C.Structure):
@@ -253,20 +254,39 @@ class Scene:
         return self
 
     # ---- textures (ITexture of the reference; evaluated on the device) --------------------------------------------
-    FORMATS = dict(R8_UNorm=1, R8G8_UNorm=2, B8G8R8_UNorm=3, B8G8R8A8_UNorm=4, R8G8B8A8_UNorm=5, R16_UNorm=8, R16G16_UNorm=9,
-                   R16G16B16A16_UNorm=10, R32_Float=11, R32G32_Float=12, R32G32B32_Float=13, R32G32B32A32_Float=14, R16_Half=16,
-                   R16G16_Half=17, R16G16B16_Half=18, R16G16B16A16_Half=19)
+    FORMATS = dict(R8_UNorm=1, R8G8_UNorm=2, B8G8R8_UNorm=3, B8G8R8A8_UNorm=4, R8G8B8A8_UNorm=5, B8G8R8A8_UNorm_Palette=6, B5G6R5_UNorm=7,
+                   R16_UNorm=8, R16G16_UNorm=9, R16G16B16A16_UNorm=10, R32_Float=11, R32G32_Float=12, R32G32B32_Float=13,
+                   R32G32B32A32_Float=14, R11G11B10_Float=15, R16_Half=16, R16G16_Half=17, R16G16B16_Half=18, R16G16B16A16_Half=19,
+                   R9G9B9E5_SharedExp=20, BC1=21, BC4=22, BC5=23)
     FILTERS = dict(nearest=0, bilinear=1, smoothstep=2)
 
-    def add_bitmap_texture(self, pixels, fmt, linear_space=True, filter="smoothstep"):
+    def add_bitmap_texture(self, pixels, fmt, linear_space=True, filter="smoothstep", palette=None, size=None):
         """pixels: C-contiguous numpy array of shape (height, width[, channels]) whose dtype/channels match `fmt`
         (uint8, uint16, float16 or float32); rows are tightly packed."""
         a = np.ascontiguousarray(pixels)
-        h, w = a.shape[0], a.shape[1]
+        if size is not None:            # block-compressed data: `pixels` is the raw block stream, size = (width, height) in texels
+            w, h = size
+            stride = 0
+        else:
+            h, w = a.shape[0], a.shape[1]
+            stride = a.strides[0]
         tid = host_lib().rth_texture_bitmap(self._h, C.c_uint32(w), C.c_uint32(h), C.c_uint32(self.FORMATS[fmt]), a.ctypes.data_as(C.c_void_p),
-                                            C.c_uint32(a.strides[0]), 1 if linear_space else 0, self.FILTERS[filter])
+                                            C.c_uint32(stride), 1 if linear_space else 0, self.FILTERS[filter])
         if tid < 0:
             raise ValueError("bad bitmap texture")
+        if palette is not None:
+            pal = np.ascontiguousarray(palette, dtype=np.uint8).reshape(-1, 4)
+            if host_lib().rth_texture_set_palette(self._h, tid, pal.ctypes.data_as(C.c_void_p), C.c_uint32(pal.shape[0])) != 0:
+                raise ValueError("bad palette")
+        return tid
+
+    def add_noise_texture(self, color_a, color_b, octaves=1):
+        return host_lib().rth_texture_noise(self._h, _color(color_a), _color(color_b), C.c_uint32(octaves))
+
+    def add_mix_texture(self, texture_a, texture_b, weight):
+        tid = host_lib().rth_texture_mix(self._h, int(texture_a), int(texture_b), int(weight))
+        if tid < 0:
+            raise ValueError("bad mix texture children")
         return tid
 
     def add_checkerboard_texture(self, color_a, color_b):

@@ -1099,30 +1099,59 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     for (uint32_t i = 0; i < s->numGlobalLights; ++i) if (s->globalLights[i] >= s->numLights) return fail(RTGPU_ERR_INVALID_ARGUMENT, "global light index out of range");
     for (uint32_t i = 0; i < s->numMaterials; ++i) if (s->materials[i].bsdf > RT_BSDF_ROUGH_PLASTIC) return fail(RTGPU_ERR_UNSUPPORTED, "unknown BSDF kind");
     if (s->numMaterials >= (1u << 22)) return fail(RTGPU_ERR_UNSUPPORTED, "more than 4M materials");   // the path flags hold a material index in 23 bits
-    // textures: formats the device decodes, rows inside the texel blob (plus the 16 bytes the reference's loads over-read)
+    // textures: known kinds and formats, rows / blocks / palettes inside the texel blob, mixes nested at most one level deep
     for (uint32_t i = 0; i < s->numTextures; ++i)
     {
         const RtTexture& t = s->textures[i];
         if (t.kind == RT_TEXTURE_CHECKERBOARD || t.kind == RT_TEXTURE_CONST) continue;
+        if (t.kind == RT_TEXTURE_NOISE) { if (t.numOctaves == 0 || t.numOctaves > 20) return fail(RTGPU_ERR_INVALID_ARGUMENT, "noise octaves must be 1..20"); continue; }
+        if (t.kind == RT_TEXTURE_MIX)
+        {
+            const uint32_t children[3] = { t.mixA, t.mixB, t.mixWeight };
+            for (uint32_t child : children)
+            {
+                if (child >= s->numTextures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix texture child index out of range");
+                const RtTexture& c = s->textures[child];
+                if (c.kind != RT_TEXTURE_MIX) continue;
+                const uint32_t grandChildren[3] = { c.mixA, c.mixB, c.mixWeight };
+                for (uint32_t g : grandChildren)
+                    if (g >= s->numTextures || s->textures[g].kind == RT_TEXTURE_MIX) return fail(RTGPU_ERR_UNSUPPORTED, "mix textures nested more than one level deep");
+            }
+            continue;
+        }
         if (t.kind != RT_TEXTURE_BITMAP) return fail(RTGPU_ERR_UNSUPPORTED, "unknown texture kind");
-        uint32_t texelSize = 0;
+        uint32_t bits = 0;
         switch (t.format)
         {
-        case RT_FORMAT_R8_UNORM: texelSize = 1; break;
-        case RT_FORMAT_R8G8_UNORM: case RT_FORMAT_R16_UNORM: case RT_FORMAT_R16_HALF: texelSize = 2; break;
-        case RT_FORMAT_B8G8R8_UNORM: texelSize = 3; break;
-        case RT_FORMAT_B8G8R8A8_UNORM: case RT_FORMAT_R8G8B8A8_UNORM: case RT_FORMAT_R16G16_UNORM: case RT_FORMAT_R32_FLOAT: case RT_FORMAT_R16G16_HALF: texelSize = 4; break;
-        case RT_FORMAT_R16G16B16_HALF: texelSize = 6; break;
-        case RT_FORMAT_R16G16B16A16_UNORM: case RT_FORMAT_R32G32_FLOAT: case RT_FORMAT_R16G16B16A16_HALF: texelSize = 8; break;
-        case RT_FORMAT_R32G32B32_FLOAT: texelSize = 12; break;
-        case RT_FORMAT_R32G32B32A32_FLOAT: texelSize = 16; break;
-        default: return fail(RTGPU_ERR_UNSUPPORTED, "bitmap format is not decoded on the device (palette, B5G6R5, R11G11B10, R9G9B9E5, BC1/4/5)");
+        case RT_FORMAT_R8_UNORM: case RT_FORMAT_B8G8R8A8_UNORM_PALETTE: case RT_FORMAT_BC5: bits = 8; break;
+        case RT_FORMAT_R8G8_UNORM: case RT_FORMAT_R16_UNORM: case RT_FORMAT_R16_HALF: case RT_FORMAT_B5G6R5_UNORM: bits = 16; break;
+        case RT_FORMAT_B8G8R8_UNORM: bits = 24; break;
+        case RT_FORMAT_B8G8R8A8_UNORM: case RT_FORMAT_R8G8B8A8_UNORM: case RT_FORMAT_R16G16_UNORM: case RT_FORMAT_R32_FLOAT: case RT_FORMAT_R16G16_HALF:
+        case RT_FORMAT_R11G11B10_FLOAT: case RT_FORMAT_R9G9B9E5_SHAREDEXP: bits = 32; break;
+        case RT_FORMAT_R16G16B16_HALF: bits = 48; break;
+        case RT_FORMAT_R16G16B16A16_UNORM: case RT_FORMAT_R32G32_FLOAT: case RT_FORMAT_R16G16B16A16_HALF: bits = 64; break;
+        case RT_FORMAT_R32G32B32_FLOAT: bits = 96; break;
+        case RT_FORMAT_R32G32B32A32_FLOAT: bits = 128; break;
+        case RT_FORMAT_BC1: case RT_FORMAT_BC4: bits = 4; break;
+        default: return fail(RTGPU_ERR_UNSUPPORTED, "unknown bitmap format");
         }
         if (t.width == 0 || t.height == 0 || t.width > 65536u || t.height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid texture size");
-        if (t.stride < t.width * texelSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture stride smaller than a row");
         if (t.filter > RT_FILTER_BILINEAR_SMOOTHSTEP) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown texture filter");
-        if (!s->texelData || t.dataOffset + (uint64_t)t.stride * (t.height - 1u) + (uint64_t)t.width * texelSize > s->texelBytes)
-            return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture rows outside texelData");
+        const bool blocks = t.format == RT_FORMAT_BC1 || t.format == RT_FORMAT_BC4 || t.format == RT_FORMAT_BC5;
+        uint64_t extent;
+        if (blocks)
+        {
+            if ((t.width & 3u) || (t.height & 3u)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "block-compressed textures need dimensions that are multiples of 4");
+            extent = (uint64_t)(t.width / 4u) * (t.height / 4u) * (t.format == RT_FORMAT_BC5 ? 16u : 8u);
+        }
+        else
+        {
+            const uint32_t texelSize = bits / 8u;
+            if (t.stride < t.width * texelSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture stride smaller than a row");
+            extent = (uint64_t)t.stride * (t.height - 1u) + (uint64_t)t.width * texelSize;
+        }
+        if (!s->texelData || t.dataOffset + extent > s->texelBytes) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture data outside texelData");
+        if (t.format == RT_FORMAT_B8G8R8A8_UNORM_PALETTE && t.paletteOffset + 1024u > s->texelBytes) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture palette (256 entries) outside texelData");
     }
     auto textureOk = [&](uint32_t index) { return index == RT_NO_TEXTURE || index < s->numTextures; };
     for (uint32_t i = 0; i < s->numMaterials; ++i)

@@ -1,7 +1,7 @@
 // Bitmap: pixel storage with the reference's format enumeration (Core/Utils/Bitmap.h:12-160).  Two uses on this path:
 // the R32G32B32_Float sum buffers of the Viewport (tight stride, Bitmap.cpp:97-100) and the texel source of
-// BitmapTexture, which the device decodes exactly as Bitmap::GetPixelBlock does.  File loaders (BMP/DDS/EXR) and the
-// block-compressed / packed formats are outside the hot-path scope.
+// BitmapTexture, which the device decodes exactly as Bitmap::GetPixelBlock does (all 23 formats).  Of the file loaders only
+// uncompressed BMP is present (DDS / EXR are outside the hot-path scope).
 #pragma once
 
 #include "../Math/Math.h"
@@ -29,11 +29,12 @@ public:
         const void* data = nullptr;   // copied; NULL leaves the pixels zero
         uint32 stride = 0;            // 0 = tight
         bool linearSpace = true;      // false: texels are sRGB, converted on every fetch (Bitmap.cpp:512-516)
+        uint32 paletteSize = 0;       // B8G8R8A8_UNorm_Palette: number of palette entries (filled through GetPalette())
     };
 
     explicit Bitmap(const char* debugName = "<unnamed>") : mDebugName(debugName) {}
 
-    static uint32 BitsPerPixel(Format format);   // 0 for formats this build cannot hold
+    static uint32 BitsPerPixel(Format format);   // 0 for Unknown
     bool Init(const InitData& initData);
     bool Init(uint32 width, uint32 height);      // R32G32B32_Float, zeroed (the Viewport's sum buffers)
     // Uncompressed 24-bit and palette-less 8-bit BMP files, rows as stored, sRGB (Bitmap::LoadBMP, Core/Utils/BitmapBMP.cpp:47-134);
@@ -51,6 +52,9 @@ public:
     float* GetData() { return reinterpret_cast<float*>(mData.data()); }                // float formats
     const float* GetData() const { return reinterpret_cast<const float*>(mData.data()); }
     size_t GetDataSize() const { return (size_t)mStride * mHeight; }
+    uint8* GetPalette() { return mPalette.data(); }
+    const uint8* GetPalette() const { return mPalette.data(); }
+    uint32 GetPaletteSize() const { return (uint32)(mPalette.size() / 4u); }
     // R32G32B32_Float only (the sum buffers): what the rendering tests read
     const math::Vector4 GetPixel(uint32 x, uint32 y, const bool forceLinearSpace = false) const;
     bool Scale(const math::Vector4& factor);
@@ -58,7 +62,7 @@ public:
     bool SaveRaw(const char* path) const;
 private:
     std::string mDebugName;
-    std::vector<uint8> mData;
+    std::vector<uint8> mData, mPalette;
     uint32 mWidth = 0, mHeight = 0, mStride = 0;
     Format mFormat = Format::Unknown;
     bool mLinearSpace = true;

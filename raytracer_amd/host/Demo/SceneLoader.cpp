@@ -1,7 +1,7 @@
 // JSON scene files -> rt::Scene + rt::Camera, field by field as Demo/SceneLoader.cpp does it (same property names,
 // same defaults, same required/optional rules, including rapidjson's integer-vs-real strictness in TryParseFloat).
-// Not ingested: "noise" / "mix" textures, CSG shapes, texture-shaped bokeh, area-light textures (commented out in
-// the reference's AreaLight too) -- LoadScene fails loudly on them.
+// Not ingested: CSG shapes, texture-shaped bokeh, area-light textures (commented out in the reference's AreaLight too)
+// -- LoadScene fails loudly on them.
 #include "SceneLoader.h"
 #include "Demo.h"
 #include "Json.h"
@@ -15,6 +15,8 @@
 #include "../Core/Shapes/RectShape.h"
 #include "../Core/Textures/CheckerboardTexture.h"
 #include "../Core/Textures/BitmapTexture.h"
+#include "../Core/Textures/NoiseTexture.h"
+#include "../Core/Textures/MixTexture.h"
 
 #include <float.h>
 #include <stdio.h>
@@ -118,7 +120,7 @@ static bool TryParseMaterialName(const MaterialsMap& materials, const Value& val
     return true;
 }
 
-static TexturePtr ParseTexture(const Value& value, const TexturesMap&, std::string& outName)
+static TexturePtr ParseTexture(const Value& value, const TexturesMap& textures, std::string& outName)
 {
     if (!value.IsObject()) { LOAD_ERROR("Texture description must be a structure"); return nullptr; }
     if (!value.HasMember("name")) { LOAD_ERROR("Texture is missing 'name' field"); return nullptr; }
@@ -143,7 +145,29 @@ static TexturePtr ParseTexture(const Value& value, const TexturesMap&, std::stri
         if (!TryParseVector3(value, "colorB", false, colorB)) return nullptr;
         return std::make_shared<CheckerboardTexture>(colorA, colorB);
     }
-    if (type == "noise" || type == "mix") { LOAD_ERROR("Texture type '%s' is not supported by the device path", type.c_str()); return nullptr; }
+    if (type == "noise")
+    {
+        Vector4 colorA = Vector4::Zero(), colorB = Vector4::Zero();
+        if (!TryParseVector3(value, "colorA", false, colorA)) return nullptr;
+        if (!TryParseVector3(value, "colorB", false, colorB)) return nullptr;
+        int numOctaves = 1;
+        if (value.HasMember("octaves"))
+        {
+            if (!value["octaves"].IsInt()) { LOAD_ERROR("Property 'octaves' must be an integer"); return nullptr; }
+            numOctaves = value["octaves"].GetInt();
+        }
+        numOctaves = numOctaves < 1 ? 1 : (numOctaves > 20 ? 20 : numOctaves);
+        return std::make_shared<NoiseTexture>(colorA, colorB, (uint32)numOctaves);
+    }
+    if (type == "mix")
+    {
+        TexturePtr texA, texB, texWeight;
+        if (!TryParseTextureName(value, "textureA", textures, texA)) return nullptr;
+        if (!TryParseTextureName(value, "textureB", textures, texB)) return nullptr;
+        if (!TryParseTextureName(value, "weight", textures, texWeight)) return nullptr;
+        if (!texA || !texB || !texWeight) { LOAD_ERROR("Mix texture '%s' needs textureA, textureB and weight", name.c_str()); return nullptr; }
+        return std::make_shared<MixTexture>(texA, texB, texWeight);
+    }
     LOAD_ERROR("Invalid texture type name: '%s'", type.c_str());
     return nullptr;
 }

@@ -1,8 +1,10 @@
 // Materials, shapes, lights, scene objects and the Scene flattening.  Host side, one-time work per scene.
+#include "../Core/Textures/MixTexture.h"
 #include "../Core/Scene/Scene.h"
 #include "../Core/BVH/BVHBuilder.h"
 
 #include <stdio.h>
+#include <functional>
 #include <map>
 
 namespace rt {
@@ -281,12 +283,16 @@ bool Scene::Flatten()
     mFlatTextures.clear(); mFlatTexels.clear();
     bool texturesOk = true;
     std::map<const ITexture*, uint32> textureIds;
-    auto internTexture = [&](const TexturePtr& t) -> uint32 {
+    std::function<uint32(const TexturePtr&)> internTexture = [&](const TexturePtr& t) -> uint32 {
         if (!t) return RT_NO_TEXTURE;
         auto it = textureIds.find(t.get());
         if (it != textureIds.end()) return it->second;
         RtTexture flat;
         if (!t->Describe(flat, mFlatTexels)) { texturesOk = false; return RT_NO_TEXTURE; }
+        if (const MixTexture* mix = dynamic_cast<const MixTexture*>(t.get()))   // children first: their indices go into the mix
+        {
+            flat.mixA = internTexture(mix->GetTextureA()); flat.mixB = internTexture(mix->GetTextureB()); flat.mixWeight = internTexture(mix->GetTextureMask());
+        }
         const uint32 id = (uint32)mFlatTextures.size();
         mFlatTextures.push_back(flat);
         textureIds[t.get()] = id;

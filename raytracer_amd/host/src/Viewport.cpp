@@ -4,6 +4,8 @@
 #include "../Core/Textures/BitmapTexture.h"
 #include "../Core/Textures/CheckerboardTexture.h"
 #include "../Core/Textures/ConstTexture.h"
+#include "../Core/Textures/NoiseTexture.h"
+#include "../Core/Textures/MixTexture.h"
 #include "../../../include/rtgpu.h"
 
 #include <stdio.h>
@@ -68,18 +70,20 @@ bool Camera::GetDesc(RtCamera& out) const
 // ---------------------------------------------------------------------------------------------------
 // Bitmap
 // ---------------------------------------------------------------------------------------------------
-uint32 Bitmap::BitsPerPixel(Format format)   // Bitmap::BitsPerPixel, Core/Utils/Bitmap.cpp:34-66 (formats the device decodes)
+uint32 Bitmap::BitsPerPixel(Format format)   // Bitmap::BitsPerPixel, Core/Utils/Bitmap.cpp:17-46
 {
     switch (format)
     {
-    case Format::R8_UNorm: return 8;
-    case Format::R8G8_UNorm: case Format::R16_UNorm: case Format::R16_Half: return 16;
+    case Format::R8_UNorm: case Format::B8G8R8A8_UNorm_Palette: case Format::BC5: return 8;
+    case Format::R8G8_UNorm: case Format::R16_UNorm: case Format::R16_Half: case Format::B5G6R5_UNorm: return 16;
     case Format::B8G8R8_UNorm: return 24;
-    case Format::B8G8R8A8_UNorm: case Format::R8G8B8A8_UNorm: case Format::R16G16_UNorm: case Format::R32_Float: case Format::R16G16_Half: return 32;
+    case Format::B8G8R8A8_UNorm: case Format::R8G8B8A8_UNorm: case Format::R16G16_UNorm: case Format::R32_Float: case Format::R16G16_Half:
+    case Format::R11G11B10_Float: case Format::R9G9B9E5_SharedExp: return 32;
     case Format::R16G16B16_Half: return 48;
     case Format::R16G16B16A16_UNorm: case Format::R32G32_Float: case Format::R16G16B16A16_Half: return 64;
     case Format::R32G32B32_Float: return 96;
     case Format::R32G32B32A32_Float: return 128;
+    case Format::BC1: case Format::BC4: return 4;
     default: return 0;
     }
 }
@@ -92,11 +96,12 @@ bool Bitmap::Init(const InitData& initData)
         fprintf(stderr, "[rt] ERROR: Invalid bitmap format\n");
         return false;
     }
-    const uint32 tight = initData.width * (bits / 8u);
+    const uint32 tight = (uint32)((uint64)initData.width * bits / 8u);   // ComputeDataStride, Bitmap.cpp:97-100 (block formats: bytes per texel row)
     mStride = initData.stride > tight ? initData.stride : tight;   // Max(stride, ComputeDataStride), Bitmap.cpp:245
     mWidth = initData.width; mHeight = initData.height; mFormat = initData.format; mLinearSpace = initData.linearSpace;
     mData.assign((size_t)mStride * mHeight, 0);
     if (initData.data) memcpy(mData.data(), initData.data, mData.size());
+    mPalette.assign((size_t)initData.paletteSize * 4u, 0);   // B8G8R8A8 entries, filled by the caller (the reference's Init allocates only)
     return true;
 }
 
@@ -166,7 +171,7 @@ bool BitmapTexture::Describe(RtTexture& out, std::vector<uint8>& texels) const
     memset(&out, 0, sizeof(out));
     if (!mBitmap || Bitmap::BitsPerPixel(mBitmap->GetFormat()) == 0)
     {
-        fprintf(stderr, "[rt] ERROR: bitmap texture '%s' has no pixels in a format the device decodes\n", GetName());
+        fprintf(stderr, "[rt] ERROR: bitmap texture '%s' has no pixels\n", GetName());
         return false;
     }
     out.kind = RT_TEXTURE_BITMAP;
@@ -177,7 +182,30 @@ bool BitmapTexture::Describe(RtTexture& out, std::vector<uint8>& texels) const
     while (texels.size() % 16u) texels.push_back(0);
     out.dataOffset = texels.size();
     texels.insert(texels.end(), mBitmap->GetBytes(), mBitmap->GetBytes() + mBitmap->GetDataSize());
+    if (mBitmap->GetFormat() == Bitmap::Format::B8G8R8A8_UNorm_Palette)
+    {
+        while (texels.size() % 16u) texels.push_back(0);
+        out.paletteOffset = texels.size();
+        texels.insert(texels.end(), mBitmap->GetPalette(), mBitmap->GetPalette() + mBitmap->GetPaletteSize() * 4u);
+        if (mBitmap->GetPaletteSize() < 256u) texels.insert(texels.end(), (256u - mBitmap->GetPaletteSize()) * 4u, 0);   // any index byte stays in range
+    }
     return true;
+}
+
+bool NoiseTexture::Describe(RtTexture& out, std::vector<uint8>&) const
+{
+    memset(&out, 0, sizeof(out));
+    out.kind = RT_TEXTURE_NOISE;
+    out.numOctaves = mNumOctaves;
+    memcpy(out.colorA, &mColorA, 16); memcpy(out.colorB, &mColorB, 16);
+    return true;
+}
+
+bool MixTexture::Describe(RtTexture& out, std::vector<uint8>&) const
+{
+    memset(&out, 0, sizeof(out));
+    out.kind = RT_TEXTURE_MIX;   // the child indices are filled by Scene::Flatten, which interns the children first
+    return mTextureA && mTextureB && mTextureMask;
 }
 
 bool CheckerboardTexture::Describe(RtTexture& out, std::vector<uint8>&) const

@@ -7,6 +7,8 @@
 #include "../Core/Textures/BitmapTexture.h"
 #include "../Core/Textures/CheckerboardTexture.h"
 #include "../Core/Textures/ConstTexture.h"
+#include "../Core/Textures/NoiseTexture.h"
+#include "../Core/Textures/MixTexture.h"
 #include "../Demo/Demo.h"
 #include "../Demo/MeshLoader.h"
 #include "../Demo/ObjReader.h"
@@ -96,6 +98,7 @@ RTH_API int rth_texture_bitmap(void* sh, uint32_t width, uint32_t height, uint32
     SceneHandle* s = static_cast<SceneHandle*>(sh);
     Bitmap::InitData init;
     init.width = width; init.height = height; init.format = (Bitmap::Format)format; init.data = data; init.stride = stride;
+    if (init.format == Bitmap::Format::B8G8R8A8_UNorm_Palette) init.paletteSize = 256;
     init.linearSpace = linearSpace != 0;
     BitmapPtr bitmap = std::make_shared<Bitmap>("texture");
     if (!bitmap->Init(init)) return -1;
@@ -115,6 +118,30 @@ RTH_API int rth_texture_const(void* sh, const float color[4])
     SceneHandle* s = static_cast<SceneHandle*>(sh);
     s->textures.push_back(std::make_shared<ConstTexture>(LoadColor(color)));
     return (int)s->textures.size() - 1;
+}
+RTH_API int rth_texture_noise(void* sh, const float colorA[4], const float colorB[4], uint32_t octaves)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    s->textures.push_back(std::make_shared<NoiseTexture>(LoadColor(colorA), LoadColor(colorB), octaves));
+    return (int)s->textures.size() - 1;
+}
+RTH_API int rth_texture_mix(void* sh, int a, int b, int weight)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    const int n = (int)s->textures.size();
+    if (a < 0 || b < 0 || weight < 0 || a >= n || b >= n || weight >= n) return -1;
+    s->textures.push_back(std::make_shared<MixTexture>(s->textures[(size_t)a], s->textures[(size_t)b], s->textures[(size_t)weight]));
+    return (int)s->textures.size() - 1;
+}
+// palette of a B8G8R8A8_UNorm_Palette bitmap texture: numEntries * 4 bytes (B, G, R, A)
+RTH_API int rth_texture_set_palette(void* sh, int texture, const uint8_t* entries, uint32_t numEntries)
+{
+    SceneHandle* s = static_cast<SceneHandle*>(sh);
+    if (texture < 0 || texture >= (int)s->textures.size()) return -1;
+    BitmapTexture* bt = dynamic_cast<BitmapTexture*>(s->textures[(size_t)texture].get());
+    if (!bt || !bt->GetBitmap() || bt->GetBitmap()->GetPaletteSize() < numEntries) return -1;
+    memcpy(bt->GetBitmap()->GetPalette(), entries, (size_t)numEntries * 4u);
+    return 0;
 }
 // slot: 0 baseColor, 1 emission, 2 roughness, 3 metalness, 4 normal map (strength = normalMapStrength)
 RTH_API int rth_material_set_texture(void* sh, int material, int slot, int texture, float strength)

@@ -78,6 +78,10 @@ def textured_scene(aspect, triangles=6000, seed=11, skip=()):
     t_normal_h = s.add_bitmap_texture(rng.uniform(0.3, 0.7, size=(12, 10, 2)).astype(np.float16), "R16G16_Half", filter="bilinear")
     t_check = s.add_checkerboard_texture((0.9, 0.2, 0.1), (0.1, 0.3, 0.9, 1.0))
     t_const = s.add_const_texture((0.5, 0.75, 1.0, 0.0))
+    t_noise = s.add_noise_texture((0.9, 0.8, 0.7), (0.2, 0.1, 0.4), octaves=4)
+    t_mix = s.add_mix_texture(t_albedo, t_check, t_noise)
+    bc1 = rng.randint(0, 256, size=(16 // 4) * (8 // 4) * 8).astype(np.uint8)
+    t_bc1 = s.add_bitmap_texture(bc1, "BC1", linear_space=False, filter="bilinear", size=(16, 8))
     env = rng.uniform(0.0, 3.0, size=(16, 32, 4)).astype(np.float16)
     t_env = s.add_bitmap_texture(env, "R16G16B16A16_Half", filter="smoothstep")
 
@@ -99,6 +103,9 @@ def textured_scene(aspect, triangles=6000, seed=11, skip=()):
     if 9 not in skip: s.set_material_texture(mats[5], "emission", t_emit)
     if 10 not in skip: s.set_material_texture(mats[6], "roughness", t_metal)
     if 11 not in skip: s.set_material_texture(mats[7], "baseColor", t_const)
+    if 15 not in skip: s.set_material_texture(mats[4], "baseColor", t_mix)
+    if 16 not in skip: s.set_material_texture(mats[6], "baseColor", t_bc1)
+    if 17 not in skip: s.set_material_texture(mats[5], "roughness", t_noise)
     s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
 
     ball = s.add_material("roughPlastic", (0.8, 0.8, 0.8), roughness=0.3)

@@ -33,7 +33,7 @@ def test_struct_layouts_agree(built):
     o = oracle_lib.lib()
     for what, ty in enumerate((ra.RtSceneDesc, ra.RtPassParams, ra.RtObject, ra.RtLight, ra.RtMaterial, ra.RtCamera, ra.RtTexture)):
         assert o.rto_sizeof(what) == C.sizeof(ty), ty.__name__
-    assert C.sizeof(ra.RtNode) == 32 and C.sizeof(ra.RtMaterial) == 80 and C.sizeof(ra.RtTexture) == 80 and C.sizeof(ra.RtCounters) == 128
+    assert C.sizeof(ra.RtNode) == 32 and C.sizeof(ra.RtMaterial) == 80 and C.sizeof(ra.RtTexture) == 96 and C.sizeof(ra.RtCounters) == 128
 
 
 def test_no_gpu_means_loud_failure_not_fallback(built):

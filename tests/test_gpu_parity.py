@@ -90,7 +90,8 @@ def test_mesh_two_level_bvh_bit_exact(built):
 
 def test_device_texture_decode_matches_the_reference_vectors(built):
     """Every record of tests/golden/texture_kat.bin (BitmapTexture::Evaluate / CheckerboardTexture::Evaluate outputs of the
-    REFERENCE: 16 texel formats x colour spaces x filters, wrap and texel-edge coordinates) evaluated ON THE DEVICE through
+    REFERENCE: all 23 texel formats x colour spaces x filters, wrap and texel-edge coordinates, noise and (nested) mix
+    textures) evaluated ON THE DEVICE through
     rtgpu_evaluate_textures: bit-exact."""
     import kat_io
     k = kat_io.load_texture_kat()
@@ -121,7 +122,7 @@ def test_textured_materials_normal_maps_and_environment_map(built):
     w, h = 160, 90
     scene, camera = scene_zoo.textured_scene(w / h)
     d = scene.desc.contents
-    assert d.numTextures == 10 and d.texelBytes > 0
+    assert d.numTextures == 13 and d.texelBytes > 0   # 8 bitmaps (one BC1), checkerboard, const, noise, mix, environment map
     out = run_both(scene, camera, w, h, passes=3, max_ray_depth=6)
     assert_identical(*out)
     # the textures are really in play: the same scene without them renders differently

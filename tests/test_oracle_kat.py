@@ -70,7 +70,8 @@ def test_xoroshiro_bit_exact(built):
 
 
 def test_textures_on_the_shading_path_bit_exact(built):
-    """BitmapTexture::Evaluate (16 formats x sRGB/linear x 3 filters, wrap/edge coordinates), CheckerboardTexture,
+    """BitmapTexture::Evaluate (all 23 texel formats incl. palette, packed floats and BC1/4/5, x sRGB/linear x 3 filters,
+    wrap/edge coordinates), CheckerboardTexture, NoiseTexture (1/3/6 octaves), MixTexture (incl. a mix of mixes),
     Material::EvaluateShadingData + GetNormalVector with textured parameters, BackgroundLight with an environment
     map: all produced by the reference (texture_kat.bin); the oracle must reproduce every float bit for bit."""
     import ctypes as C
@@ -85,7 +86,7 @@ def test_textures_on_the_shading_path_bit_exact(built):
         got = np.array(out4[:], dtype=np.float32)
         assert np.array_equal(got.view(np.uint32), rec["out"].view(np.uint32)), (int(rec["texture"]), rec["uv"], got, rec["out"])
         formats.add((k["textures"][int(rec["texture"])].kind, k["textures"][int(rec["texture"])].format))
-    assert len(formats) == 17   # 16 bitmap formats + checkerboard
+    assert len(formats) == 26   # 23 bitmap formats + checkerboard + noise + mix
     out14 = (C.c_float * 14)()
     for rec in k["materials"]:
         mat = ra.RtMaterial.from_buffer_copy(rec["material"].tobytes())
