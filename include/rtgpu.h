@@ -424,6 +424,22 @@ typedef struct RtPostprocessParams   /* PostprocessParams, Core/Rendering/PostPr
 /* frontBufferBGRA: host, width * height uint32 (0x00RRGGBB), row y = sum-buffer row y.  Synchronises. */
 int rtgpu_postprocess(RtgpuContext* ctx, const RtPostprocessParams* params, uint32_t* frontBufferBGRA);
 
+/* ---------------------------------------------------------------------------------------------
+ * Adaptive rendering support (Viewport::ComputeBlockError / UpdateBlocksList, Core/Rendering/Viewport.cpp:552-700).
+ * The block list lives on the host (the mirror's rt::Viewport keeps the reference's splitting logic); the device
+ * computes the error estimates and restricts the passes to the pixels of the active blocks.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct RtBlock { uint32_t minX, maxX, minY, maxY; } RtBlock;   /* Block: [minX, maxX) x [minY, maxY) in sum-buffer coordinates */
+
+/* outErrors[i] = Viewport::ComputeBlockError(blocks[i]) with imageScalingFactor = 1 / numPasses: per pixel
+ * (|a-b|.x + 2 |a-b|.y + |a-b|.z) / sqrt(RT_EPSILON + a.x + 2 a.y + a.z), a = sum / n, b = 2 secondarySum / n, summed
+ * row by row in the reference's order, times sqrt(blockArea / imageArea) / blockArea.  Synchronises. */
+int rtgpu_compute_block_errors(RtgpuContext* ctx, uint32_t numPasses, uint32_t numBlocks, const RtBlock* blocks, float* outErrors);
+
+/* Restricts the following passes to the pixels covered by the blocks (intersected with the shard's tiles);
+ * numBlocks = 0 restores the whole image.  Blocks must not overlap.  Synchronises. */
+int rtgpu_set_active_blocks(RtgpuContext* ctx, uint32_t numBlocks, const RtBlock* blocks);
+
 /* Evaluates textures of the uploaded scene on the device: out[4*i..] = ITexture::Evaluate(textures[textureIndex[i]],
  * (uv[2*i], uv[2*i+1])).  Host pointers; synchronous.  Exists so that the device decode of every texel format can be
  * checked against the reference's vectors directly (tests/golden/texture_kat.bin). */

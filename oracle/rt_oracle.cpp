@@ -394,6 +394,29 @@ void rto_postprocess(const float* sumRGB, uint32_t width, uint32_t height, const
         }
 }
 
+// Viewport::ComputeBlockError, Core/Rendering/Viewport.cpp:552-581
+float rto_block_error(const float* sumRGB, const float* secondaryRGB, uint32_t width, uint32_t height, uint32_t numPasses,
+                      uint32_t minX, uint32_t maxX, uint32_t minY, uint32_t maxY)
+{
+    const float imageScalingFactor = 1.0f / (float)numPasses;
+    float totalError = 0.0f;
+    for (uint32_t y = minY; y < maxY; ++y)
+    {
+        float rowError = 0.0f;
+        for (uint32_t x = minX; x < maxX; ++x)
+        {
+            const V4 a = imageScalingFactor * load3(sumRGB + 3 * ((size_t)y * width + x));
+            const V4 b = (2.0f * imageScalingFactor) * load3(secondaryRGB + 3 * ((size_t)y * width + x));
+            const V4 diff = abs4(a - b);
+            const float error = (diff.x + 2.0f * diff.y + diff.z) / sqrtf(RTO_EPSILON + a.x + 2.0f * a.y + a.z);
+            rowError += error;
+        }
+        totalError += rowError;
+    }
+    const uint32_t totalArea = width * height, blockArea = (maxX - minX) * (maxY - minY);
+    return totalError * sqrtf((float)blockArea / (float)totalArea) / (float)blockArea;
+}
+
 uint32_t rto_sizeof(int what)
 {
     switch (what)

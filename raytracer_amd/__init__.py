@@ -119,6 +119,10 @@ class RtPostprocessParams(C.Structure):
                 ("ditherSeed", C.c_uint32)]
 
 
+class RtBlock(C.Structure):
+    _fields_ = [("minX", C.c_uint32), ("maxX", C.c_uint32), ("minY", C.c_uint32), ("maxY", C.c_uint32)]
+
+
 class RtCamera(C.Structure):
     _fields_ = [("localToWorld", C.c_float * 16), ("aspectRatio", C.c_float), ("tanHalfFoV", C.c_float), ("dofEnable", C.c_uint32),
                 ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2)]
@@ -407,6 +411,21 @@ class Viewport:
         """Submit one pass with explicit constants (used by the parity tests)."""
         if host_lib().rth_viewport_render_pass_with(self._h, C.byref(params)) != 0:
             raise RuntimeError("render pass failed: %s" % (rtgpu_lib().rtgpu_last_error() or b"").decode())
+
+    def set_adaptive(self, enable=True, num_initial_passes=10, min_block_size=4, max_block_size=256, subdivision_treshold=0.005,
+                     convergence_treshold=0.0001):
+        """RenderingParams::adaptiveSettings (Core/Rendering/Context.h:35-43); resets the viewport."""
+        if host_lib().rth_viewport_set_adaptive(self._h, int(bool(enable)), C.c_uint32(num_initial_passes), C.c_uint32(min_block_size),
+                                                C.c_uint32(max_block_size), C.c_float(subdivision_treshold), C.c_float(convergence_treshold)) != 0:
+            raise ValueError("bad adaptive settings")
+
+    def progress(self):
+        """RenderingProgress + the active block list [(minX, maxX, minY, maxY), ...]."""
+        err, conv, pixels = C.c_float(), C.c_float(), C.c_uint32()
+        n = host_lib().rth_viewport_progress(self._h, C.byref(err), C.byref(conv), C.byref(pixels), None, 0)
+        blocks = np.zeros((max(n, 1), 4), dtype=np.uint32)
+        host_lib().rth_viewport_progress(self._h, None, None, None, blocks.ctypes.data_as(C.c_void_p), C.c_uint32(n))
+        return dict(averageError=err.value, converged=conv.value, activePixels=pixels.value, blocks=[tuple(int(v) for v in b) for b in blocks[:n]])
 
     def front_buffer(self, exposure=0.0, contrast=0.8, saturation=0.98, dithering=0.005, tonemapper=3, color_filter=(1.0, 1.0, 1.0, 1.0),
                      dither_seed=0):

@@ -767,6 +767,42 @@ __global__ void __launch_bounds__(RT_BLOCK) k_postprocess(const float* __restric
     front[i] = postProcessPixel(sum[3 * (size_t)i + 0], sum[3 * (size_t)i + 1], sum[3 * (size_t)i + 2], x, y, params, colorScale.c);
 }
 
+// Viewport::ComputeBlockError (Viewport.cpp:552-581) in two steps that keep the reference's summation order: one thread
+// per (block, row) adds the pixel errors of its row left to right, then one thread per block adds the rows top to bottom.
+struct ErrorRow { uint32_t block, y; };
+__global__ void __launch_bounds__(RT_BLOCK) k_block_error_rows(const float* __restrict__ sum, const float* __restrict__ secondary, uint32_t width,
+                                                               const RtBlock* __restrict__ blocks, const ErrorRow* __restrict__ rows, uint32_t numRows,
+                                                               float imageScalingFactor, float* __restrict__ rowErrors)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numRows) return;
+    const RtBlock b = blocks[rows[i].block];
+    const uint32_t y = rows[i].y;
+    const float scaleB = 2.0f * imageScalingFactor;
+    float rowError = 0.0f;
+    for (uint32_t x = b.minX; x < b.maxX; ++x)
+    {
+        const size_t p = 3 * ((size_t)y * width + x);
+        const float ax = imageScalingFactor * sum[p], ay = imageScalingFactor * sum[p + 1], az = imageScalingFactor * sum[p + 2];
+        const float bx = scaleB * secondary[p], by = scaleB * secondary[p + 1], bz = scaleB * secondary[p + 2];
+        const float dx = fabsf(ax - bx), dy = fabsf(ay - by), dz = fabsf(az - bz);
+        const float error = (dx + 2.0f * dy + dz) / sqrtf(RTD_EPSILON + ax + 2.0f * ay + az);
+        rowError += error;
+    }
+    rowErrors[i] = rowError;
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_block_error_total(const RtBlock* __restrict__ blocks, const uint32_t* __restrict__ firstRow, uint32_t numBlocks,
+                                                                const float* __restrict__ rowErrors, uint32_t totalArea, float* __restrict__ outErrors)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numBlocks) return;
+    const RtBlock b = blocks[i];
+    float totalError = 0.0f;
+    for (uint32_t r = 0; r < b.maxY - b.minY; ++r) totalError += rowErrors[firstRow[i] + r];
+    const uint32_t blockArea = (b.maxX - b.minX) * (b.maxY - b.minY);
+    outErrors[i] = totalError * sqrtf((float)blockArea / (float)totalArea) / (float)blockArea;
+}
+
 // ITexture::Evaluate for a list of (texture, uv) pairs -- rtgpu_evaluate_textures
 __global__ void __launch_bounds__(RT_BLOCK) k_evaluate_textures(const RtSceneDesc scene, uint32_t count, const uint32_t* __restrict__ textureIndex,
                                                                 const float* __restrict__ uv, float* __restrict__ out)
@@ -831,6 +867,7 @@ struct RtgpuContext
     float* secondary = nullptr;
     uint32_t* slotPixel = nullptr;
     uint32_t numSlots = 0;
+    std::vector<uint8_t> activeMask;   // adaptive rendering: 1 = pixel inside an active block; empty = whole image
 
     // Batch lanes.  Every batch of passes runs on ONE lane = its own stream, path-state arena, queues and work
     // counters; consecutive batches alternate lanes, so the drain of a persistent traversal launch (a handful of
@@ -1195,7 +1232,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
 
 // slot -> pixel table: owned 64x64 tiles (tile % worldSize == rank), 8x8 blocks inside a tile, so that a
 // wave covers an 8x8 pixel block (coherent primary rays)
-static std::vector<uint32_t> buildSlotTable(uint32_t width, uint32_t height, RtgpuShard shard)
+static std::vector<uint32_t> buildSlotTable(uint32_t width, uint32_t height, RtgpuShard shard, const std::vector<uint8_t>& activeMask)
 {
     std::vector<uint32_t> slots;
     slots.reserve((size_t)width * height / (shard.worldSize ? shard.worldSize : 1) + 4096);
@@ -1211,10 +1248,27 @@ static std::vector<uint32_t> buildSlotTable(uint32_t width, uint32_t height, Rtg
                         for (uint32_t px = 0; px < 8; ++px)
                         {
                             const uint32_t x = tx * 64 + bx * 8 + px, y = ty * 64 + by * 8 + py;
-                            if (x < width && y < height) slots.push_back(x | (y << 16));
+                            if (x < width && y < height && (activeMask.empty() || activeMask[(size_t)y * width + x])) slots.push_back(x | (y << 16));
                         }
         }
     return slots;
+}
+
+// slot -> pixel table of the pixels this context renders: owned tiles, active blocks
+static int rebuildSlots(RtgpuContext* c)
+{
+    if (c->slotPixel) { (void)hipFree(c->slotPixel); c->slotPixel = nullptr; }
+    const std::vector<uint32_t> slots = buildSlotTable(c->width, c->height, c->shard, c->activeMask);
+    c->numSlots = (uint32_t)slots.size();
+    // launches of a batch should stay large enough to fill 256 CUs: a 1/8 shard of a 1080p frame batches 16 passes
+    // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
+    if (!c->passBatchFromEnv) c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
+    if (c->numSlots)
+    {
+        HIP_TRY(hipMalloc((void**)&c->slotPixel, slots.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->slotPixel, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return RTGPU_OK;
 }
 
 static int rebuildFilm(RtgpuContext* c)
@@ -1226,17 +1280,8 @@ static int rebuildFilm(RtgpuContext* c)
     HIP_TRY(hipMalloc((void**)&c->secondary, n * sizeof(float)));
     HIP_TRY(hipMemset(c->sum, 0, n * sizeof(float)));
     HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
-    const std::vector<uint32_t> slots = buildSlotTable(c->width, c->height, c->shard);
-    c->numSlots = (uint32_t)slots.size();
-    // launches of a batch should stay large enough to fill 256 CUs: a 1/8 shard of a 1080p frame batches 16 passes
-    // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
-    if (!c->passBatchFromEnv) c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
-    if (c->numSlots)
-    {
-        HIP_TRY(hipMalloc((void**)&c->slotPixel, slots.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(c->slotPixel, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
-    return RTGPU_OK;
+    c->activeMask.clear();   // a new film starts with the whole image active
+    return rebuildSlots(c);
 }
 
 RTGPU_API int rtgpu_resize(RtgpuContext* c, uint32_t width, uint32_t height)
@@ -1505,6 +1550,75 @@ RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
     int r = rtgpu_synchronize(c); if (r) return r;
     c->countIntersections = enable != 0;
     return RTGPU_OK;
+}
+
+static int checkBlocks(RtgpuContext* c, uint32_t numBlocks, const RtBlock* blocks)
+{
+    if (numBlocks && !blocks) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (uint32_t i = 0; i < numBlocks; ++i)
+        if (blocks[i].minX >= blocks[i].maxX || blocks[i].minY >= blocks[i].maxY || blocks[i].maxX > c->width || blocks[i].maxY > c->height)
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "block outside the viewport or empty");
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_compute_block_errors(RtgpuContext* c, uint32_t numPasses, uint32_t numBlocks, const RtBlock* blocks, float* outErrors)
+{
+    if (!c || (numBlocks && !outErrors)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    if (numPasses == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numPasses must be > 0");
+    int r = checkBlocks(c, numBlocks, blocks); if (r) return r;
+    if (numBlocks == 0) return RTGPU_OK;
+    r = rtgpu_synchronize(c); if (r) return r;
+    std::vector<ErrorRow> rows; std::vector<uint32_t> firstRow(numBlocks);
+    for (uint32_t i = 0; i < numBlocks; ++i)
+    {
+        firstRow[i] = (uint32_t)rows.size();
+        for (uint32_t y = blocks[i].minY; y < blocks[i].maxY; ++y) rows.push_back({ i, y });
+    }
+    RtBlock* dBlocks = nullptr; ErrorRow* dRows = nullptr; uint32_t* dFirst = nullptr; float* dRowErrors = nullptr; float* dOut = nullptr;
+    hipError_t e = hipMalloc((void**)&dBlocks, numBlocks * sizeof(RtBlock));
+    if (e == hipSuccess) e = hipMalloc((void**)&dRows, rows.size() * sizeof(ErrorRow));
+    if (e == hipSuccess) e = hipMalloc((void**)&dFirst, numBlocks * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&dRowErrors, rows.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dOut, numBlocks * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(dBlocks, blocks, numBlocks * sizeof(RtBlock), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dRows, rows.data(), rows.size() * sizeof(ErrorRow), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dFirst, firstRow.data(), numBlocks * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+    {
+        hipStream_t st = c->lanes[0].stream;
+        const uint32_t numRows = (uint32_t)rows.size();
+        hipLaunchKernelGGL(k_block_error_rows, dim3((numRows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, c->sum, c->secondary, c->width, dBlocks, dRows, numRows,
+                           1.0f / (float)numPasses, dRowErrors);
+        hipLaunchKernelGGL(k_block_error_total, dim3((numBlocks + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, dBlocks, dFirst, numBlocks, dRowErrors, c->width * c->height, dOut);
+        e = hipStreamSynchronize(st);
+    }
+    if (e == hipSuccess) e = hipMemcpy(outErrors, dOut, numBlocks * sizeof(float), hipMemcpyDeviceToHost);
+    for (void* p : { (void*)dBlocks, (void*)dRows, (void*)dFirst, (void*)dRowErrors, (void*)dOut }) if (p) (void)hipFree(p);
+    if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_compute_block_errors: ") + hipGetErrorString(e));
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_set_active_blocks(RtgpuContext* c, uint32_t numBlocks, const RtBlock* blocks)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    int r = checkBlocks(c, numBlocks, blocks); if (r) return r;
+    r = rtgpu_synchronize(c); if (r) return r;
+    c->activeMask.clear();
+    if (numBlocks)
+    {
+        c->activeMask.assign((size_t)c->width * c->height, 0);
+        for (uint32_t i = 0; i < numBlocks; ++i)
+            for (uint32_t y = blocks[i].minY; y < blocks[i].maxY; ++y)
+                for (uint32_t x = blocks[i].minX; x < blocks[i].maxX; ++x)
+                {
+                    uint8_t& m = c->activeMask[(size_t)y * c->width + x];
+                    if (m) return fail(RTGPU_ERR_INVALID_ARGUMENT, "active blocks overlap");
+                    m = 1;
+                }
+    }
+    return rebuildSlots(c);
 }
 
 RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, uint32_t* frontBufferBGRA)

@@ -19,6 +19,8 @@ public:
     bool ReadSum(float* sumRGB, float* secondaryRGB) override;
     bool GetCounters(RayTracingCounters& outTotals) override;
     bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) override;
+    bool ComputeBlockErrors(uint32 numPasses, const std::vector<RtBlock>& blocks, std::vector<float>& outErrors) override;
+    bool SetActiveBlocks(const std::vector<RtBlock>& blocks) override;
 
     // for debugging (the reference's UI pokes these: Demo/Demo_UserInterface.cpp:467-469)
     math::Vector4 mLightSamplingWeight;

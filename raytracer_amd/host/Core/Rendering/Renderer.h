@@ -28,6 +28,9 @@ public:
     virtual bool GetCounters(RayTracingCounters& outTotals) = 0;             // totals since Reset; synchronises
     // Viewport::PostProcessTile over the whole sum buffer -> 0x00RRGGBB pixels; synchronises
     virtual bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) = 0;
+    // adaptive rendering: Viewport::ComputeBlockError for a list of blocks (synchronises); restrict the next passes to blocks (empty = all)
+    virtual bool ComputeBlockErrors(uint32 numPasses, const std::vector<RtBlock>& blocks, std::vector<float>& outErrors) = 0;
+    virtual bool SetActiveBlocks(const std::vector<RtBlock>& blocks) = 0;
 
 protected:
     const Scene& mScene;

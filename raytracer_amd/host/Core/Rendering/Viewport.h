@@ -2,7 +2,8 @@
 // Render() performs the pass prologue of Viewport::Render (Core/Rendering/Viewport.cpp:200-242) on the
 // host -- Halton seeds, anti-aliasing offset -- then hands ONE pass to the renderer instead of fanning
 // 32x32 tiles out to a thread pool.  GetFrontBuffer() runs Viewport::PostProcessTile (Viewport.cpp:495-550) on the device for the
-// whole image; bloom and adaptive rendering are not implemented.
+// whole image (no bloom).  Adaptive rendering keeps the reference's block list logic (Viewport.cpp:552-700) on the host; the
+// error estimates come from the device.
 #pragma once
 
 #include "Renderer.h"
@@ -41,7 +42,11 @@ public:
     const PostprocessParams& GetPostprocessParams() const { return mPostprocessParams; }
     uint32 GetWidth() const { return mWidth; }
     uint32 GetHeight() const { return mHeight; }
-    const RenderingProgress& GetProgress() const { return mProgress; }
+    // averageError: with adaptive rendering off the reference recomputes it after every second pass; here it is evaluated when
+    // asked for, at an even pass count (otherwise the value of the last evaluation is returned)
+    const RenderingProgress& GetProgress();
+    const std::vector<RtBlock>& GetBlocks() const { return mBlocks; }
+    uint32 GetPassesFinished() const { return mProgress.passesFinished; }
     // counters of the LAST pass (synchronises), like the reference
     const RayTracingCounters& GetCounters();
     // totals since Reset (synchronises)
@@ -53,7 +58,7 @@ public:
     // The per-pass constants Render() would use next; advances the Halton sequence and the generator
     // exactly like Render().  Exposed so parity tests can feed identical constants to the CPU oracle.
     bool NextPassParams(const Camera& camera, RtPassParams& outParams);
-    void FinishPass() { mProgress.passesFinished++; mSumDirty = true; }
+    void FinishPass();
 
 private:
     RendererPtr mRenderer;
@@ -61,6 +66,10 @@ private:
     HaltonSequence mHaltonSequence;
     RenderingParams mParams;
     RenderingProgress mProgress;
+    void BuildInitialBlocksList();
+    bool UpdateBlocksList();
+    std::vector<RtBlock> mBlocks;
+    uint32 mErrorEvaluatedAtPass = 0;
     Bitmap mSum, mSecondarySum, mFrontBuffer;
     PostprocessParams mPostprocessParams;
     uint32 mWidth = 0, mHeight = 0;

@@ -279,7 +279,9 @@ void Viewport::Reset()
     mSecondarySum.Clear();
     mSumDirty = false;
     mCounters.Reset(); mTotalsAtLastPass.Reset(); mTotalsBeforeLastPass.Reset();
-    if (mRenderer) mRenderer->Reset();
+    mErrorEvaluatedAtPass = 0;
+    BuildInitialBlocksList();   // Viewport::Reset -> BuildInitialBlocksList, Viewport.cpp:120-138
+    if (mRenderer) { mRenderer->Reset(); mRenderer->SetActiveBlocks({}); }
 }
 
 bool Viewport::SetRenderer(const RendererPtr& renderer)
@@ -339,9 +341,89 @@ bool Viewport::Render(const Camera& camera)
     }
     RtPassParams params;
     if (!NextPassParams(camera, params)) return false;
-    if (!mRenderer->RenderPass(params)) return false;
+    const bool nothingLeft = mParams.adaptiveSettings.enable && mProgress.passesFinished > 0 && mBlocks.empty();
+    if (!nothingLeft && !mRenderer->RenderPass(params)) return false;
     FinishPass();
     return true;
+}
+
+// the tail of Viewport::Render, Viewport.cpp:264-277
+void Viewport::FinishPass()
+{
+    mProgress.passesFinished++;
+    mSumDirty = true;
+    if (mProgress.passesFinished % 2 == 0 && mParams.adaptiveSettings.enable && mRenderer) UpdateBlocksList();
+}
+
+const RenderingProgress& Viewport::GetProgress()
+{
+    // Viewport::ComputeError (Viewport.cpp:179-183), lazily: the sum buffers must hold an even number of passes
+    if (!mParams.adaptiveSettings.enable && mRenderer && mProgress.passesFinished > 0 && mProgress.passesFinished % 2 == 0 &&
+        mErrorEvaluatedAtPass != mProgress.passesFinished)
+    {
+        std::vector<float> error;
+        const RtBlock whole = { 0, mWidth, 0, mHeight };
+        if (mRenderer->ComputeBlockErrors(mProgress.passesFinished, { whole }, error)) mProgress.averageError = error[0];
+        mErrorEvaluatedAtPass = mProgress.passesFinished;
+    }
+    return mProgress;
+}
+
+void Viewport::BuildInitialBlocksList()   // Viewport.cpp:618-646
+{
+    mBlocks.clear();
+    const uint32 blockSize = mParams.adaptiveSettings.maxBlockSize;
+    if (mWidth == 0 || mHeight == 0 || blockSize == 0) { mProgress.activeBlocks = 0; return; }
+    const uint32 rows = 1 + (mHeight - 1) / blockSize, columns = 1 + (mWidth - 1) / blockSize;
+    for (uint32 j = 0; j < rows; ++j)
+        for (uint32 i = 0; i < columns; ++i)
+        {
+            RtBlock block;
+            block.minY = j * blockSize; block.maxY = std::min(mHeight, (j + 1) * blockSize);
+            block.minX = i * blockSize; block.maxX = std::min(mWidth, (i + 1) * blockSize);
+            mBlocks.push_back(block);
+        }
+    mProgress.activeBlocks = (uint32)mBlocks.size();
+}
+
+bool Viewport::UpdateBlocksList()   // Viewport.cpp:648-733
+{
+    const AdaptiveRenderingSettings& settings = mParams.adaptiveSettings;
+    if (mProgress.passesFinished < settings.numInitialPasses) return true;
+    std::vector<float> errors;
+    if (!mRenderer->ComputeBlockErrors(mProgress.passesFinished, mBlocks, errors)) return false;
+    // Same walk as the reference: swap-and-pop removal, so a block swapped into slot i is not looked at in this update.
+    // Every block that IS visited still sits at its original index, which is why the errors can be computed up front.
+    std::vector<RtBlock> newBlocks;
+    for (uint32 i = 0; i < mBlocks.size(); ++i)
+    {
+        const RtBlock block = mBlocks[i];
+        const float blockError = errors[i];
+        const uint32 width = block.maxX - block.minX, height = block.maxY - block.minY;
+        if (blockError < settings.convergenceTreshold)
+        {
+            mBlocks[i] = mBlocks.back(); errors[i] = errors.back();   // block is fully converged - remove it
+            mBlocks.pop_back(); errors.pop_back();
+            continue;
+        }
+        if ((blockError < settings.subdivisionTreshold) && (width > settings.minBlockSize || height > settings.minBlockSize))
+        {
+            mBlocks[i] = mBlocks.back(); errors[i] = errors.back();   // block is somewhat converged - split it into two parts
+            mBlocks.pop_back(); errors.pop_back();
+            RtBlock childA = block, childB = block;
+            if (width > height) { const uint32 halfPoint = (block.minX + block.maxX) / 2u; childA.maxX = halfPoint; childB.minX = halfPoint; }
+            else { const uint32 halfPoint = (block.minY + block.maxY) / 2u; childA.maxY = halfPoint; childB.minY = halfPoint; }
+            newBlocks.push_back(childA);
+            newBlocks.push_back(childB);
+        }
+    }
+    for (const RtBlock& block : newBlocks) mBlocks.push_back(block);
+    mProgress.activePixels = 0;
+    for (const RtBlock& block : mBlocks) mProgress.activePixels += (block.maxX - block.minX) * (block.maxY - block.minY);
+    mProgress.converged = 1.0f - (float)mProgress.activePixels / (float)(mWidth * mHeight);
+    mProgress.activeBlocks = (uint32)mBlocks.size();
+    if (mBlocks.empty()) return true;   // everything converged: Render() stops submitting passes (the reference renders zero tiles)
+    return mRenderer->SetActiveBlocks(mBlocks);
 }
 
 const Bitmap& Viewport::GetSumBuffer()
@@ -501,6 +583,17 @@ bool PathTracerMIS::RenderPass(const RtPassParams& params)
 }
 
 bool PathTracerMIS::ReadSum(float* sumRGB, float* secondaryRGB) { return mCtx && rtgpu_read_sum(mCtx, sumRGB, secondaryRGB) == RTGPU_OK; }
+
+bool PathTracerMIS::ComputeBlockErrors(uint32 numPasses, const std::vector<RtBlock>& blocks, std::vector<float>& outErrors)
+{
+    outErrors.assign(blocks.size(), 0.0f);
+    return mCtx && rtgpu_compute_block_errors(mCtx, numPasses, (uint32)blocks.size(), blocks.data(), outErrors.data()) == RTGPU_OK;
+}
+
+bool PathTracerMIS::SetActiveBlocks(const std::vector<RtBlock>& blocks)
+{
+    return mCtx && rtgpu_set_active_blocks(mCtx, (uint32)blocks.size(), blocks.data()) == RTGPU_OK;
+}
 
 bool PathTracerMIS::PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA)
 {

@@ -385,7 +385,30 @@ RTH_API int rth_viewport_set_shard(void* v, uint32_t rank, uint32_t world)
     PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(vh->renderer.get());
     return (pt && pt->SetShard(rank, world)) ? 0 : -1;
 }
-RTH_API uint32_t rth_viewport_passes_finished(void* v) { return static_cast<ViewportHandle*>(v)->viewport.GetProgress().passesFinished; }
+RTH_API uint32_t rth_viewport_passes_finished(void* v) { return static_cast<ViewportHandle*>(v)->viewport.GetPassesFinished(); }
+// adaptive rendering (RenderingParams::adaptiveSettings) and progress
+RTH_API int rth_viewport_set_adaptive(void* v, int enable, uint32_t numInitialPasses, uint32_t minBlockSize, uint32_t maxBlockSize, float subdivisionTreshold, float convergenceTreshold)
+{
+    Viewport& vp = static_cast<ViewportHandle*>(v)->viewport;
+    RenderingParams p = vp.GetRenderingParams();
+    p.adaptiveSettings.enable = enable != 0; p.adaptiveSettings.numInitialPasses = numInitialPasses; p.adaptiveSettings.minBlockSize = minBlockSize;
+    p.adaptiveSettings.maxBlockSize = maxBlockSize; p.adaptiveSettings.subdivisionTreshold = subdivisionTreshold; p.adaptiveSettings.convergenceTreshold = convergenceTreshold;
+    if (!vp.SetRenderingParams(p)) return -1;
+    vp.Reset();
+    return 0;
+}
+// out: averageError, converged, activePixels, activeBlocks; blocks (may be NULL): up to maxBlocks x {minX, maxX, minY, maxY}; returns the block count
+RTH_API int rth_viewport_progress(void* v, float* averageError, float* converged, uint32_t* activePixels, uint32_t* blocks, uint32_t maxBlocks)
+{
+    Viewport& vp = static_cast<ViewportHandle*>(v)->viewport;
+    const RenderingProgress& p = vp.GetProgress();
+    if (averageError) *averageError = p.averageError;
+    if (converged) *converged = p.converged;
+    if (activePixels) *activePixels = p.activePixels;
+    const std::vector<RtBlock>& b = vp.GetBlocks();
+    for (size_t i = 0; blocks && i < b.size() && i < maxBlocks; ++i) memcpy(blocks + 4 * i, &b[i], 16);
+    return (int)b.size();
+}
 
 // ---- known-answer-test entry points for the host-side algorithms -----------------------------------
 // boxes: n * 6 floats (min xyz, max xyz).  outNodes: capacity 2n nodes of 8 uint32.  outOrder: n.

@@ -276,6 +276,88 @@ def test_reset_restarts_the_accumulation(built):
     assert np.array_equal(vp.sum_buffer().view(np.uint32), first.view(np.uint32)) and vp.counters() == c_first
 
 
+def _oracle_block_error(sum_buffer, secondary, passes, block):
+    o = oracle_lib.lib()
+    o.rto_block_error.restype = C.c_float
+    h, w = sum_buffer.shape[:2]
+    return o.rto_block_error(sum_buffer.ctypes.data_as(C.c_void_p), secondary.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), C.c_uint32(passes),
+                             C.c_uint32(block[0]), C.c_uint32(block[1]), C.c_uint32(block[2]), C.c_uint32(block[3]))
+
+
+def test_block_errors_and_average_error_match_oracle(built):
+    """Viewport::ComputeBlockError on the device (row-wise then block-wise sums in the reference's order) against the oracle's
+    restatement on the same sum buffers: bit-identical floats for arbitrary blocks and for the whole image (averageError)."""
+    w, h = 200, 136
+    scene, camera = scenes.cornell_box(w / h)
+    vp = ra.Viewport(w, h, seed=7, max_ray_depth=4)
+    vp.set_renderer(scene)
+    vp.render(camera, 6)
+    s, s2 = vp.sum_buffer(secondary=True)
+    s, s2 = np.ascontiguousarray(s), np.ascontiguousarray(s2)
+    blocks = [(0, w, 0, h), (0, 64, 0, 64), (64, 200, 10, 11), (199, 200, 135, 136), (3, 130, 50, 136)]
+    arr = (ra.RtBlock * len(blocks))(*[ra.RtBlock(*b) for b in blocks])
+    out = (C.c_float * len(blocks))()
+    assert ra.rtgpu_lib().rtgpu_compute_block_errors(vp.device_context(), C.c_uint32(6), C.c_uint32(len(blocks)), arr, out) == 0
+    for b, got in zip(blocks, out):
+        ref = _oracle_block_error(s, s2, 6, b)
+        assert np.float32(got).view(np.uint32) == np.float32(ref).view(np.uint32), (b, got, ref)
+    assert vp.progress()["averageError"] == out[0] > 0.0
+    bad = (ra.RtBlock * 1)(ra.RtBlock(0, w + 1, 0, h))
+    assert ra.rtgpu_lib().rtgpu_compute_block_errors(vp.device_context(), C.c_uint32(6), C.c_uint32(1), bad, out) == -1
+
+
+def test_adaptive_rendering_follows_the_reference_block_logic(built):
+    """RenderingParams::adaptiveSettings through the mirror's Viewport: after the initial passes, every second pass the blocks
+    are re-evaluated (converged ones dropped, half-converged ones split) and only active blocks keep receiving samples.  The
+    image must equal what the oracle produces when it is fed the same pass constants and the same per-pass pixel masks, and the
+    block list must equal a Python replay of UpdateBlocksList driven by oracle block errors."""
+    w, h = 128, 96
+    scene, camera = scenes.cornell_box(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise(); desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=11, max_ray_depth=3)
+    vp.set_renderer(scene)
+    settings = dict(num_initial_passes=4, min_block_size=8, max_block_size=64, subdivision_treshold=0.35, convergence_treshold=0.12)
+    vp.set_adaptive(True, **settings)
+    blocks = [(x, min(w, x + 64), y, min(h, y + 64)) for y in range(0, h, 64) for x in range(0, w, 64)]
+    assert vp.progress()["blocks"] == blocks
+    ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32); cnt = np.zeros(16, dtype=np.uint64)
+    saw_split = saw_drop = False
+    for n in range(1, 13):
+        p = vp.next_pass_params(camera)
+        mask = np.zeros((h, w), dtype=bool)
+        for (x0, x1, y0, y1) in blocks:
+            mask[y0:y1, x0:x1] = True
+        # oracle pass into scratch buffers, then keep only the active pixels
+        t = np.zeros_like(ref); t2 = np.zeros_like(ref)
+        oracle_lib.render_pass(desc, p, w, h, t, t2, None, threads=8)
+        ref[mask] += t[mask]; ref2[mask] += t2[mask]
+        if blocks:
+            vp.render_pass_with(p)      # = RenderPass + FinishPass (which runs UpdateBlocksList after every second pass)
+        else:
+            ra.host_lib().rth_viewport_finish_pass(vp._h)   # the mirror's Render() submits nothing once every block has converged
+        if n % 2 == 0 and n >= settings["num_initial_passes"]:
+            new_blocks, i, cur = [], 0, list(blocks)
+            while i < len(cur):
+                b = cur[i]
+                err = _oracle_block_error(ref, ref2, n, b)
+                bw, bh = b[1] - b[0], b[3] - b[2]
+                if err < settings["convergence_treshold"]:
+                    cur[i] = cur[-1]; cur.pop(); saw_drop = True; i += 1; continue
+                if err < settings["subdivision_treshold"] and (bw > settings["min_block_size"] or bh > settings["min_block_size"]):
+                    cur[i] = cur[-1]; cur.pop(); saw_split = True
+                    if bw > bh:
+                        half = (b[0] + b[1]) // 2; new_blocks += [(b[0], half, b[2], b[3]), (half, b[1], b[2], b[3])]
+                    else:
+                        half = (b[2] + b[3]) // 2; new_blocks += [(b[0], b[1], b[2], half), (b[0], b[1], half, b[3])]
+                i += 1
+            blocks = cur + new_blocks
+        assert vp.progress()["blocks"] == blocks, n
+    img, img2 = vp.sum_buffer(secondary=True)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)) and np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
+    assert saw_split and saw_drop
+
+
 def test_depth_of_field(built):
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
