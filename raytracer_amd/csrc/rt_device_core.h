@@ -326,119 +326,7 @@ RT_DEV bool rayIsNaNFree(const Ray& r)
            ((__float_as_uint(r.originDivDir.x) & inf) != inf) && ((__float_as_uint(r.originDivDir.y) & inf) != inf) && ((__float_as_uint(r.originDivDir.z) & inf) != inf);
 }
 
-// Tests both children of an interior node (Traversal_Single.h:44-63).  Returns the children as
-// (childIndex, leaves) words so that descending needs no further load.
-struct ChildTest { bool hitA, hitB; float distanceA, distanceB; uint32_t aChild, aLeaves, bChild, bLeaves; };
-
-template <bool kShadow>
-__device__ __forceinline__ static ChildTest testChildren(const RtNode* nodes, uint32_t firstChild, const Ray& ray, float maxDistance, Counters& cnt)
-{
-    const NodePair n = loadNodePair(nodes, firstChild);
-    ChildTest t;
-    t.hitA = intersectBoxRay(ray, V4(n.a0.x, n.a0.y, n.a0.z, 0.0f), V4(n.a1.x, n.a1.y, n.a1.z, 0.0f), t.distanceA);
-    t.hitB = intersectBoxRay(ray, V4(n.b0.x, n.b0.y, n.b0.z, 0.0f), V4(n.b1.x, n.b1.y, n.b1.z, 0.0f), t.distanceB);
-    t.hitA = t.hitA && (t.distanceA < maxDistance);   // box occlusion
-    t.hitB = t.hitB && (t.distanceB < maxDistance);
-    if (kShadow) cnt.c[C_BOX_SHADOW] += 2;
-    else { cnt.c[C_BOX] += 2; cnt.c[C_BOX_PASS] += (t.hitA ? 1u : 0u) + (t.hitB ? 1u : 0u); }
-    t.aChild = __float_as_uint(n.a0.w); t.aLeaves = __float_as_uint(n.a1.w);
-    t.bChild = __float_as_uint(n.b0.w); t.bLeaves = __float_as_uint(n.b1.w);
-    return t;
-}
-
-// GenericTraverse<MeshShape> + MeshShape::Traverse_Leaf, Traversal_Single.h:16-96, MeshShape.cpp:134-168
-RT_DEV void meshTraverse(const RtSceneDesc& d, const RtMesh& mesh, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
-{
-    if (mesh.numNodes == 0) return;
-    const RtNode* nodes = d.meshNodes + mesh.firstNode;
-    const RtTriangle* tris = d.triangles + mesh.firstTriangle;
-    uint32_t stack[RT_MESH_STACK_SIZE];
-    uint32_t stackSize = 0;
-    // current node as its (childIndex, leaves) words; the root's own box is never tested (like the reference)
-    uint32_t curChild = nodes[0].childIndex, curLeaves = nodes[0].leaves;
-    for (;;)
-    {
-        const uint32_t numLeaves = leavesOf(curLeaves);
-        if (numLeaves != 0)
-        {
-            cnt.c[C_TRI] += numLeaves;
-            for (uint32_t i = 0; i < numLeaves; ++i)
-            {
-                const uint32_t triangleIndex = curChild + i;
-                V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
-                float u, v, dist;
-                if (intersectTriangleRay(ray, v0, e1, e2, u, v, dist))
-                {
-                    if (dist < hit.distance)
-                    {
-                        hit.distance = dist; hit.subObjectId = triangleIndex; hit.objectId = objectID; hit.u = u; hit.v = v;
-                        cnt.c[C_TRI_PASS]++;
-                    }
-                }
-            }
-        }
-        else
-        {
-            const ChildTest t = testChildren<false>(nodes, curChild, ray, hit.distance, cnt);
-            if (t.hitA && t.hitB)
-            {
-                const bool swap = t.distanceB < t.distanceA;   // descend into the nearer child, defer the other
-                stack[stackSize++] = curChild + (swap ? 0u : 1u);
-                curChild = swap ? t.bChild : t.aChild; curLeaves = swap ? t.bLeaves : t.aLeaves;
-                continue;
-            }
-            if (t.hitA) { curChild = t.aChild; curLeaves = t.aLeaves; continue; }
-            if (t.hitB) { curChild = t.bChild; curLeaves = t.bLeaves; continue; }
-        }
-        if (stackSize == 0) break;
-        const uint32_t idx = stack[--stackSize];
-        curChild = nodes[idx].childIndex; curLeaves = nodes[idx].leaves;
-    }
-}
-
-// GenericTraverse_Shadow<MeshShape> + MeshShape::Traverse_Leaf_Shadow, Traversal_Single.h:99-179, MeshShape.cpp:175-207
-RT_DEV bool meshTraverseShadow(const RtSceneDesc& d, const RtMesh& mesh, const Ray& ray, Hit& hit, Counters& cnt)
-{
-    if (mesh.numNodes == 0) return false;
-    const RtNode* nodes = d.meshNodes + mesh.firstNode;
-    const RtTriangle* tris = d.triangles + mesh.firstTriangle;
-    uint32_t stack[RT_MESH_STACK_SIZE];
-    uint32_t stackSize = 0;
-    uint32_t curChild = nodes[0].childIndex, curLeaves = nodes[0].leaves;
-    for (;;)
-    {
-        const uint32_t numLeaves = leavesOf(curLeaves);
-        if (numLeaves != 0)
-        {
-            cnt.c[C_TRI_SHADOW] += numLeaves;
-            for (uint32_t i = 0; i < numLeaves; ++i)
-            {
-                V4 v0, e1, e2; loadTriangle(tris + curChild + i, v0, e1, e2);
-                float u, v, dist;
-                if (intersectTriangleRay(ray, v0, e1, e2, u, v, dist))
-                {
-                    if (dist < hit.distance) { hit.distance = dist; return true; }
-                }
-            }
-        }
-        else
-        {
-            const ChildTest t = testChildren<true>(nodes, curChild, ray, hit.distance, cnt);
-            if (t.hitA && t.hitB)
-            {
-                stack[stackSize++] = curChild + 1u;   // no ordering for occlusion rays: A first, B deferred
-                curChild = t.aChild; curLeaves = t.aLeaves;
-                continue;
-            }
-            if (t.hitA) { curChild = t.aChild; curLeaves = t.aLeaves; continue; }
-            if (t.hitB) { curChild = t.bChild; curLeaves = t.bLeaves; continue; }
-        }
-        if (stackSize == 0) break;
-        const uint32_t idx = stack[--stackSize];
-        curChild = nodes[idx].childIndex; curLeaves = nodes[idx].leaves;
-    }
-    return false;
-}
+// (the traversal loops themselves are the per-lane state machine of rt_device_traverse.h)
 
 // ILight::TestRayHit: AreaLight.cpp:43-53 (nearDist, may be negative); Point/Spot never hit (PointLight.cpp:35, SpotLight.cpp:41)
 RT_DEV bool lightTestRayHit(const RtLight& L, const Ray& ray, float& outDistance)
@@ -446,126 +334,6 @@ RT_DEV bool lightTestRayHit(const RtLight& L, const Ray& ray, float& outDistance
     if (L.type != RT_LIGHT_AREA) return false;
     ShapeHit sh;
     if (shapeIntersect(L.shapeKind, L.shapeParam, ray, sh)) { outDistance = sh.nearDist; return true; }
-    return false;
-}
-
-// Scene::Traverse_Object, Scene.cpp:128-145 -> ShapeSceneObject/LightSceneObject::Traverse
-RT_DEV void traverseObject(const RtSceneDesc& d, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
-{
-    const RtObject& obj = d.objects[objectID];
-    const M4 inv = loadM4(obj.invTransform);
-    const Ray lray = transformRayUnsafe(inv, ray);
-    if (obj.objectKind == RT_OBJECT_LIGHT)   // SceneObject_Light.cpp:27-38
-    {
-        float lightDistance;
-        if (lightTestRayHit(d.lights[obj.lightIndex], lray, lightDistance))
-        {
-            if (lightDistance > 0.0f && lightDistance < hit.distance)
-            {
-                hit.distance = lightDistance; hit.objectId = objectID; hit.subObjectId = RT_LIGHT_OBJECT;
-            }
-        }
-        return;
-    }
-    if (obj.shapeKind == RT_SHAPE_MESH) { meshTraverse(d, d.meshes[obj.meshIndex], lray, hit, objectID, cnt); return; }
-    ShapeHit sh;                              // IShape::Traverse, Shape.cpp:19-45
-    if (shapeIntersect(obj.shapeKind, obj.shapeParam, lray, sh))
-    {
-        if (sh.nearDist > 0.0f && sh.nearDist < hit.distance) { hit.distance = sh.nearDist; hit.objectId = objectID; hit.subObjectId = sh.subObjectId; return; }
-        if (sh.farDist > 0.0f && sh.farDist < hit.distance) { hit.distance = sh.farDist; hit.objectId = objectID; hit.subObjectId = sh.subObjectId; return; }
-    }
-}
-// Scene::Traverse_Object_Shadow, Scene.cpp:147-165
-RT_DEV bool traverseObjectShadow(const RtSceneDesc& d, const Ray& ray, Hit& hit, uint32_t objectID, Counters& cnt)
-{
-    const RtObject& obj = d.objects[objectID];
-    const M4 inv = loadM4(obj.invTransform);
-    const Ray lray = transformRayUnsafe(inv, ray);
-    if (obj.objectKind == RT_OBJECT_LIGHT)   // SceneObject_Light.cpp:40-53
-    {
-        float lightDistance;
-        if (lightTestRayHit(d.lights[obj.lightIndex], lray, lightDistance))
-        {
-            if (lightDistance < hit.distance) { hit.distance = lightDistance; return true; }
-        }
-        return false;
-    }
-    if (obj.shapeKind == RT_SHAPE_MESH) return meshTraverseShadow(d, d.meshes[obj.meshIndex], lray, hit, cnt);
-    ShapeHit sh;                              // IShape::Traverse_Shadow, Shape.cpp:47-57
-    if (!shapeIntersect(obj.shapeKind, obj.shapeParam, lray, sh)) return false;
-    return sh.farDist > 0.0f && sh.nearDist < hit.distance;
-}
-
-// Scene::Traverse, Scene.cpp:219-243 (+ GenericTraverse<Scene>, Scene::Traverse_Leaf :167-178)
-RT_DEV void sceneTraverse(const RtSceneDesc& d, const Ray& ray, Hit& hit, Counters& cnt)
-{
-    const uint32_t numObjects = d.numObjects;
-    if (numObjects == 0) return;
-    if (numObjects == 1) { traverseObject(d, ray, hit, 0, cnt); return; }
-    if (d.numTopNodes == 0) return;
-    const RtNode* nodes = d.topNodes;
-    uint32_t stack[RT_TOP_STACK_SIZE];
-    uint32_t stackSize = 0;
-    uint32_t curChild = nodes[0].childIndex, curLeaves = nodes[0].leaves;
-    for (;;)
-    {
-        const uint32_t numLeaves = leavesOf(curLeaves);
-        if (numLeaves != 0)
-        {
-            for (uint32_t i = 0; i < numLeaves; ++i) traverseObject(d, ray, hit, curChild + i, cnt);
-        }
-        else
-        {
-            const ChildTest t = testChildren<false>(nodes, curChild, ray, hit.distance, cnt);
-            if (t.hitA && t.hitB)
-            {
-                const bool swap = t.distanceB < t.distanceA;
-                stack[stackSize++] = curChild + (swap ? 0u : 1u);
-                curChild = swap ? t.bChild : t.aChild; curLeaves = swap ? t.bLeaves : t.aLeaves;
-                continue;
-            }
-            if (t.hitA) { curChild = t.aChild; curLeaves = t.aLeaves; continue; }
-            if (t.hitB) { curChild = t.bChild; curLeaves = t.bLeaves; continue; }
-        }
-        if (stackSize == 0) break;
-        const uint32_t idx = stack[--stackSize];
-        curChild = nodes[idx].childIndex; curLeaves = nodes[idx].leaves;
-    }
-}
-// Scene::Traverse_Shadow, Scene.cpp:245-261 (+ Scene::Traverse_Leaf_Shadow :180-194)
-RT_DEV bool sceneTraverseShadow(const RtSceneDesc& d, const Ray& ray, Hit& hit, Counters& cnt)
-{
-    const uint32_t numObjects = d.numObjects;
-    if (numObjects == 0) return false;
-    if (numObjects == 1) return traverseObjectShadow(d, ray, hit, 0, cnt);
-    if (d.numTopNodes == 0) return false;
-    const RtNode* nodes = d.topNodes;
-    uint32_t stack[RT_TOP_STACK_SIZE];
-    uint32_t stackSize = 0;
-    uint32_t curChild = nodes[0].childIndex, curLeaves = nodes[0].leaves;
-    for (;;)
-    {
-        const uint32_t numLeaves = leavesOf(curLeaves);
-        if (numLeaves != 0)
-        {
-            for (uint32_t i = 0; i < numLeaves; ++i) if (traverseObjectShadow(d, ray, hit, curChild + i, cnt)) return true;
-        }
-        else
-        {
-            const ChildTest t = testChildren<true>(nodes, curChild, ray, hit.distance, cnt);
-            if (t.hitA && t.hitB)
-            {
-                stack[stackSize++] = curChild + 1u;
-                curChild = t.aChild; curLeaves = t.aLeaves;
-                continue;
-            }
-            if (t.hitA) { curChild = t.aChild; curLeaves = t.aLeaves; continue; }
-            if (t.hitB) { curChild = t.bChild; curLeaves = t.bLeaves; continue; }
-        }
-        if (stackSize == 0) break;
-        const uint32_t idx = stack[--stackSize];
-        curChild = nodes[idx].childIndex; curLeaves = nodes[idx].leaves;
-    }
     return false;
 }
 

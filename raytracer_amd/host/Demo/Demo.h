@@ -4,9 +4,11 @@
 
 #include <string>
 
+#include "../Core/Math/Math.h"   // RAYLIB_API
+
 struct Options
 {
     std::string dataPath;
 };
 
-extern Options gOptions;
+extern RAYLIB_API Options gOptions;

@@ -15,10 +15,10 @@ namespace helpers {
 
 using MaterialsMap = std::map<std::string, rt::MaterialPtr>;
 
-rt::BitmapPtr LoadBitmapObject(const std::string& baseDir, const std::string& path);
-rt::TexturePtr LoadTexture(const std::string& baseDir, const std::string& path);
-rt::MeshShapePtr LoadMesh(const std::string& filePath, MaterialsMap& outMaterials, const float scale = 1.0f);
-rt::MaterialPtr CreateDefaultMaterial(MaterialsMap& outMaterials);
+RAYLIB_API rt::BitmapPtr LoadBitmapObject(const std::string& baseDir, const std::string& path);
+RAYLIB_API rt::TexturePtr LoadTexture(const std::string& baseDir, const std::string& path);
+RAYLIB_API rt::MeshShapePtr LoadMesh(const std::string& filePath, MaterialsMap& outMaterials, const float scale = 1.0f);
+RAYLIB_API rt::MaterialPtr CreateDefaultMaterial(MaterialsMap& outMaterials);
 
 // The vertex streams LoadMesh hands to MeshShape::Initialize (MeshLoader.cpp:372-392), exposed for the parity tests.
 struct MeshStreams
@@ -28,6 +28,6 @@ struct MeshStreams
     std::vector<rt::math::Float2> texCoords;
     std::vector<rt::MaterialPtr> materials;
 };
-bool LoadMeshStreams(const std::string& filePath, MaterialsMap& outMaterials, const float scale, MeshStreams& out);
+RAYLIB_API bool LoadMeshStreams(const std::string& filePath, MaterialsMap& outMaterials, const float scale, MeshStreams& out);
 
 } // namespace helpers

@@ -21,7 +21,7 @@
 #include <float.h>
 #include <stdio.h>
 
-Options gOptions;
+RAYLIB_API Options gOptions;
 
 namespace helpers {
 

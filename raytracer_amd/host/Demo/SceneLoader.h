@@ -8,6 +8,6 @@
 
 namespace helpers {
 
-bool LoadScene(const std::string& path, rt::Scene& scene, rt::Camera& camera);
+RAYLIB_API bool LoadScene(const std::string& path, rt::Scene& scene, rt::Camera& camera);
 
 } // namespace helpers

@@ -3,6 +3,7 @@
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,3 +31,31 @@ def test_reference_rendering_tests_pass_on_gpu(built):
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 test(s) failed" in out.stdout
+
+
+DEMO = os.path.join(ROOT, "raytracer_amd", "lib", "rt_demo")
+
+
+def test_headless_demo_fails_loudly_without_a_gpu(built):
+    """The headless Demo (host/Demo/headless/Main.cpp: LoadScene -> Viewport -> GetFrontBuffer -> BMP) is built by build();
+    on a machine without a GPU it must say so instead of rendering on some fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    scene = os.path.join(ROOT, "tests", "golden", "obj", "scene.json")
+    r = subprocess.run([DEMO, "-s", scene, "--data", os.path.dirname(scene) + "/", "-w", "64", "-h", "48", "--passes", "1"], capture_output=True, text=True)
+    assert r.returncode == 1 and "not available" in r.stderr
+
+
+@pytest.mark.gpu
+def test_headless_demo_renders_the_ingested_scene(built, tmp_path):
+    scene = os.path.join(ROOT, "tests", "golden", "obj", "scene.json")
+    out = tmp_path / "out.bmp"
+    r = subprocess.run([DEMO, "-s", scene, "--data", os.path.dirname(scene) + "/", "-w", "160", "-h", "100", "--passes", "8", "--depth", "5", "--output", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Msamples/s" in r.stdout
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 160 * 3 * 100
+    pixels = np.frombuffer(data[54:], dtype=np.uint8)
+    assert pixels.max() > 100 and len(np.unique(pixels)) > 50      # an image, not a constant
