@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RTGPU_ABI_VERSION 2u
+#define RTGPU_ABI_VERSION 3u
 
 typedef enum RtgpuStatus
 {
@@ -293,6 +293,8 @@ typedef struct RtCamera
     float    focalPlaneDistance;
     float    aperture;
     float    _pad[2];
+    float    worldToScreen[16];  /* Camera::mWorldToScreen as SetPerspective left it (Camera.cpp:39-48): read by the
+                                  * bidirectional integrator only (Camera::WorldToFilm, Camera.cpp:120-134) */
 } RtCamera;
 
 typedef enum RtLightSampling { RT_LIGHT_SAMPLING_SINGLE = 0, RT_LIGHT_SAMPLING_ALL = 1 } RtLightSampling;

@@ -58,6 +58,8 @@
 #include "Scene/Object/SceneObject_Shape.h"
 #include "Scene/Object/SceneObject_Light.h"
 #include "Scene/Camera.h"
+#include "Rendering/Film.h"
+#include "Math/Packed.h"
 #include "Material/Material.h"
 #include "Textures/BitmapTexture.h"
 #include "Textures/CheckerboardTexture.h"
@@ -137,6 +139,9 @@ enum
     KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41,
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
     KAT_CAMERA_RAY = 60,
+    // bidirectional (VCM) building blocks
+    KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44, KAT_BSDF_PDFS = 52,
+    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63,
     // host-side algorithms (checked against raytracer_amd's host library, not the oracle)
     KAT_HOST_EULER = 100, KAT_HOST_INVERSE = 101,
 };
@@ -1065,6 +1070,225 @@ static void genPostprocess()
     writeRaw("postprocess_kat.bin", out.data(), out.size() * 4);
 }
 
+// =====================================================================================================
+// Building blocks of the bidirectional integrator (VertexConnectionAndMerging.cpp): ILight::Emit, Illuminate /
+// GetRadiance with rendererSupportsSolidAngleSampling = false and their emission pdfs, BSDF reverse pdfs and
+// BSDF::Pdf, Camera::WorldToFilm / PdfW, the jittered film splat and the packed photon fields.
+// =====================================================================================================
+static std::unique_ptr<ILight> makeLight(int i, Lcg& g, RtLight& L, Matrix4& xf)
+{
+    const int type = i % 5;
+    float p[4] = { 0, 0, 0, 0 }, p2[4] = { 0, 0, 0, 0 };
+    uint32_t shapeKind = 0;
+    const Vector4 color(g.range(0.0f, 6.0f), g.range(0.0f, 6.0f), g.range(0.0f, 6.0f), (i % 7 == 0) ? 1.0f : 0.0f);
+    std::unique_ptr<ILight> light;
+    float cosAngle = 0.0f; uint32_t isDelta = 0;
+    if (type == 0)
+    {
+        shapeKind = (uint32_t)((i / 5) % 3);
+        std::unique_ptr<IShape> shape = makeShape(shapeKind, g, p, p2);
+        light = std::make_unique<AreaLight>(ShapePtr(std::move(shape)), color);
+    }
+    else if (type == 1) light = std::make_unique<BackgroundLight>(color);
+    else if (type == 2)
+    {
+        const float angle = ((i / 5) % 3 == 0) ? 0.005f : g.range(0.02f, 0.8f);
+        auto dl = std::make_unique<DirectionalLight>(color, angle);
+        cosAngle = dl->mCosAngle; isDelta = dl->mIsDelta ? 1u : 0u;
+        light = std::move(dl);
+    }
+    else if (type == 3) light = std::make_unique<PointLight>(color);
+    else
+    {
+        const float angle = ((i / 5) % 4 == 0) ? 0.005f : g.range(0.1f, 1.4f);
+        auto sl = std::make_unique<SpotLight>(color, angle);
+        cosAngle = sl->mCosAngle; isDelta = sl->mIsDelta ? 1u : 0u;
+        light = std::move(sl);
+    }
+    xf = randomRigid(g);
+    fillLight(L, *light, xf, shapeKind, p, p2);
+    L.cosAngle = cosAngle; L.isDelta = isDelta;
+    return light;
+}
+
+static void genBidirLights()
+{
+    const int N = 1280;
+    const uint32_t LW = sizeof(RtLight) / 4;
+    KatWriter ke("light_emit", KAT_LIGHT_EMIT, LW + 5, 15), ki("light_illuminate_bidir", KAT_LIGHT_ILLUMINATE_BIDIR, LW + 16 + 3, 12),
+        kr("light_radiance_bidir", KAT_LIGHT_RADIANCE_BIDIR, LW + 13, 6);
+    Lcg g(120);
+    RenderingContext* ctx = new RenderingContext();
+    for (int i = 0; i < N; ++i)
+    {
+        const int type = i % 5;
+        RtLight L; Matrix4 xf;
+        std::unique_ptr<ILight> light = makeLight(i, g, L, xf);
+        // --- Emit
+        {
+            const Float3 up(g.unit(), g.unit(), g.unit()); const Float2 ud(g.unit(), g.unit());
+            float* in = ke.addIn(); memcpy(in, &L, sizeof(L)); in[LW] = up.x; in[LW + 1] = up.y; in[LW + 2] = up.z; in[LW + 3] = ud.x; in[LW + 4] = ud.y;
+            const ILight::EmitParam param = { xf, ctx->wavelength, up, ud };
+            ILight::EmitResult res; memset(&res, 0, sizeof(res));
+            const RayColor c = light->Emit(param, res);
+            float* out = ke.addOut(); put4(out, c.value); put4(out + 4, res.position); put4(out + 8, res.direction);
+            out[12] = res.directPdfA; out[13] = res.emissionPdfW; out[14] = res.cosAtLight;
+        }
+        // --- Illuminate without solid-angle sampling (all five results)
+        {
+            IntersectionData isect;
+            const Vector4 n = g.dir(); Vector4 t, b; BuildOrthonormalBasis(n, t, b);
+            isect.frame[0] = t; isect.frame[1] = b; isect.frame[2] = n; isect.frame[3] = g.vec(-6.0f, 6.0f);
+            const Float3 u(g.unit(), g.unit(), g.unit());
+            float* in = ki.addIn(); memcpy(in, &L, sizeof(L)); putM(in + LW, isect.frame); in[LW + 16] = u.x; in[LW + 17] = u.y; in[LW + 18] = u.z;
+            const ILight::IlluminateParam param = { xf.Inverse(), xf, isect, ctx->wavelength, u, false };
+            ILight::IlluminateResult res;
+            const RayColor rad = light->Illuminate(param, res);
+            float* out = ki.addOut(); put4(out, rad.value);
+            put4(out + 4, res.directionToLight); out[8] = res.distance; out[9] = res.directPdfW; out[10] = res.emissionPdfW; out[11] = res.cosAtLight;
+        }
+        // --- GetRadiance without solid-angle sampling + emission pdf
+        if (type <= 2)
+        {
+            const Ray lray(g.vec(-6.0f, 6.0f), g.dir());
+            const Vector4 hit = g.vec(-2.0f, 2.0f);
+            const float cosAtLight = g.range(-0.3f, 1.0f);
+            float* in = kr.addIn(); memcpy(in, &L, sizeof(L)); put4(in + LW, lray.origin); put4(in + LW + 4, lray.dir); put4(in + LW + 8, hit); in[LW + 12] = cosAtLight;
+            const ILight::RadianceParam param = { *ctx, lray, hit, cosAtLight, false };
+            float pdfA = 0.0f, pdfW = 0.0f;
+            const RayColor rad = light->GetRadiance(param, &pdfA, &pdfW);
+            float* out = kr.addOut(); put4(out, rad.value); out[4] = rad.AlmostZero() ? 0.0f : pdfA; out[5] = rad.AlmostZero() ? 0.0f : pdfW;
+        }
+    }
+    ke.save(); ki.save(); kr.save();
+}
+
+static void genBidirBsdf()
+{
+    const int N = 4608;
+    KatWriter ke("bsdf_pdfs", KAT_BSDF_PDFS, 24, 8);
+    Lcg g(121);
+    Wavelength wavelength;
+    for (int i = 0; i < N; ++i)
+    {
+        const uint32_t kind = (uint32_t)(i % 9);
+        Material mat;
+        mat.SetBsdf(kBsdfNames[kind]);
+        mat.baseColor = Vector4(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), (i % 11 == 0) ? 1.0f : 0.0f);
+        mat.emission = Vector4::Zero();
+        // rough metal / rough plastic below the specular threshold leave *outReversePdfW unwritten (RoughMetalBSDF.cpp:71-75,
+        // RoughPlasticBSDF.cpp:95-98): keep those two above the threshold here
+        mat.roughness = (i % 13 == 0 && kind != 6 && kind != 8) ? 0.001f : g.range(0.02f, 1.0f);
+        mat.metalness = 0.0f;
+        mat.IoR = (kind == 5 || kind == 6) ? g.range(0.0f, 3.0f) : g.range(1.05f, 2.2f);
+        mat.K = g.range(0.0f, 8.0f);
+        mat.Compile();
+        RtMaterial M; memset(&M, 0, sizeof(M));
+        memcpy(M.emission, &mat.emission.baseValue, 16); memcpy(M.baseColor, &mat.baseColor.baseValue, 16);
+        M.roughness = mat.roughness.baseValue; M.metalness = mat.metalness.baseValue; M.IoR = mat.IoR; M.K = mat.K; M.bsdf = kind;
+        SampledMaterialParameters mp;
+        mp.baseColor = RayColor(mat.baseColor.baseValue); mp.emissionColor = RayColor(mat.emission.baseValue);
+        mp.roughness = M.roughness; mp.metalness = M.metalness; mp.IoR = M.IoR;
+
+        Vector4 outgoing = g.dir();
+        if (i % 3 != 0) outgoing.z = Abs(outgoing.z);
+        Vector4 incoming = g.dir();
+        if (i % 4 != 0) incoming.z = -Abs(incoming.z);
+        float* in = ke.addIn(); memcpy(in, &M, 64); put4(in + 16, outgoing); put4(in + 20, incoming);
+        const BSDF::EvaluationContext ec = { mat, mp, wavelength, outgoing, incoming };
+        float pdf = 0.0f, rev = 0.0f;
+        const RayColor c = mat.GetBSDF()->Evaluate(ec, &pdf, &rev);
+        float* out = ke.addOut(); put4(out, c.value); out[4] = c.AlmostZero() ? 0.0f : pdf; out[5] = c.AlmostZero() ? 0.0f : rev;
+        out[6] = mat.GetBSDF()->Pdf(ec, BSDF::ForwardPdf); out[7] = mat.GetBSDF()->Pdf(ec, BSDF::ReversePdf);
+    }
+    ke.save();
+}
+
+static void genBidirCameraFilm()
+{
+    // ---- Camera::WorldToFilm / PdfW: RtCamera, world position, direction -> visible, film coords, pdf
+    {
+        const int N = 1024;
+        const uint32_t CW = sizeof(RtCamera) / 4;
+        KatWriter k("camera_film", KAT_CAMERA_FILM, CW + 8, 6);
+        Lcg g(122);
+        for (int i = 0; i < N; ++i)
+        {
+            Camera cam;
+            const Float3 euler(g.range(-1.5f, 1.5f), g.range(-3.0f, 3.0f), g.range(-0.5f, 0.5f));
+            cam.SetTransform(Transform(g.vec(-10.0f, 10.0f), Quaternion::FromEulerAngles(euler)));
+            cam.SetPerspective(g.range(0.5f, 2.4f), g.range(0.2f, 2.0f));
+            RtCamera C; memset(&C, 0, sizeof(C));
+            memcpy(C.localToWorld, &cam.mLocalToWorld, 64);
+            memcpy(C.worldToScreen, &cam.mWorldToScreen, 64);
+            C.aspectRatio = cam.mAspectRatio; C.tanHalfFoV = cam.mTanHalfFoV;
+            // mostly points in front of the camera, inside or near the frustum
+            Vector4 local = Vector4(g.range(-1.5f, 1.5f), g.range(-1.5f, 1.5f), 1.0f, 0.0f) * g.range(0.05f, 30.0f);
+            if (i % 9 == 0) local.z = -local.z;
+            if (i % 31 == 0) local.z = 0.005f;     // inside the near plane
+            const Vector4 world = cam.mLocalToWorld.TransformPoint(local);
+            const Vector4 dir = (i % 2) ? (world - cam.mLocalToWorld.GetTranslation()).Normalized3() : g.dir();
+            float* in = k.addIn(); memcpy(in, &C, sizeof(C)); put4(in + CW, world); put4(in + CW + 4, dir);
+            Vector4 film = Vector4::Zero();
+            const bool ok = cam.WorldToFilm(world, film);
+            float* out = k.addOut(); out[0] = bitsf(ok ? 1u : 0u);
+            if (ok) { out[1] = film.x; out[2] = film.y; out[3] = film.z; out[4] = film.w; }
+            out[5] = cam.PdfW(dir);
+        }
+        k.save();
+    }
+    // ---- Film::AccumulateColor(pos, color, random): which pixel receives the splat, and the generator state after
+    {
+        const int N = 2048;
+        KatWriter k("film_splat", KAT_FILM_SPLAT, 4 + 8, 2 + 8);
+        Lcg g(123);
+        for (int i = 0; i < N; ++i)
+        {
+            const uint32_t w = 1 + g.u32() % 96, h = 1 + g.u32() % 64;
+            Bitmap sum;
+            Bitmap::InitData id; id.width = w; id.height = h; id.format = Bitmap::Format::R32G32B32_Float;
+            sum.Init(id);
+            memset(sum.GetData(), 0, (size_t)w * h * 12);
+            Film film(sum, nullptr);
+            Vector4 pos(g.range(-0.1f, 1.1f), g.range(-0.1f, 1.1f), 0.0f, 0.0f);
+            if (i % 5 == 0) { pos.x = (float)(g.u32() % (w + 1)) / (float)w; pos.y = (float)(g.u32() % (h + 1)) / (float)h; }   // pixel borders
+            Random rng;
+            for (int s = 0; s < 2; ++s) { rng.mSeedSimd4[s] = VectorInt4((int32)g.u32(), (int32)g.u32(), (int32)g.u32(), (int32)g.u32()); }
+            float* in = k.addIn(); in[0] = pos.x; in[1] = pos.y; in[2] = bitsf(w); in[3] = bitsf(h);
+            memcpy(in + 4, &rng.mSeedSimd4[0], 16); memcpy(in + 8, &rng.mSeedSimd4[1], 16);
+            film.AccumulateColor(pos, Vector4(1.0f, 2.0f, 3.0f, 0.0f), rng);
+            uint32_t px = 0xFFFFFFFFu, py = 0xFFFFFFFFu;
+            const float* data = reinterpret_cast<const float*>(sum.GetData());
+            for (uint32_t y = 0; y < h; ++y) for (uint32_t x = 0; x < w; ++x) if (data[3 * ((size_t)y * w + x)] != 0.0f) { px = x; py = y; }
+            float* out = k.addOut(); out[0] = bitsf(px); out[1] = bitsf(py);
+            memcpy(out + 2, &rng.mSeedSimd4[0], 16); memcpy(out + 6, &rng.mSeedSimd4[1], 16);
+        }
+        k.save();
+    }
+    // ---- photon fields: PackedUnitVector3 and PackedColorRgbHdr round trips (packed bits and the unpacked vector)
+    {
+        const int N = 2048;
+        KatWriter k("packed_photon", KAT_PACKED_PHOTON, 8, 11);
+        Lcg g(124);
+        for (int i = 0; i < N; ++i)
+        {
+            Vector4 d = g.dir();
+            if (i % 17 == 0) d = Vector4(0.0f, 0.0f, (i & 1) ? 1.0f : -1.0f, 0.0f);
+            if (i % 19 == 0) d = Vector4((i & 1) ? 1.0f : -1.0f, 0.0f, 0.0f, 0.0f);
+            Vector4 c(g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), g.range(0.0f, 1.0f), 0.0f);
+            c *= (i % 3 == 0) ? g.range(0.0f, 1000.0f) : g.range(0.0f, 2.0f);
+            if (i % 23 == 0) c = Vector4::Zero();
+            float* in = k.addIn(); put4(in, d); put4(in + 4, c);
+            PackedUnitVector3 pd; pd.FromVector(d);
+            PackedColorRgbHdr pc; pc.FromVector(c);
+            float* out = k.addOut();
+            memcpy(out, &pd, 4); memcpy(out + 1, &pc, 8);
+            put4(out + 3, pd.ToVector()); put4(out + 7, pc.ToVector());
+        }
+        k.save();
+    }
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -1081,6 +1305,9 @@ int main(int argc, char** argv)
     genTextures();
     genObjMesh();
     genPostprocess();
+    genBidirLights();
+    genBidirBsdf();
+    genBidirCameraFilm();
     printf("done\n");
     return 0;
 }

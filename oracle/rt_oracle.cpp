@@ -12,6 +12,7 @@
 //       (Tests/RaytracingTests.cpp:263-523), restated in tests/test_furnace_oracle.py.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include "rto_core.h"
+#include "rto_vcm.h"
 
 #include <stdlib.h>
 #include <stdio.h>
@@ -120,6 +121,8 @@ enum
     KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41,
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
     KAT_CAMERA_RAY = 60,
+    KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44, KAT_BSDF_PDFS = 52,
+    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63,
     KAT_SAMPLER = 70,
 };
 
@@ -260,6 +263,65 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             s.bx = s.by = 0; s.salt = 0; s.generated = 0; s.fallback.s[0] = 1; s.fallback.s[1] = 2;
             const Ray ray = cameraGenerateRay(cam, V4(i[CW], i[CW + 1], 0.0f, 0.0f), s);
             putV4(o, ray.origin); putV4(o + 4, ray.dir); putV4(o + 8, ray.invDir); putV4(o + 12, ray.originDivDir); break;
+        }
+        case KAT_LIGHT_EMIT:      // in: RtLight, positionSample[3], directionSample[2]
+        {
+            const int LW = (int)(sizeof(RtLight) / 4);
+            RtLight L; memcpy(&L, i, sizeof(RtLight));
+            EmitResult er; er.position = zero4(); er.direction = zero4(); er.directPdfA = er.emissionPdfW = er.cosAtLight = 0.0f;
+            const V4 c = lightEmit(nullptr, L, i + LW, i + LW + 3, er);
+            putV4(o, c); putV4(o + 4, er.position); putV4(o + 8, er.direction); o[12] = er.directPdfA; o[13] = er.emissionPdfW; o[14] = er.cosAtLight; break;
+        }
+        case KAT_LIGHT_ILLUMINATE_BIDIR: // in: RtLight, frame[16], u[3]; rendererSupportsSolidAngleSampling = false
+        {
+            const int LW = (int)(sizeof(RtLight) / 4);
+            RtLight L; memcpy(&L, i, sizeof(RtLight));
+            Intersection is; is.frame = loadM4(i + LW); is.texCoord = zero4(); is.material = 0;
+            IlluminateResult ir;
+            const V4 rad = lightIlluminate(nullptr, L, is, i + LW + 16, ir, false);
+            putV4(o, rad); putV4(o + 4, ir.directionToLight); o[8] = ir.distance; o[9] = ir.directPdfW; o[10] = ir.emissionPdfW; o[11] = ir.cosAtLight; break;
+        }
+        case KAT_LIGHT_RADIANCE_BIDIR:
+        {
+            const int LW = (int)(sizeof(RtLight) / 4);
+            RtLight L; memcpy(&L, i, sizeof(RtLight));
+            Ray ray; ray.origin = load4(i + LW); ray.dir = load4(i + LW + 4); ray.invDir = zero4(); ray.originDivDir = zero4();
+            float pdfA = 0.0f, pdfW = 0.0f;
+            const V4 rad = lightGetRadiance(nullptr, L, ray, load4(i + LW + 8), i[LW + 12], pdfA, &pdfW, false);
+            putV4(o, rad); o[4] = almostZero4(rad) ? 0.0f : pdfA; o[5] = almostZero4(rad) ? 0.0f : pdfW; break;
+        }
+        case KAT_BSDF_PDFS:       // in: RtMaterial, outgoingDir[4], incomingDir[4]   out: colour, pdf, reverse pdf, Pdf(Forward), Pdf(Reverse)
+        {
+            RtMaterial m = katMaterial(i);
+            ShadingData sd; sd.intersection.texCoord = zero4(); materialEvaluateShadingData(nullptr, m, sd);
+            float pdf = 0.0f, rev = 0.0f;
+            const V4 c = bsdfEvaluate(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), pdf, &rev);
+            putV4(o, c); o[4] = almostZero4(c) ? 0.0f : pdf; o[5] = almostZero4(c) ? 0.0f : rev;
+            o[6] = bsdfPdf(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), false);
+            o[7] = bsdfPdf(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), true); break;
+        }
+        case KAT_CAMERA_FILM:     // in: RtCamera, world position[4], direction[4]   out: visible, film coords[4], PdfW
+        {
+            const int CW = (int)(sizeof(RtCamera) / 4);
+            RtCamera cam; memcpy(&cam, i, sizeof(RtCamera));
+            V4 film = zero4();
+            const bool ok = cameraWorldToFilm(cam, load4(i + CW), film);
+            o[0] = bitsf(ok ? 1u : 0u); o[1] = ok ? film.x : 0.0f; o[2] = ok ? film.y : 0.0f; o[3] = ok ? film.z : 0.0f; o[4] = ok ? film.w : 0.0f;
+            o[5] = cameraDirectionPdfW(cam, load4(i + CW + 4)); break;
+        }
+        case KAT_FILM_SPLAT:      // in: pos[2], width, height, mSeedSimd4[0..1]   out: x, y (0xFFFFFFFF = outside), generator state after
+        {
+            RandomSimd rng; memcpy(rng.seed0, i + 4, 16); memcpy(rng.seed1, i + 8, 16);
+            uint32_t x = 0xFFFFFFFFu, y = 0xFFFFFFFFu;
+            if (!filmSplatPixel(V4(i[0], i[1], 0.0f, 0.0f), fbits(i[2]), fbits(i[3]), rng, x, y)) { x = y = 0xFFFFFFFFu; }
+            o[0] = bitsf(x); o[1] = bitsf(y); memcpy(o + 2, rng.seed0, 16); memcpy(o + 6, rng.seed1, 16); break;
+        }
+        case KAT_PACKED_PHOTON:   // in: direction[4], colour[4]   out: packed direction, packed colour (2 words), unpacked direction[4], colour[4]
+        {
+            const uint32_t pd = packUnitVector(load4(i));
+            const PackedColor pc = packColorHdr(load4(i + 4));
+            o[0] = bitsf(pd); memcpy(o + 1, &pc, 8);
+            putV4(o + 3, unpackUnitVector(pd)); putV4(o + 7, unpackColorHdr(pc)); break;
         }
         default: return -1;
         }
@@ -415,6 +477,59 @@ float rto_block_error(const float* sumRGB, const float* secondaryRGB, uint32_t w
     }
     const uint32_t totalArea = width * height, blockArea = (maxX - minX) * (maxY - minY);
     return totalError * sqrtf((float)blockArea / (float)totalArea) / (float)blockArea;
+}
+
+// ---- bidirectional integrator (VertexConnectionAndMerging) -- see rto_vcm.h for the parity status ------------------------
+// settings: 8 words { maxPathLength, useVertexConnection, useVertexMerging, initialMergingRadius, minMergingRadius,
+// mergingRadiusMultiplier, 0, 0 } followed by the five float4 weights (bsdf, light, vertexConnecting, cameraConnecting, merging)
+void* rto_vcm_create(const uint32_t* settingsWords)
+{
+    VcmRenderer* r = new VcmRenderer();
+    if (settingsWords)
+    {
+        r->s.maxPathLength = settingsWords[0]; r->s.useVertexConnection = settingsWords[1]; r->s.useVertexMerging = settingsWords[2];
+        r->s.initialMergingRadius = bitsf(settingsWords[3]); r->s.minMergingRadius = bitsf(settingsWords[4]); r->s.mergingRadiusMultiplier = bitsf(settingsWords[5]);
+        memcpy(r->s.bsdfSamplingWeight, settingsWords + 8, 16); memcpy(r->s.lightSamplingWeight, settingsWords + 12, 16);
+        memcpy(r->s.vertexConnectingWeight, settingsWords + 16, 16); memcpy(r->s.cameraConnectingWeight, settingsWords + 20, 16);
+        memcpy(r->s.vertexMergingWeight, settingsWords + 24, 16);
+    }
+    return r;
+}
+void rto_vcm_destroy(void* h) { delete static_cast<VcmRenderer*>(h); }
+uint32_t rto_vcm_num_photons(void* h) { return (uint32_t)static_cast<VcmRenderer*>(h)->recorded.size(); }
+
+// One pass over the whole film, pixels in row-major order.  Camera-path radiance goes to sum (+ secondarySum when non-null);
+// light-path splats go to lightSum when it is non-null (so the two estimators can be compared separately), else to sum.
+int rto_vcm_render_pass(void* h, const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t passNumber,
+                        float* sum, float* secondarySum, float* lightSum, uint64_t* counters)
+{
+    VcmRenderer* r = static_cast<VcmRenderer*>(h);
+    r->preRender(passNumber, width, height);
+    Counters c; memset(&c, 0, sizeof(c));
+    VcmCtx* ctx = new VcmCtx();
+    ctx->scene = scene; ctx->params = params; ctx->r = r; ctx->counters = &c;
+    ctx->width = width; ctx->height = height;
+    ctx->sum = lightSum ? lightSum : sum; ctx->secondarySum = lightSum ? nullptr : secondarySum;
+    ctx->sampler.seed = params->seed; ctx->sampler.numDims = params->numDimensions; ctx->sampler.blueNoise = scene->blueNoise;
+    ctx->sampler.blueNoiseLayers = (scene->blueNoise && params->useBlueNoise) ? 4u : 0u;
+    const V4 invSize(1.0f / (float)(int32_t)width, 1.0f / (float)(int32_t)height, 0.0f, 0.0f);
+    const V4 sampleOffset(params->sampleOffset[0], params->sampleOffset[1], 0.0f, 0.0f);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            const uint32_t realY = height - 1u - y;
+            const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
+            ctx->sampler.resetPixel(x, y, params->rngKey);
+            ctx->simd.resetPixel(x, y, params->rngKey);
+            const Ray ray = cameraGenerateRay(params->camera, coords, ctx->sampler);
+            const V4 color = vcmRenderPixel(*ctx, ray, passNumber);
+            float* p = sum + 3 * ((size_t)y * width + x);
+            p[0] = p[0] + color.x; p[1] = p[1] + color.y; p[2] = p[2] + color.z;
+            if (secondarySum) { float* q = secondarySum + 3 * ((size_t)y * width + x); q[0] = q[0] + color.x; q[1] = q[1] + color.y; q[2] = q[2] + color.z; }
+        }
+    delete ctx;
+    if (counters) for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
+    return 0;
 }
 
 uint32_t rto_sizeof(int what)

@@ -126,9 +126,15 @@ static inline float shapeSurfaceArea(uint32_t kind, const float* p)
     return 4.0f * p[0] * p[1];                                                           // RectShape.cpp:27-30
 }
 
-// IShape::Sample(u, &normal)  (area sampling): BoxShape.cpp:127-179, RectShape.cpp:51-64
+// IShape::Sample(u, &normal)  (area sampling): BoxShape.cpp:127-179, RectShape.cpp:51-64, SphereShape.cpp:47-63
 static inline V4 shapeSampleArea(uint32_t kind, const float* p, const float u[3], V4& outNormal)
 {
+    if (kind == RT_SHAPE_SPHERE)
+    {
+        const V4 point = getSphere(u[0], u[1]);
+        outNormal = point;
+        return point * p[0];
+    }
     if (kind == RT_SHAPE_RECT)
     {
         outNormal = V4(0.0f, 0.0f, 1.0f, 0.0f);
@@ -809,7 +815,10 @@ static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ra
 // =====================================================================================================
 // Lights -- Core/Scene/Light/*.cpp
 // =====================================================================================================
-struct IlluminateResult { V4 directionToLight; float distance, directPdfW, cosAtLight; };
+struct IlluminateResult { V4 directionToLight; float distance, directPdfW, emissionPdfW, cosAtLight; };
+static const float kSceneRadius = 30.0f;   // BackgroundLight.cpp:16, DirectionalLight.cpp:14
+static inline float uniformSpherePdf() { return RTO_INV_PI / 4.0f; }                       // Geometry.h:22-25
+static inline float uniformCirclePdf(float radius) { return 1.0f / (RTO_PI * Sqr(radius)); }   // Geometry.h:32-35
 
 // ILight::Illuminate; returns radiance (4 lanes)
 // BackgroundLight::GetBackgroundColor, BackgroundLight.cpp:45-61
@@ -819,20 +828,41 @@ static inline V4 backgroundColor(const RtSceneDesc* d, const RtLight& L, V4 dir)
     if (L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluate(d, L.texture, cartesianToSpherical(dir)));
     return color;
 }
-static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
+// solidAngle = IlluminateParam::rendererSupportsSolidAngleSampling (true for PathTracerMIS, false for the bidirectional integrator)
+static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out, bool solidAngle = true)
 {
-    out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
+    out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.emissionPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
     const V4 color = load4(L.color);
     switch (L.type)
     {
-    case RT_LIGHT_AREA:          // AreaLight.cpp:55-107 (rendererSupportsSolidAngleSampling = true)
+    case RT_LIGHT_AREA:          // AreaLight.cpp:55-107
     {
         const M4 worldToLight = loadM4(L.invTransform), lightToWorld = loadM4(L.transform);
-        const V4 ref = transformPoint(worldToLight, isect.frame.r[3]);
-        ShapeSample s;
-        if (!shapeSampleFrom(L.shapeKind, L.shapeParam, ref, u, s)) return zero4();
-        out.directionToLight = transformVector(lightToWorld, s.direction);
-        out.distance = s.distance; out.cosAtLight = s.cosAtSurface; out.directPdfW = s.pdf;
+        if (solidAngle)
+        {
+            const V4 ref = transformPoint(worldToLight, isect.frame.r[3]);
+            ShapeSample s;
+            if (!shapeSampleFrom(L.shapeKind, L.shapeParam, ref, u, s)) return zero4();
+            out.directionToLight = transformVector(lightToWorld, s.direction);
+            out.distance = s.distance; out.cosAtLight = s.cosAtSurface; out.directPdfW = s.pdf;
+        }
+        else                     // :79-104: a point on the surface; the normal goes through TransformPoint like the reference
+        {
+            V4 normalLocalSpace;
+            const V4 samplePositionLocalSpace = shapeSampleArea(L.shapeKind, L.shapeParam, u, normalLocalSpace);
+            const V4 lightPointWorldSpace = transformPoint(lightToWorld, samplePositionLocalSpace);
+            const V4 normalWorldSpace = transformPoint(lightToWorld, normalLocalSpace);
+            out.directionToLight = lightPointWorldSpace - isect.frame.r[3];
+            const float sqrDistance = sqrLength3(out.directionToLight);
+            out.distance = sqrtf(sqrDistance);
+            out.directionToLight = out.directionToLight / out.distance;
+            const float cosNormalDir = dot3(neg(normalWorldSpace), out.directionToLight);
+            if (cosNormalDir < RTO_EPSILON) return zero4();
+            const float invArea = 1.0f / shapeSurfaceArea(L.shapeKind, L.shapeParam);
+            out.cosAtLight = cosNormalDir;
+            out.directPdfW = invArea * sqrDistance / cosNormalDir;
+            out.emissionPdfW = cosNormalDir * invArea * RTO_INV_PI;
+        }
         return color;
     }
     case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:63-76
@@ -840,6 +870,7 @@ static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const I
         const V4 dirLocal = getHemisphere(u[0], u[1]);
         out.directionToLight = localToWorld(isect, dirLocal);
         out.directPdfW = uniformHemispherePdf();
+        out.emissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius);
         out.distance = FLT_MAX;
         out.cosAtLight = 1.0f;
         return backgroundColor(d, L, out.directionToLight);
@@ -860,6 +891,7 @@ static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const I
             dir = normalized3(dir);
         }
         out.directionToLight = transformVectorNeg(loadM4(L.transform), dir);
+        out.emissionPdfW = out.directPdfW * uniformCirclePdf(kSceneRadius);
         out.cosAtLight = 1.0f;
         out.distance = FLT_MAX;
         return color;
@@ -869,6 +901,7 @@ static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const I
         out.directionToLight = load4(L.transform + 12) - isect.frame.r[3];
         const float sqrDistance = sqrLength3(out.directionToLight);
         out.directPdfW = sqrDistance;
+        out.emissionPdfW = RTO_INV_PI / 4.0f;
         out.distance = sqrtf(sqrDistance);
         out.directionToLight = out.directionToLight / out.distance;
         out.cosAtLight = 1.0f;
@@ -882,6 +915,7 @@ static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const I
         out.distance = sqrtf(sqrDistance);
         out.directionToLight = out.directionToLight / out.distance;
         out.cosAtLight = 1.0f;
+        out.emissionPdfW = L.isDelta ? 1.0f : sphereCapPdf(L.cosAngle);
         const float angle = dot3(out.directionToLight, neg(V4(0, 0, 1, 0)));
         if (angle < L.cosAngle) return zero4();
         return color;
@@ -890,24 +924,119 @@ static inline V4 lightIlluminate(const RtSceneDesc* d, const RtLight& L, const I
 }
 
 // ILight::GetRadiance for a ray that hit / escaped; ray and hitPoint are in light space.
-static inline V4 lightGetRadiance(const RtSceneDesc* d, const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
+static inline V4 lightGetRadiance(const RtSceneDesc* d, const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA,
+                                  float* outEmissionPdfW = nullptr, bool solidAngle = true)
 {
     switch (L.type)
     {
     case RT_LIGHT_AREA:          // AreaLight.cpp:109-147
+    {
         if (cosAtLight < RTO_EPSILON) return zero4();
-        outDirectPdfA = shapePdf(L.shapeKind, L.shapeParam, lray.origin, hitPoint);
+        const float invArea = 1.0f / shapeSurfaceArea(L.shapeKind, L.shapeParam);
+        outDirectPdfA = solidAngle ? shapePdf(L.shapeKind, L.shapeParam, lray.origin, hitPoint) : invArea;
+        if (outEmissionPdfW) *outEmissionPdfW = cosAtLight * invArea * RTO_INV_PI;
         return load4(L.color);
+    }
     case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:78-92
         outDirectPdfA = uniformHemispherePdf();
+        if (outEmissionPdfW) *outEmissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius);
         return backgroundColor(d, L, lray.dir);
     case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:94-121
         if (L.isDelta) return zero4();
         if (dot3(lray.dir, V4(0, 0, 1, 0)) > -L.cosAngle) return zero4();
         outDirectPdfA = sphereCapPdf(L.cosAngle);
+        if (outEmissionPdfW) *outEmissionPdfW = outDirectPdfA * uniformCirclePdf(kSceneRadius);
         return load4(L.color);
     default:                     // point/spot cannot be hit (ILight::GetRadiance Light.cpp:28-32 is fatal)
         return zero4();
+    }
+}
+
+// ILight::Emit: a photon leaving the light (bidirectional integrator).  positionSample = 3 floats, directionSample = 2.
+struct EmitResult { V4 position, direction; float directPdfA, emissionPdfW, cosAtLight; };
+static inline V4 lightEmit(const RtSceneDesc* d, const RtLight& L, const float up[3], const float ud[2], EmitResult& out)
+{
+    const M4 lightToWorld = loadM4(L.transform);
+    switch (L.type)
+    {
+    case RT_LIGHT_AREA:          // AreaLight.cpp:149-185
+    {
+        V4 normalLocalSpace;
+        const V4 samplePositionLocalSpace = shapeSampleArea(L.shapeKind, L.shapeParam, up, normalLocalSpace);
+        out.position = transformPoint(lightToWorld, samplePositionLocalSpace);
+        V4 tangentLocalSpace, bitangentLocalSpace;
+        buildOrthonormalBasis(normalLocalSpace, tangentLocalSpace, bitangentLocalSpace);
+        const V4 randomDir = getHemisphereCos(ud[0], ud[1]);
+        const V4 dirLocalSpace = randomDir.x * tangentLocalSpace + randomDir.y * bitangentLocalSpace + randomDir.z * normalLocalSpace;
+        out.direction = transformVector(lightToWorld, dirLocalSpace);
+        const float cosAtLight = randomDir.z;
+        const float invArea = 1.0f / shapeSurfaceArea(L.shapeKind, L.shapeParam);
+        out.cosAtLight = cosAtLight;
+        out.directPdfA = invArea;
+        out.emissionPdfW = invArea * cosAtLight * RTO_INV_PI;
+        return load4(L.color) * cosAtLight;
+    }
+    case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:92-116
+    {
+        out.direction = getSphere(ud[0], ud[1]);
+        const V4 uv = getCircle(up[0], up[1]);
+        V4 u, v;
+        buildOrthonormalBasis(out.direction, u, v);
+        out.position = kSceneRadius * (u * uv.x + v * uv.y - out.direction);
+        out.directPdfA = uniformHemispherePdf();
+        out.emissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius);
+        out.cosAtLight = 1.0f;
+        return backgroundColor(d, L, neg(out.direction));
+    }
+    case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:120-135 (SampleDirection :47-78); the origin disc is NOT transformed
+    {
+        V4 dir = zero4();
+        if (L.isDelta) { out.directPdfA = 1.0f; dir = V4(0, 0, 1, 0); }
+        else
+        {
+            out.directPdfA = sphereCapPdf(L.cosAngle);
+            const float phi = RTO_2PI * ud[1];
+            const V4 sinCosPhi = sinCos(phi);
+            float cosTheta = Lerp(L.cosAngle, 1.0f, ud[0]);
+            float sinThetaSqr = 1.0f - Sqr(cosTheta);
+            float sinTheta = sqrtf(sinThetaSqr);
+            dir.x = sinTheta * sinCosPhi.x; dir.y = sinTheta * sinCosPhi.y; dir.z = cosTheta;
+            dir = normalized3(dir);
+        }
+        out.direction = transformVector(lightToWorld, neg(dir));
+        const V4 uv = getCircle(up[0], up[1]);
+        out.position = V4(uv.x, uv.y, -1.0f, 0.0f) * kSceneRadius;
+        out.cosAtLight = 1.0f;
+        out.emissionPdfW = out.directPdfA * uniformCirclePdf(kSceneRadius);
+        return load4(L.color);
+    }
+    case RT_LIGHT_POINT:         // PointLight.cpp:51-62
+        out.position = lightToWorld.r[3];
+        out.direction = getSphere(ud[0], ud[1]);
+        out.emissionPdfW = RTO_INV_PI / 4.0f;
+        out.directPdfA = 1.0f;
+        out.cosAtLight = 1.0f;
+        return load4(L.color);
+    default:                     // RT_LIGHT_SPOT, SpotLight.cpp:63-93
+    {
+        if (L.isDelta) { out.emissionPdfW = 1.0f; out.direction = V4(0, 0, 1, 0); }
+        else
+        {
+            const float phi = RTO_2PI * ud[1];
+            const V4 sinCosPhi = sinCos(phi);
+            float cosTheta = Lerp(L.cosAngle, 1.0f, ud[0]);
+            float sinThetaSqr = 1.0f - Sqr(cosTheta);
+            float sinTheta = sqrtf(sinThetaSqr);
+            V4 dir = zero4();
+            dir.x = sinTheta * sinCosPhi.x; dir.y = sinTheta * sinCosPhi.y; dir.z = cosTheta;
+            out.direction = normalized3(dir);
+            out.emissionPdfW = sphereCapPdf(L.cosAngle);
+        }
+        out.position = lightToWorld.r[3];
+        out.directPdfA = 1.0f;
+        out.cosAtLight = 1.0f;
+        return load4(L.color);
+    }
     }
 }
 
@@ -920,6 +1049,7 @@ enum { EV_NULL = 0, EV_DIFFUSE_REFLECTION = 1, EV_GLOSSY_REFLECTION = 4, EV_GLOS
        EV_SPECULAR = 48 };   // BSDF.h:25-43
 
 struct MatParams { V4 baseColor, emission; float roughness, metalness, IoR; };   // SampledMaterialParameters ShadingData.h:12-19
+static inline bool bsdfIsDelta(uint32_t bsdf) { return bsdf == RT_BSDF_DIELECTRIC || bsdf == RT_BSDF_METAL; }   // BSDF::IsDelta, *BSDF.h:12
 
 // GGX microfacet, Core/Material/BSDF/Microfacet.h:10-60 (alpha = roughness^2)
 struct Microfacet
@@ -1149,7 +1279,7 @@ static bool bsdfSampleImpl(uint32_t bsdf, const RtMaterial& mat, const MatParams
     }
 }
 
-static inline V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)   // PlasticBSDF.cpp:66-99
+static inline V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf, float* outRev = nullptr)   // PlasticBSDF.cpp:66-99
 {
     const float NdotV = outgoingDir.z;
     const float NdotL = -incomingDir.z;
@@ -1162,12 +1292,15 @@ static inline V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 inc
     const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
     const float diffuseProbability = 1.0f - specularProbability;
     outPdf = NdotL * RTO_INV_PI * diffuseProbability;
+    if (outRev) *outRev = NdotV * RTO_INV_PI * diffuseProbability;
     return mp.baseColor * (NdotL * RTO_INV_PI * (1.0f - Fi) * (1.0f - Fo));
 }
 
 // BSDF::Evaluate.  outPdf is left untouched on the early-out paths exactly like the reference (the
-// caller only reads it when the returned colour is not AlmostZero).
-static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)
+// caller only reads it when the returned colour is not AlmostZero).  outRev = *outReversePdfW (bidirectional integrator).
+// The reference leaves *outReversePdfW unwritten when RoughPlasticBSDF falls back to PlasticBSDF (RoughPlasticBSDF.cpp:95-98,
+// an uninitialised read in its callers); here that case gets PlasticBSDF's reverse pdf.
+static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf, float* outRev = nullptr)
 {
     switch (bsdf)
     {
@@ -1178,6 +1311,7 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
         {
             outPdf = NdotL * RTO_INV_PI;
+            if (outRev) *outRev = NdotV * RTO_INV_PI;
             return mp.baseColor * splat(NdotL * RTO_INV_PI);
         }
         return zero4();
@@ -1188,6 +1322,7 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
         {
             outPdf = NdotL * RTO_INV_PI;
+            if (outRev) *outRev = NdotV * RTO_INV_PI;
             const float LdotV = Max(0.0f, dot3(outgoingDir, neg(incomingDir)));
             const float roughness = mp.roughness;
             const float s2 = roughness * roughness;
@@ -1200,7 +1335,7 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         }
         return zero4();
     }
-    case RT_BSDF_DIELECTRIC: outPdf = 0.0f; return zero4();       // DielectricBSDF.cpp:105-121
+    case RT_BSDF_DIELECTRIC: outPdf = 0.0f; if (outRev) *outRev = 0.0f; return zero4();       // DielectricBSDF.cpp:105-121
     case RT_BSDF_ROUGH_DIELECTRIC:                                // RoughDielectricBSDF.cpp:117-193
     {
         const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
@@ -1234,9 +1369,10 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
             color = Abs(VdotH * LdotH) * (1.0f - F) * G * D / (denom * Abs(NdotV));
         }
         outPdf = pdf;
+        if (outRev) *outRev = pdf;
         return splat(color);
     }
-    case RT_BSDF_METAL: outPdf = 0.0f; return zero4();            // MetalBSDF.cpp:37-54
+    case RT_BSDF_METAL: outPdf = 0.0f; if (outRev) *outRev = 0.0f; return zero4();            // MetalBSDF.cpp:37-54
     case RT_BSDF_ROUGH_METAL:                                     // RoughMetalBSDF.cpp:67-107
     {
         const float roughness = mp.roughness;
@@ -1250,13 +1386,14 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         const float G = microfacet.G(NdotV, NdotL);
         const float F = fresnelMetal(VdotH, mat.IoR, mat.K);
         outPdf = microfacet.Pdf(m) / (4.0f * VdotH);
+        if (outRev) *outRev = outPdf;
         return mp.baseColor * splat(F * G * D / (4.0f * NdotV));
     }
-    case RT_BSDF_PLASTIC: return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+    case RT_BSDF_PLASTIC: return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf, outRev);
     default:                                                      // RT_BSDF_ROUGH_PLASTIC, RoughPlasticBSDF.cpp:90-158
     {
         const float roughness = mp.roughness;
-        if (roughness < kSpecularEventRoughnessTreshold) return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf, outRev);
         const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
         if (NdotV < kCosEpsilon || NdotL < kCosEpsilon) return zero4();
         const float ior = mp.IoR;
@@ -1284,9 +1421,20 @@ static V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
             }
         }
         outPdf = diffusePdf * diffuseProbability + specularPdf * specularProbability;
+        if (outRev) *outRev = (NdotV * RTO_INV_PI) * diffuseProbability + specularPdf * specularProbability;
         return diffuseTerm + specularTerm;
     }
     }
+}
+
+// BSDF::Pdf(ctx, dir): every implementation repeats the pdf expressions of its Evaluate and returns 0 where Evaluate
+// returns black without writing them (DiffuseBSDF.cpp:56-75, RoughDiffuseBSDF.cpp:75-94, PlasticBSDF.cpp:101-128,
+// RoughMetalBSDF.cpp:109-137, RoughDielectricBSDF.cpp:195-253, RoughPlasticBSDF.cpp:160-216; delta BSDFs: 0).
+static inline float bsdfPdf(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, bool reverse)
+{
+    float fwd = 0.0f, rev = 0.0f;
+    bsdfEvaluate(bsdf, mat, mp, outgoingDir, incomingDir, fwd, &rev);
+    return reverse ? rev : fwd;
 }
 
 struct ShadingData { Intersection intersection; V4 outgoingDirWorldSpace; MatParams mp; };   // ShadingData.h:21-30
@@ -1307,11 +1455,11 @@ static inline void materialEvaluateShadingData(const RtSceneDesc* d, const RtMat
     sd.mp.IoR = mat.IoR;
 }
 // Material::Evaluate, Material.cpp:160-180
-static inline V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW)
+static inline V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW, float* outRevPdfW = nullptr)
 {
     const V4 incomingLocal = worldToLocal(sd.intersection, incomingDirWorldSpace);
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    return bsdfEvaluate(mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW);
+    return bsdfEvaluate(mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW, outRevPdfW);
 }
 // Material::Sample, Material.cpp:182-232
 static inline V4 materialSample(const RtMaterial& mat, const ShadingData& sd, const float u[3], V4& outIncomingDirWorldSpace, float& outPdfW, uint32_t& outEvent)

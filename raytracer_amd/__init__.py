@@ -125,7 +125,8 @@ class RtBlock(C.Structure):
 
 class RtCamera(C.Structure):
     _fields_ = [("localToWorld", C.c_float * 16), ("aspectRatio", C.c_float), ("tanHalfFoV", C.c_float), ("dofEnable", C.c_uint32),
-                ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2)]
+                ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2),
+                ("worldToScreen", C.c_float * 16)]
 
 
 class RtPassParams(C.Structure):

@@ -38,9 +38,14 @@ public:
     float barrelDistortionVariableFactor;
     bool enableBarellDistortion;
 
+    // mLocalToWorld.FastInverseNoScale() * Matrix4::MakePerspective(aspect, FoV, 0.01f, 1000.0f) in the reference's
+    // operation order (Matrix4.h:186-193, Matrix4.cpp:15-24 and :35-70)
+    RAYLIB_API static math::Matrix4 ComputeWorldToScreen(const math::Matrix4& localToWorld, float aspectRatio, float tanHalfFoV);
+
 private:
     float mTanHalfFoV;
     math::Matrix4 mLocalToWorld;
+    math::Matrix4 mWorldToScreen;   // as SetPerspective left it (reference Camera.cpp:39-48): not refreshed by SetTransform
 };
 
 } // namespace rt

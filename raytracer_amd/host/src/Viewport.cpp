@@ -28,6 +28,7 @@ Camera::Camera()
     , enableBarellDistortion(false)
     , mTanHalfFoV(tanf(DegToRad(20.0f) * 0.5f))
     , mLocalToWorld(Matrix4::Identity())
+    , mWorldToScreen(Matrix4::Identity())
 {
 }
 
@@ -42,6 +43,50 @@ void Camera::SetPerspective(float aspectRatio, float FoV)
     mAspectRatio = aspectRatio;
     mFieldOfView = FoV;
     mTanHalfFoV = tanf(mFieldOfView * 0.5f);
+    mWorldToScreen = ComputeWorldToScreen(mLocalToWorld, mAspectRatio, mTanHalfFoV);
+}
+
+Matrix4 Camera::ComputeWorldToScreen(const Matrix4& l, float aspectRatio, float tanHalfFoV)
+{
+    // FastInverseNoScale: Transpose3 of the three axes (their w lanes end up as c.y, c.w, c.w), then the negated
+    // transform of the translation
+    const Vector4 a = l[0], b = l[1], c = l[2], t = l[3];
+    Matrix4 inv;
+    inv[0] = Vector4(a.x, b.x, c.x, c.y);
+    inv[1] = Vector4(a.y, b.y, c.y, c.w);
+    inv[2] = Vector4(a.z, b.z, c.z, c.w);
+    {
+        float r[4];
+        for (int k = 0; k < 4; ++k)
+        {
+            float v = t.x * (&inv[0].x)[k];
+            v = fmaf(-t.y, (&inv[1].x)[k], -v);
+            v = fmaf(-t.z, (&inv[2].x)[k], v);
+            r[k] = v;
+        }
+        inv[3] = Vector4(r[0], r[1], r[2], r[3]);
+    }
+    const float nearZ = 0.01f, farZ = 1000.0f;
+    const float yScale = 1.0f / tanHalfFoV;
+    const float xScale = yScale / aspectRatio;
+    const Vector4 p[4] = { Vector4(xScale, 0.0f, 0.0f, 0.0f), Vector4(0.0f, yScale, 0.0f, 0.0f),
+                           Vector4(0.0f, 0.0f, farZ / (farZ - nearZ), 1.0f), Vector4(0.0f, 0.0f, -nearZ * farZ / (farZ - nearZ), 0.0f) };
+    Matrix4 out;
+    for (int i = 0; i < 4; ++i)
+    {
+        const float* ai = &inv[i].x;
+        float r[4];
+        for (int k = 0; k < 4; ++k)
+        {
+            float v = ai[0] * (&p[0].x)[k];
+            v = fmaf(ai[1], (&p[1].x)[k], v);
+            v = fmaf(ai[2], (&p[2].x)[k], v);
+            v = fmaf(ai[3], (&p[3].x)[k], v);
+            r[k] = v;
+        }
+        out[i] = Vector4(r[0], r[1], r[2], r[3]);
+    }
+    return out;
 }
 
 bool Camera::GetDesc(RtCamera& out) const
@@ -54,6 +99,7 @@ bool Camera::GetDesc(RtCamera& out) const
     out.bokehShape = 0;
     out.focalPlaneDistance = mDOF.focalPlaneDistance;
     out.aperture = mDOF.aperture;
+    mWorldToScreen.Store(out.worldToScreen);
     if (mDOF.enable && mDOF.bokehShape != BokehShape::Circle)
     {
         fprintf(stderr, "[rt] ERROR: only circular bokeh is supported by the device path\n");

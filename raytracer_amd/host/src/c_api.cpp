@@ -286,6 +286,11 @@ RTH_API int rth_load_mesh_streams(const char* path, float scale, uint32_t* numVe
     if (materialIndices) memcpy(materialIndices, m.materialIndices.data(), m.materialIndices.size() * 4);
     return 0;
 }
+RTH_API void rth_kat_world_to_screen(const float localToWorld[16], float aspectRatio, float tanHalfFoV, float out[16])
+{
+    Matrix4 l; memcpy(&l, localToWorld, 64);
+    Camera::ComputeWorldToScreen(l, aspectRatio, tanHalfFoV).Store(out);
+}
 RTH_API int rth_kat_parse_double(const char* text, double* out) { return helpers::obj::TryParseDouble(text, text + strlen(text), out) ? 0 : -1; }
 
 RTH_API int rth_scene_build(void* sh) { return static_cast<SceneHandle*>(sh)->scene.BuildBVH() ? 0 : -1; }

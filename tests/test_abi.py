@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported(built):
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), "librtgpu.so does not export %s" % n
-    assert lib.rtgpu_abi_version() == 2
+    assert lib.rtgpu_abi_version() == 3
 
 
 def test_struct_layouts_agree(built):

@@ -130,3 +130,19 @@ def test_json_loader_rejects_what_the_reference_rejects(built, tmp_path):
     bad.write_text('{"objects": [')
     with pytest.raises(ValueError):
         ra.Scene().load_json(bad)
+
+
+def test_camera_world_to_screen_matches_reference(built):
+    """Camera::SetPerspective's mWorldToScreen (FastInverseNoScale x MakePerspective, with the reference's operation
+    order and its stray w lanes) recomputed by the host mirror from the camera_film.kat inputs: bit-exact."""
+    import ctypes as C
+    import kat_io
+    _, inputs, _ = kat_io.load_kat("camera_film.kat")
+    cw = C.sizeof(ra.RtCamera) // 4
+    h = ra.host_lib()
+    h.rth_kat_world_to_screen.restype = None
+    for row in inputs[:256]:
+        cam = ra.RtCamera.from_buffer_copy(row[:cw].tobytes())
+        out = (C.c_float * 16)()
+        h.rth_kat_world_to_screen(cam.localToWorld, C.c_float(cam.aspectRatio), C.c_float(cam.tanHalfFoV), out)
+        assert np.array_equal(np.frombuffer(out, np.uint32), np.frombuffer(cam.worldToScreen, np.uint32))
