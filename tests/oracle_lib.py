@@ -71,3 +71,41 @@ def xoroshiro(s0, s1, count):
     out = np.zeros(count, dtype=np.uint64)
     lib().rto_kat_xoroshiro(C.c_uint64(s0), C.c_uint64(s1), C.c_uint32(count), out.ctypes.data_as(C.POINTER(C.c_uint64)))
     return out
+
+
+class Vcm:
+    """The oracle's VertexConnectionAndMerging restatement (oracle/rto_vcm.h): holds the photons between passes."""
+
+    def __init__(self, max_path_length=10, use_vertex_connection=True, use_vertex_merging=True, initial_merging_radius=0.02,
+                 min_merging_radius=0.02, merging_radius_multiplier=1.0, bsdf_weight=1.0, light_weight=1.0, vertex_connecting_weight=1.0,
+                 camera_connecting_weight=1.0, vertex_merging_weight=1.0):
+        words = np.zeros(28, dtype=np.uint32)
+        words[0] = max_path_length; words[1] = int(use_vertex_connection); words[2] = int(use_vertex_merging)
+        words[3:6] = np.array([initial_merging_radius, min_merging_radius, merging_radius_multiplier], dtype=np.float32).view(np.uint32)
+        for k, wgt in enumerate((bsdf_weight, light_weight, vertex_connecting_weight, camera_connecting_weight, vertex_merging_weight)):
+            words[8 + 4 * k:12 + 4 * k] = np.full(4, wgt, dtype=np.float32).view(np.uint32)
+        self.settings = words
+        lib().rto_vcm_create.restype = C.c_void_p
+        lib().rto_vcm_num_photons.restype = C.c_uint32
+        self._h = C.c_void_p(lib().rto_vcm_create(words.ctypes.data_as(C.POINTER(C.c_uint32))))
+        self.passes = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rto_vcm_destroy(self._h)
+            self._h = None
+
+    def num_photons(self):
+        return int(lib().rto_vcm_num_photons(self._h))
+
+    def render_pass(self, scene_desc_ptr, params, width, height, sum_buf, secondary=None, light_sum=None, counters=None):
+        if counters is None:
+            counters = np.zeros(16, dtype=np.uint64)
+        fp = C.POINTER(C.c_float)
+        r = lib().rto_vcm_render_pass(self._h, scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(self.passes),
+                                      sum_buf.ctypes.data_as(fp), secondary.ctypes.data_as(fp) if secondary is not None else None,
+                                      light_sum.ctypes.data_as(fp) if light_sum is not None else None, counters.ctypes.data_as(C.POINTER(C.c_uint64)))
+        if r != 0:
+            raise RuntimeError("rto_vcm_render_pass failed")
+        self.passes += 1
+        return counters

@@ -1,0 +1,97 @@
+"""The oracle's restatement of the reference's bidirectional integrator (oracle/rto_vcm.h, VertexConnectionAndMerging.cpp).
+
+Its building blocks are pinned bit-exactly to the reference by golden vectors (tests/test_oracle_kat.py: light_emit,
+light_illuminate_bidir, light_radiance_bidir, bsdf_pdfs, camera_film, film_splat, packed_photon).  The integrator itself is
+checked here the way the reference checks it (the "VCM" leg of RenderingTest.* in Tests/RaytracingTests.cpp, same
+tolerances) and, where the reference's estimator is consistent, against the PathTracerMIS oracle in expectation."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import raytracer_amd as ra
+from raytracer_amd import scenes
+
+
+def render_vcm(scene, camera, w, h, passes, seed=2024, with_pt=False, **vcm_args):
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=seed, max_ray_depth=9, light_sampling_all=True)
+    cam = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32); pt = np.zeros((h, w, 3), dtype=np.float32)
+    vcm = oracle_lib.Vcm(**vcm_args)
+    for _ in range(passes):
+        p = vp.next_pass_params(camera)
+        vcm.render_pass(desc, p, w, h, cam, None, light)
+        if with_pt:
+            oracle_lib.render_pass(desc, p, w, h, pt, threads=8)
+    n = np.float32(passes)
+    return cam / n, light / n, pt / n, vcm
+
+
+def test_vcm_empty_scene_and_background_only(built):
+    """RenderingTest.EmptyScene / BackgroundLightOnly, VCM leg (Tests/RaytracingTests.cpp:263-315)."""
+    w = h = 32
+    cam0 = ra.Camera((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 90.0)
+    c, l, _, _ = render_vcm(ra.Scene().build(), cam0, w, h, 1)
+    assert np.all(c == 0.0) and np.all(l == 0.0)
+    scene = ra.Scene()
+    scene.add_background_light((1.0, 2.0, 3.0))
+    scene.build()
+    c, l, _, _ = render_vcm(scene, cam0, w, h, 1)
+    assert np.all(np.abs(c + l - np.array([1.0, 2.0, 3.0], dtype=np.float32)) <= 0.01)
+
+
+@pytest.mark.parametrize("bsdf,passes,expected,tol,kwargs", [
+    ("diffuse", 100, (0.4, 1.2, 2.4), 0.05, {}),
+    ("null", 1, (3.0, 2.0, 1.0), 0.0, {"base_color": (0.0, 0.0, 0.0), "emission": (3.0, 2.0, 1.0)}),
+    ("metal", 20, (0.4, 1.2, 2.4), 0.05, {"ior": 0.0, "k": 100.0}),
+    ("dielectric", 1000, (1.0, 2.0, 3.0), 0.075, {"base_color": (1.0, 1.0, 1.0)}),
+])
+def test_vcm_reference_furnace_tests(built, bsdf, passes, expected, tol, kwargs):
+    """RenderingTest.FurnaceTest_*, VCM leg (Tests/RaytracingTests.cpp:317-523): every pixel within the reference's tolerance."""
+    w = h = 32
+    scene, camera = scenes.furnace(bsdf, **kwargs)
+    c, l, _, _ = render_vcm(scene, camera, w, h, passes)
+    img = c + l
+    assert np.isfinite(img).all()
+    assert np.all(np.abs(img - np.array(expected, dtype=np.float32)) <= tol + 1e-6), float(np.abs(img - np.array(expected)).max())
+
+
+def _two_estimator_scene(aspect):
+    s = ra.Scene()
+    d1 = s.add_material("diffuse", (0.8, 0.6, 0.4))
+    d2 = s.add_material("roughPlastic", (0.3, 0.7, 0.9), roughness=0.3)
+    d3 = s.add_material("roughMetal", (0.9, 0.8, 0.6), roughness=0.4)
+    s.add_rect((8.0, 8.0), ra.transform_from_euler((0.0, -1.0, 0.0), (-90.0, 0.0, 0.0)), d1)
+    s.add_sphere(0.9, ra.transform_from_euler((-1.5, 0.0, 0.0)), d2)
+    s.add_box((0.7, 0.9, 0.6), ra.transform_from_euler((1.5, 0.0, 0.5), (0.0, 30.0, 0.0)), d3)
+    s.add_point_light((20.0, 18.0, 15.0), ra.transform_from_euler((0.5, 3.0, 1.0)))
+    s.add_background_light((0.2, 0.3, 0.5))
+    s.build()
+    return s, ra.Camera((0.5, 2.5, 7.0), (15.0, 180.0, 0.0), aspect, 55.0)
+
+
+def test_vcm_agrees_with_the_path_tracer_in_expectation(built):
+    """Point + background light (the two light types whose Emit / Illuminate pair is consistent in the reference): the
+    bidirectional estimate (camera paths + light-path splats) and PathTracerMIS converge to the same image.  Vertex
+    connection only is unbiased; with merging the bias at radius 0.02 stays inside the same 3 % band on the image mean.
+    Both estimators contribute (the light image is not empty), and photons are recorded for the next pass."""
+    w, h = 48, 36
+    scene, camera = _two_estimator_scene(w / h)
+    for kwargs in ({"use_vertex_merging": False}, {}):
+        c, l, pt, vcm = render_vcm(scene, camera, w, h, 96, with_pt=True, **kwargs)
+        total = c + l
+        assert np.isfinite(total).all()
+        assert l.mean() > 0.005 * total.mean()
+        rel = np.abs(total.mean(axis=(0, 1)) - pt.mean(axis=(0, 1))) / pt.mean(axis=(0, 1))
+        assert np.all(rel < 0.03), rel
+        assert (vcm.num_photons() > 0) == (not kwargs)
+
+
+def test_vcm_passes_are_reproducible(built):
+    """Same seed, same scene: identical bits (the per-pixel generator convention makes the oracle a function of its inputs)."""
+    w, h = 40, 30
+    scene, camera = _two_estimator_scene(w / h)
+    a = render_vcm(scene, camera, w, h, 3)
+    b = render_vcm(scene, camera, w, h, 3)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
