@@ -393,6 +393,39 @@ int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
  * always maintained.  Synchronises. */
 int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
 
+/* ---------------------------------------------------------------------------------------------
+ * Integrator selection.  RT_INTEGRATOR_PATH_TRACER_MIS (default) is rt::PathTracerMIS; RT_INTEGRATOR_VCM is
+ * rt::VertexConnectionAndMerging (Core/Rendering/VertexConnectionAndMerging.cpp, renderer name "VCM"): per pixel one light
+ * sub-path (light vertices connected to the camera -> film splats, photons recorded for the next pass) and one camera
+ * sub-path (light hits, next event estimation, connections to the pixel's light vertices, merging with the previous pass's
+ * photons through the hash grid of Core/Utils/HashGrid.h).  RtVcmParams carries the public knobs of the class
+ * (VertexConnectionAndMerging.h:35-53) with the constructor's defaults (.cpp:53-71).  RtPassParams::maxRayDepth,
+ * lightSamplingStrategy, the Russian-roulette depth and the two weights are ignored by VCM (the reference's class does not
+ * read them); passIndex == 0 restarts the merging radius and drops the recorded photons (PreRender, .cpp:84-138).
+ * The draws the reference takes from the per-thread generator come from a per-pixel generator keyed by
+ * RtPassParams::rngKey; film splats are float atomics (their summation order is not defined -- in the reference neither).
+ * VCM needs the whole frame on one device: shard {0, 1} and no active-block restriction.  Synchronises. */
+typedef enum RtIntegrator { RT_INTEGRATOR_PATH_TRACER_MIS = 0, RT_INTEGRATOR_VCM = 1 } RtIntegrator;
+typedef struct RtVcmParams
+{
+    uint32_t maxPathLength;            /* mMaxPathLength = 10 */
+    uint32_t useVertexConnection;      /* mUseVertexConnection = true */
+    uint32_t useVertexMerging;         /* mUseVertexMerging = true */
+    float    initialMergingRadius;     /* 0.02 */
+    float    minMergingRadius;         /* 0.02 */
+    float    mergingRadiusMultiplier;  /* 1.0 */
+    uint32_t _pad[2];
+    float    bsdfSamplingWeight[4];        /* mBSDFSamplingWeight      = 1 */
+    float    lightSamplingWeight[4];       /* mLightSamplingWeight     = 1 */
+    float    vertexConnectingWeight[4];    /* mVertexConnectingWeight  = 1 */
+    float    cameraConnectingWeight[4];    /* mCameraConnectingWeight  = 1 */
+    float    vertexMergingWeight[4];       /* mVertexMergingWeight     = 1 */
+} RtVcmParams;
+#define RT_VCM_MAX_PATH_LENGTH 16u
+int rtgpu_set_integrator(RtgpuContext* ctx, uint32_t integrator, const RtVcmParams* vcm /* NULL: defaults */);
+/* number of photons recorded by the last VCM pass (the merge set of the next one).  Synchronises. */
+int rtgpu_vcm_num_photons(RtgpuContext* ctx, uint32_t* outCount);
+
 /* Batch lanes (1..6, default 3).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
  * alternating HIP streams with their own path-state arenas, so the drain of one batch's traversal launches (a few
  * very long rays) overlaps with the next batch's kernels.  The film is still summed in pass order.  Performance

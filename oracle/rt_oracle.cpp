@@ -313,7 +313,7 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
         {
             RandomSimd rng; memcpy(rng.seed0, i + 4, 16); memcpy(rng.seed1, i + 8, 16);
             uint32_t x = 0xFFFFFFFFu, y = 0xFFFFFFFFu;
-            if (!filmSplatPixel(V4(i[0], i[1], 0.0f, 0.0f), fbits(i[2]), fbits(i[3]), rng, x, y)) { x = y = 0xFFFFFFFFu; }
+            if (!filmSplatPixel(V4(i[0], i[1], 0.0f, 0.0f), fbits(i[2]), fbits(i[3]), rng.getVector4(), x, y)) { x = y = 0xFFFFFFFFu; }
             o[0] = bitsf(x); o[1] = bitsf(y); memcpy(o + 2, rng.seed0, 16); memcpy(o + 6, rng.seed1, 16); break;
         }
         case KAT_PACKED_PHOTON:   // in: direction[4], colour[4]   out: packed direction, packed colour (2 words), unpacked direction[4], colour[4]
@@ -522,6 +522,7 @@ int rto_vcm_render_pass(void* h, const RtSceneDesc* scene, const RtPassParams* p
             ctx->sampler.resetPixel(x, y, params->rngKey);
             ctx->simd.resetPixel(x, y, params->rngKey);
             const Ray ray = cameraGenerateRay(params->camera, coords, ctx->sampler);
+            c.c[C_PRIMARY]++;
             const V4 color = vcmRenderPixel(*ctx, ray, passNumber);
             float* p = sum + 3 * ((size_t)y * width + x);
             p[0] = p[0] + color.x; p[1] = p[1] + color.y; p[2] = p[2] + color.z;

@@ -75,14 +75,14 @@ static inline float cameraDirectionPdfW(const RtCamera& cam, V4 direction)
 
 // ---- Film::AccumulateColor(pos, color, random), Core/Rendering/Film.cpp:41-77: the receiving pixel -------------------
 // returns false when the splat falls outside the film
-static inline bool filmSplatPixel(V4 pos, uint32_t width, uint32_t height, RandomSimd& rng, uint32_t& outX, uint32_t& outY)
+// (u = the Random::GetVector4 draw of :51)
+static inline bool filmSplatPixel(V4 pos, uint32_t width, uint32_t height, V4 u, uint32_t& outX, uint32_t& outY)
 {
     const V4 filmSize((float)width, (float)height, 0.0f, 0.0f);
     const V4 filmCoords = pos * filmSize + V4(0.0f, 0.5f, 0.0f, 0.0f);
     int32_t ix = cvtRN(filmCoords.x), iy = cvtRN(filmCoords.y);
     {
         const float fracX = filmCoords.x - (float)ix, fracY = filmCoords.y - (float)iy;
-        const V4 u = rng.getVector4();
         if (u.x < fracX) ix++;
         if (u.y < fracY) iy++;
     }
@@ -360,10 +360,10 @@ static inline bool vcmGenerateLightSample(VcmCtx& ctx, VcmPathState& outPath)
 }
 
 // Film::AccumulateColor(pos, value, random) on the oracle's float3 buffers
-static inline void vcmSplat(VcmCtx& ctx, V4 filmPos, V4 value)
+static inline void vcmSplat(VcmCtx& ctx, V4 filmPos, V4 value, V4 jitter)
 {
     uint32_t x, y;
-    if (!filmSplatPixel(filmPos, ctx.width, ctx.height, ctx.simd, x, y)) return;
+    if (!filmSplatPixel(filmPos, ctx.width, ctx.height, jitter, x, y)) return;
     float* p = ctx.sum + 3 * ((size_t)y * ctx.width + x);
     p[0] = p[0] + value.x; p[1] = p[1] + value.y; p[2] = p[2] + value.z;
     if (ctx.secondarySum) { float* q = ctx.secondarySum + 3 * ((size_t)y * ctx.width + x); q[0] = q[0] + value.x; q[1] = q[1] + value.y; q[2] = q[2] + value.z; }
@@ -387,6 +387,11 @@ static inline void vcmConnectToCamera(VcmCtx& ctx, const VcmLightVertex& lv)
 
     V4 filmPos;
     if (!cameraWorldToFilm(cam, samplePos, filmPos)) return;
+    // CONVENTION: the reference draws the film jitter inside Film::AccumulateColor, i.e. only for connections that turn out
+    // visible (:940-965).  Its generator is per-thread and entropy-seeded, so the stream position carries no meaning; here
+    // the draw is taken when the connection is set up, so that the per-pixel stream does not depend on a visibility
+    // result (a wavefront implementation only learns it one kernel later).  The draws are i.i.d.: same estimator.
+    const V4 jitter = ctx.simd.getVector4();
     if (vcmShadowed(ctx, samplePos, dirToCamera, cameraDistance)) return;
 
     const float cosToCamera = dot3(dirToCamera, lv.shadingData.intersection.frame.r[2]);
@@ -398,7 +403,7 @@ static inline void vcmConnectToCamera(VcmCtx& ctx, const VcmLightVertex& lv)
     const float misWeight = 1.0f / (wLight + 1.0f);
     V4 contribution = (cameraFactor * lv.throughput) * (misWeight * cameraPdfA / (cosToCamera));
     contribution = contribution * load4(ctx.r->s.cameraConnectingWeight);
-    vcmSplat(ctx, filmPos, contribution);
+    vcmSplat(ctx, filmPos, contribution, jitter);
 }
 
 // VertexConnectionAndMerging::TraceLightPath, :320-426

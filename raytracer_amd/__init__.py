@@ -386,6 +386,23 @@ class Viewport:
         self.has_renderer = True
         self.reset()
 
+    def set_vcm(self, max_path_length=10, use_vertex_connection=True, use_vertex_merging=True, initial_merging_radius=0.02,
+                min_merging_radius=0.02, merging_radius_multiplier=1.0, bsdf_weight=1.0, light_weight=1.0, vertex_connecting_weight=1.0,
+                camera_connecting_weight=1.0, vertex_merging_weight=1.0):
+        """The public members of rt::VertexConnectionAndMerging (renderer name "VCM"); takes effect with the next pass."""
+        w = (C.c_float * 5)(bsdf_weight, light_weight, vertex_connecting_weight, camera_connecting_weight, vertex_merging_weight)
+        r = host_lib().rth_viewport_set_vcm(self._h, C.c_uint32(max_path_length), int(bool(use_vertex_connection)), int(bool(use_vertex_merging)),
+                                            C.c_float(initial_merging_radius), C.c_float(min_merging_radius), C.c_float(merging_radius_multiplier), w)
+        if r != 0:
+            raise RuntimeError("set_vcm: the viewport's renderer is not \"VCM\"")
+
+    def vcm_num_photons(self):
+        n = C.c_uint32(0)
+        ctx = C.c_void_p(host_lib().rth_viewport_device_ctx(self._h))
+        if rtgpu_lib().rtgpu_vcm_num_photons(ctx, C.byref(n)) != 0:
+            raise RuntimeError(rtgpu_lib().rtgpu_last_error().decode())
+        return int(n.value)
+
     def set_shard(self, rank, world_size):
         if host_lib().rth_viewport_set_shard(self._h, C.c_uint32(rank), C.c_uint32(world_size)) != 0:
             raise RuntimeError("set_shard failed")

@@ -127,6 +127,12 @@ RT_DEV float shapeSurfaceArea(uint32_t kind, const float* p)
 // IShape::Sample(u, &normal)  (area sampling): BoxShape.cpp:127-179, RectShape.cpp:51-64
 RT_DEV V4 shapeSampleArea(uint32_t kind, const float* p, const float u[3], V4& outNormal)
 {
+    if (kind == RT_SHAPE_SPHERE)   // SphereShape.cpp:47-63 (bidirectional integrator only)
+    {
+        const V4 point = getSphere(u[0], u[1]);
+        outNormal = point;
+        return point * p[0];
+    }
     if (kind == RT_SHAPE_RECT)
     {
         outNormal = V4(0.0f, 0.0f, 1.0f, 0.0f);
@@ -981,7 +987,7 @@ RT_DEV bool bsdfSampleImpl(uint32_t bsdf, const RtMaterial& mat, const MatParams
     }
 }
 
-RT_DEV V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)   // PlasticBSDF.cpp:66-99
+RT_DEV V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf, float* outRev = nullptr)   // PlasticBSDF.cpp:66-99
 {
     const float NdotV = outgoingDir.z;
     const float NdotL = -incomingDir.z;
@@ -994,12 +1000,15 @@ RT_DEV V4 bsdfEvaluatePlastic(const MatParams& mp, V4 outgoingDir, V4 incomingDi
     const float specularProbability = specularWeight / (specularWeight + diffuseWeight);
     const float diffuseProbability = 1.0f - specularProbability;
     outPdf = NdotL * RTD_INV_PI * diffuseProbability;
+    if (outRev) *outRev = NdotV * RTD_INV_PI * diffuseProbability;
     return mp.baseColor * (NdotL * RTD_INV_PI * (1.0f - Fi) * (1.0f - Fo));
 }
 
 // BSDF::Evaluate.  outPdf is left untouched on the early-out paths exactly like the reference (the
 // caller only reads it when the returned colour is not AlmostZero).
-RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf)
+// outRev = *outReversePdfW (bidirectional integrator only).  The reference leaves it unwritten when RoughPlasticBSDF falls back to
+// PlasticBSDF (RoughPlasticBSDF.cpp:95-98, an uninitialised read in its callers); here that case gets PlasticBSDF's reverse pdf.
+RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp, V4 outgoingDir, V4 incomingDir, float& outPdf, float* outRev = nullptr)
 {
     switch (bsdf)
     {
@@ -1010,6 +1019,7 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
         {
             outPdf = NdotL * RTD_INV_PI;
+            if (outRev) *outRev = NdotV * RTD_INV_PI;
             return mp.baseColor * splat(NdotL * RTD_INV_PI);
         }
         return zero4();
@@ -1020,6 +1030,7 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         if (NdotV > kCosEpsilon && NdotL > kCosEpsilon)
         {
             outPdf = NdotL * RTD_INV_PI;
+            if (outRev) *outRev = NdotV * RTD_INV_PI;
             const float LdotV = Max(0.0f, dot3(outgoingDir, neg(incomingDir)));
             const float roughness = mp.roughness;
             const float s2 = roughness * roughness;
@@ -1032,7 +1043,7 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         }
         return zero4();
     }
-    case RT_BSDF_DIELECTRIC: outPdf = 0.0f; return zero4();       // DielectricBSDF.cpp:105-121
+    case RT_BSDF_DIELECTRIC: outPdf = 0.0f; if (outRev) *outRev = 0.0f; return zero4();       // DielectricBSDF.cpp:105-121
     case RT_BSDF_ROUGH_DIELECTRIC:                                // RoughDielectricBSDF.cpp:117-193
     {
         const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
@@ -1066,9 +1077,10 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
             color = Abs(VdotH * LdotH) * (1.0f - F) * G * D / (denom * Abs(NdotV));
         }
         outPdf = pdf;
+        if (outRev) *outRev = pdf;
         return splat(color);
     }
-    case RT_BSDF_METAL: outPdf = 0.0f; return zero4();            // MetalBSDF.cpp:37-54
+    case RT_BSDF_METAL: outPdf = 0.0f; if (outRev) *outRev = 0.0f; return zero4();            // MetalBSDF.cpp:37-54
     case RT_BSDF_ROUGH_METAL:                                     // RoughMetalBSDF.cpp:67-107
     {
         const float roughness = mp.roughness;
@@ -1082,13 +1094,14 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
         const float G = microfacet.G(NdotV, NdotL);
         const float F = fresnelMetal(VdotH, mat.IoR, mat.K);
         outPdf = microfacet.Pdf(m) / (4.0f * VdotH);
+        if (outRev) *outRev = outPdf;
         return mp.baseColor * splat(F * G * D / (4.0f * NdotV));
     }
-    case RT_BSDF_PLASTIC: return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+    case RT_BSDF_PLASTIC: return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf, outRev);
     default:                                                      // RT_BSDF_ROUGH_PLASTIC, RoughPlasticBSDF.cpp:90-158
     {
         const float roughness = mp.roughness;
-        if (roughness < kSpecularEventRoughnessTreshold) return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf);
+        if (roughness < kSpecularEventRoughnessTreshold) return bsdfEvaluatePlastic(mp, outgoingDir, incomingDir, outPdf, outRev);
         const float NdotV = outgoingDir.z, NdotL = -incomingDir.z;
         if (NdotV < kCosEpsilon || NdotL < kCosEpsilon) return zero4();
         const float ior = mp.IoR;
@@ -1116,6 +1129,7 @@ RT_DEV V4 bsdfEvaluate(uint32_t bsdf, const RtMaterial& mat, const MatParams& mp
             }
         }
         outPdf = diffusePdf * diffuseProbability + specularPdf * specularProbability;
+        if (outRev) *outRev = (NdotV * RTD_INV_PI) * diffuseProbability + specularPdf * specularProbability;
         return diffuseTerm + specularTerm;
     }
     }
@@ -1144,11 +1158,11 @@ RT_DEV void materialEvaluateShadingData(const RtSceneDesc& d, const RtMaterial& 
 // Material::Evaluate, Material.cpp:160-180
 // kLean: every material of the scene uses the diffuse BSDF
 template <bool kLean>
-__device__ __forceinline__ static V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW)
+__device__ __forceinline__ static V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW, float* outRevPdfW = nullptr)
 {
     const V4 incomingLocal = worldToLocal(sd.intersection, incomingDirWorldSpace);
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    return bsdfEvaluate(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW);
+    return bsdfEvaluate(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW, outRevPdfW);
 }
 // Material::Sample, Material.cpp:182-232
 template <bool kLean>

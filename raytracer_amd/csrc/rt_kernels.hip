@@ -756,6 +756,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
     flushCounters(cnt, counters);
 }
 
+#include "rt_vcm.inl"
+
 // Viewport::PostProcessTile (Viewport.cpp:495-550): sum buffer -> 0x00RRGGBB front buffer, one thread per pixel
 struct PostScale { float c[3]; };
 __global__ void __launch_bounds__(RT_BLOCK) k_postprocess(const float* __restrict__ sum, uint32_t* __restrict__ front, uint32_t width, uint32_t height,
@@ -900,6 +902,23 @@ struct RtgpuContext
     bool seedEventUsed[RT_SEED_RING];
     uint32_t seedCursor = 0;
 
+    // bidirectional integrator (rt_vcm.inl); runs one pass at a time on lane 0's stream
+    struct Vcm
+    {
+        bool enabled = false;
+        RtVcmParams params;
+        float mergingRadiusVC = 0.0f, mergingRadiusVM = 0.0f;
+        Paths lightPaths = { nullptr, 0, 0 }, cameraPaths = { nullptr, 0, 0 };
+        VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
+        uint32_t* queues[4] = { nullptr, nullptr, nullptr, nullptr };          // light ping-pong, camera ping-pong
+        uint32_t* shadowQueues[4] = { nullptr, nullptr, nullptr, nullptr };
+        uint32_t* counts = nullptr;                                               // 6 planes of RT_VCM_COUNT_PLANE
+        DevPass* passDev = nullptr; uint32_t* seedDev = nullptr;
+        VcmPhotonGrid grid;
+        bool havePhotons = false;     // the arena holds the photons of the previous pass
+        uint32_t requestsPerVertex = 0;
+    } vcm;
+
     // timing
     bool timing = false;
     struct Timed { int kc; hipEvent_t a, b; };
@@ -980,6 +999,7 @@ struct LaunchTimer
 };
 
 static int flushPending(RtgpuContext* c);
+static void freeVcm(RtgpuContext* c);
 
 template <typename T>
 static int uploadArray(RtgpuContext* c, const T* host, size_t count, const T** outDev)
@@ -1080,6 +1100,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
     for (uint32_t i = 0; i < RT_MAX_LANES; ++i)
     {
         freePaths(c->lanes[i]);
+        if (i == 0) freeVcm(c);
         if (c->lanes[i].queueCounts) (void)hipFree(c->lanes[i].queueCounts);
         if (c->lanes[i].accumulated) (void)hipEventDestroy(c->lanes[i].accumulated);
     }
@@ -1456,6 +1477,219 @@ static int flushPending(RtgpuContext* c)
     return RTGPU_OK;
 }
 
+// =====================================================================================================
+// Bidirectional integrator: host side (kernels in rt_vcm.inl)
+// =====================================================================================================
+#define RT_VCM_COUNT_PLANE (RT_VCM_MAX_PATH_LENGTH + 4u)
+
+static void freeVcm(RtgpuContext* c)
+{
+    RtgpuContext::Vcm& v = c->vcm;
+    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount,
+                     v.queues[0], v.queues[1], v.queues[2], v.queues[3], v.shadowQueues[0], v.shadowQueues[1], v.shadowQueues[2], v.shadowQueues[3], v.counts,
+                     v.passDev, v.seedDev };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    vcmFreePhotonGrid(v.grid);
+    const bool enabled = v.enabled; const RtVcmParams params = v.params;
+    v = RtgpuContext::Vcm();
+    v.enabled = enabled; v.params = params;
+}
+
+static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
+{
+    RtgpuContext::Vcm& v = c->vcm;
+    const uint32_t requests = c->numLights + maxLV;
+    if (v.arena.recs && v.arena.capacity >= c->numSlots && v.arena.maxLV >= maxLV && v.requestsPerVertex >= requests) return RTGPU_OK;
+    HIP_TRY(syncLanes(c));
+    freeVcm(c);
+    const size_t cap = c->numSlots ? c->numSlots : 1;
+    if ((unsigned long long)cap * (requests ? requests : 1u) >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x shadow requests per vertex exceeds the request index range");
+    HIP_TRY(hipMalloc((void**)&v.lightPaths.base, ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * cap * sizeof(float4)));
+    v.lightPaths.capacity = (uint32_t)cap; v.lightPaths.maxLights = 1;
+    HIP_TRY(hipMalloc((void**)&v.cameraPaths.base, ((size_t)R_NUM_BASE + (size_t)(requests ? requests : 1u) * RT_SHADOW_RECORDS) * cap * sizeof(float4)));
+    v.cameraPaths.capacity = (uint32_t)cap; v.cameraPaths.maxLights = requests ? requests : 1u;
+    HIP_TRY(hipMalloc((void**)&v.arena.recs, (size_t)V_NUM * cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&v.arena.lightVertices, (size_t)maxLV * RT_VCM_LV_RECORDS * cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&v.arena.photonRaw, (size_t)maxLV * 2 * cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(v.arena.photonCount, 0, cap * sizeof(uint32_t)));
+    v.arena.capacity = (uint32_t)cap; v.arena.maxLV = maxLV;
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));
+    for (int k = 2; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)6 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.passDev, sizeof(DevPass)));
+    HIP_TRY(hipMalloc((void**)&v.seedDev, (size_t)RTGPU_MAX_DIMENSIONS * sizeof(uint32_t)));
+    v.requestsPerVertex = requests;
+    v.havePhotons = false;
+    return RTGPU_OK;
+}
+
+static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc, uint32_t* cursor)
+{
+    const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
+    LaunchTimer t(c, stream, KC_TRACE);
+#define RT_VCM_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, stream, c->sceneDev, paths, tq, tqc, tsq, tsc, cursor, c->counters, c->tune)
+    if (stackClass == 24u) { if (c->countIntersections) RT_VCM_TRACE(24, true); else RT_VCM_TRACE(24, false); }
+    else if (stackClass == 32u) { if (c->countIntersections) RT_VCM_TRACE(32, true); else RT_VCM_TRACE(32, false); }
+    else { if (c->countIntersections) RT_VCM_TRACE(64, true); else RT_VCM_TRACE(64, false); }
+#undef RT_VCM_TRACE
+}
+
+// One VertexConnectionAndMerging pass: PreRender (.cpp:84-170) on the host, then the launch sequence of rt_vcm.inl
+static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
+{
+    RtgpuContext::Vcm& v = c->vcm;
+    const RtVcmParams& vp = v.params;
+    if (c->shard.rank != 0 || c->shard.worldSize != 1) return fail(RTGPU_ERR_UNSUPPORTED, "VCM needs the whole frame on one device (shard {0, 1})");
+    if (!c->activeMask.empty()) return fail(RTGPU_ERR_UNSUPPORTED, "VCM does not support active-block restriction");
+    const uint32_t maxLV = vp.maxPathLength > 1u ? vp.maxPathLength - 1u : 1u;
+    if (c->numLights + maxLV > 64u) return fail(RTGPU_ERR_UNSUPPORTED, "VCM: lights + light vertices per pixel must not exceed 64");
+    { int r = flushPending(c); if (r) return r; }
+    HIP_TRY(syncLanes(c));
+    { int r = ensureVcm(c, maxLV); if (r) return r; }
+    hipStream_t stream = c->lanes[0].stream;
+    const uint32_t passNumber = p->passIndex;
+
+    // PreRender(passNumber, film), :84-124
+    const uint32_t lightPathsCount = c->height * c->width;
+    if (passNumber == 0u) { v.mergingRadiusVC = vp.initialMergingRadius; v.mergingRadiusVM = vp.initialMergingRadius; v.havePhotons = false; }
+    else
+    {
+        v.mergingRadiusVM = v.mergingRadiusVC;
+        v.mergingRadiusVC *= vp.mergingRadiusMultiplier;
+        v.mergingRadiusVC = v.mergingRadiusVC > vp.minMergingRadius ? v.mergingRadiusVC : vp.minMergingRadius;
+    }
+    VcmDev dev; memset(&dev, 0, sizeof(dev));
+    dev.maxPathLength = vp.maxPathLength; dev.useVertexConnection = vp.useVertexConnection; dev.useVertexMerging = vp.useVertexMerging; dev.iteration = passNumber;
+    dev.vertexMergingNormalizationFactor = 1.0f / ((v.mergingRadiusVM * v.mergingRadiusVM) * RTD_PI * lightPathsCount);
+    {
+        const float etaVCM = RTD_PI * (v.mergingRadiusVC * v.mergingRadiusVC) * lightPathsCount;
+        dev.misVertexMergingWeightFactorVC = (vp.useVertexMerging && passNumber > 0u) ? etaVCM : 0.0f;
+        dev.misVertexConnectionWeightFactorVC = vp.useVertexConnection ? (1.f / etaVCM) : 0.0f;
+    }
+    {
+        const float etaVCM = RTD_PI * (v.mergingRadiusVM * v.mergingRadiusVM) * lightPathsCount;
+        dev.misVertexMergingWeightFactorVM = vp.useVertexMerging ? etaVCM : 0.0f;
+        dev.misVertexConnectionWeightFactorVM = vp.useVertexConnection ? (1.f / etaVCM) : 0.0f;
+    }
+    memcpy(dev.bsdfSamplingWeight, vp.bsdfSamplingWeight, 16); memcpy(dev.lightSamplingWeight, vp.lightSamplingWeight, 16);
+    memcpy(dev.vertexConnectingWeight, vp.vertexConnectingWeight, 16); memcpy(dev.cameraConnectingWeight, vp.cameraConnectingWeight, 16);
+    memcpy(dev.vertexMergingWeight, vp.vertexMergingWeight, 16);
+
+    // PreRenderGlobal, :140-170: last pass's photons become the merge set
+    HashGridView grid; memset(&grid, 0, sizeof(grid));
+    if (vp.useVertexMerging && v.havePhotons)
+    {
+        VcmPhotonInput in = { v.arena.photonRaw, v.arena.photonCount, c->slotPixel, c->numSlots, v.arena.capacity, c->width, c->height, v.arena.maxLV };
+        const int e = vcmBuildPhotonGrid(in, v.mergingRadiusVM, stream, v.grid);
+        if (e != 0) return fail(e == (int)hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_DEVICE, std::string("photon grid: ") + hipGetErrorString((hipError_t)e));
+        grid.photons = reinterpret_cast<const Photon*>(v.grid.photons); grid.indices = v.grid.indices; grid.cellEnds = v.grid.cellEnds;
+        grid.radiusSqr = v.grid.radiusSqr; grid.invCellSize = v.grid.invCellSize; grid.hashTableMask = v.grid.hashTableMask; grid.numPhotons = v.grid.numPhotons;
+        if (v.grid.numPhotons) HIP_TRY(hipMemcpyAsync(grid.boxMin, v.grid.boxMin, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+
+    // pass constants
+    DevPass pass; memset(&pass, 0, sizeof(pass));
+    pass.camera = p->camera; pass.seed = v.seedDev; pass.numDimensions = p->numDimensions;
+    pass.blueNoiseLayers = (c->sceneDev.blueNoise && p->useBlueNoise) ? 4u : 0u;
+    pass.sampleOffset[0] = p->sampleOffset[0]; pass.sampleOffset[1] = p->sampleOffset[1];
+    pass.passIndex = p->passIndex; pass.maxRayDepth = vp.maxPathLength; pass.rngKey[0] = p->rngKey[0]; pass.rngKey[1] = p->rngKey[1];
+    pass.width = c->width; pass.height = c->height;
+    if (p->numDimensions) HIP_TRY(hipMemcpyAsync(v.seedDev, p->seed, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(v.passDev, &pass, sizeof(pass), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));   // `pass` and the caller's seed array are host temporaries
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)6 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
+    uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE; uint32_t* csc = v.counts + 4 * RT_VCM_COUNT_PLANE; uint32_t* ccur = v.counts + 5 * RT_VCM_COUNT_PLANE;
+    uint32_t** lq = v.queues; uint32_t** cq = v.queues + 2; uint32_t** lsq = v.shadowQueues; uint32_t** csq = v.shadowQueues + 2;
+
+    const uint32_t maxBlocks = c->numCUs * 8u;
+    const uint32_t blocksNeeded = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
+    const dim3 grid1(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), block(RT_BLOCK);
+
+    {
+        LaunchTimer t(c, stream, KC_GENERATE);
+        hipLaunchKernelGGL(k_generate, grid1, block, 0, stream, c->sceneDev, v.passDev, c->numSlots, v.cameraPaths, c->slotPixel, c->numSlots, cq[0], cpc + 0, c->counters);
+        hipLaunchKernelGGL(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, c->numSlots, lq[0], lpc + 0);
+    }
+    // light sub-paths
+    for (uint32_t b = 0; b < maxLV; ++b)
+    {
+        const bool haveShadow = b > 0 && vp.useVertexConnection;
+        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b);
+        LaunchTimer t(c, stream, KC_SHADE);
+        hipLaunchKernelGGL(k_vcm_light_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
+                           lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);
+    }
+    if (vp.useVertexConnection)
+    {
+        launchTrace(c, stream, v.lightPaths, nullptr, nullptr, lsq[(maxLV - 1u) & 1u], lsc + (maxLV - 1u), lcur + maxLV);
+        LaunchTimer t(c, stream, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_vcm_light_finish, grid1, block, 0, stream, v.passDev, v.lightPaths, c->numSlots, c->sum, c->secondary, c->counters);
+    }
+    // camera sub-paths
+    for (uint32_t d = 0; d < vp.maxPathLength; ++d)
+    {
+        const bool haveShadow = d > 0;
+        launchTrace(c, stream, v.cameraPaths, cq[d & 1u], cpc + d, haveShadow ? csq[(d - 1u) & 1u] : nullptr, haveShadow ? csc + (d - 1u) : nullptr, ccur + d);
+        LaunchTimer t(c, stream, KC_SHADE);
+        hipLaunchKernelGGL(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.cameraPaths, v.arena, grid, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
+                           csq[d & 1u], csc + d, c->counters);
+    }
+    launchTrace(c, stream, v.cameraPaths, nullptr, nullptr, csq[(vp.maxPathLength - 1u) & 1u], csc + (vp.maxPathLength - 1u), ccur + vp.maxPathLength);
+    {
+        LaunchTimer t(c, stream, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_vcm_camera_finish, grid1, block, 0, stream, v.passDev, dev, v.cameraPaths, v.arena, c->numSlots, c->sum, c->secondary, c->width, c->counters);
+    }
+    HIP_TRY(hipGetLastError());
+    v.havePhotons = vp.useVertexMerging != 0u;
+    return RTGPU_OK;
+}
+
+static void defaultVcmParams(RtVcmParams& vp)
+{
+    memset(&vp, 0, sizeof(vp));
+    vp.maxPathLength = 10; vp.useVertexConnection = 1; vp.useVertexMerging = 1;
+    vp.initialMergingRadius = 0.02f; vp.minMergingRadius = 0.02f; vp.mergingRadiusMultiplier = 1.0f;
+    for (int k = 0; k < 4; ++k) vp.bsdfSamplingWeight[k] = vp.lightSamplingWeight[k] = vp.vertexConnectingWeight[k] = vp.cameraConnectingWeight[k] = vp.vertexMergingWeight[k] = 1.0f;
+}
+
+RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const RtVcmParams* vcm)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (integrator != RT_INTEGRATOR_PATH_TRACER_MIS && integrator != RT_INTEGRATOR_VCM) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    RtVcmParams vp; defaultVcmParams(vp);
+    if (vcm) vp = *vcm;
+    if (integrator == RT_INTEGRATOR_VCM)
+    {
+        if (vp.maxPathLength < 1u || vp.maxPathLength > RT_VCM_MAX_PATH_LENGTH) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxPathLength must be 1..16");
+        if (!(vp.initialMergingRadius >= vp.minMergingRadius) || !(vp.minMergingRadius > 0.0f)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "merging radii: initial >= min > 0 required");
+        if (!(vp.mergingRadiusMultiplier > 0.0f && vp.mergingRadiusMultiplier <= 1.0f)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mergingRadiusMultiplier must be in (0, 1]");
+    }
+    c->vcm.enabled = integrator == RT_INTEGRATOR_VCM;
+    c->vcm.params = vp;
+    c->vcm.havePhotons = false;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_vcm_num_photons(RtgpuContext* c, uint32_t* outCount)
+{
+    if (!c || !outCount) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    *outCount = 0;
+    if (!c->vcm.havePhotons || !c->vcm.arena.photonCount) return RTGPU_OK;
+    std::vector<uint32_t> counts(c->numSlots);
+    HIP_TRY(hipMemcpy(counts.data(), c->vcm.arena.photonCount, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    unsigned long long total = 0; for (uint32_t n : counts) total += n;
+    *outCount = (uint32_t)total;
+    return RTGPU_OK;
+}
+
 RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
 {
     if (!c || !p) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1466,6 +1700,7 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     if (p->maxRayDepth >= 255u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxRayDepth must be < 255");
     if (p->camera.dofEnable && p->camera.bokehShape != 0) return fail(RTGPU_ERR_UNSUPPORTED, "only circular bokeh is implemented");
     if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
+    if (c->vcm.enabled) return vcmRenderPass(c, p);
 
     CtxPending pd;
     DevPass& pass = pd.pass;

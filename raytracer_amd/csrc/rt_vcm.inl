@@ -1,0 +1,669 @@
+// rt_vcm.inl -- wavefront form of the reference's bidirectional integrator (Core/Rendering/VertexConnectionAndMerging.cpp),
+// included by rt_kernels.hip (it reuses the path-record arena, the persistent traversal kernel and the context).
+//
+// One pass over the whole frame (RenderPixel, :172-318, for every pixel):
+//
+//   generate                     camera rays (as for PathTracerMIS)                                   Viewport.cpp:305-331
+//   photon grid                  HashGrid::Build over the photons recorded by the PREVIOUS pass        :126-170, HashGrid.h:17-71
+//   vcm_emit                     GenerateLightSample                                                    :428-491
+//   for vertex = 1 .. maxPathLength-1:                                         TraceLightPath,         :320-426
+//       trace                    closest hit of the light sub-paths + the camera-connection shadow rays of the previous vertex
+//       vcm_light_shade          splat the previous vertex's connection if visible; store the light vertex and the photon;
+//                                ConnectToCamera (:908-966) up to the shadow ray; AdvancePath (:493-578)
+//   trace + vcm_light_finish     the connections of each path's last vertex
+//   for vertex = 1 .. maxPathLength:                                            camera sub-path,        :184-314
+//       trace                    closest hit + the shadow rays queued by the previous vertex
+//       vcm_camera_shade         fold the previous vertex's visible next-event / connection / merging terms into the radiance;
+//                                light hit (EvaluateLight :580-635); SampleLights (:637-731), ConnectVertices (:746-821) to the
+//                                pixel's light vertices and MergeVertices (:823-906) at this vertex; AdvancePath
+//   trace + vcm_camera_finish    last vertex's terms, Film::AccumulateColor
+//
+// Shadow-ray results arrive one kernel after the terms that need them are computed; the terms are stored per request and
+// folded in afterwards IN THE REFERENCE'S ORDER (lights, then light vertices, then merging), so the camera-path radiance is
+// independent of the schedule (bit-identical to a scalar evaluation of the same pixel).  Film splats are float atomics.
+
+#include "rt_device_vcm.h"
+#include "rt_vcm_photons.h"
+
+// ---- per-slot state beyond the PathTracerMIS records ---------------------------------------------------------------------
+enum VcmRecord : uint32_t
+{
+    V_MIS,      // dVC, dVM, dVCM | path length (bits 0-7), isFiniteLight << 9
+    V_SIMD0,    // Random::mSeedSimd4[0] (two 64-bit lanes)
+    V_SIMD1,    // Random::mSeedSimd4[1]
+    V_MERGE,    // camera stage: throughput * vertexMergingColor (rgb) of the vertex whose terms are pending | 1 = present
+    V_NUM
+};
+#define RT_VCM_LV_RECORDS 6u   // light vertex: {pos | material, pathLength << 24}, {tangent | roughness}, {normal | metalness},
+                               //               {outgoing dir | dVC}, {baseColor}, {throughput | dVCM}
+struct VcmArena
+{
+    float4* recs;            // V_NUM x capacity
+    float4* lightVertices;   // maxLV x RT_VCM_LV_RECORDS x capacity
+    float4* photonRaw;       // maxLV x 2 x capacity (this pass's photons, per slot)
+    uint32_t* lvCount;       // light vertices of the slot's light sub-path
+    uint32_t* photonCount;
+    uint32_t capacity, maxLV;
+};
+RT_DEV float4& vrec(const VcmArena& a, uint32_t record, uint32_t slot) { return a.recs[(size_t)record * a.capacity + slot]; }
+RT_DEV float4& lvrec(const VcmArena& a, uint32_t vertex, uint32_t record, uint32_t slot) { return a.lightVertices[((size_t)vertex * RT_VCM_LV_RECORDS + record) * a.capacity + slot]; }
+
+struct VcmDev   // VertexConnectionAndMerging members after PreRender (.cpp:84-124)
+{
+    uint32_t maxPathLength, useVertexConnection, useVertexMerging, iteration;
+    float misVertexMergingWeightFactorVC, misVertexConnectionWeightFactorVC, misVertexMergingWeightFactorVM, misVertexConnectionWeightFactorVM;
+    float vertexMergingNormalizationFactor;
+    float bsdfSamplingWeight[4], lightSamplingWeight[4], vertexConnectingWeight[4], cameraConnectingWeight[4], vertexMergingWeight[4];
+};
+
+RT_DEV float vcmPdfWtoA(float pdfW, float distance, float cosThere) { return pdfW * Abs(cosThere) / Sqr(distance); }   // :25-28
+
+RT_DEV void loadSimd(RandomSimd& r, const VcmArena& a, uint32_t slot)
+{
+    const float4 s0 = vrec(a, V_SIMD0, slot), s1 = vrec(a, V_SIMD1, slot);
+    r.seed0[0] = (uint64_t)ubits(s0.x) | ((uint64_t)ubits(s0.y) << 32); r.seed0[1] = (uint64_t)ubits(s0.z) | ((uint64_t)ubits(s0.w) << 32);
+    r.seed1[0] = (uint64_t)ubits(s1.x) | ((uint64_t)ubits(s1.y) << 32); r.seed1[1] = (uint64_t)ubits(s1.z) | ((uint64_t)ubits(s1.w) << 32);
+}
+RT_DEV void storeSimd(const RandomSimd& r, const VcmArena& a, uint32_t slot)
+{
+    vrec(a, V_SIMD0, slot) = f4(fbits((uint32_t)r.seed0[0]), fbits((uint32_t)(r.seed0[0] >> 32)), fbits((uint32_t)r.seed0[1]), fbits((uint32_t)(r.seed0[1] >> 32)));
+    vrec(a, V_SIMD1, slot) = f4(fbits((uint32_t)r.seed1[0]), fbits((uint32_t)(r.seed1[0] >> 32)), fbits((uint32_t)r.seed1[1]), fbits((uint32_t)(r.seed1[1] >> 32)));
+}
+
+// one global atomic per wave: lanes with pred == true append `value`
+RT_DEV void waveAppend(uint32_t* __restrict__ queue, uint32_t* __restrict__ count, bool pred, uint32_t value)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (pred) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// ShadingData of a stored light vertex
+RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_t vertex, uint32_t slot, ShadingData& sd, V4& throughput, float& dVC, float& dVCM, uint32_t& pathLength)
+{
+    const float4 r0 = lvrec(a, vertex, 0, slot), r1 = lvrec(a, vertex, 1, slot), r2 = lvrec(a, vertex, 2, slot), r3 = lvrec(a, vertex, 3, slot);
+    const float4 r4 = lvrec(a, vertex, 4, slot), r5 = lvrec(a, vertex, 5, slot);
+    sd.intersection.frame.r[0] = V4(r1.x, r1.y, r1.z, 0.0f);
+    sd.intersection.frame.r[2] = V4(r2.x, r2.y, r2.z, 0.0f);
+    sd.intersection.frame.r[1] = cross3(sd.intersection.frame.r[0], sd.intersection.frame.r[2]);   // as Scene::EvaluateIntersection left it (Scene.cpp:345)
+    sd.intersection.frame.r[3] = V4(r0.x, r0.y, r0.z, 0.0f);
+    sd.intersection.texCoord = zero4();
+    sd.intersection.material = ubits(r0.w) & 0x00FFFFFFu;
+    pathLength = ubits(r0.w) >> 24;
+    sd.outgoingDirWorldSpace = V4(r3.x, r3.y, r3.z, 0.0f);
+    sd.mp.baseColor = V4(r4.x, r4.y, r4.z, r4.w); sd.mp.emission = zero4();
+    sd.mp.roughness = r1.w; sd.mp.metalness = r2.w; sd.mp.IoR = scene.materials[sd.intersection.material].IoR;
+    throughput = V4(r5.x, r5.y, r5.z, 0.0f);
+    dVC = r3.w; dVCM = r5.w;
+}
+
+// ---- light stage ---------------------------------------------------------------------------------------------------------
+
+// GenerateLightSample, :428-491.  The scalar generator (Random::GetInt) is the pixel's Sampler::fallback stream, which lives in
+// the CAMERA arena's R_RNG record (k_generate has reset it for this pass).
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const Paths cp,
+                                                       const VcmArena a, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
+                                                       uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount)
+{
+    const DevPass& pass = passes[0];
+    const uint32_t rounded = (numSlots + 63u) & ~63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < rounded; slot += stride)
+    {
+        bool ok = false;
+        if (slot < numSlots)
+        {
+            const uint32_t pix = slotPixel[slot];
+            const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
+            RandomSimd simd; simd.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
+            a.lvCount[slot] = 0u; a.photonCount[slot] = 0u;
+            prec(lp, R_SAMPLER, slot) = f4(0.0f, 0.0f, 0.0f, fbits(0u));
+            if (scene.numLights != 0u)
+            {
+                const float4 rng = prec(cp, R_RNG, slot);
+                Xoroshiro fb;
+                fb.s[0] = (uint64_t)ubits(rng.x) | ((uint64_t)ubits(rng.y) << 32); fb.s[1] = (uint64_t)ubits(rng.z) | ((uint64_t)ubits(rng.w) << 32);
+                const float lightPickProbability = 1.0f / (float)scene.numLights;
+                const uint32_t lightIndex = (uint32_t)xoroshiroNext(fb) % scene.numLights;
+                prec(cp, R_RNG, slot) = f4(fbits((uint32_t)fb.s[0]), fbits((uint32_t)(fb.s[0] >> 32)), fbits((uint32_t)fb.s[1]), fbits((uint32_t)(fb.s[1] >> 32)));
+                const RtLight& light = scene.lights[lightIndex];
+                const V4 ps = simd.getVector4(); const V4 ds = simd.getVector4();
+                const float up[3] = { ps.x, ps.y, ps.z }, ud[2] = { ds.x, ds.y };
+                EmitResult er; er.position = zero4(); er.direction = zero4(); er.directPdfA = er.emissionPdfW = er.cosAtLight = 0.0f;
+                const V4 emitted = lightEmit(scene, light, up, ud, er);
+                if (!almostZero4(emitted))
+                {
+                    er.directPdfA *= lightPickProbability;
+                    er.emissionPdfW *= lightPickProbability;
+                    const float emissionInvPdfW = 1.0f / er.emissionPdfW;
+                    er.position = er.position + er.direction * 0.0005f;
+                    const V4 throughput = emitted * emissionInvPdfW;
+                    const bool isFiniteLight = (light.flags & RT_LIGHT_FLAG_FINITE) != 0u;
+                    const float dVCM = er.directPdfA * emissionInvPdfW;
+                    float dVC = 0.0f;
+                    if ((light.flags & RT_LIGHT_FLAG_DELTA) == 0u)
+                    {
+                        const float cosAtLight = isFiniteLight ? er.cosAtLight : 1.0f;
+                        dVC = cosAtLight * emissionInvPdfW;
+                    }
+                    const float dVM = dVC * vcm.misVertexConnectionWeightFactorVC;
+                    prec(lp, R_ORIGIN, slot) = f4(er.position.x, er.position.y, er.position.z, fbits(0u));   // "depth" 0: no 1e-3 offset on the emitted ray
+                    prec(lp, R_DIR, slot) = f4(er.direction.x, er.direction.y, er.direction.z, 0.0f);
+                    prec(lp, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
+                    vrec(a, V_MIS, slot) = f4(dVC, dVM, dVCM, fbits(1u | (isFiniteLight ? 0x200u : 0u)));
+                    ok = true;
+                }
+            }
+            storeSimd(simd, a, slot);
+        }
+        waveAppend(queue, queueCount, ok, slot);
+    }
+}
+
+// the pending camera connection of a light-path vertex: splat it if the shadow ray reached the camera
+RT_DEV void resolveSplat(const Paths& lp, uint32_t slot, float* __restrict__ sum, float* __restrict__ secondary, bool evenPass, Counters& cnt)
+{
+    const float4 dirTmax = pshadow(lp, 0, 0, slot);
+    if (dirTmax.w < 0.0f) return;
+    cnt.c[C_SHADOW_HIT]++;
+    const float4 c = pshadow(lp, 0, 1, slot);
+    const uint32_t target = ubits(c.w);
+    if (target == 0xFFFFFFFFu) return;
+    atomicAdd(&sum[3 * (size_t)target + 0], c.x); atomicAdd(&sum[3 * (size_t)target + 1], c.y); atomicAdd(&sum[3 * (size_t)target + 2], c.z);
+    if (evenPass) { atomicAdd(&secondary[3 * (size_t)target + 0], c.x); atomicAdd(&secondary[3 * (size_t)target + 1], c.y); atomicAdd(&secondary[3 * (size_t)target + 2], c.z); }
+}
+
+// AdvancePath, :493-578.  Returns false when the walk ends; on success the new ray / throughput / MIS quantities are stored.
+RT_DEV bool vcmAdvancePath(const RtSceneDesc& scene, const VcmDev& vcm, const Paths& p, const VcmArena& a, uint32_t slot, const ShadingData& sd, const RtMaterial& mat,
+                           const float sample[3], V4 throughput, float dVC, float dVM, float dVCM, uint32_t length, uint32_t extraBits)
+{
+    V4 incomingDirWorldSpace = zero4(); float bsdfDirPdf = 0.0f; uint32_t sampledEvent = EV_NULL;
+    const V4 bsdfValue = materialSample<false>(mat, sd, sample, incomingDirWorldSpace, bsdfDirPdf, sampledEvent);
+    const float cosThetaOut = Abs(dot3(incomingDirWorldSpace, sd.intersection.frame.r[2]));
+    if (sampledEvent == EV_NULL) return false;
+    throughput = throughput * bsdfValue;
+    if (almostZero4(throughput)) return false;
+    length++;
+    bool lastSpecular;
+    if (sampledEvent & EV_SPECULAR)
+    {
+        dVC *= cosThetaOut;
+        dVM *= cosThetaOut;
+        dVCM = 0.0f;
+        lastSpecular = true;
+    }
+    else
+    {
+        const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
+        const V4 incomingLocal = neg(worldToLocal(sd.intersection, incomingDirWorldSpace));
+        const float bsdfRevPdf = bsdfPdf(mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, true);
+        const float invBsdfDirPdf = 1.0f / bsdfDirPdf;
+        const float newVC = (cosThetaOut * invBsdfDirPdf) * (dVC * bsdfRevPdf + dVCM + vcm.misVertexMergingWeightFactorVC);
+        const float newVM = (cosThetaOut * invBsdfDirPdf) * (dVM * bsdfRevPdf + dVCM * vcm.misVertexConnectionWeightFactorVC + 1.0f);
+        dVC = newVC; dVM = newVM;
+        dVCM = invBsdfDirPdf;
+        lastSpecular = false;
+    }
+    // depth field > 0: the traversal adds the 1e-3 offset to Ray(origin, direction) (:528-529); bit 8 = lastSpecular, bits 9.. = material + 1
+    prec(p, R_ORIGIN, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
+                                 fbits(((length - 1u) & 0xFFu) | (lastSpecular ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
+    prec(p, R_DIR, slot) = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, 0.0f);
+    prec(p, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
+    vrec(a, V_MIS, slot) = f4(dVC, dVM, dVCM, fbits(length | extraBits));
+    return true;
+}
+
+// One vertex of TraceLightPath's loop, :334-425
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const VcmArena a,
+                                                              const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                              uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                              uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                              float* __restrict__ sum, float* __restrict__ secondary, unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const DevPass& pass = passes[0];
+    const bool evenPass = (pass.passIndex % 2u) == 0u;
+    const uint32_t count = *countIn;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        bool alive = false, needRay = false;
+        uint32_t slot = 0;
+        if (i < count)
+        {
+            slot = queueIn[i];
+            const float4 rOrigin = prec(lp, R_ORIGIN, slot), rDir = prec(lp, R_DIR, slot), rTp = prec(lp, R_TP, slot);
+            const float4 rHit = prec(lp, R_HIT, slot), rSampler = prec(lp, R_SAMPLER, slot), rMis = vrec(a, V_MIS, slot);
+            if (ubits(rSampler.w) != 0u) resolveSplat(lp, slot, sum, secondary, evenPass, cnt);
+            uint32_t pending = 0u;
+            const Ray ray = makePathRay(rOrigin, rDir, ubits(rOrigin.w) & 0xFFu);
+            V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+            float dVC = rMis.x, dVM = rMis.y, dVCM = rMis.z;
+            const uint32_t length = ubits(rMis.w) & 0xFFu;
+            const bool isFiniteLight = (ubits(rMis.w) & 0x200u) != 0u;
+            Hit hit; hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+            cnt.c[C_RAYS]++;
+            if (hit.objectId != RT_INVALID_OBJECT && hit.subObjectId != RT_LIGHT_OBJECT)
+            {
+                ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
+                sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                sd.outgoingDirWorldSpace = neg(ray.dir);
+                const RtMaterial& mat = scene.materials[sd.intersection.material];
+                materialEvaluateShadingData<false>(scene, mat, sd);
+                {
+                    if (length > 1u || isFiniteLight) dVCM *= Sqr(hit.distance);
+                    const float cosTheta = dot3(ray.dir, sd.intersection.frame.r[2]);
+                    const float invMis = 1.0f / Abs(cosTheta);
+                    dVCM *= invMis; dVC *= invMis; dVM *= invMis;
+                }
+                RandomSimd simd; loadSimd(simd, a, slot);
+                if (!bsdfIsDelta(mat.bsdf))
+                {
+                    if (vcm.useVertexConnection)
+                    {
+                        const uint32_t k = a.lvCount[slot];
+                        a.lvCount[slot] = k + 1u;
+                        const V4 pos = sd.intersection.frame.r[3], tg = sd.intersection.frame.r[0], nr = sd.intersection.frame.r[2], og = sd.outgoingDirWorldSpace;
+                        lvrec(a, k, 0, slot) = f4(pos.x, pos.y, pos.z, fbits(sd.intersection.material | (length << 24)));
+                        lvrec(a, k, 1, slot) = f4(tg.x, tg.y, tg.z, sd.mp.roughness);
+                        lvrec(a, k, 2, slot) = f4(nr.x, nr.y, nr.z, sd.mp.metalness);
+                        lvrec(a, k, 3, slot) = f4(og.x, og.y, og.z, dVC);
+                        lvrec(a, k, 4, slot) = f4(sd.mp.baseColor.x, sd.mp.baseColor.y, sd.mp.baseColor.z, sd.mp.baseColor.w);
+                        lvrec(a, k, 5, slot) = f4(throughput.x, throughput.y, throughput.z, dVCM);
+
+                        // ConnectToCamera, :908-966
+                        const RtCamera& cam = pass.camera;
+                        V4 dirToCamera = load4(cam.localToWorld + 12) - pos;
+                        const float cameraDistanceSqr = sqrLength3(dirToCamera);
+                        const float cameraDistance = sqrtf(cameraDistanceSqr);
+                        dirToCamera = dirToCamera / cameraDistance;
+                        float bsdfPdfW = 0.0f, bsdfRevPdfW = 0.0f;
+                        const V4 cameraFactor = materialEvaluate<false>(mat, sd, neg(dirToCamera), bsdfPdfW, &bsdfRevPdfW);
+                        float tmax = -1.0f; V4 contribution = zero4(); uint32_t target = 0xFFFFFFFFu;
+                        V4 filmPos;
+                        if (!almostZero4(cameraFactor) && cameraWorldToFilm(cam, pos, filmPos))
+                        {
+                            const V4 jitter = simd.getVector4();   // drawn when the connection is set up (the reference draws it inside Film::AccumulateColor,
+                                                                    // i.e. only for visible connections; its stream is per-thread and entropy-seeded, so the position carries no meaning)
+                            tmax = cameraDistance * 0.999f;
+                            const float cosToCamera = dot3(dirToCamera, nr);
+                            if (cosToCamera > FLT_EPSILON)
+                            {
+                                const float cameraPdfW = cameraDirectionPdfW(cam, neg(dirToCamera));
+                                const float cameraPdfA = cameraPdfW * cosToCamera / cameraDistanceSqr;
+                                const float wLight = cameraPdfA * (vcm.misVertexMergingWeightFactorVC + dVCM + dVC * bsdfRevPdfW);
+                                const float misWeight = 1.0f / (wLight + 1.0f);
+                                contribution = (cameraFactor * throughput) * (misWeight * cameraPdfA / (cosToCamera));
+                                contribution = contribution * load4(vcm.cameraConnectingWeight);
+                                uint32_t fx, fy;
+                                if (filmSplatPixel(filmPos, pass.width, pass.height, jitter, fx, fy)) target = fy * pass.width + fx;
+                            }
+                        }
+                        pshadow(lp, 0, 0, slot) = f4(dirToCamera.x, dirToCamera.y, dirToCamera.z, tmax);
+                        pshadow(lp, 0, 1, slot) = f4(contribution.x, contribution.y, contribution.z, fbits(target));
+                        prec(lp, R_SH_P, slot) = f4(pos.x, pos.y, pos.z, 0.0f);
+                        pending = 1u;
+                        needRay = tmax >= 0.0f;
+                    }
+                    if (vcm.useVertexMerging)
+                    {
+                        const uint32_t k = a.photonCount[slot];
+                        a.photonCount[slot] = k + 1u;
+                        float lum; uint32_t chroma;
+                        packColorHdr(throughput, lum, chroma);
+                        a.photonRaw[(size_t)(k * 2u + 0u) * a.capacity + slot] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, lum);
+                        a.photonRaw[(size_t)(k * 2u + 1u) * a.capacity + slot] = f4(fbits(chroma), fbits(packUnitVector(sd.outgoingDirWorldSpace)), dVM, dVCM);
+                    }
+                }
+                if (length + 2u <= vcm.maxPathLength)
+                {
+                    const V4 v = simd.getVector4();
+                    const float sample[3] = { v.x, v.y, v.z };
+                    alive = vcmAdvancePath(scene, vcm, lp, a, slot, sd, mat, sample, throughput, dVC, dVM, dVCM, length, isFiniteLight ? 0x200u : 0u);
+                }
+                storeSimd(simd, a, slot);
+            }
+            prec(lp, R_SAMPLER, slot).w = fbits(pending);
+        }
+        waveAppend(shadowQueue, shadowCount, needRay, slot);   // request id = light 0 * capacity + slot
+        waveAppend(queueOut, countOut, alive, slot);
+    }
+    flushCounters(cnt, counters);
+}
+
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_finish(const DevPass* __restrict__ passes, const Paths lp, uint32_t numSlots, float* __restrict__ sum,
+                                                               float* __restrict__ secondary, unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const bool evenPass = (passes[0].passIndex % 2u) == 0u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+        if (ubits(prec(lp, R_SAMPLER, slot).w) != 0u) resolveSplat(lp, slot, sum, secondary, evenPass, cnt);
+    flushCounters(cnt, counters);
+}
+
+// ---- camera stage --------------------------------------------------------------------------------------------------------
+
+// pending terms of the previous camera vertex: R_SAMPLER.w = numLightRequests | numConnectionRequests << 8 | merging << 16
+RT_DEV void vcmResolvePending(const Paths& cp, const VcmArena& a, const VcmDev& vcm, uint32_t slot, uint32_t pendingBits, V4& resultColor, Counters& cnt)
+{
+    if (pendingBits == 0u) return;
+    const uint32_t numLightRequests = pendingBits & 0xFFu, numConnections = (pendingBits >> 8) & 0xFFu;
+    const float4 tp4 = prec(cp, R_SH_TP, slot);
+    const V4 tp(tp4.x, tp4.y, tp4.z, 0.0f);
+    if (pendingBits & 0x1000000u)   // SampleLights ran for this vertex, :719-731 and :254-259
+    {
+        V4 accumulatedColor = zero4();
+        for (uint32_t l = 0; l < numLightRequests; ++l)
+        {
+            if (pshadow(cp, l, 0, slot).w < 0.0f) continue;
+            cnt.c[C_SHADOW_HIT]++;
+            const float4 c = pshadow(cp, l, 1, slot);
+            accumulatedColor = accumulatedColor + V4(c.x, c.y, c.z, 0.0f);
+        }
+        accumulatedColor = accumulatedColor * load4(vcm.lightSamplingWeight);
+        resultColor = mulAdd(tp, accumulatedColor, resultColor);
+    }
+    if (pendingBits & 0x2000000u)   // vertex connections, :262-283
+    {
+        V4 vertexConnectionColor = zero4();
+        for (uint32_t j = 0; j < numConnections; ++j)
+        {
+            const uint32_t r = numLightRequests + j;
+            if (pshadow(cp, r, 0, slot).w < 0.0f) continue;
+            cnt.c[C_SHADOW_HIT]++;
+            const float4 c = pshadow(cp, r, 1, slot);
+            const float4 lvTp = lvrec(a, ubits(c.w), 5, slot);
+            vertexConnectionColor = mulAdd(V4(lvTp.x, lvTp.y, lvTp.z, 0.0f), V4(c.x, c.y, c.z, 0.0f), vertexConnectionColor);
+        }
+        vertexConnectionColor = vertexConnectionColor * load4(vcm.vertexConnectingWeight);
+        resultColor = mulAdd(tp, vertexConnectionColor, resultColor);
+    }
+    if (pendingBits & 0x10000u)     // merging, :286-292
+    {
+        const float4 m = vrec(a, V_MERGE, slot);
+        resultColor = mulAdd(V4(m.x, m.y, m.z, 0.0f), vcm.vertexMergingNormalizationFactor, resultColor);
+    }
+}
+
+// EvaluateLight, :580-635 (isect == nullptr for global lights)
+RT_DEV V4 vcmEvaluateLight(const RtSceneDesc& scene, const VcmDev& vcm, const RtLight& light, const float* invTransform, const Intersection* isect, const Ray& ray,
+                           uint32_t length, bool lastSpecular, float dVC, float dVCM)
+{
+    const M4 worldToLight = loadM4(invTransform);
+    const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+    const float cosAtLight = isect ? -dot3(isect->frame.r[2], ray.dir) : 1.0f;
+    const V4 lightSpaceHitPoint = isect ? transformPoint(worldToLight, isect->frame.r[3]) : zero4();
+    float directPdfA = 0.0f, emissionPdfW = 0.0f;
+    V4 lightContribution = lightGetRadianceBidir(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA, emissionPdfW);
+    if (almostZero4(lightContribution)) return zero4();
+    if (length > 1u)
+    {
+        const bool useVertexMerging = vcm.useVertexMerging && vcm.iteration > 0u;
+        if (useVertexMerging && !vcm.useVertexConnection)
+        {
+            if (!lastSpecular) return zero4();
+        }
+        else
+        {
+            const float wCamera = directPdfA * dVCM + emissionPdfW * dVC;
+            const float misWeight = 1.0f / (1.0f + wCamera);
+            lightContribution = lightContribution * misWeight;
+        }
+    }
+    lightContribution = lightContribution * load4(vcm.bsdfSamplingWeight);
+    return lightContribution;
+}
+
+// One vertex of RenderPixel's loop, :201-314
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths cp, const VcmArena a,
+                                                               const HashGridView grid,
+                                                               const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                               uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount, unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const DevPass& pass = passes[0];
+    const uint32_t count = *countIn;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        bool alive = false;
+        uint32_t slot = 0;
+        unsigned long long rayMask = 0ull;   // requests of this vertex that need a shadow ray (at most 64 per vertex, checked by the host)
+        if (i < count)
+        {
+            slot = queueIn[i];
+            const float4 rOrigin = prec(cp, R_ORIGIN, slot), rDir = prec(cp, R_DIR, slot), rTp = prec(cp, R_TP, slot);
+            const float4 rResult = prec(cp, R_RESULT, slot), rHit = prec(cp, R_HIT, slot), rSampler = prec(cp, R_SAMPLER, slot);
+            const uint32_t flags = ubits(rOrigin.w);
+            const uint32_t depth = flags & 0xFFu, length = depth + 1u;
+            const bool lastSpecular = (flags & 0x100u) != 0u;
+            const uint32_t pix = ubits(rResult.w);
+            const Ray ray = makePathRay(rOrigin, rDir, depth);
+            V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+            vcmResolvePending(cp, a, vcm, slot, ubits(rSampler.w), resultColor, cnt);
+            float dVC, dVM, dVCM;
+            if (depth == 0u)   // :186-193
+            {
+                const float cameraPdf = cameraDirectionPdfW(pass.camera, ray.dir);
+                dVC = 0.0f; dVM = 0.0f; dVCM = 1.0f / cameraPdf;
+            }
+            else { const float4 rMis = vrec(a, V_MIS, slot); dVC = rMis.x; dVM = rMis.y; dVCM = rMis.z; }
+            Hit hit; hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+            cnt.c[C_RAYS]++;
+            uint32_t pendingBits = 0u;
+            bool samplerStored = false;
+            do
+            {
+                if (hit.objectId == RT_INVALID_OBJECT)
+                {
+                    V4 result = zero4();   // EvaluateGlobalLights, :733-744
+                    for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
+                    {
+                        const RtLight& light = scene.lights[scene.globalLights[g]];
+                        result = result + vcmEvaluateLight(scene, vcm, light, light.invTransform, nullptr, ray, length, lastSpecular, dVC, dVCM);
+                    }
+                    resultColor = mulAdd(throughput, result, resultColor);
+                    break;
+                }
+                ShadingData sd;
+                sd.intersection.material = (flags >> 9) - 1u;   // the path's one ShadingData keeps the previous vertex's material (see k_shade)
+                sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                {
+                    const float cosTheta = dot3(ray.dir, sd.intersection.frame.r[2]);
+                    const float invMis = 1.0f / Abs(cosTheta);
+                    dVCM *= Sqr(hit.distance);
+                    dVCM *= invMis; dVC *= invMis; dVM *= invMis;
+                }
+                if (hit.subObjectId == RT_LIGHT_OBJECT)
+                {
+                    const RtObject& obj = scene.objects[hit.objectId];
+                    const V4 lightColor = vcmEvaluateLight(scene, vcm, scene.lights[obj.lightIndex], obj.invTransform, &sd.intersection, ray, length, lastSpecular, dVC, dVCM);
+                    resultColor = mulAdd(throughput, lightColor, resultColor);
+                    break;
+                }
+                sd.outgoingDirWorldSpace = neg(ray.dir);
+                const RtMaterial& mat = scene.materials[sd.intersection.material];
+                materialEvaluateShadingData<false>(scene, mat, sd);
+                resultColor = mulAdd(throughput, sd.mp.emission, resultColor);
+                if (length >= vcm.maxPathLength) break;
+                const bool isDeltaBsdf = bsdfIsDelta(mat.bsdf);
+                const V4 pos = sd.intersection.frame.r[3];
+
+                Sampler sampler; loadSampler(sampler, cp, slot, pix, rSampler, pass, scene.blueNoise);
+
+                // SampleLights / SampleLight, :637-731
+                uint32_t numLightRequests = 0u;
+                if (!isDeltaBsdf && vcm.useVertexConnection)
+                {
+                    for (uint32_t l = 0; l < scene.numLights; ++l)
+                    {
+                        const RtLight& light = scene.lights[l];
+                        float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
+                        float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
+                        IlluminateResult ir; float emissionPdfW;
+                        const V4 radiance = lightIlluminateBidir(scene, light, sd.intersection, u, ir, emissionPdfW);
+                        if (!almostZero4(radiance))
+                        {
+                            float bsdfPdfW = 0.0f, bsdfRevPdfW = 0.0f;
+                            const V4 bsdfFactor = materialEvaluate<false>(mat, sd, neg(ir.directionToLight), bsdfPdfW, &bsdfRevPdfW);
+                            if (!almostZero4(bsdfFactor))
+                            {
+                                dir = ir.directionToLight; tmax = ir.distance * 0.999f;
+                                const float lightPickProbability = 1.0f;
+                                const bool isDeltaLight = (light.flags & RT_LIGHT_FLAG_DELTA) != 0u;
+                                const float continuationProbability = 1.0f;
+                                bsdfPdfW *= isDeltaLight ? 0.0f : continuationProbability;
+                                bsdfRevPdfW *= continuationProbability;
+                                const float cosToLight = dot3(sd.intersection.frame.r[2], ir.directionToLight);
+                                if (cosToLight > FLT_EPSILON)
+                                {
+                                    const float wLight = bsdfPdfW / (lightPickProbability * ir.directPdfW);
+                                    const float wCamera = (emissionPdfW * cosToLight / (ir.directPdfW * ir.cosAtLight)) * (vcm.misVertexMergingWeightFactorVC + dVCM + dVC * bsdfRevPdfW);
+                                    const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                                    contribution = (radiance * bsdfFactor) * (misWeight / (lightPickProbability * ir.directPdfW));
+                                }
+                            }
+                        }
+                        pshadow(cp, l, 0, slot) = f4(dir.x, dir.y, dir.z, tmax);
+                        pshadow(cp, l, 1, slot) = f4(contribution.x, contribution.y, contribution.z, 0.0f);
+                        if (tmax >= 0.0f) rayMask |= 1ull << l;
+                    }
+                    numLightRequests = scene.numLights;
+                    pendingBits |= 0x1000000u;
+                }
+
+                // ConnectVertices to the light vertices of this pixel, :262-283 and :746-821
+                uint32_t numConnections = 0u;
+                const uint32_t numLightVertices = a.lvCount[slot];
+                if (!isDeltaBsdf && vcm.useVertexConnection && numLightVertices > 0u)
+                {
+                    for (uint32_t v = 0; v < numLightVertices; ++v)
+                    {
+                        ShadingData lsd; V4 lvThroughput; float lvVC, lvVCM; uint32_t lvLength;
+                        loadLightVertex(scene, a, v, slot, lsd, lvThroughput, lvVC, lvVCM, lvLength);
+                        if (lvLength + length + 1u > vcm.maxPathLength) break;
+                        V4 lightDir = lsd.intersection.frame.r[3] - pos;
+                        const float distanceSqr = sqrLength3(lightDir);
+                        const float distance = sqrtf(distanceSqr);
+                        lightDir = lightDir / distance;
+                        const float cosCameraVertex = dot3(sd.intersection.frame.r[2], lightDir);
+                        const float cosLightVertex = dot3(lsd.intersection.frame.r[2], neg(lightDir));
+                        float tmax = -1.0f; V4 contribution = zero4();
+                        if (!(cosCameraVertex <= 0.0f || cosLightVertex <= 0.0f))
+                        {
+                            const float geometryTerm = 1.0f / distanceSqr;
+                            float cameraBsdfPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
+                            const V4 cameraFactor = materialEvaluate<false>(mat, sd, neg(lightDir), cameraBsdfPdfW, &cameraBsdfRevPdfW);
+                            if (!almostZero4(cameraFactor))
+                            {
+                                float lightBsdfPdfW = 0.0f, lightBsdfRevPdfW = 0.0f;
+                                const V4 lightFactor = materialEvaluate<false>(scene.materials[lsd.intersection.material], lsd, lightDir, lightBsdfPdfW, &lightBsdfRevPdfW);
+                                if (!almostZero4(lightFactor))
+                                {
+                                    tmax = distance * 0.999f;
+                                    const float continuationProbability = 1.0f;
+                                    lightBsdfPdfW *= continuationProbability;
+                                    lightBsdfRevPdfW *= continuationProbability;
+                                    const float cameraBsdfPdfA = vcmPdfWtoA(cameraBsdfPdfW, distance, cosLightVertex);
+                                    const float lightBsdfPdfA = vcmPdfWtoA(lightBsdfPdfW, distance, cosCameraVertex);
+                                    const float wLight = cameraBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + lvVCM + lvVC * lightBsdfRevPdfW);
+                                    const float wCamera = lightBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + dVCM + dVC * cameraBsdfRevPdfW);
+                                    const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                                    contribution = (cameraFactor * lightFactor) * (geometryTerm * misWeight);
+                                }
+                            }
+                        }
+                        const uint32_t r = numLightRequests + numConnections;
+                        pshadow(cp, r, 0, slot) = f4(lightDir.x, lightDir.y, lightDir.z, tmax);
+                        pshadow(cp, r, 1, slot) = f4(contribution.x, contribution.y, contribution.z, fbits(v));
+                        if (tmax >= 0.0f) rayMask |= 1ull << r;
+                        numConnections++;
+                    }
+                    pendingBits |= 0x2000000u;
+                }
+
+                // MergeVertices, :823-906
+                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u)
+                {
+                    V4 contribution = zero4();
+                    auto query = [&](uint32_t photonIndex)
+                    {
+                        const Photon& photon = grid.photons[photonIndex];
+                        const V4 lightDirection = unpackUnitVector(photon.direction);
+                        const float cosToLight = dot3(sd.intersection.frame.r[2], lightDirection);
+                        if (cosToLight < FLT_EPSILON) return;
+                        float cameraBsdfDirPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
+                        const V4 cameraBsdfFactor = materialEvaluate<false>(mat, sd, neg(lightDirection), cameraBsdfDirPdfW, &cameraBsdfRevPdfW);
+                        if (almostZero4(cameraBsdfFactor)) return;
+                        const V4 photonThroughput = unpackColorHdr(photon.lum, photon.chroma);
+                        const float wLight = photon.dVCM * vcm.misVertexConnectionWeightFactorVM + photon.dVM * cameraBsdfDirPdfW;
+                        const float wCamera = dVCM * vcm.misVertexConnectionWeightFactorVM + dVM * cameraBsdfRevPdfW;
+                        const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                        const float weight = misWeight / cosToLight;
+                        contribution = mulAdd(cameraBsdfFactor * photonThroughput, weight, contribution);
+                    };
+                    hashGridProcess(grid, pos, query);
+                    const V4 vertexMergingColor = contribution * load4(vcm.vertexMergingWeight);
+                    const V4 m = throughput * vertexMergingColor;
+                    vrec(a, V_MERGE, slot) = f4(m.x, m.y, m.z, 0.0f);
+                    pendingBits |= 0x10000u;
+                }
+                pendingBits |= numLightRequests | (numConnections << 8);
+                if (pendingBits != 0u)
+                {
+                    prec(cp, R_SH_P, slot) = f4(pos.x, pos.y, pos.z, 0.0f);
+                    prec(cp, R_SH_TP, slot) = f4(throughput.x, throughput.y, throughput.z, 0.0f);
+                }
+
+                // AdvancePath, :493-578 (length > maxPathLength cannot hold here, :308-311)
+                {
+                    float sample[3]; sample[0] = sampler.getFloat(); sample[1] = sampler.getFloat(); sample[2] = sampler.getFloat();
+                    alive = vcmAdvancePath(scene, vcm, cp, a, slot, sd, mat, sample, throughput, dVC, dVM, dVCM, length, 0u);
+                }
+                storeSampler(sampler, cp, slot, hit.v, pendingBits);
+                samplerStored = true;
+            } while (false);
+            if (!samplerStored) prec(cp, R_SAMPLER, slot).w = fbits(pendingBits);
+            prec(cp, R_RESULT, slot) = f4(resultColor.x, resultColor.y, resultColor.z, rResult.w);
+        }
+        // the shadow requests of this vertex (wave-uniform loop: every lane's lowest pending request per round)
+        for (unsigned long long pendingMask = rayMask; __ballot(pendingMask != 0ull) != 0ull; pendingMask &= pendingMask - 1ull)
+        {
+            const bool has = pendingMask != 0ull;
+            const uint32_t r = has ? (uint32_t)(__ffsll((long long)pendingMask) - 1) : 0u;
+            waveAppend(shadowQueue, shadowCount, has, r * cp.capacity + slot);
+        }
+        waveAppend(queueOut, countOut, alive, slot);
+    }
+    flushCounters(cnt, counters);
+}
+
+// the last vertex's pending terms, then Film::AccumulateColor(x, y, color) (Film.cpp:25-39)
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_finish(const DevPass* __restrict__ passes, const VcmDev vcm, const Paths cp, const VcmArena a, uint32_t numSlots,
+                                                                float* __restrict__ sum, float* __restrict__ secondary, uint32_t width, unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const bool evenPass = (passes[0].passIndex % 2u) == 0u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    {
+        const float4 rResult = prec(cp, R_RESULT, slot);
+        V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+        vcmResolvePending(cp, a, vcm, slot, ubits(prec(cp, R_SAMPLER, slot).w), resultColor, cnt);
+        const uint32_t pix = ubits(rResult.w);
+        const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
+        sum[idx + 0] = sum[idx + 0] + resultColor.x; sum[idx + 1] = sum[idx + 1] + resultColor.y; sum[idx + 2] = sum[idx + 2] + resultColor.z;
+        if (evenPass) { secondary[idx + 0] = secondary[idx + 0] + resultColor.x; secondary[idx + 1] = secondary[idx + 1] + resultColor.y; secondary[idx + 2] = secondary[idx + 2] + resultColor.z; }
+    }
+    flushCounters(cnt, counters);
+}

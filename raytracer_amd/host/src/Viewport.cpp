@@ -1,6 +1,7 @@
 // Camera, Bitmap, Viewport and the renderer factory.  Host side.
 #include "../Core/Rendering/Viewport.h"
 #include "../Core/Rendering/PathTracerMIS.h"
+#include "../Core/Rendering/VertexConnectionAndMerging.h"
 #include "../Core/Textures/BitmapTexture.h"
 #include "../Core/Textures/CheckerboardTexture.h"
 #include "../Core/Textures/ConstTexture.h"
@@ -551,7 +552,13 @@ RendererPtr CreateRenderer(const std::string& name, const Scene& scene)
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
-    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer MIS\")\n", name.c_str());
+    if (name == "VCM")
+    {
+        std::shared_ptr<VertexConnectionAndMerging> r(new VertexConnectionAndMerging(scene));
+        if (!r->GetDeviceContext()) return nullptr;
+        return r;
+    }
+    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer MIS\" and \"VCM\")\n", name.c_str());
     return nullptr;
 }
 
@@ -626,6 +633,37 @@ bool PathTracerMIS::RenderPass(const RtPassParams& params)
         return false;
     }
     return true;
+}
+
+VertexConnectionAndMerging::VertexConnectionAndMerging(const Scene& scene)
+    : PathTracerMIS(scene)
+    , mVertexConnectingWeight(1.0f), mVertexMergingWeight(1.0f), mCameraConnectingWeight(1.0f)
+    , mMaxPathLength(10), mInitialMergingRadius(0.02f), mMinMergingRadius(0.02f), mMergingRadiusMultiplier(1.0f)   // VertexConnectionAndMerging.cpp:53-71
+    , mUseVertexConnection(true), mUseVertexMerging(true)
+{
+    memset(&mApplied, 0, sizeof(mApplied));
+}
+
+const char* VertexConnectionAndMerging::GetName() const { return "VCM"; }
+
+bool VertexConnectionAndMerging::RenderPass(const RtPassParams& params)
+{
+    RtVcmParams vp; memset(&vp, 0, sizeof(vp));
+    vp.maxPathLength = mMaxPathLength; vp.useVertexConnection = mUseVertexConnection ? 1u : 0u; vp.useVertexMerging = mUseVertexMerging ? 1u : 0u;
+    vp.initialMergingRadius = mInitialMergingRadius; vp.minMergingRadius = mMinMergingRadius; vp.mergingRadiusMultiplier = mMergingRadiusMultiplier;
+    memcpy(vp.bsdfSamplingWeight, &mBSDFSamplingWeight, 16); memcpy(vp.lightSamplingWeight, &mLightSamplingWeight, 16);
+    memcpy(vp.vertexConnectingWeight, &mVertexConnectingWeight, 16); memcpy(vp.cameraConnectingWeight, &mCameraConnectingWeight, 16);
+    memcpy(vp.vertexMergingWeight, &mVertexMergingWeight, 16);
+    if (!mHaveApplied || memcmp(&vp, &mApplied, sizeof(vp)) != 0)
+    {
+        if (!GetDeviceContext() || rtgpu_set_integrator(GetDeviceContext(), RT_INTEGRATOR_VCM, &vp) != RTGPU_OK)
+        {
+            fprintf(stderr, "[rt] ERROR: cannot select the VCM integrator: %s\n", rtgpu_last_error());
+            return false;
+        }
+        mApplied = vp; mHaveApplied = true;
+    }
+    return PathTracerMIS::RenderPass(params);
 }
 
 bool PathTracerMIS::ReadSum(float* sumRGB, float* secondaryRGB) { return mCtx && rtgpu_read_sum(mCtx, sumRGB, secondaryRGB) == RTGPU_OK; }

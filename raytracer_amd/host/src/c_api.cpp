@@ -3,6 +3,7 @@
 // Core/ which in turn call the device C-ABI of include/rtgpu.h.
 #include "../Core/Rendering/Viewport.h"
 #include "../Core/Rendering/PathTracerMIS.h"
+#include "../Core/Rendering/VertexConnectionAndMerging.h"
 #include "../Core/BVH/BVHBuilder.h"
 #include "../Core/Textures/BitmapTexture.h"
 #include "../Core/Textures/CheckerboardTexture.h"
@@ -338,6 +339,22 @@ RTH_API int rth_viewport_set_renderer(void* v, void* sh, const char* name, int d
     vh->renderer = CreateRenderer(name, static_cast<SceneHandle*>(sh)->scene);
     if (!vh->renderer) return -2;
     return vh->viewport.SetRenderer(vh->renderer) ? 0 : -1;
+}
+// the public knobs of the "VCM" renderer (no-op with -3 when the viewport's renderer is not VCM); weights = 5 scalars:
+// bsdf, light, vertexConnecting, cameraConnecting, vertexMerging
+RTH_API int rth_viewport_set_vcm(void* v, uint32_t maxPathLength, int useVertexConnection, int useVertexMerging, float initialMergingRadius,
+                                 float minMergingRadius, float mergingRadiusMultiplier, const float* weights)
+{
+    VertexConnectionAndMerging* r = dynamic_cast<VertexConnectionAndMerging*>(static_cast<ViewportHandle*>(v)->renderer.get());
+    if (!r) return -3;
+    r->mMaxPathLength = maxPathLength; r->mUseVertexConnection = useVertexConnection != 0; r->mUseVertexMerging = useVertexMerging != 0;
+    r->mInitialMergingRadius = initialMergingRadius; r->mMinMergingRadius = minMergingRadius; r->mMergingRadiusMultiplier = mergingRadiusMultiplier;
+    if (weights)
+    {
+        r->mBSDFSamplingWeight = Vector4(weights[0]); r->mLightSamplingWeight = Vector4(weights[1]); r->mVertexConnectingWeight = Vector4(weights[2]);
+        r->mCameraConnectingWeight = Vector4(weights[3]); r->mVertexMergingWeight = Vector4(weights[4]);
+    }
+    return 0;
 }
 RTH_API void rth_viewport_reset(void* v) { static_cast<ViewportHandle*>(v)->viewport.Reset(); }
 RTH_API int rth_viewport_render(void* v, void* camera, uint32_t numPasses)

@@ -1,0 +1,142 @@
+"""GPU parity of the bidirectional integrator (renderer "VCM", RT_INTEGRATOR_VCM) against the oracle's restatement of
+VertexConnectionAndMerging.cpp (oracle/rto_vcm.h; its building blocks are pinned to the reference by golden vectors).
+
+* camera sub-paths (light hits, next event estimation, vertex connections, vertex merging): BIT-EXACT sum buffers and
+  identical ray counters -- tested with mCameraConnectingWeight = 0, which makes every film splat add zero;
+* the photon set recorded by a pass: identical count;
+* full image (camera paths + light-path splats): the splats are float atomics, so the per-pixel float sum has no defined
+  order (in the reference neither: tiles splat concurrently); tolerance 1e-5 relative to the pixel value + 1e-6 absolute;
+* the reference's own RenderingTest.* (VCM leg) with the reference's tolerances."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_zoo
+import raytracer_amd as ra
+from raytracer_amd import scenes
+from test_vcm_oracle import _two_estimator_scene
+
+pytestmark = pytest.mark.gpu
+
+COMPARED = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests", "numPassedRayBoxTests",
+            "numRayTriangleTests", "numPassedRayTriangleTests", "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
+            "numShadowRayTriangleTests")
+
+
+def run_both(scene, camera, w, h, passes, seed=99, **vcm_args):
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=seed)
+    vp.set_renderer(scene, name="VCM")
+    vp.set_vcm(**vcm_args)
+    cam = np.zeros((h, w, 3), dtype=np.float32); cam2 = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    vcm = oracle_lib.Vcm(**vcm_args)
+    photons = []
+    for i in range(passes):
+        p = vp.next_pass_params(camera)
+        vp.render_pass_with(p)
+        vcm.render_pass(desc, p, w, h, cam, cam2 if i % 2 == 0 else None, light, cnt)
+        photons.append((vp.vcm_num_photons(), vcm.num_photons()))
+    img, img2 = vp.sum_buffer(secondary=True)
+    return img, img2, vp.counters(), cam, cam2, light, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, photons
+
+
+def assert_camera_paths_identical(out):
+    img, img2, counters, cam, cam2, light, ref_counters, photons = out
+    assert np.isfinite(cam).all() and not light.any()
+    nbad = int(np.count_nonzero(img.view(np.uint32) != cam.view(np.uint32)))
+    assert nbad == 0, "%d of %d sum-buffer values differ (max abs %.3e)" % (nbad, cam.size, float(np.abs(img - cam).max()))
+    assert np.array_equal(img2.view(np.uint32), cam2.view(np.uint32))
+    for n in COMPARED:
+        assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
+    for got, want in photons:
+        assert got == want
+
+
+def test_vcm_camera_paths_bit_exact_point_and_background(built):
+    """Three passes (merging is active from the second one on: photon order, hash grid and range query must all match)."""
+    w, h = 96, 72
+    scene, camera = _two_estimator_scene(w / h)
+    out = run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0)
+    assert_camera_paths_identical(out)
+    assert out[7][-1][0] > 500     # photons are recorded (most light paths of the background light miss this small scene)
+
+
+def test_vcm_merging_with_a_large_radius_bit_exact(built):
+    """Radius 0.4: every camera vertex merges with many photons (long cell lists, all 8 neighbour cells populated), so the
+    photon order, the hashed cell ranges and the in-radius test all shape the float sums.  Merging only, then the full
+    combination."""
+    w, h = 96, 72
+    scene, camera = _two_estimator_scene(w / h)
+    out = run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, use_vertex_connection=False, initial_merging_radius=0.4, min_merging_radius=0.4)
+    assert_camera_paths_identical(out)
+    # merging really contributes: the same run without photons (first pass only) is darker in the indirectly lit pixels
+    first = run_both(scene, camera, w, h, 1, camera_connecting_weight=0.0, use_vertex_connection=False, initial_merging_radius=0.4, min_merging_radius=0.4)
+    assert out[0].sum() > 3.2 * first[0].sum()
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, initial_merging_radius=0.4, min_merging_radius=0.25,
+                                           merging_radius_multiplier=0.8))
+
+
+def test_vcm_camera_paths_bit_exact_all_lights_all_bsdfs(built):
+    """Every light type (area lights: the reference's non-solid-angle branch) and every BSDF; 13 lights + 9 light vertices
+    = 22 shadow requests per camera vertex."""
+    w, h = 80, 60
+    scene, camera = scene_zoo.all_lights_scene(w / h)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0))
+
+
+def test_vcm_camera_paths_bit_exact_cornell_connection_only_and_merging_only(built):
+    w, h = 64, 48
+    scene, camera = scenes.cornell_box(w / h)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0, use_vertex_merging=False))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, use_vertex_connection=False))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0, max_path_length=4))
+
+
+def test_vcm_mesh_scene_camera_paths_bit_exact(built):
+    w, h = 96, 54
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
+
+
+def test_vcm_full_image_with_light_path_splats(built):
+    w, h = 96, 72
+    scene, camera = _two_estimator_scene(w / h)
+    img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 4)
+    assert light.mean() > 0.01 * cam.mean()            # the light image is a real part of the estimate
+    total = cam + light
+    assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6), float(np.abs(img - total).max())
+    # the secondary buffer holds the even passes of both estimators: between 30 % and 70 % of the image energy
+    assert 0.3 * img.sum() < img2.sum() < 0.7 * img.sum()
+    for n in COMPARED:
+        assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
+
+
+@pytest.mark.parametrize("bsdf,passes,expected,tol,kwargs", [
+    ("diffuse", 100, (0.4, 1.2, 2.4), 0.05, {}),
+    ("null", 1, (3.0, 2.0, 1.0), 0.0, {"base_color": (0.0, 0.0, 0.0), "emission": (3.0, 2.0, 1.0)}),
+    ("metal", 20, (0.4, 1.2, 2.4), 0.05, {"ior": 0.0, "k": 100.0}),
+    ("dielectric", 1000, (1.0, 2.0, 3.0), 0.075, {"base_color": (1.0, 1.0, 1.0)}),
+])
+def test_reference_furnace_tests_vcm_on_gpu(built, bsdf, passes, expected, tol, kwargs):
+    """RenderingTest.FurnaceTest_*, VCM leg (Tests/RaytracingTests.cpp:317-523), on the device."""
+    w = h = 32
+    scene, camera = scenes.furnace(bsdf, **kwargs)
+    vp = ra.Viewport(w, h, seed=2024)
+    vp.set_renderer(scene, name="VCM")
+    vp.render(camera, passes)
+    img = vp.sum_buffer() / np.float32(passes)
+    assert np.isfinite(img).all()
+    assert np.all(np.abs(img - np.array(expected, dtype=np.float32)) <= tol + 1e-6), float(np.abs(img - np.array(expected)).max())
+
+
+def test_vcm_rejects_sharding(built):
+    w, h = 64, 64
+    scene, camera = _two_estimator_scene(1.0)
+    vp = ra.Viewport(w, h, seed=1)
+    vp.set_renderer(scene, name="VCM")
+    vp.set_shard(0, 2)
+    with pytest.raises(RuntimeError):
+        vp.render_pass_with(vp.next_pass_params(camera))
