@@ -127,9 +127,10 @@ RT_DEV V4 unpackColorHdr(float y, uint32_t chroma)
 struct Photon { float px, py, pz, lum; uint32_t chroma, direction; float dVM, dVCM; };
 
 // ---- Core/Utils/HashGrid.h ---------------------------------------------------------------------------------------------
+// `photons` is stored in mIndices order (photon j of the view = mPhotons[mIndices[j]]), so a cell's photons are contiguous
 struct HashGridView
 {
-    const Photon* photons; const uint32_t* indices; const uint32_t* cellEnds;
+    const Photon* photons; const uint32_t* cellEnds;
     float boxMin[3]; float radiusSqr, invCellSize; uint32_t hashTableMask, numPhotons;
 };
 RT_DEV int32_t cvtT(float f) { return (f >= 2147483648.0f || f < -2147483648.0f || f != f) ? (int32_t)0x80000000 : (int32_t)f; }   // _mm_cvttps_epi32
@@ -164,10 +165,9 @@ RT_DEV void hashGridProcess(const HashGridView& g, V4 queryPos, Query& query)
         const uint32_t rangeStart = ci == 0 ? 0 : g.cellEnds[ci - 1], rangeEnd = g.cellEnds[ci];
         for (uint32_t j = rangeStart; j < rangeEnd; ++j)
         {
-            const uint32_t particleIndex = g.indices[j];
-            const Photon& ph = g.photons[particleIndex];
+            const Photon& ph = g.photons[j];
             const float distSqr = sqrLength3(queryPos - V4(ph.px, ph.py, ph.pz, 0.0f));
-            if (distSqr <= g.radiusSqr) query(particleIndex);
+            if (distSqr <= g.radiusSqr) query(j);
         }
     }
 }

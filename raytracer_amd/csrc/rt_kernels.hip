@@ -1586,7 +1586,7 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
         VcmPhotonInput in = { v.arena.photonRaw, v.arena.photonCount, c->slotPixel, c->numSlots, v.arena.capacity, c->width, c->height, v.arena.maxLV };
         const int e = vcmBuildPhotonGrid(in, v.mergingRadiusVM, stream, v.grid);
         if (e != 0) return fail(e == (int)hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_DEVICE, std::string("photon grid: ") + hipGetErrorString((hipError_t)e));
-        grid.photons = reinterpret_cast<const Photon*>(v.grid.photons); grid.indices = v.grid.indices; grid.cellEnds = v.grid.cellEnds;
+        grid.photons = reinterpret_cast<const Photon*>(v.grid.sorted); grid.cellEnds = v.grid.cellEnds;
         grid.radiusSqr = v.grid.radiusSqr; grid.invCellSize = v.grid.invCellSize; grid.hashTableMask = v.grid.hashTableMask; grid.numPhotons = v.grid.numPhotons;
         if (v.grid.numPhotons) HIP_TRY(hipMemcpyAsync(grid.boxMin, v.grid.boxMin, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

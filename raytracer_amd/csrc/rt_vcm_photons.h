@@ -16,6 +16,7 @@ struct VcmPhotonInput
 struct VcmPhotonGrid
 {
     float4* photons = nullptr;       // 2 float4 per photon (32 bytes, VertexConnectionAndMerging::Photon)
+    float4* sorted = nullptr;        // the same photons in mIndices order (what the range query reads)
     uint32_t* indices = nullptr;     // HashGrid::mIndices
     uint32_t* cellEnds = nullptr;    // HashGrid::mCellEnds (after Build: the END offset of every cell)
     float* boxMin = nullptr;         // 3 floats (device)

@@ -65,11 +65,20 @@ __global__ void __launch_bounds__(VP_BLOCK) k_photon_cells(const float4* __restr
     atomicAdd(&cellCounts[cell], 1u);
 }
 
+// photons in hash-grid order: the range query then walks contiguous memory instead of chasing mIndices
+__global__ void __launch_bounds__(VP_BLOCK) k_photon_gather(const float4* __restrict__ photons, const uint32_t* __restrict__ indices, uint32_t numPhotons, float4* __restrict__ sorted)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= numPhotons) return;
+    const uint32_t i = indices[j];
+    sorted[2 * (size_t)j + 0] = photons[2 * (size_t)i + 0]; sorted[2 * (size_t)j + 1] = photons[2 * (size_t)i + 1];
+}
+
 static uint32_t nextPowerOfTwo(uint32_t v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; v++; return v; }   // Math.h:235-245
 
 void vcmFreePhotonGrid(VcmPhotonGrid& g)
 {
-    void* ptrs[] = { g.photons, g.cellEnds, g.boxMin, g.pixelCounts, g.pixelOffsets, g.keys[0], g.keys[1], g.values[0], g.values[1], g.temp };   // indices aliases values[]
+    void* ptrs[] = { g.photons, g.sorted, g.cellEnds, g.boxMin, g.pixelCounts, g.pixelOffsets, g.keys[0], g.keys[1], g.values[0], g.values[1], g.temp };   // indices aliases values[]
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (g.totalHost) (void)hipHostFree(g.totalHost);
     g = VcmPhotonGrid();
@@ -124,11 +133,12 @@ int vcmBuildPhotonGrid(const VcmPhotonInput& in, float radius, hipStream_t strea
 
     if (g.photonCapacity < numPhotons)
     {
-        void* ptrs[] = { g.photons, g.keys[0], g.keys[1], g.values[0], g.values[1] };
+        void* ptrs[] = { g.photons, g.sorted, g.keys[0], g.keys[1], g.values[0], g.values[1] };
         for (void* p : ptrs) if (p) (void)hipFree(p);
-        g.photons = nullptr; g.indices = nullptr; g.keys[0] = g.keys[1] = g.values[0] = g.values[1] = nullptr;
+        g.photons = nullptr; g.sorted = nullptr; g.indices = nullptr; g.keys[0] = g.keys[1] = g.values[0] = g.values[1] = nullptr;
         const size_t cap = (size_t)numPhotons + numPhotons / 4 + 1024;
         VP_TRY(hipMalloc((void**)&g.photons, cap * 2 * sizeof(float4)));
+        VP_TRY(hipMalloc((void**)&g.sorted, cap * 2 * sizeof(float4)));
         for (int k = 0; k < 2; ++k) { VP_TRY(hipMalloc((void**)&g.keys[k], cap * sizeof(uint32_t))); VP_TRY(hipMalloc((void**)&g.values[k], cap * sizeof(uint32_t))); }
         g.photonCapacity = cap;
     }
@@ -157,6 +167,7 @@ int vcmBuildPhotonGrid(const VcmPhotonInput& in, float radius, hipStream_t strea
     { int r = ensureTemp(g, need); if (r) return r; }
     VP_TRY(hipcub::DeviceRadixSort::SortPairs(g.temp, need, dk, dv, (int)numPhotons, 0, endBit, stream));
     g.indices = dv.Current();
+    hipLaunchKernelGGL(k_photon_gather, photonGrid, block, 0, stream, g.photons, g.indices, numPhotons, g.sorted);
     need = 0;
     VP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, need, cellCounts, g.cellEnds, (int)hashTableSize, stream));
     { int r = ensureTemp(g, need); if (r) return r; }
