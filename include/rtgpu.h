@@ -437,8 +437,12 @@ int rtgpu_set_concurrency(RtgpuContext* ctx, uint32_t lanes);
  * Post-processing of the sum buffer into the displayable front buffer: Viewport::PostProcessTile
  * (Core/Rendering/Viewport.cpp:495-550) per pixel -- scale by 1 / numPasses, saturation, contrast as
  * FastExp(FastLog(c) * contrast), exposure and colour filter, tone mapping (Core/Color/ColorHelpers.h:78-132),
- * dithering, Vector4::ToBGR().  Bloom (bloomFactor > 0) needs the blurred image pyramid and is not implemented:
- * RTGPU_ERR_UNSUPPORTED.  Dithering uses a per-pixel hash of (x, y, ditherSeed) instead of the reference's
+ * dithering, Vector4::ToBGR().  Bloom (bloomFactor > 0): the five blurred copies of the sum buffer of
+ * Viewport::PerformPostProcess (:432-452; Bitmap::GaussianBlur, Core/Utils/Bitmap.cpp:880-1020, sigma = 2 * 2.5^i, 8 box
+ * blurs per direction as running sums in the reference's order) are rebuilt from the current sum buffer by every call and
+ * mixed in as PostProcessTile does (:512-524).  The reference's blur reads and writes out of bounds unless the width is a
+ * multiple of 4, both sizes are <= 4096 and > 195 (its widest window): other sizes return RTGPU_ERR_UNSUPPORTED with
+ * bloomFactor > 0.  Dithering uses a per-pixel hash of (x, y, ditherSeed) instead of the reference's
  * per-thread generator (which makes the reference's own front buffer thread-schedule dependent).
  * --------------------------------------------------------------------------------------------- */
 typedef enum RtTonemapper { RT_TONEMAPPER_CLAMPED = 0, RT_TONEMAPPER_REINHARD = 1, RT_TONEMAPPER_HEJL_BURGESS_DAWSON = 2, RT_TONEMAPPER_ACES = 3 } RtTonemapper;
@@ -450,7 +454,7 @@ typedef struct RtPostprocessParams   /* PostprocessParams, Core/Rendering/PostPr
     float    contrast;
     float    saturation;
     float    ditheringStrength;
-    float    bloomFactor;         /* must be 0 */
+    float    bloomFactor;         /* PostprocessParams::bloomFactor (0 = off) */
     uint32_t tonemapper;          /* RtTonemapper */
     uint32_t numPasses;           /* pixelScaling = 1 / numPasses (1 + passesFinished at the time of the call, :502) */
     uint32_t ditherSeed;

@@ -1289,6 +1289,51 @@ static void genBidirCameraFilm()
     }
 }
 
+// =====================================================================================================
+// Bloom: Bitmap::GaussianBlur (Core/Utils/Bitmap.cpp:880-1020) as Viewport::PerformPostProcess drives it
+// (Viewport.cpp:432-452): level i = GaussianBlur(copy of level i-1, sigma = 2 * 2.5^i, n = 8).  The input image is a
+// deterministic function of the pixel index (reproduced by the test), only outputs are stored:
+//   bloom_kat.bin = { magic, count } then per case { width, height, numLevels, lattice step, sigma0 bits }
+//                   followed, per level, by the 64-bit sum of all float bits and the pixels of the lattice (x % step == 0, y % step == 0)
+// =====================================================================================================
+static float bloomInput(uint32_t i)   // same integer recipe as tests/test_bloom.py
+{
+    uint32_t h = i * 2654435761u + 0x9E3779B9u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    const float base = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return (h & 0x3Fu) == 0u ? base * 400.0f : base * 2.0f;    // a few very bright pixels, like fireflies / light sources
+}
+
+static void genBloom()
+{
+    std::vector<uint32_t> out;
+    struct Case { uint32_t w, h, levels, step; float sigma0; };
+    const Case cases[] = { { 64, 48, 2, 1, 2.0f }, { 100, 36, 1, 1, 1.3f }, { 272, 208, 5, 4, 2.0f } };
+    out.push_back(0x4D4F4C42u); out.push_back((uint32_t)(sizeof(cases) / sizeof(cases[0])));
+    for (const Case& c : cases)
+    {
+        Bitmap img("bloom");
+        Bitmap::InitData id; id.width = c.w; id.height = c.h; id.format = Bitmap::Format::R32G32B32_Float;
+        if (!img.Init(id)) { fprintf(stderr, "Bitmap::Init failed\n"); exit(1); }
+        float* data = reinterpret_cast<float*>(img.GetData());
+        for (uint32_t i = 0; i < c.w * c.h * 3; ++i) data[i] = bloomInput(i);
+        out.push_back(c.w); out.push_back(c.h); out.push_back(c.levels); out.push_back(c.step); out.push_back(fbits(c.sigma0));
+        float blurSigma = c.sigma0;
+        for (uint32_t level = 0; level < c.levels; ++level)
+        {
+            if (!img.GaussianBlur(blurSigma, 8)) { fprintf(stderr, "GaussianBlur failed\n"); exit(1); }
+            blurSigma *= 2.5f;
+            uint64_t sum = 0;
+            for (uint32_t i = 0; i < c.w * c.h * 3; ++i) sum += fbits(data[i]);
+            out.push_back((uint32_t)sum); out.push_back((uint32_t)(sum >> 32));
+            for (uint32_t y = 0; y < c.h; y += c.step)
+                for (uint32_t x = 0; x < c.w; x += c.step)
+                    for (int k = 0; k < 3; ++k) out.push_back(fbits(data[3 * (y * c.w + x) + k]));
+        }
+    }
+    writeRaw("bloom_kat.bin", out.data(), out.size() * 4);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -1308,6 +1353,7 @@ int main(int argc, char** argv)
     genBidirLights();
     genBidirBsdf();
     genBidirCameraFilm();
+    genBloom();
     printf("done\n");
     return 0;
 }

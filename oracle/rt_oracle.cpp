@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <algorithm>
 #include <thread>
 #include <atomic>
 
@@ -454,6 +455,100 @@ void rto_postprocess(const float* sumRGB, uint32_t width, uint32_t height, const
             const float* px = sumRGB + 3 * ((size_t)y * width + x);
             out[(size_t)y * width + x] = postProcessPixel(px[0], px[1], px[2], x, y, *params, colorScale);
         }
+}
+
+// ---- bloom -------------------------------------------------------------------------------------------------------
+// BoxBlur_Internal, Core/Utils/Bitmap.cpp:880-914 (one colour channel; the reference runs the four lanes of a Vector4 in lockstep)
+static void boxBlurInternal(float* targetLine, const float* srcLine, const uint32_t radius, const uint32_t width)
+{
+    const float factor = 1.0f / (float)(2 * radius + 1);
+    const float* srcLineBegin = srcLine; const float* srcLineEnd = srcLine;
+    const float firstValue = srcLine[0];
+    const float lastValue = srcLine[width - 1];
+    float val = firstValue * (float)(radius + 1);
+    for (uint32_t j = 0; j < radius; j++) val = val + *(srcLineBegin++);
+    for (uint32_t j = 0; j <= radius; j++) { val = val + (*(srcLineBegin++) - firstValue); *(targetLine++) = val * factor; }
+    for (uint32_t j = radius + 1; j < width - radius; j++) { val = val + (*(srcLineBegin++) - *(srcLineEnd++)); *(targetLine++) = val * factor; }
+    for (uint32_t j = width - radius; j < width; j++) { val = val + (lastValue - *(srcLineEnd++)); *(targetLine++) = val * factor; }
+}
+// Bitmap::GaussianBlur, :917-1020, on a tight float3 image.  Lines are processed per channel; the line buffers are as long as the
+// reference's (4096) so that a window wider than the line reads the same kind of stale entries -- callers keep to sizes where it does not.
+int rto_gaussian_blur(float* rgb, uint32_t width, uint32_t height, float sigma, uint32_t n)
+{
+    const uint32_t MaxLineSize = 4096;
+    if (width > MaxLineSize || height > MaxLineSize) return -1;
+    float wIdeal = sqrtf((12.0f * sigma * sigma / n) + 1.0f);
+    uint32_t wl = (uint32_t)floorf(wIdeal);
+    if (wl % 2 == 0) wl--;
+    const uint32_t wu = wl + 2;
+    const float mIdeal = (12.0f * sigma * sigma - n * wl * wl - 4.0f * n * wl - 3.0f * n) / (-4.0f * wl - 4.0f);
+    const float m = roundf(mIdeal);
+    std::vector<float> tempA(MaxLineSize, 0.0f), tempB(MaxLineSize, 0.0f);
+    for (int channel = 0; channel < 3; ++channel)
+    {
+        for (uint32_t y = 0; y < height; ++y)   // horizontal blur, :943-965
+        {
+            float* rowPtr = rgb + 3 * (size_t)y * width + channel;
+            for (uint32_t x = 0; x < width; ++x) tempB[x] = rowPtr[3 * (size_t)x];
+            float* sourceLinePtr = tempB.data(); float* targetLinePtr = tempA.data();
+            for (uint32_t i = 0; i < n; ++i)
+            {
+                const uint32_t radius = i < m ? wl : wu;
+                boxBlurInternal(targetLinePtr, sourceLinePtr, radius, width);
+                std::swap(sourceLinePtr, targetLinePtr);
+            }
+            for (uint32_t x = 0; x < width; ++x) rowPtr[3 * (size_t)x] = targetLinePtr[x];   // as written in the reference: the buffer the LAST blur read from
+        }
+    }
+    for (int channel = 0; channel < 3; ++channel)
+    {
+        for (uint32_t x = 0; x < width; ++x)    // vertical blur, :968-1011 (four columns at a time there; columns are independent)
+        {
+            float* colPtr = rgb + 3 * (size_t)x + channel;
+            for (uint32_t y = 0; y < height; ++y) tempA[y] = colPtr[3 * (size_t)y * width];
+            float* sourceLinePtr = tempA.data(); float* targetLinePtr = tempB.data();
+            for (uint32_t j = 0; j < n; ++j)
+            {
+                const uint32_t radius = j < m ? wl : wu;
+                boxBlurInternal(targetLinePtr, sourceLinePtr, radius, height);
+                std::swap(sourceLinePtr, targetLinePtr);
+            }
+            for (uint32_t y = 0; y < height; ++y) colPtr[3 * (size_t)y * width] = tempA[y];
+        }
+    }
+    return 0;
+}
+
+// Viewport::PerformPostProcess + PostProcessTile with bloom (Viewport.cpp:432-452, 512-524)
+int rto_postprocess_bloom(const float* sumRGB, uint32_t width, uint32_t height, const RtPostprocessParams* params, uint32_t* out)
+{
+    const size_t count = (size_t)width * height * 3;
+    std::vector<std::vector<float>> blurred(5);
+    float blurSigma = 2.0f;
+    for (int i = 0; i < 5; ++i)
+    {
+        blurred[i].assign(i == 0 ? sumRGB : blurred[i - 1].data(), (i == 0 ? sumRGB : blurred[i - 1].data()) + count);
+        if (rto_gaussian_blur(blurred[i].data(), width, height, blurSigma, 8) != 0) return -1;
+        blurSigma *= 2.5f;
+    }
+    const float bloomWeights[] = { 0.35f, 0.25f, 0.15f, 0.15f, 0.1f };
+    const float exposureScale = powf(2.0f, params->exposure);
+    const float colorScale[3] = { params->colorFilter[0] * exposureScale, params->colorFilter[1] * exposureScale, params->colorFilter[2] * exposureScale };
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            const size_t i = (size_t)y * width + x;
+            float rgb[3];
+            for (int k = 0; k < 3; ++k)
+            {
+                const float v = sumRGB[3 * i + k] * (1.0f - params->bloomFactor);
+                float bloomColor = 0.0f;
+                for (int l = 0; l < 5; ++l) bloomColor = fmaf(blurred[l][3 * i + k], bloomWeights[l], bloomColor);
+                rgb[k] = fmaf(bloomColor, params->bloomFactor, v);
+            }
+            out[i] = postProcessPixel(rgb[0], rgb[1], rgb[2], x, y, *params, colorScale);
+        }
+    return 0;
 }
 
 // Viewport::ComputeBlockError, Core/Rendering/Viewport.cpp:552-581

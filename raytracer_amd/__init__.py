@@ -446,13 +446,13 @@ class Viewport:
         return dict(averageError=err.value, converged=conv.value, activePixels=pixels.value, blocks=[tuple(int(v) for v in b) for b in blocks[:n]])
 
     def front_buffer(self, exposure=0.0, contrast=0.8, saturation=0.98, dithering=0.005, tonemapper=3, color_filter=(1.0, 1.0, 1.0, 1.0),
-                     dither_seed=0):
+                     dither_seed=0, bloom=0.0):
         """Viewport::PostProcessTile on the device (defaults = PostprocessParams(), Core/Rendering/PostProcess.cpp:6-14):
         the (H, W) uint32 0x00RRGGBB front buffer of the passes rendered so far."""
         p = RtPostprocessParams()
         for k in range(4):
             p.colorFilter[k] = color_filter[k]
-        p.exposure, p.contrast, p.saturation, p.ditheringStrength, p.bloomFactor = exposure, contrast, saturation, dithering, 0.0
+        p.exposure, p.contrast, p.saturation, p.ditheringStrength, p.bloomFactor = exposure, contrast, saturation, dithering, bloom
         p.tonemapper, p.numPasses, p.ditherSeed = int(tonemapper), max(1, self.passes_finished), int(dither_seed)
         out = np.zeros((self.height, self.width), dtype=np.uint32)
         if rtgpu_lib().rtgpu_postprocess(self.device_context(), C.byref(p), out.ctypes.data_as(C.c_void_p)) != 0:

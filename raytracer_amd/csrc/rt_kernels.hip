@@ -769,6 +769,68 @@ __global__ void __launch_bounds__(RT_BLOCK) k_postprocess(const float* __restric
     front[i] = postProcessPixel(sum[3 * (size_t)i + 0], sum[3 * (size_t)i + 1], sum[3 * (size_t)i + 2], x, y, params, colorScale.c);
 }
 
+// ---- bloom: Bitmap::GaussianBlur (Core/Utils/Bitmap.cpp:880-1020) ---------------------------------------------------------
+// n box blurs per line, each a running sum in the reference's order (BoxBlur_Internal, :880-914), so a line is sequential;
+// one thread per (line, colour channel).  The two line buffers live in global scratch, element-major (element e of
+// thread t at [e * numThreads + t]) so that the threads of a wave touch consecutive words.
+struct BlurPlan { uint32_t n, wl, wu; float m; };
+RT_DEV void boxBlurLine(float* __restrict__ dst, const float* __restrict__ src, uint32_t radius, uint32_t width, uint32_t stride)
+{
+    const float factor = 1.0f / (float)(2u * radius + 1u);
+    uint32_t b = 0, e = 0, t = 0;
+    const float firstValue = src[0], lastValue = src[(size_t)(width - 1u) * stride];
+    float val = firstValue * (float)(radius + 1u);
+    for (uint32_t j = 0; j < radius; j++) val = val + src[(size_t)(b++) * stride];
+    for (uint32_t j = 0; j <= radius; j++) { val = val + (src[(size_t)(b++) * stride] - firstValue); dst[(size_t)(t++) * stride] = val * factor; }
+    for (uint32_t j = radius + 1u; j < width - radius; j++) { val = val + (src[(size_t)(b++) * stride] - src[(size_t)(e++) * stride]); dst[(size_t)(t++) * stride] = val * factor; }
+    for (uint32_t j = width - radius; j < width; j++) { val = val + (lastValue - src[(size_t)(e++) * stride]); dst[(size_t)(t++) * stride] = val * factor; }
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_blur_lines(float* __restrict__ image, uint32_t width, uint32_t height, uint32_t vertical, const BlurPlan plan,
+                                                         float* __restrict__ lineA, float* __restrict__ lineB)
+{
+    const uint32_t numLines = vertical ? width : height, length = vertical ? height : width;
+    const uint32_t numThreads = numLines * 3u;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= numThreads) return;
+    const uint32_t line = t / 3u, channel = t - line * 3u;
+    const size_t pixelStride = vertical ? (size_t)width * 3u : 3u;
+    float* px = image + (vertical ? (size_t)line * 3u : (size_t)line * width * 3u) + channel;
+    // horizontal: source = B, target = A (:952-953); vertical: source = A, target = B (:983-984)
+    float* source = (vertical ? lineA : lineB) + t;
+    float* target = (vertical ? lineB : lineA) + t;
+    for (uint32_t e = 0; e < length; ++e) source[(size_t)e * numThreads] = px[(size_t)e * pixelStride];
+    for (uint32_t i = 0; i < plan.n; ++i)
+    {
+        const uint32_t radius = (float)i < plan.m ? plan.wl : plan.wu;
+        boxBlurLine(target, source, radius, length, numThreads);
+        float* tmp = source; source = target; target = tmp;
+    }
+    // horizontal reads targetLinePtr AFTER the last swap (:961-964: the buffer the last blur read from, i.e. n-1 blurs);
+    // vertical reads tempLineA (:1003-1009: the last blur's output for even n)
+    const float* result = vertical ? lineA + t : target;
+    for (uint32_t e = 0; e < length; ++e) px[(size_t)e * pixelStride] = result[(size_t)e * numThreads];
+}
+
+// Viewport::PostProcessTile with bloom (:512-524): rgb * (1 - bloomFactor) + bloomFactor * sum of weighted blur levels
+struct BloomLevels { const float* level[5]; };
+__global__ void __launch_bounds__(RT_BLOCK) k_postprocess_bloom(const float* __restrict__ sum, const BloomLevels blurred, uint32_t* __restrict__ front, uint32_t width, uint32_t height,
+                                                                const RtPostprocessParams params, const PostScale colorScale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t y = i / width, x = i - y * width;
+    const float bloomWeights[5] = { 0.35f, 0.25f, 0.15f, 0.15f, 0.1f };
+    float rgb[3];
+    for (int k = 0; k < 3; ++k)
+    {
+        float v = sum[3 * (size_t)i + k] * (1.0f - params.bloomFactor);
+        float bloomColor = 0.0f;
+        for (int l = 0; l < 5; ++l) bloomColor = __fmaf_rn(blurred.level[l][3 * (size_t)i + k], bloomWeights[l], bloomColor);
+        rgb[k] = __fmaf_rn(bloomColor, params.bloomFactor, v);
+    }
+    front[i] = postProcessPixel(rgb[0], rgb[1], rgb[2], x, y, params, colorScale.c);
+}
+
 // Viewport::ComputeBlockError (Viewport.cpp:552-581) in two steps that keep the reference's summation order: one thread
 // per (block, row) adds the pixel errors of its row left to right, then one thread per block adds the rows top to bottom.
 struct ErrorRow { uint32_t block, y; };
@@ -1860,7 +1922,28 @@ RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, u
 {
     if (!c || !p || !frontBufferBGRA) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
-    if (p->bloomFactor > 0.0f) return fail(RTGPU_ERR_UNSUPPORTED, "bloom is not implemented");
+    // bloom: the reference's blur works on 4 columns at a time and on 4096-entry line buffers without bounds checks
+    // (Bitmap.cpp:925-931, :941, :978-990): sizes it would read or write out of bounds for are refused here
+    const bool bloom = p->bloomFactor > 0.0f;
+    BlurPlan plans[5];
+    if (bloom)
+    {
+        if (c->width > 4096u || c->height > 4096u || (c->width % 4u) != 0u) return fail(RTGPU_ERR_UNSUPPORTED, "bloom: width must be a multiple of 4 and both sizes <= 4096 (Bitmap::GaussianBlur)");
+        float blurSigma = 2.0f;   // Viewport.cpp:438-444
+        for (int l = 0; l < 5; ++l)
+        {
+            const uint32_t n = 8u;
+            const float sigma = blurSigma;
+            float wIdeal = sqrtf((12.0f * sigma * sigma / n) + 1.0f);   // Bitmap.cpp:935-946
+            uint32_t wl = (uint32_t)floorf(wIdeal);
+            if (wl % 2u == 0u) wl--;
+            const uint32_t wu = wl + 2u;
+            const float mIdeal = (12.0f * sigma * sigma - n * wl * wl - 4.0f * n * wl - 3.0f * n) / (-4.0f * wl - 4.0f);
+            plans[l].n = n; plans[l].wl = wl; plans[l].wu = wu; plans[l].m = roundf(mIdeal);
+            if (c->width <= 2u * wu + 1u || c->height <= 2u * wu + 1u) return fail(RTGPU_ERR_UNSUPPORTED, "bloom: the image is smaller than the widest blur window (2 * 97 + 1 pixels)");
+            blurSigma *= 2.5f;
+        }
+    }
     if (p->tonemapper > RT_TONEMAPPER_ACES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown tonemapper");
     if (p->numPasses == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numPasses must be > 0");
     int r = rtgpu_synchronize(c); if (r) return r;
@@ -1869,10 +1952,32 @@ RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, u
     HIP_TRY(hipMalloc((void**)&dFront, pixels * sizeof(uint32_t)));
     const float exposureScale = powf(2.0f, p->exposure);   // colorScale on the host like the reference (Viewport.cpp:453)
     const PostScale scale = { { p->colorFilter[0] * exposureScale, p->colorFilter[1] * exposureScale, p->colorFilter[2] * exposureScale } };
-    hipLaunchKernelGGL(k_postprocess, dim3((uint32_t)((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, c->lanes[0].stream, c->sum, dFront, c->width, c->height, *p, scale);
-    hipError_t e = hipStreamSynchronize(c->lanes[0].stream);
+    hipStream_t stream = c->lanes[0].stream;
+    hipError_t e = hipSuccess;
+    float* dBlur = nullptr; float* dLines = nullptr;
+    if (!bloom) hipLaunchKernelGGL(k_postprocess, dim3((uint32_t)((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, c->sum, dFront, c->width, c->height, *p, scale);
+    else
+    {
+        // mBlurredImages[i] = GaussianBlur(copy of (i == 0 ? mSum : mBlurredImages[i - 1]), sigma_i, 8), Viewport.cpp:436-445
+        e = hipMalloc((void**)&dBlur, pixels * 3 * sizeof(float) * 5);
+        if (e == hipSuccess) e = hipMalloc((void**)&dLines, pixels * 3 * sizeof(float) * 2);
+        BloomLevels levels;
+        for (int l = 0; l < 5 && e == hipSuccess; ++l)
+        {
+            float* img = dBlur + (size_t)l * pixels * 3;
+            levels.level[l] = img;
+            e = hipMemcpyAsync(img, l == 0 ? c->sum : dBlur + (size_t)(l - 1) * pixels * 3, pixels * 3 * sizeof(float), hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(k_blur_lines, dim3((c->height * 3u + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, img, c->width, c->height, 0u, plans[l], dLines, dLines + pixels * 3);
+            hipLaunchKernelGGL(k_blur_lines, dim3((c->width * 3u + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, stream, img, c->width, c->height, 1u, plans[l], dLines, dLines + pixels * 3);
+        }
+        if (e == hipSuccess) hipLaunchKernelGGL(k_postprocess_bloom, dim3((uint32_t)((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, c->sum, levels, dFront, c->width, c->height, *p, scale);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) e = hipMemcpy(frontBufferBGRA, dFront, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipFree(dFront);
+    if (dBlur) (void)hipFree(dBlur);
+    if (dLines) (void)hipFree(dLines);
     if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_postprocess: ") + hipGetErrorString(e));
     return RTGPU_OK;
 }

@@ -15,7 +15,7 @@ struct PostprocessParams
     float contrast = 0.8f;
     float saturation = 0.98f;
     float ditheringStrength = 0.005f;  // applied after tonemapping
-    float bloomFactor = 0.0f;          // bloom multiplier (bloom is not implemented on the device: must stay 0)
+    float bloomFactor = 0.0f;          // bloom multiplier
     Tonemapper tonemapper = Tonemapper::ACES;
 };
 

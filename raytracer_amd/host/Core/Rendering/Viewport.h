@@ -2,7 +2,7 @@
 // Render() performs the pass prologue of Viewport::Render (Core/Rendering/Viewport.cpp:200-242) on the
 // host -- Halton seeds, anti-aliasing offset -- then hands ONE pass to the renderer instead of fanning
 // 32x32 tiles out to a thread pool.  GetFrontBuffer() runs Viewport::PostProcessTile (Viewport.cpp:495-550) on the device for the
-// whole image (no bloom).  Adaptive rendering keeps the reference's block list logic (Viewport.cpp:552-700) on the host; the
+// whole image (bloom included: the five blurred copies are rebuilt from the sum buffer on demand).  Adaptive rendering keeps the reference's block list logic (Viewport.cpp:552-700) on the host; the
 // error estimates come from the device.
 #pragma once
 

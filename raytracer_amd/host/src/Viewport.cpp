@@ -485,7 +485,6 @@ const Bitmap& Viewport::GetSumBuffer()
 
 bool Viewport::SetPostprocessParams(const PostprocessParams& params)
 {
-    if (params.bloomFactor > 0.0f) { fprintf(stderr, "[rt] ERROR: bloom is not supported by the device path\n"); return false; }
     mPostprocessParams = params;
     return true;
 }
