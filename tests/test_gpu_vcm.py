@@ -140,3 +140,21 @@ def test_vcm_rejects_sharding(built):
     vp.set_shard(0, 2)
     with pytest.raises(RuntimeError):
         vp.render_pass_with(vp.next_pass_params(camera))
+
+
+def test_vcm_full_size_mesh_textures_and_depth_of_field(built):
+    """The benchmark's 262 176-triangle mesh (background + directional light: the un-transformed emission disc of
+    DirectionalLight::Emit), the textured scene (normal maps, environment map: light vertices store the EVALUATED material
+    parameters) and a thin-lens camera (Camera::WorldToFilm ignores the lens, like the reference)."""
+    w, h = 240, 135
+    scene, camera = scenes.sponza_class(w / h)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
+    w, h = 112, 64
+    scene, camera = scene_zoo.textured_scene(w / h)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
+    scene, camera = scenes.cornell_box(w / h)
+    camera.set_dof(True, 11.0, 0.3)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
+    img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 3)
+    total = cam + light
+    assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6)
