@@ -971,7 +971,8 @@ struct RtgpuContext
         RtVcmParams params;
         float mergingRadiusVC = 0.0f, mergingRadiusVM = 0.0f;
         Paths lightPaths = { nullptr, 0, 0 }, cameraPaths = { nullptr, 0, 0 };
-        VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
+        VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
+        uint32_t* mergeQueue = nullptr;
         uint32_t* queues[4] = { nullptr, nullptr, nullptr, nullptr };          // light ping-pong, camera ping-pong
         uint32_t* shadowQueues[4] = { nullptr, nullptr, nullptr, nullptr };
         uint32_t* counts = nullptr;                                               // 6 planes of RT_VCM_COUNT_PLANE
@@ -1547,7 +1548,7 @@ static int flushPending(RtgpuContext* c)
 static void freeVcm(RtgpuContext* c)
 {
     RtgpuContext::Vcm& v = c->vcm;
-    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount,
+    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue,
                      v.queues[0], v.queues[1], v.queues[2], v.queues[3], v.shadowQueues[0], v.shadowQueues[1], v.shadowQueues[2], v.shadowQueues[3], v.counts,
                      v.passDev, v.seedDev };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1573,6 +1574,8 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
     HIP_TRY(hipMalloc((void**)&v.arena.recs, (size_t)V_NUM * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.arena.lightVertices, (size_t)maxLV * RT_VCM_LV_RECORDS * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonRaw, (size_t)maxLV * 2 * cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&v.arena.cameraVertex, (size_t)RT_VCM_LV_RECORDS * cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&v.mergeQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMemset(v.arena.photonCount, 0, cap * sizeof(uint32_t)));
@@ -1580,7 +1583,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
     for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));
     for (int k = 2; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)6 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.passDev, sizeof(DevPass)));
     HIP_TRY(hipMalloc((void**)&v.seedDev, (size_t)RTGPU_MAX_DIMENSIONS * sizeof(uint32_t)));
     v.requestsPerVertex = requests;
@@ -1664,9 +1667,10 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions) HIP_TRY(hipMemcpyAsync(v.seedDev, p->seed, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v.passDev, &pass, sizeof(pass), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `pass` and the caller's seed array are host temporaries
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)6 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE; uint32_t* csc = v.counts + 4 * RT_VCM_COUNT_PLANE; uint32_t* ccur = v.counts + 5 * RT_VCM_COUNT_PLANE;
+    uint32_t* cmc = v.counts + 6 * RT_VCM_COUNT_PLANE;
     uint32_t** lq = v.queues; uint32_t** cq = v.queues + 2; uint32_t** lsq = v.shadowQueues; uint32_t** csq = v.shadowQueues + 2;
 
     const uint32_t maxBlocks = c->numCUs * 8u;
@@ -1693,6 +1697,7 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
         LaunchTimer t(c, stream, KC_ACCUMULATE);
         hipLaunchKernelGGL(k_vcm_light_finish, grid1, block, 0, stream, v.passDev, v.lightPaths, c->numSlots, c->sum, c->secondary, c->counters);
     }
+    static const uint32_t mergeCooperativeMin = getenv("RTGPU_VCM_MERGE_COOP") ? (uint32_t)atoi(getenv("RTGPU_VCM_MERGE_COOP")) : RT_VCM_COOPERATIVE_MERGE_MIN;   // tuning knob
     // camera sub-paths
     for (uint32_t d = 0; d < vp.maxPathLength; ++d)
     {
@@ -1700,7 +1705,9 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
         launchTrace(c, stream, v.cameraPaths, cq[d & 1u], cpc + d, haveShadow ? csq[(d - 1u) & 1u] : nullptr, haveShadow ? csc + (d - 1u) : nullptr, ccur + d);
         LaunchTimer t(c, stream, KC_SHADE);
         hipLaunchKernelGGL(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.cameraPaths, v.arena, grid, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
-                           csq[d & 1u], csc + d, c->counters);
+                           csq[d & 1u], csc + d, v.mergeQueue, cmc + d, c->counters);
+        if (grid.numPhotons != 0u && vp.useVertexMerging && passNumber > 0u)
+            hipLaunchKernelGGL(k_vcm_merge, grid1, block, 0, stream, c->sceneDev, dev, v.arena, grid, v.mergeQueue, cmc + d, mergeCooperativeMin);
     }
     launchTrace(c, stream, v.cameraPaths, nullptr, nullptr, csq[(vp.maxPathLength - 1u) & 1u], csc + (vp.maxPathLength - 1u), ccur + vp.maxPathLength);
     {

@@ -43,9 +43,11 @@ struct VcmArena
     float4* photonRaw;       // maxLV x 2 x capacity (this pass's photons, per slot)
     uint32_t* lvCount;       // light vertices of the slot's light sub-path
     uint32_t* photonCount;
+    float4* cameraVertex;    // RT_VCM_LV_RECORDS x capacity: the camera vertex whose merge query is pending (w of record 3 = dVM)
     uint32_t capacity, maxLV;
 };
 RT_DEV float4& vrec(const VcmArena& a, uint32_t record, uint32_t slot) { return a.recs[(size_t)record * a.capacity + slot]; }
+RT_DEV float4& cvrec(const VcmArena& a, uint32_t record, uint32_t slot) { return a.cameraVertex[(size_t)record * a.capacity + slot]; }
 RT_DEV float4& lvrec(const VcmArena& a, uint32_t vertex, uint32_t record, uint32_t slot) { return a.lightVertices[((size_t)vertex * RT_VCM_LV_RECORDS + record) * a.capacity + slot]; }
 
 struct VcmDev   // VertexConnectionAndMerging members after PreRender (.cpp:84-124)
@@ -434,7 +436,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                                                                const HashGridView grid,
                                                                const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                                uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
-                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount, unsigned long long* counters)
+                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                               uint32_t* __restrict__ mergeQueue, uint32_t* __restrict__ mergeCount, unsigned long long* counters)
 {
     __shared__ uint32_t sCount, sBase;
     if (threadIdx.x == 0) sCount = 0u;
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
     {
-        bool alive = false;
+        bool alive = false, wantMerge = false;
         uint32_t slot = 0;
         unsigned long long rayMask = 0ull;   // requests of this vertex that need a shadow ray (at most 64 per vertex, checked by the host)
         if (i < count)
@@ -603,30 +606,18 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                     pendingBits |= 0x2000000u;
                 }
 
-                // MergeVertices, :823-906
-                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u)
+                // MergeVertices, :823-906: the range query runs in k_vcm_merge (wave-cooperative for long photon lists); this
+                // vertex is handed over as a record.  With no photons HashGrid::Process returns at once and the term is +0.
+                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u && grid.numPhotons != 0u)
                 {
-                    V4 contribution = zero4();
-                    auto query = [&](uint32_t photonIndex)
-                    {
-                        const Photon& photon = grid.photons[photonIndex];
-                        const V4 lightDirection = unpackUnitVector(photon.direction);
-                        const float cosToLight = dot3(sd.intersection.frame.r[2], lightDirection);
-                        if (cosToLight < FLT_EPSILON) return;
-                        float cameraBsdfDirPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
-                        const V4 cameraBsdfFactor = materialEvaluate<false>(mat, sd, neg(lightDirection), cameraBsdfDirPdfW, &cameraBsdfRevPdfW);
-                        if (almostZero4(cameraBsdfFactor)) return;
-                        const V4 photonThroughput = unpackColorHdr(photon.lum, photon.chroma);
-                        const float wLight = photon.dVCM * vcm.misVertexConnectionWeightFactorVM + photon.dVM * cameraBsdfDirPdfW;
-                        const float wCamera = dVCM * vcm.misVertexConnectionWeightFactorVM + dVM * cameraBsdfRevPdfW;
-                        const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
-                        const float weight = misWeight / cosToLight;
-                        contribution = mulAdd(cameraBsdfFactor * photonThroughput, weight, contribution);
-                    };
-                    hashGridProcess(grid, pos, query);
-                    const V4 vertexMergingColor = contribution * load4(vcm.vertexMergingWeight);
-                    const V4 m = throughput * vertexMergingColor;
-                    vrec(a, V_MERGE, slot) = f4(m.x, m.y, m.z, 0.0f);
+                    const V4 tg = sd.intersection.frame.r[0], nr = sd.intersection.frame.r[2], og = sd.outgoingDirWorldSpace;
+                    cvrec(a, 0, slot) = f4(pos.x, pos.y, pos.z, fbits(sd.intersection.material));
+                    cvrec(a, 1, slot) = f4(tg.x, tg.y, tg.z, sd.mp.roughness);
+                    cvrec(a, 2, slot) = f4(nr.x, nr.y, nr.z, sd.mp.metalness);
+                    cvrec(a, 3, slot) = f4(og.x, og.y, og.z, dVM);
+                    cvrec(a, 4, slot) = f4(sd.mp.baseColor.x, sd.mp.baseColor.y, sd.mp.baseColor.z, sd.mp.baseColor.w);
+                    cvrec(a, 5, slot) = f4(throughput.x, throughput.y, throughput.z, dVCM);
+                    wantMerge = true;
                     pendingBits |= 0x10000u;
                 }
                 pendingBits |= numLightRequests | (numConnections << 8);
@@ -653,8 +644,149 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
             shadowQueue[shadowAt++] = (uint32_t)(__ffsll((long long)pendingMask) - 1) * cp.capacity + slot;
         const uint32_t pathAt = blockReserve(alive ? 1u : 0u, countOut, &sCount, &sBase);
         if (alive) queueOut[pathAt] = slot;
+        const uint32_t mergeAt = blockReserve(wantMerge ? 1u : 0u, mergeCount, &sCount, &sBase);
+        if (wantMerge) mergeQueue[mergeAt] = slot;
     }
     flushCounters(cnt, counters);
+}
+
+// MergeVertices, :823-906 + HashGrid::Process, HashGrid.h:73-143, for the camera vertices queued by k_vcm_camera_shade.
+// The reference adds the photons' terms with one fma chain in grid order; the chain is kept, the work in front of it is spread:
+// a query with few candidate photons is one lane's loop; a query with many (a caustic, the footprint of a spot light:
+// thousands of photons per cell) is taken by the whole wave -- 64 photons are tested and their BSDF terms evaluated at a time,
+// then every lane replays the fma chain over the contributing lanes in order (shuffles), so the sum is the sequential one.
+#define RT_VCM_COOPERATIVE_MERGE_MIN 64u   // measured plateau 48-96 (profiles/r01_tuning_sweep.txt)
+struct MergeRanges { uint32_t start[8], end[8]; uint32_t numCells, total; };
+RT_DEV void mergeCellRanges(const HashGridView& g, V4 queryPos, MergeRanges& r)
+{
+    const V4 distMin = queryPos - V4(g.boxMin[0], g.boxMin[1], g.boxMin[2], 0.0f);
+    const V4 cellCoords = mulSub(distMin, splat(g.invCellSize), splat(0.5f));
+    const int32_t cx = cvtT(cellCoords.x), cy = cvtT(cellCoords.y), cz = cvtT(cellCoords.z);
+    uint32_t visitedCells[8];
+    r.numCells = 0; r.total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i)
+    {
+        const uint32_t x = (uint32_t)cx + (i & 1), y = (uint32_t)cy + ((i >> 1) & 1), z = (uint32_t)cz + (i >> 2);
+        const uint32_t ci = hashCellIndex(x, y, z, g.hashTableMask);
+        bool visited = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) if (j < r.numCells && visitedCells[j] == ci) visited = true;
+        if (!visited)
+        {
+            visitedCells[r.numCells] = ci;
+            r.start[r.numCells] = ci == 0 ? 0 : g.cellEnds[ci - 1]; r.end[r.numCells] = g.cellEnds[ci];
+            r.total += r.end[r.numCells] - r.start[r.numCells];
+            r.numCells++;
+        }
+    }
+}
+// one photon against one camera vertex: false = no contribution; else term = cameraBsdfFactor * photon throughput, weight = misWeight / cosToLight
+RT_DEV bool mergePhoton(const RtSceneDesc& scene, const VcmDev& vcm, const HashGridView& g, uint32_t j, const ShadingData& sd, V4 pos, float dVCM, float dVM, V4& term, float& weight)
+{
+    const Photon& photon = g.photons[j];
+    const float distSqr = sqrLength3(pos - V4(photon.px, photon.py, photon.pz, 0.0f));
+    if (!(distSqr <= g.radiusSqr)) return false;
+    const V4 lightDirection = unpackUnitVector(photon.direction);
+    const float cosToLight = dot3(sd.intersection.frame.r[2], lightDirection);
+    if (cosToLight < FLT_EPSILON) return false;
+    float cameraBsdfDirPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
+    const V4 cameraBsdfFactor = materialEvaluate<false>(scene.materials[sd.intersection.material], sd, neg(lightDirection), cameraBsdfDirPdfW, &cameraBsdfRevPdfW);
+    if (almostZero4(cameraBsdfFactor)) return false;
+    const V4 photonThroughput = unpackColorHdr(photon.lum, photon.chroma);
+    const float wLight = photon.dVCM * vcm.misVertexConnectionWeightFactorVM + photon.dVM * cameraBsdfDirPdfW;
+    const float wCamera = dVCM * vcm.misVertexConnectionWeightFactorVM + dVM * cameraBsdfRevPdfW;
+    const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
+    weight = misWeight / cosToLight;
+    term = cameraBsdfFactor * photonThroughput;
+    return true;
+}
+RT_DEV void loadCameraVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_t slot, ShadingData& sd, V4& throughput, float& dVM, float& dVCM)
+{
+    const float4 r0 = cvrec(a, 0, slot), r1 = cvrec(a, 1, slot), r2 = cvrec(a, 2, slot), r3 = cvrec(a, 3, slot), r4 = cvrec(a, 4, slot), r5 = cvrec(a, 5, slot);
+    sd.intersection.frame.r[0] = V4(r1.x, r1.y, r1.z, 0.0f);
+    sd.intersection.frame.r[2] = V4(r2.x, r2.y, r2.z, 0.0f);
+    sd.intersection.frame.r[1] = cross3(sd.intersection.frame.r[0], sd.intersection.frame.r[2]);
+    sd.intersection.frame.r[3] = V4(r0.x, r0.y, r0.z, 0.0f);
+    sd.intersection.texCoord = zero4();
+    sd.intersection.material = ubits(r0.w);
+    sd.outgoingDirWorldSpace = V4(r3.x, r3.y, r3.z, 0.0f);
+    sd.mp.baseColor = V4(r4.x, r4.y, r4.z, r4.w); sd.mp.emission = zero4();
+    sd.mp.roughness = r1.w; sd.mp.metalness = r2.w; sd.mp.IoR = scene.materials[sd.intersection.material].IoR;
+    throughput = V4(r5.x, r5.y, r5.z, 0.0f);
+    dVM = r3.w; dVCM = r5.w;
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene, const VcmDev vcm, const VcmArena a, const HashGridView grid,
+                                                        const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, uint32_t cooperativeMin)
+{
+    __shared__ uint32_t sStart[RT_BLOCK][8], sEnd[RT_BLOCK][8];
+    const uint32_t count = *queueCount;
+    const uint32_t rounded = (count + 63u) & ~63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63u, waveBase = threadIdx.x & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        const bool valid = i < count;
+        uint32_t slot = 0;
+        ShadingData sd; V4 throughput = zero4(); float dVM = 0.0f, dVCM = 0.0f;
+        MergeRanges r; r.numCells = 0; r.total = 0;
+        V4 contribution = zero4();
+        if (valid)
+        {
+            slot = queue[i];
+            loadCameraVertex(scene, a, slot, sd, throughput, dVM, dVCM);
+            mergeCellRanges(grid, sd.intersection.frame.r[3], r);
+        }
+        const bool big = valid && r.total >= cooperativeMin;
+        if (valid && !big)
+        {
+            for (uint32_t c = 0; c < r.numCells; ++c)
+                for (uint32_t j = r.start[c]; j < r.end[c]; ++j)
+                {
+                    V4 term; float weight;
+                    if (mergePhoton(scene, vcm, grid, j, sd, sd.intersection.frame.r[3], dVCM, dVM, term, weight)) contribution = mulAdd(term, weight, contribution);
+                }
+        }
+        unsigned long long mBig = __ballot(big);
+        if (mBig != 0ull)
+        {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sStart[threadIdx.x][c] = c < (int)r.numCells ? r.start[c] : 0u; sEnd[threadIdx.x][c] = c < (int)r.numCells ? r.end[c] : 0u; }
+            // (a wave only reads what its own lanes wrote: no block barrier needed, the LDS writes are ordered before the reads of the same wave)
+            for (; mBig != 0ull; mBig &= mBig - 1ull)
+            {
+                const int q = __ffsll((long long)mBig) - 1;
+                const uint32_t qSlot = (uint32_t)__shfl((int)slot, q);
+                ShadingData qsd; V4 qThroughput; float qVM, qVCM;
+                loadCameraVertex(scene, a, qSlot, qsd, qThroughput, qVM, qVCM);   // same address in all lanes: one broadcast fetch
+                const V4 qPos = qsd.intersection.frame.r[3];
+                V4 acc = zero4();
+                for (uint32_t c = 0; c < 8u; ++c)
+                {
+                    const uint32_t start = sStart[waveBase + (uint32_t)q][c], end = sEnd[waveBase + (uint32_t)q][c];
+                    for (uint32_t base = start; base < end; base += 64u)
+                    {
+                        const uint32_t j = base + lane;
+                        V4 term = zero4(); float weight = 0.0f;
+                        const bool contributes = j < end && mergePhoton(scene, vcm, grid, j, qsd, qPos, qVCM, qVM, term, weight);
+                        for (unsigned long long m = __ballot(contributes); m != 0ull; m &= m - 1ull)
+                        {
+                            const int b = __ffsll((long long)m) - 1;
+                            const V4 t(__shfl(term.x, b), __shfl(term.y, b), __shfl(term.z, b), __shfl(term.w, b));
+                            acc = mulAdd(t, __shfl(weight, b), acc);
+                        }
+                    }
+                }
+                if ((int)lane == q) contribution = acc;
+            }
+        }
+        if (valid)
+        {
+            const V4 vertexMergingColor = contribution * load4(vcm.vertexMergingWeight);
+            const V4 m = throughput * vertexMergingColor;
+            vrec(a, V_MERGE, slot) = f4(m.x, m.y, m.z, 0.0f);
+        }
+    }
 }
 
 // the last vertex's pending terms, then Film::AccumulateColor(x, y, color) (Film.cpp:25-39)
