@@ -405,7 +405,13 @@ int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
  * The draws the reference takes from the per-thread generator come from a per-pixel generator keyed by
  * RtPassParams::rngKey; film splats are float atomics (their summation order is not defined -- in the reference neither).
  * VCM needs the whole frame on one device: shard {0, 1} and no active-block restriction.  Synchronises. */
-typedef enum RtIntegrator { RT_INTEGRATOR_PATH_TRACER_MIS = 0, RT_INTEGRATOR_VCM = 1 } RtIntegrator;
+typedef enum RtIntegrator
+{
+    RT_INTEGRATOR_PATH_TRACER_MIS = 0,
+    RT_INTEGRATOR_VCM = 1,
+    RT_INTEGRATOR_PATH_TRACER = 2   /* rt::PathTracer ("Path Tracer", Core/Rendering/PathTracer.cpp): BSDF sampling only -- no next event
+                                     * estimation, no MIS; lightSamplingStrategy and the two weights of RtPassParams are ignored */
+} RtIntegrator;
 typedef struct RtVcmParams
 {
     uint32_t maxPathLength;            /* mMaxPathLength = 10 */

@@ -28,7 +28,7 @@ extern "C" {
 // Viewport::RenderTile pixel loop (Core/Rendering/Viewport.cpp:305-357) over rows [y0, y1)
 static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                        uint32_t shardRank, uint32_t shardWorld, uint32_t y0, uint32_t y1,
-                       float* sum, float* secondary, Counters* counters)
+                       float* sum, float* secondary, Counters* counters, bool plain = false)
 {
     RenderCtx ctx;
     ctx.scene = scene; ctx.params = params; ctx.counters = counters;
@@ -58,7 +58,7 @@ static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uin
             const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
             ctx.sampler.resetPixel(x, y, params->rngKey);
             const Ray ray = cameraGenerateRay(params->camera, coords, ctx.sampler);
-            const V4 color = renderPixel(ctx, ray);
+            const V4 color = plain ? renderPixelPlain(ctx, ray) : renderPixel(ctx, ray);
             float* px = sum + 3 * ((size_t)y * width + x);                 // Film::AccumulateColor Film.cpp:25-39
             px[0] = px[0] + color.x; px[1] = px[1] + color.y; px[2] = px[2] + color.z;
             if (evenPass && secondary)
@@ -73,14 +73,27 @@ static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uin
 
 // One pass of the hot path on the CPU.  counters: uint64[16] accumulated (layout of RtCounters).
 // numThreads <= 1: single thread.  Rows are split statically; the result does not depend on numThreads.
+static int renderPassImpl(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, bool plain);
 int rto_render_pass(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                     uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads)
+{
+    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, false);
+}
+// the renderer "Path Tracer" (Core/Rendering/PathTracer.cpp)
+int rto_render_pass_plain(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads)
+{
+    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, true);
+}
+static int renderPassImpl(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, bool plain)
 {
     if (!scene || !params || !sum || !counters || width == 0 || height == 0) return -1;
     if (numThreads <= 1)
     {
         Counters c; memset(&c, 0, sizeof(c));
-        renderRows(scene, params, width, height, shardRank, shardWorld, 0, height, sum, secondary, &c);
+        renderRows(scene, params, width, height, shardRank, shardWorld, 0, height, sum, secondary, &c, plain);
         for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
         return 0;
     }
@@ -97,7 +110,7 @@ int rto_render_pass(const RtSceneDesc* scene, const RtPassParams* params, uint32
                 const uint32_t r = nextRow.fetch_add(chunk);
                 if (r >= height) break;
                 const uint32_t r1 = r + chunk < height ? r + chunk : height;
-                renderRows(scene, params, width, height, shardRank, shardWorld, r, r1, sum, secondary, &cs[(size_t)t]);
+                renderRows(scene, params, width, height, shardRank, shardWorld, r, r1, sum, secondary, &cs[(size_t)t], plain);
             }
         });
     }

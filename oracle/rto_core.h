@@ -1682,6 +1682,72 @@ static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
 }
 
 
+// PathTracer::RenderPixel, Core/Rendering/PathTracer.cpp:73-171 (renderer "Path Tracer": BSDF sampling only -- no next event
+// estimation, no MIS weights, the sampling weights of PathTracerMIS do not exist)
+static inline V4 renderPixelPlain(RenderCtx& ctx, const Ray& primaryRay)
+{
+    Hit hitPoint; hitPoint.objectId = RT_INVALID_OBJECT; hitPoint.subObjectId = 0; hitPoint.u = hitPoint.v = 0.0f;
+    Ray ray = primaryRay;
+    ShadingData shadingData; shadingData.intersection.material = RT_NO_MATERIAL;
+    V4 resultColor = zero4();
+    V4 throughput = splat(1.0f);
+    uint32_t depth = 0;
+    const RtSceneDesc* scene = ctx.scene;
+    for (;;)
+    {
+        hitPoint.objectId = RT_INVALID_OBJECT;
+        hitPoint.distance = INFINITY;
+        sceneTraverse(scene, ray, hitPoint, *ctx.counters);
+        if (hitPoint.distance == INFINITY)
+        {
+            V4 result = zero4();   // EvaluateGlobalLights, :47-71
+            for (uint32_t g = 0; g < scene->numGlobalLights; ++g)
+            {
+                const RtLight& light = scene->lights[scene->globalLights[g]];
+                const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
+                float pdf = 0.0f;
+                result = result + lightGetRadiance(scene, light, lightSpaceRay, zero4(), 1.0f, pdf);
+            }
+            resultColor = mulAdd(throughput, result, resultColor);
+            break;
+        }
+        sceneEvaluateIntersection(scene, ray, hitPoint, shadingData.intersection, *ctx.counters);
+        shadingData.outgoingDirWorldSpace = neg(ray.dir);
+        if (hitPoint.subObjectId == RT_LIGHT_OBJECT)   // EvaluateLight, :26-45
+        {
+            const RtObject& obj = scene->objects[hitPoint.objectId];
+            const M4 worldToLight = loadM4(obj.invTransform);
+            const float cosAtLight = -dot3(shadingData.intersection.frame.r[2], ray.dir);
+            float pdf = 0.0f;
+            const V4 lightColor = lightGetRadiance(scene, scene->lights[obj.lightIndex], transformRayUnsafe(worldToLight, ray),
+                                                   transformPoint(worldToLight, shadingData.intersection.frame.r[3]), cosAtLight, pdf);
+            resultColor = mulAdd(throughput, lightColor, resultColor);
+            break;
+        }
+        const RtMaterial& mat = scene->materials[shadingData.intersection.material];
+        materialEvaluateShadingData(scene, mat, shadingData);
+        resultColor = mulAdd(throughput, shadingData.mp.emission, resultColor);
+        if (depth >= ctx.params->maxRayDepth) break;
+        if (depth >= ctx.params->minRussianRouletteDepth)
+        {
+            const float minColorValue = 0.125f;
+            float threshold = minColorValue + (1.0f - minColorValue) * colorMax(shadingData.mp.baseColor);
+            if (ctx.sampler.getFloat() > threshold) break;
+            throughput = throughput * (1.0f / threshold);
+        }
+        float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
+        float u[3]; u[0] = ctx.sampler.getFloat(); u[1] = ctx.sampler.getFloat(); u[2] = ctx.sampler.getFloat();
+        const V4 bsdfValue = materialSample(mat, shadingData, u, incomingDirWorldSpace, pdf, event);
+        throughput = throughput * bsdfValue;   // a failed Sample() returns black (Material.cpp:182-232)
+        if (almostZero4(throughput)) break;
+        ray = makeRay(shadingData.intersection.frame.r[3], incomingDirWorldSpace);
+        ray.origin = ray.origin + ray.dir * 0.001f;
+        depth++;
+    }
+    ctx.counters->c[C_RAYS] += (uint64_t)depth + 1;
+    return resultColor;
+}
+
 // =====================================================================================================
 // Post-processing -- Viewport::PostProcessTile (Core/Rendering/Viewport.cpp:495-550), lane-wise over rgb(+w)
 // =====================================================================================================

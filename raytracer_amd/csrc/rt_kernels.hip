@@ -518,8 +518,10 @@ RT_DEV void flushAppendBuffer(const uint32_t* buf, uint32_t& count, uint32_t& ba
     __syncthreads();
 }
 
-// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395)
-template <bool kLean>
+// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395).
+// kPlain: the renderer "Path Tracer" instead (PathTracer::RenderPixel, Core/Rendering/PathTracer.cpp:73-171): the same walk without
+// next event estimation, MIS weights and sampling weights.
+template <bool kLean, bool kPlain = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
                                                     const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                     uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
@@ -578,14 +580,15 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                         const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
                         float directPdfW = 0.0f;
                         const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
-                        if (!almostZero4(lightContribution))
+                        if (kPlain) result = result + lightContribution;   // PathTracer::EvaluateGlobalLights, PathTracer.cpp:47-71
+                        else if (!almostZero4(lightContribution))
                         {
                             float misWeight = 1.0f;
                             if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
                             result = mulAdd(lightContribution, misWeight, result);
                         }
                     }
-                    result = result * bsdfSamplingWeight;
+                    if (!kPlain) result = result * bsdfSamplingWeight;
                     resultColor = mulAdd(throughput, result, resultColor);
                     break;
                 }
@@ -609,7 +612,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                     const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
                     float directPdfA = 0.0f;
                     V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
-                    if (!almostZero4(lightContribution))
+                    if (kPlain) resultColor = mulAdd(throughput, lightContribution, resultColor);   // PathTracer::EvaluateLight, PathTracer.cpp:26-45
+                    else if (!almostZero4(lightContribution))
                     {
                         float misWeight = 1.0f;
                         if (depth > 0 && !lastSpecular)
@@ -632,14 +636,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
                 materialEvaluateShadingData<kLean>(scene, mat, sd);
 
                 // emission, PathTracerMIS.cpp:309-317
-                resultColor = mulAdd(throughput, sd.mp.emission * bsdfSamplingWeight, resultColor);
+                resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);
 
                 Sampler sampler; loadSampler(sampler, paths, slot, pix, rSampler, pass, scene.blueNoise);
                 sampler.seed = passes[slot / slotsPerPass].seed;
 
                 // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
                 uint32_t numRequests = 0;
-                if (scene.numLights != 0)
+                if (!kPlain && scene.numLights != 0)
                 {
                     if (pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE)
                     {
@@ -964,6 +968,7 @@ struct RtgpuContext
     bool seedEventUsed[RT_SEED_RING];
     uint32_t seedCursor = 0;
 
+    bool plainPathTracer = false;      // RT_INTEGRATOR_PATH_TRACER: k_shade<false, true>
     // bidirectional integrator (rt_vcm.inl); runs one pass at a time on lane 0's stream
     struct Vcm
     {
@@ -1501,7 +1506,7 @@ static int flushPending(RtgpuContext* c)
     for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
     {
         const bool haveClosest = depth <= maxRayDepth;
-        const bool haveShadow = depth > 0 && c->numLights != 0;
+        const bool haveShadow = depth > 0 && c->numLights != 0 && !c->plainPathTracer;
         if (haveClosest || haveShadow)
         {
             const uint32_t* tq = haveClosest ? l.queues[depth & 1u] : nullptr;
@@ -1519,7 +1524,12 @@ static int flushPending(RtgpuContext* c)
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE(L) hipLaunchKernelGGL((k_shade<L>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth, \
                                              l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters)
-            if (c->leanScene) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
+            if (c->plainPathTracer)
+            {
+                hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth,
+                                   l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters);
+            }
+            else if (c->leanScene) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
         }
     }
     // the film is summed in pass order: this batch's accumulate runs after the previous batch's
@@ -1730,7 +1740,7 @@ static void defaultVcmParams(RtVcmParams& vp)
 RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const RtVcmParams* vcm)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
-    if (integrator != RT_INTEGRATOR_PATH_TRACER_MIS && integrator != RT_INTEGRATOR_VCM) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (integrator != RT_INTEGRATOR_PATH_TRACER_MIS && integrator != RT_INTEGRATOR_VCM && integrator != RT_INTEGRATOR_PATH_TRACER) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
     int r = rtgpu_synchronize(c); if (r) return r;
     RtVcmParams vp; defaultVcmParams(vp);
     if (vcm) vp = *vcm;
@@ -1741,6 +1751,7 @@ RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const R
         if (!(vp.mergingRadiusMultiplier > 0.0f && vp.mergingRadiusMultiplier <= 1.0f)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mergingRadiusMultiplier must be in (0, 1]");
     }
     c->vcm.enabled = integrator == RT_INTEGRATOR_VCM;
+    c->plainPathTracer = integrator == RT_INTEGRATOR_PATH_TRACER;
     c->vcm.params = vp;
     c->vcm.havePhotons = false;
     return RTGPU_OK;

@@ -36,4 +36,12 @@ private:
     std::vector<uint16> mBlueNoise;
 };
 
+// "Path Tracer": the same device pipeline without next event estimation and MIS (reference: Core/Rendering/PathTracer.h)
+class RAYLIB_API PathTracer : public PathTracerMIS
+{
+public:
+    explicit PathTracer(const Scene& scene);
+    const char* GetName() const override;
+};
+
 } // namespace rt

@@ -551,13 +551,19 @@ RendererPtr CreateRenderer(const std::string& name, const Scene& scene)
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
+    if (name == "Path Tracer")
+    {
+        std::shared_ptr<PathTracer> r(new PathTracer(scene));
+        if (!r->GetDeviceContext()) return nullptr;
+        return r;
+    }
     if (name == "VCM")
     {
         std::shared_ptr<VertexConnectionAndMerging> r(new VertexConnectionAndMerging(scene));
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
-    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer MIS\" and \"VCM\")\n", name.c_str());
+    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer\", \"Path Tracer MIS\" and \"VCM\")\n", name.c_str());
     return nullptr;
 }
 
@@ -633,6 +639,13 @@ bool PathTracerMIS::RenderPass(const RtPassParams& params)
     }
     return true;
 }
+
+PathTracer::PathTracer(const Scene& scene) : PathTracerMIS(scene)
+{
+    if (GetDeviceContext() && rtgpu_set_integrator(GetDeviceContext(), RT_INTEGRATOR_PATH_TRACER, nullptr) != RTGPU_OK)
+        fprintf(stderr, "[rt] ERROR: cannot select the plain path tracer: %s\n", rtgpu_last_error());
+}
+const char* PathTracer::GetName() const { return "Path Tracer"; }
 
 VertexConnectionAndMerging::VertexConnectionAndMerging(const Scene& scene)
     : PathTracerMIS(scene)

@@ -1,7 +1,7 @@
 // The reference's RenderingTest.* suite (Tests/RaytracingTests.cpp:263-523) written against this repository's
 // C++ mirror of the reference API: same scene set-up calls, same 32x32 viewport, same pass counts, same
 // per-pixel tolerances on the (un-tone-mapped) sum buffer.  The reference loops over {"Path Tracer", "Path Tracer MIS", "VCM"}
-// (Tests/RaytracingTests.cpp:17-22); the two names that exist here are run the same way.  No gtest in the image: a tiny harness.
+// (Tests/RaytracingTests.cpp:17-22) and so does this.  No gtest in the image: a tiny harness.
 //
 // Build (tests/test_cpp_api.py does this):
 //   g++ -std=c++17 -O1 -I raytracer_amd/host tests/cpp/rendering_tests.cpp -L raytracer_amd/lib -lraytracer_amd_host -lrtgpu
@@ -21,8 +21,8 @@
 using namespace rt;
 using namespace math;
 
-static const char* gRendererNames[] = { "Path Tracer MIS", "VCM" };
-static const char* gRendererName = gRendererNames[0];
+static const char* gRendererNames[] = { "Path Tracer", "Path Tracer MIS", "VCM" };   // Tests/RaytracingTests.cpp:17-22
+static const char* gRendererName = gRendererNames[1];
 static constexpr uint32 ViewportSize = 32;
 static int gFailures = 0;
 
@@ -132,7 +132,7 @@ int main()
         printf("no GPU renderer available\n");
         return 2;
     }
-    if (CreateRenderer("Path Tracer", *std::make_unique<Scene>()) != nullptr) { printf("\"Path Tracer\" must not exist\n"); return 1; }
+    if (CreateRenderer("Light Tracer", *std::make_unique<Scene>()) != nullptr) { printf("\"Light Tracer\" must not exist\n"); return 1; }
 
     for (const char* rendererName : gRendererNames)
     {

@@ -26,11 +26,11 @@ def lib():
     return _lib
 
 
-def render_pass(scene_desc_ptr, params, width, height, sum_buf, secondary=None, counters=None, shard=(0, 1), threads=1):
-    """One pass of the oracle into sum_buf (H, W, 3 float32, accumulated in place)."""
+def render_pass(scene_desc_ptr, params, width, height, sum_buf, secondary=None, counters=None, shard=(0, 1), threads=1, plain=False):
+    """One pass of the oracle into sum_buf (H, W, 3 float32, accumulated in place).  plain: the renderer "Path Tracer"."""
     if counters is None:
         counters = np.zeros(16, dtype=np.uint64)
-    r = lib().rto_render_pass(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(shard[0]), C.c_uint32(shard[1]),
+    r = (lib().rto_render_pass_plain if plain else lib().rto_render_pass)(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(shard[0]), C.c_uint32(shard[1]),
                               sum_buf.ctypes.data_as(C.POINTER(C.c_float)),
                               secondary.ctypes.data_as(C.POINTER(C.c_float)) if secondary is not None else None,
                               counters.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads))

@@ -500,3 +500,26 @@ def test_full_size_sponza_class_properties(built):
         rays += vp.counters()["numRays"]
     assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
     assert rays == cw["numRays"]
+
+
+def test_plain_path_tracer_bit_exact(built):
+    """Renderer "Path Tracer" (PathTracer.cpp: BSDF sampling only): all lights x all BSDFs, the mesh scene and the Cornell box
+    against the oracle's restatement -- images and counters identical; no shadow rays are cast."""
+    for scene, camera, w, h in ((lambda a: scene_zoo.all_lights_scene(a), None, 96, 72), (lambda a: scene_zoo.mesh_scene(a, triangles=20000), None, 96, 54),
+                                (lambda a: scenes.cornell_box(a), None, 80, 60)):
+        sc, cam = scene(w / h)
+        desc = sc.desc
+        bn = ra.load_blue_noise()
+        desc.contents.blueNoise = bn.ctypes.data
+        vp = ra.Viewport(w, h, seed=7, max_ray_depth=6)
+        vp.set_renderer(sc, name="Path Tracer")
+        ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
+        cnt = np.zeros(16, dtype=np.uint64)
+        for _ in range(3):
+            p = vp.next_pass_params(cam)
+            vp.render_pass_with(p)
+            oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=8, plain=True)
+        img, img2 = vp.sum_buffer(secondary=True)
+        out = (img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)})
+        assert_identical(*out)
+        assert out[2]["numShadowRays"] == 0 and out[2]["numRays"] > 3 * w * h
