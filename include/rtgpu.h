@@ -409,9 +409,18 @@ typedef enum RtIntegrator
 {
     RT_INTEGRATOR_PATH_TRACER_MIS = 0,
     RT_INTEGRATOR_VCM = 1,
-    RT_INTEGRATOR_PATH_TRACER = 2   /* rt::PathTracer ("Path Tracer", Core/Rendering/PathTracer.cpp): BSDF sampling only -- no next event
+    RT_INTEGRATOR_PATH_TRACER = 2,  /* rt::PathTracer ("Path Tracer", Core/Rendering/PathTracer.cpp): BSDF sampling only -- no next event
                                      * estimation, no MIS; lightSamplingStrategy and the two weights of RtPassParams are ignored */
+    RT_INTEGRATOR_DEBUG = 3         /* rt::DebugRenderer ("Debug", Core/Rendering/DebugRenderer.cpp): one colour per pixel from the primary
+                                     * ray's first hit, selected by rtgpu_set_debug_rendering_mode (default: TriangleID) */
 } RtIntegrator;
+/* rt::DebugRenderingMode (Core/Rendering/DebugRenderer.h:7-33; the four intersection-counter modes exist in the reference only under
+ * RT_ENABLE_INTERSECTION_COUNTERS, which is off, and are not provided) */
+typedef enum RtDebugRenderingMode
+{
+    RT_DEBUG_CAMERA_LIGHT = 0, RT_DEBUG_TRIANGLE_ID, RT_DEBUG_DEPTH, RT_DEBUG_POSITION, RT_DEBUG_NORMALS, RT_DEBUG_TANGENTS, RT_DEBUG_BITANGENTS,
+    RT_DEBUG_TEXCOORDS, RT_DEBUG_BASE_COLOR, RT_DEBUG_EMISSION, RT_DEBUG_ROUGHNESS, RT_DEBUG_METALNESS, RT_DEBUG_IOR
+} RtDebugRenderingMode;
 typedef struct RtVcmParams
 {
     uint32_t maxPathLength;            /* mMaxPathLength = 10 */
@@ -429,6 +438,8 @@ typedef struct RtVcmParams
 } RtVcmParams;
 #define RT_VCM_MAX_PATH_LENGTH 16u
 int rtgpu_set_integrator(RtgpuContext* ctx, uint32_t integrator, const RtVcmParams* vcm /* NULL: defaults */);
+/* DebugRenderer::mRenderingMode; needs RT_INTEGRATOR_DEBUG.  Synchronises. */
+int rtgpu_set_debug_rendering_mode(RtgpuContext* ctx, uint32_t mode);
 /* number of photons recorded by the last VCM pass (the merge set of the next one).  Synchronises. */
 int rtgpu_vcm_num_photons(RtgpuContext* ctx, uint32_t* outCount);
 

@@ -141,7 +141,7 @@ enum
     KAT_CAMERA_RAY = 60,
     // bidirectional (VCM) building blocks
     KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44, KAT_BSDF_PDFS = 52,
-    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63,
+    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63, KAT_HSV_TO_RGB = 64,
     // host-side algorithms (checked against raytracer_amd's host library, not the oracle)
     KAT_HOST_EULER = 100, KAT_HOST_INVERSE = 101,
 };
@@ -1334,6 +1334,25 @@ static void genBloom()
     writeRaw("bloom_kat.bin", out.data(), out.size() * 4);
 }
 
+// HSVtoRGB (Core/Color/ColorHelpers.h:133-156) as DebugRenderer's TriangleID mode drives it (DebugRenderer.cpp:98-106):
+// in = { objectId, subObjectId } -> hash -> hue, saturation -> rgb
+static void genDebug()
+{
+    const int N = 2048;
+    KatWriter k("debug_triangle_id", KAT_HSV_TO_RGB, 2, 4);
+    Lcg g(130);
+    for (int i = 0; i < N; ++i)
+    {
+        const uint32_t objectId = (i % 5 == 0) ? (uint32_t)(i / 5) : g.u32() % 64u, subObjectId = (i % 3 == 0) ? g.u32() : g.u32() % 300000u;
+        float* in = k.addIn(); in[0] = bitsf(objectId); in[1] = bitsf(subObjectId);
+        const uint64 hash = Hash((uint64)objectId | ((uint64)subObjectId << 32));
+        const float hue = (float)(uint32)hash / (float)UINT32_MAX;
+        const float saturation = 0.5f + 0.5f * (float)(uint32)(hash >> 32) / (float)UINT32_MAX;
+        put4(k.addOut(), HSVtoRGB(hue, saturation, 1.0f));
+    }
+    k.save();
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -1354,6 +1373,7 @@ int main(int argc, char** argv)
     genBidirBsdf();
     genBidirCameraFilm();
     genBloom();
+    genDebug();
     printf("done\n");
     return 0;
 }

@@ -28,7 +28,7 @@ extern "C" {
 // Viewport::RenderTile pixel loop (Core/Rendering/Viewport.cpp:305-357) over rows [y0, y1)
 static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                        uint32_t shardRank, uint32_t shardWorld, uint32_t y0, uint32_t y1,
-                       float* sum, float* secondary, Counters* counters, bool plain = false)
+                       float* sum, float* secondary, Counters* counters, int integrator = 0)
 {
     RenderCtx ctx;
     ctx.scene = scene; ctx.params = params; ctx.counters = counters;
@@ -58,7 +58,7 @@ static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uin
             const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
             ctx.sampler.resetPixel(x, y, params->rngKey);
             const Ray ray = cameraGenerateRay(params->camera, coords, ctx.sampler);
-            const V4 color = plain ? renderPixelPlain(ctx, ray) : renderPixel(ctx, ray);
+            const V4 color = integrator == 0 ? renderPixel(ctx, ray) : (integrator == 1 ? renderPixelPlain(ctx, ray) : renderPixelDebug(ctx, ray, (uint32_t)(integrator - 2)));
             float* px = sum + 3 * ((size_t)y * width + x);                 // Film::AccumulateColor Film.cpp:25-39
             px[0] = px[0] + color.x; px[1] = px[1] + color.y; px[2] = px[2] + color.z;
             if (evenPass && secondary)
@@ -74,26 +74,33 @@ static void renderRows(const RtSceneDesc* scene, const RtPassParams* params, uin
 // One pass of the hot path on the CPU.  counters: uint64[16] accumulated (layout of RtCounters).
 // numThreads <= 1: single thread.  Rows are split statically; the result does not depend on numThreads.
 static int renderPassImpl(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
-                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, bool plain);
+                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, int integrator);
 int rto_render_pass(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                     uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads)
 {
-    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, false);
+    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, 0);
 }
 // the renderer "Path Tracer" (Core/Rendering/PathTracer.cpp)
 int rto_render_pass_plain(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                           uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads)
 {
-    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, true);
+    return renderPassImpl(scene, params, width, height, shardRank, shardWorld, sum, secondary, counters, numThreads, 1);
+}
+// the renderer "Debug" (Core/Rendering/DebugRenderer.cpp) in DebugRenderingMode `mode`
+int rto_render_pass_debug(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t mode,
+                          float* sum, float* secondary, uint64_t* counters, int numThreads)
+{
+    if (mode >= DBG_NUM_MODES) return -1;
+    return renderPassImpl(scene, params, width, height, 0, 1, sum, secondary, counters, numThreads, 2 + (int)mode);
 }
 static int renderPassImpl(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
-                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, bool plain)
+                          uint32_t shardRank, uint32_t shardWorld, float* sum, float* secondary, uint64_t* counters, int numThreads, int integrator)
 {
     if (!scene || !params || !sum || !counters || width == 0 || height == 0) return -1;
     if (numThreads <= 1)
     {
         Counters c; memset(&c, 0, sizeof(c));
-        renderRows(scene, params, width, height, shardRank, shardWorld, 0, height, sum, secondary, &c, plain);
+        renderRows(scene, params, width, height, shardRank, shardWorld, 0, height, sum, secondary, &c, integrator);
         for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
         return 0;
     }
@@ -110,7 +117,7 @@ static int renderPassImpl(const RtSceneDesc* scene, const RtPassParams* params, 
                 const uint32_t r = nextRow.fetch_add(chunk);
                 if (r >= height) break;
                 const uint32_t r1 = r + chunk < height ? r + chunk : height;
-                renderRows(scene, params, width, height, shardRank, shardWorld, r, r1, sum, secondary, &cs[(size_t)t], plain);
+                renderRows(scene, params, width, height, shardRank, shardWorld, r, r1, sum, secondary, &cs[(size_t)t], integrator);
             }
         });
     }
@@ -136,7 +143,7 @@ enum
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
     KAT_CAMERA_RAY = 60,
     KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44, KAT_BSDF_PDFS = 52,
-    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63,
+    KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63, KAT_HSV_TO_RGB = 64,
     KAT_SAMPLER = 70,
 };
 
@@ -330,6 +337,7 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             if (!filmSplatPixel(V4(i[0], i[1], 0.0f, 0.0f), fbits(i[2]), fbits(i[3]), rng.getVector4(), x, y)) { x = y = 0xFFFFFFFFu; }
             o[0] = bitsf(x); o[1] = bitsf(y); memcpy(o + 2, rng.seed0, 16); memcpy(o + 6, rng.seed1, 16); break;
         }
+        case KAT_HSV_TO_RGB: putV4(o, debugTriangleIdColor(fbits(i[0]), fbits(i[1]))); break;
         case KAT_PACKED_PHOTON:   // in: direction[4], colour[4]   out: packed direction, packed colour (2 words), unpacked direction[4], colour[4]
         {
             const uint32_t pd = packUnitVector(load4(i));

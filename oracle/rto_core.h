@@ -1682,6 +1682,64 @@ static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
 }
 
 
+// DebugRenderer::RenderPixel, Core/Rendering/DebugRenderer.cpp:26-195 (renderer "Debug"; the four counter modes exist only under
+// RT_ENABLE_INTERSECTION_COUNTERS, off in the reference).  Modes = DebugRenderingMode, DebugRenderer.h:7-33.
+enum { DBG_CAMERA_LIGHT = 0, DBG_TRIANGLE_ID, DBG_DEPTH, DBG_POSITION, DBG_NORMALS, DBG_TANGENTS, DBG_BITANGENTS, DBG_TEXCOORDS,
+       DBG_BASE_COLOR, DBG_EMISSION, DBG_ROUGHNESS, DBG_METALNESS, DBG_IOR, DBG_NUM_MODES };
+static inline V4 hsvToRgb(float hue, float saturation, float value)   // Core/Color/ColorHelpers.h:133-156
+{
+    const int h_i = (int)(hue * 6.0f);
+    const float f = hue * 6 - h_i;
+    const float p = value * (1 - saturation);
+    const float q = value * (1 - f * saturation);
+    const float t = value * (1 - (1 - f) * saturation);
+    if (h_i == 0) return V4(value, t, p, 0.0f);
+    else if (h_i == 1) return V4(q, value, p, 0.0f);
+    else if (h_i == 2) return V4(p, value, t, 0.0f);
+    else if (h_i == 3) return V4(p, q, value, 0.0f);
+    else if (h_i == 4) return V4(t, p, value, 0.0f);
+    else if (h_i == 5) return V4(value, p, q, 0.0f);
+    return zero4();
+}
+static inline V4 debugTriangleIdColor(uint32_t objectId, uint32_t subObjectId)   // DebugRenderer.cpp:98-106
+{
+    const uint64_t hash = murmurFmix64((uint64_t)objectId | ((uint64_t)subObjectId << 32));
+    const float hue = (float)(uint32_t)hash / (float)UINT32_MAX;
+    const float saturation = 0.5f + 0.5f * (float)(uint32_t)(hash >> 32) / (float)UINT32_MAX;
+    return hsvToRgb(hue, saturation, 1.0f);
+}
+static inline V4 saturate4(V4 v) { return min4(splat(1.0f), max4(zero4(), v)); }   // Vector4Impl.h:68-71
+static inline V4 renderPixelDebug(RenderCtx& ctx, const Ray& ray, uint32_t mode)
+{
+    const RtSceneDesc* scene = ctx.scene;
+    Hit hitPoint; hitPoint.objectId = RT_INVALID_OBJECT; hitPoint.subObjectId = 0; hitPoint.u = hitPoint.v = 0.0f; hitPoint.distance = INFINITY;
+    sceneTraverse(scene, ray, hitPoint, *ctx.counters);
+    if (hitPoint.distance == INFINITY) return zero4();
+    if (hitPoint.subObjectId == RT_LIGHT_OBJECT) return V4(1.0f, 1.0f, 0.0f, 0.0f);
+    ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
+    if (mode != DBG_TRIANGLE_ID && mode != DBG_DEPTH)
+    {
+        if (hitPoint.distance < FLT_MAX) sceneEvaluateIntersection(scene, ray, hitPoint, sd.intersection, *ctx.counters);
+        materialEvaluateShadingData(scene, scene->materials[sd.intersection.material], sd);
+    }
+    switch (mode)
+    {
+    case DBG_CAMERA_LIGHT: { const float NdotL = dot3(ray.dir, sd.intersection.frame.r[2]); return sd.mp.baseColor * Abs(NdotL); }
+    case DBG_DEPTH: { const float invDepth = 1.0f - 1.0f / (1.0f + hitPoint.distance / 10.0f); return splat(invDepth); }
+    case DBG_TRIANGLE_ID: return debugTriangleIdColor(hitPoint.objectId, hitPoint.subObjectId);
+    case DBG_TANGENTS: return saturate4(mulAdd(sd.intersection.frame.r[0], splat(0.5f), splat(0.5f)));
+    case DBG_BITANGENTS: return saturate4(mulAdd(sd.intersection.frame.r[1], splat(0.5f), splat(0.5f)));
+    case DBG_NORMALS: return saturate4(mulAdd(sd.intersection.frame.r[2], splat(0.5f), splat(0.5f)));
+    case DBG_POSITION: return max4(zero4(), sd.intersection.frame.r[3]);
+    case DBG_TEXCOORDS: { const V4 t(sd.intersection.texCoord.x, sd.intersection.texCoord.y, 0.0f, 0.0f); return V4(t.x - floorf(t.x), t.y - floorf(t.y), 0.0f, 0.0f); }
+    case DBG_BASE_COLOR: return sd.mp.baseColor;
+    case DBG_EMISSION: return sd.mp.emission;
+    case DBG_ROUGHNESS: return splat(sd.mp.roughness);
+    case DBG_METALNESS: return splat(sd.mp.metalness);
+    default: return splat(sd.mp.IoR);
+    }
+}
+
 // PathTracer::RenderPixel, Core/Rendering/PathTracer.cpp:73-171 (renderer "Path Tracer": BSDF sampling only -- no next event
 // estimation, no MIS weights, the sampling weights of PathTracerMIS do not exist)
 static inline V4 renderPixelPlain(RenderCtx& ctx, const Ray& primaryRay)

@@ -396,6 +396,12 @@ class Viewport:
         if r != 0:
             raise RuntimeError("set_vcm: the viewport's renderer is not \"VCM\"")
 
+    def set_debug_mode(self, mode):
+        """DebugRenderer::mRenderingMode (renderer name "Debug"): 0 CameraLight, 1 TriangleID, 2 Depth, 3 Position, 4 Normals, 5 Tangents,
+        6 Bitangents, 7 TexCoords, 8 BaseColor, 9 Emission, 10 Roughness, 11 Metalness, 12 IoR."""
+        if host_lib().rth_viewport_set_debug_mode(self._h, C.c_uint32(mode)) != 0:
+            raise RuntimeError("set_debug_mode: the viewport's renderer is not \"Debug\" or the mode is unknown")
+
     def vcm_num_photons(self):
         n = C.c_uint32(0)
         ctx = C.c_void_p(host_lib().rth_viewport_device_ctx(self._h))

@@ -729,6 +729,80 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, con
     flushCounters(cnt, counters);
 }
 
+// DebugRenderer::RenderPixel after the primary ray's traversal (Core/Rendering/DebugRenderer.cpp:26-195, renderer "Debug"): one colour
+// per pixel from the first hit.  mode = DebugRenderingMode (DebugRenderer.h:7-33; the four counter modes exist only under
+// RT_ENABLE_INTERSECTION_COUNTERS, off in the reference).
+enum { DBG_CAMERA_LIGHT = 0, DBG_TRIANGLE_ID, DBG_DEPTH, DBG_POSITION, DBG_NORMALS, DBG_TANGENTS, DBG_BITANGENTS, DBG_TEXCOORDS,
+       DBG_BASE_COLOR, DBG_EMISSION, DBG_ROUGHNESS, DBG_METALNESS, DBG_IOR, DBG_NUM_MODES };
+RT_DEV V4 hsvToRgb(float hue, float saturation, float value)   // Core/Color/ColorHelpers.h:133-156
+{
+    const int h_i = (int)(hue * 6.0f);
+    const float f = hue * 6 - h_i;
+    const float p = value * (1 - saturation);
+    const float q = value * (1 - f * saturation);
+    const float t = value * (1 - (1 - f) * saturation);
+    if (h_i == 0) return V4(value, t, p, 0.0f);
+    else if (h_i == 1) return V4(q, value, p, 0.0f);
+    else if (h_i == 2) return V4(p, value, t, 0.0f);
+    else if (h_i == 3) return V4(p, q, value, 0.0f);
+    else if (h_i == 4) return V4(t, p, value, 0.0f);
+    else if (h_i == 5) return V4(value, p, q, 0.0f);
+    return zero4();
+}
+__global__ void __launch_bounds__(RT_BLOCK) k_debug_shade(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                          uint32_t mode, unsigned long long* counters)
+{
+    Counters cnt; zeroCounters(cnt);
+    const uint32_t count = *countIn;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    {
+        const uint32_t slot = queueIn[i];
+        const float4 rOrigin = prec(paths, R_ORIGIN, slot), rDir = prec(paths, R_DIR, slot), rHit = prec(paths, R_HIT, slot);
+        const Ray ray = makePathRay(rOrigin, rDir, 0u);
+        Hit hit; hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = prec(paths, R_SAMPLER, slot).x;
+        V4 color = zero4();
+        if (hit.objectId != RT_INVALID_OBJECT)
+        {
+            if (hit.subObjectId == RT_LIGHT_OBJECT) color = V4(1.0f, 1.0f, 0.0f, 0.0f);
+            else
+            {
+                ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
+                if (mode != DBG_TRIANGLE_ID && mode != DBG_DEPTH)
+                {
+                    if (hit.distance < FLT_MAX) sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                    materialEvaluateShadingData<false>(scene, scene.materials[sd.intersection.material], sd);
+                }
+                switch (mode)
+                {
+                case DBG_CAMERA_LIGHT: { const float NdotL = dot3(ray.dir, sd.intersection.frame.r[2]); color = sd.mp.baseColor * Abs(NdotL); break; }
+                case DBG_DEPTH: { const float invDepth = 1.0f - 1.0f / (1.0f + hit.distance / 10.0f); color = splat(invDepth); break; }
+                case DBG_TRIANGLE_ID:
+                {
+                    const uint64_t hash = murmurFmix64((uint64_t)hit.objectId | ((uint64_t)hit.subObjectId << 32));
+                    const float hue = (float)(uint32_t)hash / (float)UINT32_MAX;
+                    const float saturation = 0.5f + 0.5f * (float)(uint32_t)(hash >> 32) / (float)UINT32_MAX;
+                    color = hsvToRgb(hue, saturation, 1.0f);
+                    break;
+                }
+                case DBG_TANGENTS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[0], splat(0.5f), splat(0.5f)))); break;
+                case DBG_BITANGENTS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[1], splat(0.5f), splat(0.5f)))); break;
+                case DBG_NORMALS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[2], splat(0.5f), splat(0.5f)))); break;
+                case DBG_POSITION: color = max4(zero4(), sd.intersection.frame.r[3]); break;
+                case DBG_TEXCOORDS: color = V4(sd.intersection.texCoord.x - floorf(sd.intersection.texCoord.x), sd.intersection.texCoord.y - floorf(sd.intersection.texCoord.y), 0.0f, 0.0f); break;
+                case DBG_BASE_COLOR: color = sd.mp.baseColor; break;
+                case DBG_EMISSION: color = sd.mp.emission; break;
+                case DBG_ROUGHNESS: color = splat(sd.mp.roughness); break;
+                case DBG_METALNESS: color = splat(sd.mp.metalness); break;
+                default: color = splat(sd.mp.IoR); break;
+                }
+            }
+        }
+        prec(paths, R_RESULT, slot) = f4(color.x, color.y, color.z, prec(paths, R_RESULT, slot).w);
+    }
+    flushCounters(cnt, counters);
+}
+
 // Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y.  The passes of a
 // batch are added per pixel IN PASS ORDER, so the float sum is the one the reference builds pass after pass; the
 // secondary sum receives the even passes (Viewport.cpp:303).
@@ -969,6 +1043,7 @@ struct RtgpuContext
     uint32_t seedCursor = 0;
 
     bool plainPathTracer = false;      // RT_INTEGRATOR_PATH_TRACER: k_shade<false, true>
+    int debugMode = -1;                // RT_INTEGRATOR_DEBUG: DebugRenderingMode, k_debug_shade after the primary rays' traversal
     // bidirectional integrator (rt_vcm.inl); runs one pass at a time on lane 0's stream
     struct Vcm
     {
@@ -1503,7 +1578,8 @@ static int flushPending(RtgpuContext* c)
 #define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
     // bounce k: trace {closest rays of bounce k, NEE rays of bounce k-1} -> shade k; one last trace for the NEE rays of
     // the final bounce
-    for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
+    const uint32_t lastDepth = c->debugMode >= 0 ? 0u : maxRayDepth + 1u;
+    for (uint32_t depth = 0; depth <= lastDepth; ++depth)
     {
         const bool haveClosest = depth <= maxRayDepth;
         const bool haveShadow = depth > 0 && c->numLights != 0 && !c->plainPathTracer;
@@ -1524,7 +1600,9 @@ static int flushPending(RtgpuContext* c)
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE(L) hipLaunchKernelGGL((k_shade<L>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth, \
                                              l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters)
-            if (c->plainPathTracer)
+            if (c->debugMode >= 0)
+                hipLaunchKernelGGL(k_debug_shade, grid, block, 0, l.stream, c->sceneDev, l.paths, l.queues[0], pathCounts + 0, (uint32_t)c->debugMode, c->counters);
+            else if (c->plainPathTracer)
             {
                 hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth,
                                    l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters);
@@ -1740,7 +1818,7 @@ static void defaultVcmParams(RtVcmParams& vp)
 RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const RtVcmParams* vcm)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
-    if (integrator != RT_INTEGRATOR_PATH_TRACER_MIS && integrator != RT_INTEGRATOR_VCM && integrator != RT_INTEGRATOR_PATH_TRACER) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (integrator > RT_INTEGRATOR_DEBUG) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
     int r = rtgpu_synchronize(c); if (r) return r;
     RtVcmParams vp; defaultVcmParams(vp);
     if (vcm) vp = *vcm;
@@ -1752,8 +1830,19 @@ RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const R
     }
     c->vcm.enabled = integrator == RT_INTEGRATOR_VCM;
     c->plainPathTracer = integrator == RT_INTEGRATOR_PATH_TRACER;
+    c->debugMode = integrator == RT_INTEGRATOR_DEBUG ? (c->debugMode >= 0 ? c->debugMode : (int)DBG_TRIANGLE_ID) : -1;   // DebugRenderer's default mode, DebugRenderer.cpp:16
     c->vcm.params = vp;
     c->vcm.havePhotons = false;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_set_debug_rendering_mode(RtgpuContext* c, uint32_t mode)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (mode >= DBG_NUM_MODES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown DebugRenderingMode");
+    if (c->debugMode < 0) return fail(RTGPU_ERR_NOT_READY, "the integrator is not RT_INTEGRATOR_DEBUG");
+    int r = rtgpu_synchronize(c); if (r) return r;
+    c->debugMode = (int)mode;
     return RTGPU_OK;
 }
 

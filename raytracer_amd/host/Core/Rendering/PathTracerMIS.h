@@ -44,4 +44,20 @@ public:
     const char* GetName() const override;
 };
 
+// "Debug": one colour per pixel from the primary hit (reference: Core/Rendering/DebugRenderer.h)
+enum class DebugRenderingMode : uint8
+{
+    CameraLight = 0, TriangleID, Depth, Position, Normals, Tangents, Bitangents, TexCoords, BaseColor, Emission, Roughness, Metalness, IoR,
+};
+class RAYLIB_API DebugRenderer : public PathTracerMIS
+{
+public:
+    explicit DebugRenderer(const Scene& scene);
+    const char* GetName() const override;
+    bool RenderPass(const RtPassParams& params) override;
+    DebugRenderingMode mRenderingMode;
+private:
+    int mAppliedMode = -1;
+};
+
 } // namespace rt

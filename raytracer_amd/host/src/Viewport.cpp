@@ -557,13 +557,19 @@ RendererPtr CreateRenderer(const std::string& name, const Scene& scene)
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
+    if (name == "Debug")
+    {
+        std::shared_ptr<DebugRenderer> r(new DebugRenderer(scene));
+        if (!r->GetDeviceContext()) return nullptr;
+        return r;
+    }
     if (name == "VCM")
     {
         std::shared_ptr<VertexConnectionAndMerging> r(new VertexConnectionAndMerging(scene));
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
-    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer\", \"Path Tracer MIS\" and \"VCM\")\n", name.c_str());
+    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer\", \"Path Tracer MIS\", \"VCM\" and \"Debug\")\n", name.c_str());
     return nullptr;
 }
 
@@ -646,6 +652,22 @@ PathTracer::PathTracer(const Scene& scene) : PathTracerMIS(scene)
         fprintf(stderr, "[rt] ERROR: cannot select the plain path tracer: %s\n", rtgpu_last_error());
 }
 const char* PathTracer::GetName() const { return "Path Tracer"; }
+
+DebugRenderer::DebugRenderer(const Scene& scene) : PathTracerMIS(scene), mRenderingMode(DebugRenderingMode::TriangleID)
+{
+    if (GetDeviceContext() && rtgpu_set_integrator(GetDeviceContext(), RT_INTEGRATOR_DEBUG, nullptr) != RTGPU_OK)
+        fprintf(stderr, "[rt] ERROR: cannot select the debug renderer: %s\n", rtgpu_last_error());
+}
+const char* DebugRenderer::GetName() const { return "Debug"; }
+bool DebugRenderer::RenderPass(const RtPassParams& params)
+{
+    if (mAppliedMode != (int)mRenderingMode)
+    {
+        if (!GetDeviceContext() || rtgpu_set_debug_rendering_mode(GetDeviceContext(), (uint32_t)mRenderingMode) != RTGPU_OK) return false;
+        mAppliedMode = (int)mRenderingMode;
+    }
+    return PathTracerMIS::RenderPass(params);
+}
 
 VertexConnectionAndMerging::VertexConnectionAndMerging(const Scene& scene)
     : PathTracerMIS(scene)

@@ -356,6 +356,13 @@ RTH_API int rth_viewport_set_vcm(void* v, uint32_t maxPathLength, int useVertexC
     }
     return 0;
 }
+RTH_API int rth_viewport_set_debug_mode(void* v, uint32_t mode)
+{
+    DebugRenderer* r = dynamic_cast<DebugRenderer*>(static_cast<ViewportHandle*>(v)->renderer.get());
+    if (!r || mode > (uint32_t)DebugRenderingMode::IoR) return -3;
+    r->mRenderingMode = (DebugRenderingMode)mode;
+    return 0;
+}
 RTH_API void rth_viewport_reset(void* v) { static_cast<ViewportHandle*>(v)->viewport.Reset(); }
 RTH_API int rth_viewport_render(void* v, void* camera, uint32_t numPasses)
 {

@@ -109,3 +109,15 @@ class Vcm:
             raise RuntimeError("rto_vcm_render_pass failed")
         self.passes += 1
         return counters
+
+
+def render_pass_debug(scene_desc_ptr, params, width, height, mode, sum_buf, secondary=None, counters=None, threads=1):
+    """One pass of the oracle's DebugRenderer restatement (renderer "Debug", DebugRenderingMode `mode`)."""
+    if counters is None:
+        counters = np.zeros(16, dtype=np.uint64)
+    fp = C.POINTER(C.c_float)
+    r = lib().rto_render_pass_debug(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(mode), sum_buf.ctypes.data_as(fp),
+                                    secondary.ctypes.data_as(fp) if secondary is not None else None, counters.ctypes.data_as(C.POINTER(C.c_uint64)), int(threads))
+    if r != 0:
+        raise RuntimeError("rto_render_pass_debug failed")
+    return counters

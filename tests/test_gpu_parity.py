@@ -523,3 +523,29 @@ def test_plain_path_tracer_bit_exact(built):
         out = (img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)})
         assert_identical(*out)
         assert out[2]["numShadowRays"] == 0 and out[2]["numRays"] > 3 * w * h
+
+
+def test_debug_renderer_all_modes_bit_exact(built):
+    """Renderer "Debug" (DebugRenderer.cpp): the 13 DebugRenderingMode values on the textured mesh scene (normal maps, texture
+    coordinates, textured material parameters) and the all-lights scene (light hits are yellow, misses black) against the oracle's
+    restatement; the TriangleID colouring (Hash -> HSVtoRGB) is pinned to the reference by debug_triangle_id.kat."""
+    for make, w, h in ((scene_zoo.textured_scene, 96, 54), (scene_zoo.all_lights_scene, 80, 60)):
+        scene, camera = make(w / h)
+        desc = scene.desc
+        bn = ra.load_blue_noise()
+        desc.contents.blueNoise = bn.ctypes.data
+        vp = ra.Viewport(w, h, seed=11)
+        vp.set_renderer(scene, name="Debug")
+        images = []
+        for mode in range(13):
+            vp.set_debug_mode(mode)
+            vp.reset()
+            ref = np.zeros((h, w, 3), dtype=np.float32)
+            for _ in range(2):
+                p = vp.next_pass_params(camera)
+                vp.render_pass_with(p)
+                oracle_lib.render_pass_debug(desc, p, w, h, mode, ref, threads=8)
+            img = vp.sum_buffer()
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), mode
+            images.append(img.copy())
+        assert len({im.tobytes() for im in images}) >= 11   # the modes really differ (two material parameters may coincide)
