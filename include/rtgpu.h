@@ -411,8 +411,11 @@ typedef enum RtIntegrator
     RT_INTEGRATOR_VCM = 1,
     RT_INTEGRATOR_PATH_TRACER = 2,  /* rt::PathTracer ("Path Tracer", Core/Rendering/PathTracer.cpp): BSDF sampling only -- no next event
                                      * estimation, no MIS; lightSamplingStrategy and the two weights of RtPassParams are ignored */
-    RT_INTEGRATOR_DEBUG = 3         /* rt::DebugRenderer ("Debug", Core/Rendering/DebugRenderer.cpp): one colour per pixel from the primary
+    RT_INTEGRATOR_DEBUG = 3,        /* rt::DebugRenderer ("Debug", Core/Rendering/DebugRenderer.cpp): one colour per pixel from the primary
                                      * ray's first hit, selected by rtgpu_set_debug_rendering_mode (default: TriangleID) */
+    RT_INTEGRATOR_LIGHT_TRACER = 4  /* rt::LightTracer ("Light Tracer", Core/Rendering/LightTracer.cpp): one light path per pixel, every vertex
+                                     * below RtPassParams::maxRayDepth connected to the camera (film splats); same per-pixel generator
+                                     * convention and whole-frame requirement as VCM */
 } RtIntegrator;
 /* rt::DebugRenderingMode (Core/Rendering/DebugRenderer.h:7-33; the four intersection-counter modes exist in the reference only under
  * RT_ENABLE_INTERSECTION_COUNTERS, which is off, and are not provided) */

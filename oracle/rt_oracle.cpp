@@ -649,6 +649,35 @@ int rto_vcm_render_pass(void* h, const RtSceneDesc* scene, const RtPassParams* p
     return 0;
 }
 
+// the renderer "Light Tracer" (Core/Rendering/LightTracer.cpp): one pass, pixels in row-major order; all light goes to `sum`
+// (+ secondarySum) through film splats
+int rto_light_tracer_render_pass(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, float* sum, float* secondarySum, uint64_t* counters)
+{
+    Counters c; memset(&c, 0, sizeof(c));
+    VcmRenderer dummy;
+    VcmCtx* ctx = new VcmCtx();
+    ctx->scene = scene; ctx->params = params; ctx->r = &dummy; ctx->counters = &c;
+    ctx->width = width; ctx->height = height; ctx->sum = sum; ctx->secondarySum = secondarySum;
+    ctx->sampler.seed = params->seed; ctx->sampler.numDims = params->numDimensions; ctx->sampler.blueNoise = scene->blueNoise;
+    ctx->sampler.blueNoiseLayers = (scene->blueNoise && params->useBlueNoise) ? 4u : 0u;
+    const V4 invSize(1.0f / (float)(int32_t)width, 1.0f / (float)(int32_t)height, 0.0f, 0.0f);
+    const V4 sampleOffset(params->sampleOffset[0], params->sampleOffset[1], 0.0f, 0.0f);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x)
+        {
+            const uint32_t realY = height - 1u - y;
+            const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
+            ctx->sampler.resetPixel(x, y, params->rngKey);
+            ctx->simd.resetPixel(x, y, params->rngKey);
+            (void)cameraGenerateRay(params->camera, coords, ctx->sampler);   // Viewport::RenderTile generates the ray before RenderPixel ignores it
+            c.c[C_PRIMARY]++;
+            lightTracerPixel(*ctx);
+        }
+    delete ctx;
+    if (counters) for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
+    return 0;
+}
+
 uint32_t rto_sizeof(int what)
 {
     switch (what)

@@ -663,4 +663,86 @@ static inline V4 vcmRenderPixel(VcmCtx& ctx, const Ray& primaryRay, uint32_t ite
     return resultColor;
 }
 
+// =====================================================================================================
+// LightTracer::RenderPixel, Core/Rendering/LightTracer.cpp:25-183 (renderer "Light Tracer"): one light path per pixel, every vertex
+// connected to the camera; the pixel's own colour is zero.  Same generator convention as VCM (per-pixel streams, splat jitter drawn
+// when the connection is set up).  maxRayDepth comes from the rendering parameters.
+// =====================================================================================================
+static inline void lightTracerPixel(VcmCtx& ctx)
+{
+    const RtSceneDesc* scene = ctx.scene;
+    uint32_t depth = 0;
+    if (scene->numLights == 0) return;
+    const float lightPickingProbability = 1.0f / (float)scene->numLights;
+    const uint32_t lightIndex = ctx.sampler.fallbackInt() % scene->numLights;
+    const RtLight& light = scene->lights[lightIndex];
+    const V4 ps = ctx.simd.getVector4(); const V4 ds = ctx.simd.getVector4();
+    const float up[3] = { ps.x, ps.y, ps.z }, ud[2] = { ds.x, ds.y };
+    EmitResult er; er.position = zero4(); er.direction = zero4(); er.directPdfA = er.emissionPdfW = er.cosAtLight = 0.0f;
+    V4 throughput = lightEmit(scene, light, up, ud, er);
+    if (almostZero4(throughput)) return;
+    er.emissionPdfW *= lightPickingProbability;
+    er.position = er.position + er.direction * 0.0005f;
+    Ray ray = makeRay(er.position, er.direction);
+    throughput = throughput * (1.0f / er.emissionPdfW);
+    Hit hitPoint; hitPoint.subObjectId = 0; hitPoint.u = hitPoint.v = 0.0f;
+    ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
+    const RtCamera& cam = ctx.params->camera;
+    for (;;)
+    {
+        hitPoint.objectId = RT_INVALID_OBJECT;
+        hitPoint.distance = INFINITY;
+        sceneTraverse(scene, ray, hitPoint, *ctx.counters);
+        if (hitPoint.distance == INFINITY) break;
+        if (hitPoint.subObjectId == RT_LIGHT_OBJECT) break;
+        if (hitPoint.distance < FLT_MAX)
+        {
+            sceneEvaluateIntersection(scene, ray, hitPoint, sd.intersection, *ctx.counters);
+            sd.outgoingDirWorldSpace = neg(ray.dir);
+            materialEvaluateShadingData(scene, scene->materials[sd.intersection.material], sd);
+        }
+        if (depth >= ctx.params->maxRayDepth) break;
+        const RtMaterial& mat = scene->materials[sd.intersection.material];
+        {   // connect to camera, :113-153
+            const V4 cameraPos = load4(cam.localToWorld + 12);
+            const V4 samplePos = sd.intersection.frame.r[3];
+            V4 dirToCamera = cameraPos - samplePos;
+            const float cameraDistanceSqr = sqrLength3(dirToCamera);
+            const float cameraDistance = sqrtf(cameraDistanceSqr);
+            dirToCamera = dirToCamera / cameraDistance;
+            float bsdfPdfW = 0.0f;
+            const V4 cameraFactor = materialEvaluate(mat, sd, neg(dirToCamera), bsdfPdfW);
+            if (!almostZero4(cameraFactor))
+            {
+                V4 filmPos;
+                if (cameraWorldToFilm(cam, samplePos, filmPos))
+                {
+                    const V4 jitter = ctx.simd.getVector4();   // convention: drawn at set-up (the reference draws it inside AccumulateColor)
+                    Hit hp; hp.objectId = RT_INVALID_OBJECT; hp.subObjectId = 0; hp.u = hp.v = 0.0f;
+                    hp.distance = cameraDistance * 0.999f;
+                    const Ray shadowRay = makeRay(samplePos + sd.intersection.frame.r[2] * 0.0001f, dirToCamera);   // offset along the NORMAL, :138
+                    ctx.counters->c[C_SHADOW]++;
+                    if (!sceneTraverseShadow(scene, shadowRay, hp, *ctx.counters))
+                    {
+                        ctx.counters->c[C_SHADOW_HIT]++;
+                        const float cameraPdfA = cameraDirectionPdfW(cam, neg(dirToCamera)) / cameraDistanceSqr;
+                        const V4 contribution = (cameraFactor * throughput) * cameraPdfA;
+                        vcmSplat(ctx, filmPos, contribution, jitter);
+                    }
+                }
+            }
+        }
+        const V4 sv = ctx.simd.getVector4();
+        const float sample[3] = { sv.x, sv.y, sv.z };
+        V4 incomingDirWorldSpace = zero4(); float pdf = 0.0f; uint32_t event = EV_NULL;
+        const V4 bsdfValue = materialSample(mat, sd, sample, incomingDirWorldSpace, pdf, event);
+        throughput = throughput * bsdfValue;
+        if (almostZero4(throughput)) break;
+        ray = makeRay(sd.intersection.frame.r[3], incomingDirWorldSpace);
+        ray.origin = ray.origin + ray.dir * 0.001f;
+        depth++;
+    }
+    ctx.counters->c[C_RAYS] += (uint64_t)depth + 1;
+}
+
 } // namespace rto

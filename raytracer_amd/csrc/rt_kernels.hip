@@ -226,6 +226,8 @@ struct TravTuning
 {
     uint32_t refillMinIdle;   // refill once this many lanes of the wave have no ray (or all of them)
     uint32_t otherMinLanes;   // run the "other" phase (leaves, objects, finishing) once this many lanes wait for it
+    float shadowOffset;       // any-hit rays start at origin + direction * shadowOffset: 1e-4 (PathTracerMIS.cpp:86, VCM.cpp:673 ...);
+                              // 0 for the Light Tracer, whose offset is along the surface normal and already in the stored origin
 };
 
 // ONE persistent traversal kernel per bounce: it serves the closest-hit rays of the paths alive at bounce k
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         {
             const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
             Ray shadowRay = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
-            shadowRay.origin = shadowRay.origin + shadowRay.dir * 0.0001f;   // PathTracerMIS.cpp:86
+            shadowRay.origin = shadowRay.origin + shadowRay.dir * tune.shadowOffset;   // PathTracerMIS.cpp:86
             return shadowRay;
         }
         const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
@@ -1021,7 +1023,7 @@ struct RtgpuContext
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
-    TravTuning tune = { 28u, 32u };   // measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
+    TravTuning tune = { 28u, 32u, 0.0001f };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
     bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
@@ -1043,6 +1045,7 @@ struct RtgpuContext
     uint32_t seedCursor = 0;
 
     bool plainPathTracer = false;      // RT_INTEGRATOR_PATH_TRACER: k_shade<false, true>
+    bool lightTracer = false;          // RT_INTEGRATOR_LIGHT_TRACER: the light stage of rt_vcm.inl without MIS (k_lt_shade)
     int debugMode = -1;                // RT_INTEGRATOR_DEBUG: DebugRenderingMode, k_debug_shade after the primary rays' traversal
     // bidirectional integrator (rt_vcm.inl); runs one pass at a time on lane 0's stream
     struct Vcm
@@ -1679,12 +1682,14 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
     return RTGPU_OK;
 }
 
-static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc, uint32_t* cursor)
+static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc, uint32_t* cursor,
+                        float shadowOffset = 0.0001f)
 {
+    TravTuning tune = c->tune; tune.shadowOffset = shadowOffset;
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
     const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
-#define RT_VCM_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, stream, c->sceneDev, paths, tq, tqc, tsq, tsc, cursor, c->counters, c->tune)
+#define RT_VCM_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, stream, c->sceneDev, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
     if (stackClass == 24u) { if (c->countIntersections) RT_VCM_TRACE(24, true); else RT_VCM_TRACE(24, false); }
     else if (stackClass == 32u) { if (c->countIntersections) RT_VCM_TRACE(32, true); else RT_VCM_TRACE(32, false); }
     else { if (c->countIntersections) RT_VCM_TRACE(64, true); else RT_VCM_TRACE(64, false); }
@@ -1807,6 +1812,59 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
     return RTGPU_OK;
 }
 
+// One LightTracer pass (Core/Rendering/LightTracer.cpp): the VCM light stage without MIS, light vertices and photons
+static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
+{
+    RtgpuContext::Vcm& v = c->vcm;
+    if (c->shard.rank != 0 || c->shard.worldSize != 1) return fail(RTGPU_ERR_UNSUPPORTED, "the Light Tracer needs the whole frame on one device (shard {0, 1})");
+    if (!c->activeMask.empty()) return fail(RTGPU_ERR_UNSUPPORTED, "the Light Tracer does not support active-block restriction");
+    if (p->maxRayDepth + 2u > RT_VCM_COUNT_PLANE) return fail(RTGPU_ERR_UNSUPPORTED, "Light Tracer: maxRayDepth must be <= 18");
+    { int r = flushPending(c); if (r) return r; }
+    HIP_TRY(syncLanes(c));
+    { int r = ensureVcm(c, 1u); if (r) return r; }
+    hipStream_t stream = c->lanes[0].stream;
+    VcmDev dev; memset(&dev, 0, sizeof(dev));
+    dev.maxPathLength = p->maxRayDepth;   // k_lt_shade reads it as RenderingParams::maxRayDepth
+    DevPass pass; memset(&pass, 0, sizeof(pass));
+    pass.camera = p->camera; pass.seed = v.seedDev; pass.numDimensions = p->numDimensions;
+    pass.blueNoiseLayers = (c->sceneDev.blueNoise && p->useBlueNoise) ? 4u : 0u;
+    pass.sampleOffset[0] = p->sampleOffset[0]; pass.sampleOffset[1] = p->sampleOffset[1];
+    pass.passIndex = p->passIndex; pass.maxRayDepth = p->maxRayDepth; pass.rngKey[0] = p->rngKey[0]; pass.rngKey[1] = p->rngKey[1];
+    pass.width = c->width; pass.height = c->height;
+    if (p->numDimensions) HIP_TRY(hipMemcpyAsync(v.seedDev, p->seed, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(v.passDev, &pass, sizeof(pass), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
+    uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE;
+    uint32_t** lq = v.queues; uint32_t** lsq = v.shadowQueues;
+    const uint32_t maxBlocks = c->numCUs * 8u;
+    const uint32_t blocksNeeded = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
+    const dim3 grid1(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), block(RT_BLOCK);
+    {
+        LaunchTimer t(c, stream, KC_GENERATE);
+        // the camera ray is generated (it consumes the pixel's lens samples and counts as a primary ray) and then ignored, Viewport.cpp:305-331
+        hipLaunchKernelGGL(k_generate, grid1, block, 0, stream, c->sceneDev, v.passDev, c->numSlots, v.cameraPaths, c->slotPixel, c->numSlots, v.queues[2], cpc + 0, c->counters);
+        hipLaunchKernelGGL(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, c->numSlots, lq[0], lpc + 0);
+    }
+    for (uint32_t b = 0; b <= p->maxRayDepth; ++b)
+    {
+        const bool haveShadow = b > 0;
+        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0f);
+        LaunchTimer t(c, stream, KC_SHADE);
+        hipLaunchKernelGGL(k_lt_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
+                           lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);
+    }
+    launchTrace(c, stream, v.lightPaths, nullptr, nullptr, lsq[p->maxRayDepth & 1u], lsc + p->maxRayDepth, lcur + p->maxRayDepth + 1u, 0.0f);
+    {
+        LaunchTimer t(c, stream, KC_ACCUMULATE);
+        hipLaunchKernelGGL(k_vcm_light_finish, grid1, block, 0, stream, v.passDev, v.lightPaths, c->numSlots, c->sum, c->secondary, c->counters);
+    }
+    HIP_TRY(hipGetLastError());
+    v.havePhotons = false;
+    return RTGPU_OK;
+}
+
 static void defaultVcmParams(RtVcmParams& vp)
 {
     memset(&vp, 0, sizeof(vp));
@@ -1818,7 +1876,7 @@ static void defaultVcmParams(RtVcmParams& vp)
 RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const RtVcmParams* vcm)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
-    if (integrator > RT_INTEGRATOR_DEBUG) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if (integrator > RT_INTEGRATOR_LIGHT_TRACER) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
     int r = rtgpu_synchronize(c); if (r) return r;
     RtVcmParams vp; defaultVcmParams(vp);
     if (vcm) vp = *vcm;
@@ -1830,6 +1888,7 @@ RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const R
     }
     c->vcm.enabled = integrator == RT_INTEGRATOR_VCM;
     c->plainPathTracer = integrator == RT_INTEGRATOR_PATH_TRACER;
+    c->lightTracer = integrator == RT_INTEGRATOR_LIGHT_TRACER;
     c->debugMode = integrator == RT_INTEGRATOR_DEBUG ? (c->debugMode >= 0 ? c->debugMode : (int)DBG_TRIANGLE_ID) : -1;   // DebugRenderer's default mode, DebugRenderer.cpp:16
     c->vcm.params = vp;
     c->vcm.havePhotons = false;
@@ -1870,6 +1929,7 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     if (p->camera.dofEnable && p->camera.bokehShape != 0) return fail(RTGPU_ERR_UNSUPPORTED, "only circular bokeh is implemented");
     if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
     if (c->vcm.enabled) return vcmRenderPass(c, p);
+    if (c->lightTracer) return lightTracerRenderPass(c, p);
 
     CtxPending pd;
     DevPass& pass = pd.pass;

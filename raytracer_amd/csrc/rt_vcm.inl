@@ -347,6 +347,106 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
     flushCounters(cnt, counters);
 }
 
+// One vertex of LightTracer::RenderPixel's loop (Core/Rendering/LightTracer.cpp:69-181; renderer "Light Tracer"): like k_vcm_light_shade
+// without MIS quantities, light vertices and photons; every vertex below maxRayDepth is connected to the camera with
+// contribution = bsdf * throughput * PdfW / distance^2, and the shadow ray starts at samplePos + normal * 1e-4 (:138).
+__global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const VcmArena a,
+                                                       const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                       uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                       uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                       float* __restrict__ sum, float* __restrict__ secondary, unsigned long long* counters)
+{
+    __shared__ uint32_t sCount, sBase;
+    if (threadIdx.x == 0) sCount = 0u;
+    __syncthreads();
+    Counters cnt; zeroCounters(cnt);
+    const DevPass& pass = passes[0];
+    const bool evenPass = (pass.passIndex % 2u) == 0u;
+    const uint32_t maxRayDepth = vcm.maxPathLength;
+    const uint32_t count = *countIn;
+    const uint32_t rounded = (count + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        bool alive = false, needRay = false;
+        uint32_t slot = 0;
+        if (i < count)
+        {
+            slot = queueIn[i];
+            const float4 rOrigin = prec(lp, R_ORIGIN, slot), rDir = prec(lp, R_DIR, slot), rTp = prec(lp, R_TP, slot);
+            const float4 rHit = prec(lp, R_HIT, slot), rSampler = prec(lp, R_SAMPLER, slot);
+            if (ubits(rSampler.w) != 0u) resolveSplat(lp, slot, sum, secondary, evenPass, cnt);
+            uint32_t pending = 0u;
+            const uint32_t depth = ubits(rOrigin.w) & 0xFFu;
+            const Ray ray = makePathRay(rOrigin, rDir, depth);
+            V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+            Hit hit; hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+            cnt.c[C_RAYS]++;
+            if (hit.objectId != RT_INVALID_OBJECT && hit.subObjectId != RT_LIGHT_OBJECT)
+            {
+                ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
+                if (hit.distance < FLT_MAX)
+                {
+                    sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                    sd.outgoingDirWorldSpace = neg(ray.dir);
+                    materialEvaluateShadingData<false>(scene, scene.materials[sd.intersection.material], sd);
+                }
+                if (depth < maxRayDepth)
+                {
+                    const RtMaterial& mat = scene.materials[sd.intersection.material];
+                    RandomSimd simd; loadSimd(simd, a, slot);
+                    {
+                        const RtCamera& cam = pass.camera;
+                        const V4 samplePos = sd.intersection.frame.r[3];
+                        V4 dirToCamera = load4(cam.localToWorld + 12) - samplePos;
+                        const float cameraDistanceSqr = sqrLength3(dirToCamera);
+                        const float cameraDistance = sqrtf(cameraDistanceSqr);
+                        dirToCamera = dirToCamera / cameraDistance;
+                        float bsdfPdfW = 0.0f;
+                        const V4 cameraFactor = materialEvaluate<false>(mat, sd, neg(dirToCamera), bsdfPdfW);
+                        float tmax = -1.0f; V4 contribution = zero4(); uint32_t target = 0xFFFFFFFFu;
+                        V4 filmPos;
+                        if (!almostZero4(cameraFactor) && cameraWorldToFilm(cam, samplePos, filmPos))
+                        {
+                            const V4 jitter = simd.getVector4();
+                            tmax = cameraDistance * 0.999f;
+                            const float cameraPdfA = cameraDirectionPdfW(cam, neg(dirToCamera)) / cameraDistanceSqr;
+                            contribution = (cameraFactor * throughput) * cameraPdfA;
+                            uint32_t fx, fy;
+                            if (filmSplatPixel(filmPos, pass.width, pass.height, jitter, fx, fy)) target = fy * pass.width + fx;
+                        }
+                        const V4 shadowOrigin = samplePos + sd.intersection.frame.r[2] * 0.0001f;
+                        pshadow(lp, 0, 0, slot) = f4(dirToCamera.x, dirToCamera.y, dirToCamera.z, tmax);
+                        pshadow(lp, 0, 1, slot) = f4(contribution.x, contribution.y, contribution.z, fbits(target));
+                        prec(lp, R_SH_P, slot) = f4(shadowOrigin.x, shadowOrigin.y, shadowOrigin.z, 0.0f);
+                        pending = 1u;
+                        needRay = tmax >= 0.0f;
+                    }
+                    const V4 sv = simd.getVector4();
+                    const float sample[3] = { sv.x, sv.y, sv.z };
+                    V4 incomingDirWorldSpace = zero4(); float pdf = 0.0f; uint32_t event = EV_NULL;
+                    const V4 bsdfValue = materialSample<false>(mat, sd, sample, incomingDirWorldSpace, pdf, event);
+                    throughput = throughput * bsdfValue;
+                    if (!almostZero4(throughput))
+                    {
+                        prec(lp, R_ORIGIN, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, fbits(depth + 1u));
+                        prec(lp, R_DIR, slot) = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, 0.0f);
+                        prec(lp, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
+                        alive = true;
+                    }
+                    storeSimd(simd, a, slot);
+                }
+            }
+            prec(lp, R_SAMPLER, slot).w = fbits(pending);
+        }
+        const uint32_t shadowAt = blockReserve(needRay ? 1u : 0u, shadowCount, &sCount, &sBase);
+        if (needRay) shadowQueue[shadowAt] = slot;
+        const uint32_t pathAt = blockReserve(alive ? 1u : 0u, countOut, &sCount, &sBase);
+        if (alive) queueOut[pathAt] = slot;
+    }
+    flushCounters(cnt, counters);
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_finish(const DevPass* __restrict__ passes, const Paths lp, uint32_t numSlots, float* __restrict__ sum,
                                                                float* __restrict__ secondary, unsigned long long* counters)
 {

@@ -60,4 +60,12 @@ private:
     int mAppliedMode = -1;
 };
 
+// "Light Tracer": light paths connected to the camera (reference: Core/Rendering/LightTracer.h)
+class RAYLIB_API LightTracer : public PathTracerMIS
+{
+public:
+    explicit LightTracer(const Scene& scene);
+    const char* GetName() const override;
+};
+
 } // namespace rt

@@ -563,13 +563,19 @@ RendererPtr CreateRenderer(const std::string& name, const Scene& scene)
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
+    if (name == "Light Tracer")
+    {
+        std::shared_ptr<LightTracer> r(new LightTracer(scene));
+        if (!r->GetDeviceContext()) return nullptr;
+        return r;
+    }
     if (name == "VCM")
     {
         std::shared_ptr<VertexConnectionAndMerging> r(new VertexConnectionAndMerging(scene));
         if (!r->GetDeviceContext()) return nullptr;
         return r;
     }
-    fprintf(stderr, "[rt] ERROR: renderer '%s' is outside the scope of the MI355X core (only \"Path Tracer\", \"Path Tracer MIS\", \"VCM\" and \"Debug\")\n", name.c_str());
+    fprintf(stderr, "[rt] ERROR: unknown renderer '%s' (\"Path Tracer\", \"Path Tracer MIS\", \"Light Tracer\", \"VCM\", \"Debug\")\n", name.c_str());
     return nullptr;
 }
 
@@ -652,6 +658,13 @@ PathTracer::PathTracer(const Scene& scene) : PathTracerMIS(scene)
         fprintf(stderr, "[rt] ERROR: cannot select the plain path tracer: %s\n", rtgpu_last_error());
 }
 const char* PathTracer::GetName() const { return "Path Tracer"; }
+
+LightTracer::LightTracer(const Scene& scene) : PathTracerMIS(scene)
+{
+    if (GetDeviceContext() && rtgpu_set_integrator(GetDeviceContext(), RT_INTEGRATOR_LIGHT_TRACER, nullptr) != RTGPU_OK)
+        fprintf(stderr, "[rt] ERROR: cannot select the light tracer: %s\n", rtgpu_last_error());
+}
+const char* LightTracer::GetName() const { return "Light Tracer"; }
 
 DebugRenderer::DebugRenderer(const Scene& scene) : PathTracerMIS(scene), mRenderingMode(DebugRenderingMode::TriangleID)
 {

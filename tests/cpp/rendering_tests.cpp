@@ -132,7 +132,7 @@ int main()
         printf("no GPU renderer available\n");
         return 2;
     }
-    if (CreateRenderer("Light Tracer", *std::make_unique<Scene>()) != nullptr) { printf("\"Light Tracer\" must not exist\n"); return 1; }
+    if (CreateRenderer("no such renderer", *std::make_unique<Scene>()) != nullptr) { printf("unknown names must give nullptr\n"); return 1; }
 
     for (const char* rendererName : gRendererNames)
     {

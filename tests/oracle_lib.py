@@ -121,3 +121,15 @@ def render_pass_debug(scene_desc_ptr, params, width, height, mode, sum_buf, seco
     if r != 0:
         raise RuntimeError("rto_render_pass_debug failed")
     return counters
+
+
+def light_tracer_pass(scene_desc_ptr, params, width, height, sum_buf, secondary=None, counters=None):
+    """One pass of the oracle's LightTracer restatement (renderer "Light Tracer"); single-threaded (the film splats are ordered)."""
+    if counters is None:
+        counters = np.zeros(16, dtype=np.uint64)
+    fp = C.POINTER(C.c_float)
+    r = lib().rto_light_tracer_render_pass(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), sum_buf.ctypes.data_as(fp),
+                                           secondary.ctypes.data_as(fp) if secondary is not None else None, counters.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if r != 0:
+        raise RuntimeError("rto_light_tracer_render_pass failed")
+    return counters

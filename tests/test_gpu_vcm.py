@@ -158,3 +158,30 @@ def test_vcm_full_size_mesh_textures_and_depth_of_field(built):
     img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 3)
     total = cam + light
     assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6)
+
+
+def test_light_tracer_matches_the_oracle(built):
+    """Renderer "Light Tracer" (LightTracer.cpp): the image is made of film splats only (float atomics: tolerance as above); ray,
+    shadow-ray and shadow-hit counters are identical, which pins every path decision and every visibility result."""
+    w, h = 96, 72
+    for make in (_two_estimator_scene, scene_zoo.all_lights_scene):
+        scene, camera = make(w / h)
+        desc = scene.desc
+        bn = ra.load_blue_noise()
+        desc.contents.blueNoise = bn.ctypes.data
+        vp = ra.Viewport(w, h, seed=5, max_ray_depth=5)
+        vp.set_renderer(scene, name="Light Tracer")
+        ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
+        cnt = np.zeros(16, dtype=np.uint64)
+        for i in range(4):
+            p = vp.next_pass_params(camera)
+            vp.render_pass_with(p)
+            oracle_lib.light_tracer_pass(desc, p, w, h, ref, ref2 if i % 2 == 0 else None, cnt)
+        img, img2 = vp.sum_buffer(secondary=True)
+        assert ref.sum() > 0.0 and np.isfinite(ref).all()
+        assert np.all(np.abs(img - ref) <= 1e-5 * np.abs(ref) + 1e-6), float(np.abs(img - ref).max())
+        assert np.all(np.abs(img2 - ref2) <= 1e-5 * np.abs(ref2) + 1e-6)
+        counters = vp.counters()
+        ref_counters = {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}
+        for n in COMPARED:
+            assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
