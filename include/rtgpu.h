@@ -289,10 +289,11 @@ typedef struct RtCamera
     float    aspectRatio;
     float    tanHalfFoV;         /* tanf(fov/2) computed by the host (Camera.cpp:37) */
     uint32_t dofEnable;
-    uint32_t bokehShape;         /* 0 = circle (the only shape in scope) */
+    uint32_t bokehShape;         /* rt::BokehShape (Camera.h:21-28): 0 circle, 1 hexagon, 2 square (NGon and Texture are refused) */
     float    focalPlaneDistance;
     float    aperture;
-    float    _pad[2];
+    float    barrelDistortionConstFactor;      /* Camera.cpp:86-91: applied when the variable factor is not zero; its random */
+    float    barrelDistortionVariableFactor;   /* draw (ctx.randomGenerator.GetFloat()) comes from the per-pixel generator    */
     float    worldToScreen[16];  /* Camera::mWorldToScreen as SetPerspective left it (Camera.cpp:39-48): read by the
                                   * bidirectional integrator only (Camera::WorldToFilm, Camera.cpp:120-134) */
 } RtCamera;

@@ -528,7 +528,7 @@ static void genCamera()
 {
     const int N = 512;
     const uint32_t CW = sizeof(RtCamera) / 4;
-    KatWriter k("camera_ray", KAT_CAMERA_RAY, CW + 4, 16);
+    KatWriter k("camera_ray", KAT_CAMERA_RAY, CW + 8, 16);
     Lcg g(60);
     RenderingContext* ctx = new RenderingContext();
     for (int i = 0; i < N; ++i)
@@ -540,10 +540,14 @@ static void genCamera()
         cam.mDOF.enable = (i % 2) == 1;
         cam.mDOF.focalPlaneDistance = g.range(0.5f, 20.0f);
         cam.mDOF.aperture = g.range(0.01f, 0.5f);
+        cam.mDOF.bokehShape = (BokehShape)((i / 2) % 3);                 // circle, hexagon, square
+        if (i % 5 >= 3) { cam.barrelDistortionVariableFactor = g.range(0.005f, 0.05f); cam.barrelDistortionConstFactor = g.range(0.0f, 0.02f); }
         RtCamera C; memset(&C, 0, sizeof(C));
         memcpy(C.localToWorld, &cam.mLocalToWorld, 64);
         C.aspectRatio = cam.mAspectRatio; C.tanHalfFoV = cam.mTanHalfFoV; C.dofEnable = cam.mDOF.enable ? 1u : 0u;
         C.focalPlaneDistance = cam.mDOF.focalPlaneDistance; C.aperture = cam.mDOF.aperture;
+        C.bokehShape = (uint32_t)cam.mDOF.bokehShape;
+        C.barrelDistortionConstFactor = cam.barrelDistortionConstFactor; C.barrelDistortionVariableFactor = cam.barrelDistortionVariableFactor;
         const Vector4 coords(g.unit(), g.unit(), 0.0f, 0.0f);
         // the two DOF dimensions: seed values with no blue noise and a zero salt chain are not available through
         // the public API, so drive the sampler state directly: mCurrentSample = {u0, u1}, no dithering, salt = 0
@@ -551,7 +555,9 @@ static void genCamera()
         DynArray<uint32> seed; seed.PushBack(s0); seed.PushBack(s1);
         ctx->sampler.ResetFrame(seed, false);
         ctx->sampler.mBlueNoisePixelX = 0; ctx->sampler.mBlueNoisePixelY = 0; ctx->sampler.mSalt = 0; ctx->sampler.mSamplesGenerated = 0;
+        ctx->randomGenerator.mSeed[0] = ((uint64)g.u32() << 32) | g.u32(); ctx->randomGenerator.mSeed[1] = ((uint64)g.u32() << 32) | g.u32() | 1u;
         float* in = k.addIn(); memcpy(in, &C, sizeof(C)); in[CW] = coords.x; in[CW + 1] = coords.y; in[CW + 2] = bitsf(s0); in[CW + 3] = bitsf(s1);
+        memcpy(in + CW + 4, &ctx->randomGenerator.mSeed[0], 8); memcpy(in + CW + 6, &ctx->randomGenerator.mSeed[1], 8);
         const Ray r = cam.GenerateRay(coords, *ctx);
         float* out = k.addOut(); put4(out, r.origin); put4(out + 4, r.dir); put4(out + 8, r.invDir); put4(out + 12, r.originDivDir);
     }

@@ -275,13 +275,14 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             const V4 c = bsdfEvaluate(m.bsdf, m, sd.mp, load4(i + 16), load4(i + 20), pdf);
             putV4(o, c); o[4] = almostZero4(c) ? 0.0f : pdf; break;
         }
-        case KAT_CAMERA_RAY:      // in: RtCamera (sizeof/4 floats), coords[2], dof samples come from seed {u0,u1} bits
+        case KAT_CAMERA_RAY:      // in: RtCamera (sizeof/4 floats), coords[2], dof samples from seed {u0,u1} bits, Random::mSeed[2] (barrel distortion)
         {
             const int CW = (int)(sizeof(RtCamera) / 4);
             RtCamera cam; memcpy(&cam, i, sizeof(RtCamera));
             uint32_t seeds[2] = { fbits(i[CW + 2]), fbits(i[CW + 3]) };
             Sampler s; s.seed = seeds; s.numDims = 2; s.blueNoiseLayers = 0; s.blueNoise = nullptr;
-            s.bx = s.by = 0; s.salt = 0; s.generated = 0; s.fallback.s[0] = 1; s.fallback.s[1] = 2;
+            s.bx = s.by = 0; s.salt = 0; s.generated = 0;
+            memcpy(&s.fallback.s[0], i + CW + 4, 8); memcpy(&s.fallback.s[1], i + CW + 6, 8);   // Random::mSeed of ctx.randomGenerator
             const Ray ray = cameraGenerateRay(cam, V4(i[CW], i[CW + 1], 0.0f, 0.0f), s);
             putV4(o, ray.origin); putV4(o + 4, ray.dir); putV4(o + 8, ray.invDir); putV4(o + 12, ray.originDivDir); break;
         }

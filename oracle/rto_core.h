@@ -1479,7 +1479,15 @@ static inline V4 materialSample(const RtMaterial& mat, const ShadingData& sd, co
 static inline Ray cameraGenerateRay(const RtCamera& cam, V4 coords, Sampler& sampler)
 {
     const M4 transform = loadM4(cam.localToWorld);
-    const V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));   // UnipolarToBipolar Vector4ImplSSE.h:598-601
+    V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));   // UnipolarToBipolar Vector4ImplSSE.h:598-601
+    if (cam.barrelDistortionVariableFactor != 0.0f)   // barrel distortion, Camera.cpp:86-91; Random::GetFloat, Random.cpp:54-59
+    {
+        V4 radius = splat(dot2(offsetedCoords, offsetedCoords));
+        const uint32_t bits = (sampler.fallbackInt() & 0x007fffffu) | 0x3f800000u;
+        float rnd; memcpy(&rnd, &bits, 4); rnd = rnd - 1.0f;
+        radius = radius * (cam.barrelDistortionConstFactor + cam.barrelDistortionVariableFactor * rnd);
+        offsetedCoords = mulAdd(offsetedCoords, radius, offsetedCoords);
+    }
     V4 origin = transform.r[3];
     V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * cam.aspectRatio, transform.r[1] * offsetedCoords.y), cam.tanHalfFoV, transform.r[2]);
     if (cam.dofEnable)
@@ -1487,7 +1495,13 @@ static inline Ray cameraGenerateRay(const RtCamera& cam, V4 coords, Sampler& sam
         const V4 focusPoint = mulAdd(direction, cam.focalPlaneDistance, origin);
         const V4 right = transform.r[0], up = transform.r[1];
         const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
-        const V4 randomPointOnCircle = getCircle(sx, sy) * cam.aperture;
+        // Camera::GenerateBokeh, Camera.cpp:195-216 (sample = { GetFloat2(), 0 }: the hexagon's third coordinate is always 0, so only
+        // its first rhombus is ever used -- SamplingHelpers::GetHexagon, SamplingHelpers.cpp:40-57)
+        V4 bokeh;
+        if (cam.bokehShape == 1u) bokeh = V4(sx * -1.0f + sy * 0.5f, sx * 0.0f + sy * 0.8660254f, 0.0f, 0.0f);
+        else if (cam.bokehShape == 2u) bokeh = mulSub(V4(sx, sy, 0.0f, 0.0f), 2.0f, splat(1.0f));
+        else bokeh = getCircle(sx, sy);
+        const V4 randomPointOnCircle = bokeh * cam.aperture;
         origin = mulAdd(splat(randomPointOnCircle.x), right, origin);
         origin = mulAdd(splat(randomPointOnCircle.y), up, origin);
         direction = focusPoint - origin;

@@ -125,7 +125,8 @@ class RtBlock(C.Structure):
 
 class RtCamera(C.Structure):
     _fields_ = [("localToWorld", C.c_float * 16), ("aspectRatio", C.c_float), ("tanHalfFoV", C.c_float), ("dofEnable", C.c_uint32),
-                ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("_pad", C.c_float * 2),
+                ("bokehShape", C.c_uint32), ("focalPlaneDistance", C.c_float), ("aperture", C.c_float), ("barrelDistortionConstFactor", C.c_float),
+                ("barrelDistortionVariableFactor", C.c_float),
                 ("worldToScreen", C.c_float * 16)]
 
 
@@ -350,6 +351,10 @@ class Camera:
 
     def set_dof(self, enable, focal_plane_distance=2.0, aperture=0.1):
         host_lib().rth_camera_set_dof(self._h, int(bool(enable)), C.c_float(focal_plane_distance), C.c_float(aperture))
+
+    def set_lens(self, bokeh_shape=0, barrel_const=0.01, barrel_variable=0.0):
+        """DOFSettings::bokehShape (0 circle, 1 hexagon, 2 square) and the barrel-distortion factors of rt::Camera."""
+        host_lib().rth_camera_set_lens(self._h, C.c_uint32(bokeh_shape), C.c_float(barrel_const), C.c_float(barrel_variable))
 
 
 class Viewport:

@@ -164,14 +164,26 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, 
 
         // Camera::GenerateRay up to (not including) the Ray constructor, which trace/shade re-run from origin+direction
         const M4 transform = loadM4(pass.camera.localToWorld);
-        const V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));
+        V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));
+        if (pass.camera.barrelDistortionVariableFactor != 0.0f)   // barrel distortion, Camera.cpp:86-91; Random::GetFloat, Random.cpp:54-59
+        {
+            V4 radius = splat(dot2(offsetedCoords, offsetedCoords));
+            const float rnd = fbits((sampler.fallbackInt() & 0x007fffffu) | 0x3f800000u) - 1.0f;
+            radius = radius * (pass.camera.barrelDistortionConstFactor + pass.camera.barrelDistortionVariableFactor * rnd);
+            offsetedCoords = mulAdd(offsetedCoords, radius, offsetedCoords);
+        }
         V4 origin = transform.r[3];
         V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * pass.camera.aspectRatio, transform.r[1] * offsetedCoords.y), pass.camera.tanHalfFoV, transform.r[2]);
         if (pass.camera.dofEnable)
         {
             const V4 focusPoint = mulAdd(direction, pass.camera.focalPlaneDistance, origin);
             const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
-            const V4 randomPointOnCircle = getCircle(sx, sy) * pass.camera.aperture;
+            // Camera::GenerateBokeh, Camera.cpp:195-216: circle, hexagon (third sample coordinate always 0: its first rhombus), square
+            V4 bokeh;
+            if (pass.camera.bokehShape == 1u) bokeh = V4(sx * -1.0f + sy * 0.5f, sx * 0.0f + sy * 0.8660254f, 0.0f, 0.0f);
+            else if (pass.camera.bokehShape == 2u) bokeh = mulSub(V4(sx, sy, 0.0f, 0.0f), 2.0f, splat(1.0f));
+            else bokeh = getCircle(sx, sy);
+            const V4 randomPointOnCircle = bokeh * pass.camera.aperture;
             origin = mulAdd(splat(randomPointOnCircle.x), transform.r[0], origin);
             origin = mulAdd(splat(randomPointOnCircle.y), transform.r[1], origin);
             direction = focusPoint - origin;
@@ -1926,7 +1938,7 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions > RTGPU_MAX_DIMENSIONS) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numDimensions exceeds RTGPU_MAX_DIMENSIONS");
     if (p->numDimensions > 0 && !p->seed) return fail(RTGPU_ERR_INVALID_ARGUMENT, "seed is NULL");
     if (p->maxRayDepth >= 255u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxRayDepth must be < 255");
-    if (p->camera.dofEnable && p->camera.bokehShape != 0) return fail(RTGPU_ERR_UNSUPPORTED, "only circular bokeh is implemented");
+    if (p->camera.dofEnable && p->camera.bokehShape > 2u) return fail(RTGPU_ERR_UNSUPPORTED, "bokeh shapes: circle, hexagon, square (NGon is a TODO in the reference, texture-shaped bokeh is not implemented)");
     if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
     if (c->vcm.enabled) return vcmRenderPass(c, p);
     if (c->lightTracer) return lightTracerRenderPass(c, p);

@@ -97,18 +97,15 @@ bool Camera::GetDesc(RtCamera& out) const
     out.aspectRatio = mAspectRatio;
     out.tanHalfFoV = mTanHalfFoV;
     out.dofEnable = mDOF.enable ? 1u : 0u;
-    out.bokehShape = 0;
+    out.bokehShape = (uint32_t)mDOF.bokehShape;
     out.focalPlaneDistance = mDOF.focalPlaneDistance;
     out.aperture = mDOF.aperture;
+    out.barrelDistortionConstFactor = barrelDistortionConstFactor;
+    out.barrelDistortionVariableFactor = barrelDistortionVariableFactor;
     mWorldToScreen.Store(out.worldToScreen);
-    if (mDOF.enable && mDOF.bokehShape != BokehShape::Circle)
+    if (mDOF.enable && (mDOF.bokehShape == BokehShape::NGon || mDOF.bokehShape == BokehShape::Texture))
     {
-        fprintf(stderr, "[rt] ERROR: only circular bokeh is supported by the device path\n");
-        return false;
-    }
-    if (barrelDistortionVariableFactor != 0.0f)
-    {
-        fprintf(stderr, "[rt] ERROR: barrel distortion is not supported by the device path\n");
+        fprintf(stderr, "[rt] ERROR: NGon / texture-shaped bokeh is not supported by the device path\n");
         return false;
     }
     return true;

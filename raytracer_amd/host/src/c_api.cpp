@@ -312,6 +312,12 @@ RTH_API void rth_camera_set_dof(void* c, int enable, float focalPlaneDistance, f
     Camera* cam = static_cast<Camera*>(c);
     cam->mDOF.enable = enable != 0; cam->mDOF.focalPlaneDistance = focalPlaneDistance; cam->mDOF.aperture = aperture;
 }
+RTH_API void rth_camera_set_lens(void* c, uint32_t bokehShape, float barrelDistortionConstFactor, float barrelDistortionVariableFactor)
+{
+    Camera* cam = static_cast<Camera*>(c);
+    cam->mDOF.bokehShape = (BokehShape)bokehShape;
+    cam->barrelDistortionConstFactor = barrelDistortionConstFactor; cam->barrelDistortionVariableFactor = barrelDistortionVariableFactor;
+}
 RTH_API int rth_camera_desc(void* c, RtCamera* out) { return static_cast<Camera*>(c)->GetDesc(*out) ? 0 : -1; }
 
 // ---- viewport ---------------------------------------------------------------------------------------

@@ -363,6 +363,12 @@ def test_depth_of_field(built):
     scene, camera = scenes.cornell_box(w / h)
     camera.set_dof(True, 11.0, 0.3)
     assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=3))
+    # the other bokeh shapes of Camera::GenerateBokeh (hexagon: the reference only ever samples its first rhombus; square) and barrel
+    # distortion (its random factor comes from the per-pixel generator); camera_ray.kat pins all of them to the reference
+    for shape in (1, 2):
+        camera.set_lens(bokeh_shape=shape, barrel_const=0.02, barrel_variable=0.03)
+        out = run_both(scene, camera, w, h, passes=2, max_ray_depth=3)
+        assert_identical(*out)
 
 
 def test_empty_scene_and_background_only(built):
