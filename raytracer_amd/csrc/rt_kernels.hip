@@ -240,7 +240,11 @@ struct TravTuning
     uint32_t otherMinLanes;   // run the "other" phase (leaves, objects, finishing) once this many lanes wait for it
     float shadowOffset;       // any-hit rays start at origin + direction * shadowOffset: 1e-4 (PathTracerMIS.cpp:86, VCM.cpp:673 ...);
                               // 0 for the Light Tracer, whose offset is along the surface normal and already in the stored origin
+    uint32_t* overflowQueue;  // closest-hit rays still running this long after the queue ran dry are handed to k_trace_monster
+    uint32_t* overflowCount;  // (null: never)
+    uint32_t abortClosestAfter;   // ... measured in scheduling rounds of the wave after its queue is exhausted
 };
+#define RT_ABORT_CLOSEST_AFTER 768u
 
 // ONE persistent traversal kernel per bounce: it serves the closest-hit rays of the paths alive at bounce k
 // (Scene::Traverse, Scene.cpp:219-243) AND the NEE shadow rays queued by the shade of bounce k-1
@@ -315,13 +319,31 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
         }
     }
-    uint32_t drainIterations = 0;
+    uint32_t drainIterations = 0, closestDrain = 0;
     for (;;)
     {
         const bool interior = have && travIsInterior(s);
         const bool other = have && !interior;
         const unsigned long long mI = __ballot(interior), mO = __ballot(other);
         const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
+        // A closest-hit ray that is still running long after the queue ran dry is a degenerate one (an exactly axis-parallel
+        // direction turns two of three slab tests into inf - inf, and the ray walks most of the tree alone -- tens of
+        // milliseconds).  Such rays cannot be split like any-hit rays (the visiting order decides ties), so they are handed
+        // to k_trace_monster, which finds the same hit cooperatively.  Single-mesh scenes, counters off.
+        if (splitShadowRays && tune.overflowQueue && exhausted && ++closestDrain > tune.abortClosestAfter)
+        {
+            const bool abortLane = have && !s.shadow;
+            const unsigned long long mAbort = __ballot(abortLane);
+            if (mAbort != 0ull)
+            {
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t base = 0;
+                if (lane == (uint32_t)(__ffsll((long long)mAbort) - 1)) base = atomicAdd(tune.overflowCount, (uint32_t)__popcll(mAbort));
+                base = (uint32_t)__shfl((int)base, __ffsll((long long)mAbort) - 1);
+                if (abortLane) { tune.overflowQueue[base + (uint32_t)__popcll(mAbort & ((1ull << lane) - 1ull))] = slot; have = false; }
+                continue;
+            }
+        }
         // Idle lanes get work from the queue (refill) or, once the queue is used up, from a busy shadow ray of the wave
         const bool refill = !exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle);
         unsigned long long mDonors = 0ull;
@@ -450,6 +472,134 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         }
     }
     flushCounters(cnt, counters);
+}
+
+// Closest hit of a degenerate ray, found by a whole block.  The sequential result is "smallest distance; among equal distances
+// the triangle visited first".  The smallest distance does not depend on the order, so it is searched in parallel: a shared LDS
+// stack of nodes, every thread pops one, tests the two children with the reference's slab test (same NaN behaviour, culling with
+// <= the best distance so far so that every triangle AT the final distance is still visited) or the leaf's triangles, and
+// publishes hits through a 64-bit atomic min of (distance bits, triangle).  If two different triangles ever report the same
+// distance, or the stack overflows, one thread repeats the search sequentially with the ordinary state machine (exactly the
+// reference's order); otherwise the winner is unique and its record (distance, u, v from the same Moller-Trumbore evaluation)
+// is what the sequential traversal would have written.  Single-mesh scenes (the bypass path of k_trace).
+#define RT_MONSTER_BLOCK 512
+#define RT_MONSTER_STACK 8192
+__global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount)
+{
+    __shared__ uint32_t sStack[RT_MONSTER_STACK];
+    __shared__ uint32_t sTop, sTaken, sFlags;            // sFlags: 1 = tie, 2 = stack overflow
+    __shared__ unsigned long long sBest;
+    __shared__ uint32_t sSerialStack[64];
+    const uint32_t count = *queueCount;
+    if (count == 0u) return;
+    const RtMesh& mesh = scene.meshes[scene.objects[0].meshIndex];
+    const RtNode* nodes = scene.meshNodes + mesh.firstNode;
+    const RtTriangle* tris = scene.triangles + mesh.firstTriangle;
+    const M4 invTransform = loadM4(scene.objects[0].invTransform);
+    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x)
+    {
+        const uint32_t slot = queue[q];
+        const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
+        const Ray ray = transformRayUnsafe(invTransform, makePathRay(origin, dir, ubits(origin.w) & 0xFFu));
+        if (threadIdx.x == 0)
+        {
+            sStack[0] = packNode(nodes[0].childIndex, nodes[0].leaves); sTop = 1u; sFlags = 0u;
+            sBest = ((unsigned long long)0x7f800000u << 32) | 0xFFFFFFFFull;   // +inf, no triangle
+        }
+        __syncthreads();
+        for (;;)
+        {
+            const uint32_t n = sTop;
+            __syncthreads();
+            if (n == 0u || sFlags != 0u) break;
+            const uint32_t take = n < RT_MONSTER_BLOCK ? n : RT_MONSTER_BLOCK;
+            uint32_t entry = 0u;
+            const bool active = threadIdx.x < take;
+            if (active) entry = sStack[n - 1u - threadIdx.x];
+            if (threadIdx.x == 0) sTop = n - take;
+            __syncthreads();
+            if (active)
+            {
+                const float best = __uint_as_float((uint32_t)(sBest >> 32));
+                const uint32_t numLeaves = entry >> RT_NODE_LEAVES_SHIFT, first = entry & RT_NODE_CHILD_MASK;
+                if (numLeaves == 0u)
+                {
+                    const NodePair np = loadNodePair(nodes, first);
+                    float distanceA, distanceB;
+                    const bool hitA = intersectBoxRay(ray, V4(np.a0.x, np.a0.y, np.a0.z, 0.0f), V4(np.a1.x, np.a1.y, np.a1.z, 0.0f), distanceA) && distanceA <= best;
+                    const bool hitB = intersectBoxRay(ray, V4(np.b0.x, np.b0.y, np.b0.z, 0.0f), V4(np.b1.x, np.b1.y, np.b1.z, 0.0f), distanceB) && distanceB <= best;
+                    const uint32_t pushes = (hitA ? 1u : 0u) + (hitB ? 1u : 0u);
+                    if (pushes != 0u)
+                    {
+                        const uint32_t at = atomicAdd(&sTop, pushes);
+                        if (at + pushes > RT_MONSTER_STACK) atomicOr(&sFlags, 2u);
+                        else
+                        {
+                            uint32_t k = at;
+                            if (hitA) sStack[k++] = packNode(__float_as_uint(np.a0.w), __float_as_uint(np.a1.w));
+                            if (hitB) sStack[k] = packNode(__float_as_uint(np.b0.w), __float_as_uint(np.b1.w));
+                        }
+                    }
+                }
+                else
+                {
+                    for (uint32_t i = 0; i < numLeaves; ++i)
+                    {
+                        const uint32_t triangleIndex = first + i;
+                        V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
+                        float u, v, dist;
+                        if (intersectTriangleRay(ray, v0, e1, e2, u, v, dist) && dist <= best)
+                        {
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | triangleIndex;
+                            const unsigned long long old = atomicMin(&sBest, key);
+                            if ((uint32_t)(old >> 32) == __float_as_uint(dist) && (uint32_t)old != triangleIndex) atomicOr(&sFlags, 1u);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+        {
+            if (sFlags == 0u)
+            {
+                const uint32_t triangleIndex = (uint32_t)sBest;
+                if (triangleIndex == 0xFFFFFFFFu) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), __uint_as_float(0x7f800000u), 0.0f);
+                else
+                {
+                    V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
+                    float u = 0.0f, v = 0.0f, dist = 0.0f;
+                    (void)intersectTriangleRay(ray, v0, e1, e2, u, v, dist);
+                    prec(paths, R_HIT, slot) = f4(fbits(0u), fbits(triangleIndex), dist, u);
+                    prec(paths, R_SAMPLER, slot).x = v;
+                }
+            }
+            else
+            {
+                // the sequential traversal, exactly as k_trace's bypass path runs it
+                Counters cnt; zeroCounters(cnt);
+                const LdsStack stack = { sSerialStack, 1u };
+                TravState s;
+                s.ray = ray; s.nanFree = false; s.shadow = false; s.occluded = false;
+                s.hitDistance = __uint_as_float(0x7f800000u);
+                s.stackSize = 0; s.levelBase = 0; s.leafNext = 1; s.leafEnd = 1; s.objectId = 0; s.triBase = mesh.firstTriangle;
+                s.nodes = nodes; s.cur = packNode(nodes[0].childIndex, nodes[0].leaves); s.mode = TRAV_MESH;
+                auto reloadWorldRay = [&]() -> Ray { return ray; };
+                auto onHit = [&](uint32_t objectId, uint32_t subObjectId, float distance, float u, float v)
+                {
+                    prec(paths, R_HIT, slot) = f4(fbits(objectId), fbits(subObjectId), distance, u);
+                    prec(paths, R_SAMPLER, slot).x = v;
+                };
+                while (s.mode != TRAV_DONE)
+                {
+                    if (travIsInterior(s)) travStepInterior<false, true>(s, stack, cnt);
+                    else travStepOther<false>(s, scene, stack, cnt, reloadWorldRay, onHit);
+                }
+                if (s.hitDistance == __uint_as_float(0x7f800000u)) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), s.hitDistance, 0.0f);
+            }
+        }
+        __syncthreads();
+    }
 }
 
 RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
@@ -1035,7 +1185,7 @@ struct RtgpuContext
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
-    TravTuning tune = { 28u, 32u, 0.0001f };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
+    TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
     bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
@@ -1068,6 +1218,7 @@ struct RtgpuContext
         Paths lightPaths = { nullptr, 0, 0 }, cameraPaths = { nullptr, 0, 0 };
         VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
         uint32_t* mergeQueue = nullptr;
+        uint32_t* overflowQueue = nullptr;   // closest-hit rays k_trace hands to k_trace_monster
         uint32_t* queues[4] = { nullptr, nullptr, nullptr, nullptr };          // light ping-pong, camera ping-pong
         uint32_t* shadowQueues[4] = { nullptr, nullptr, nullptr, nullptr };
         uint32_t* counts = nullptr;                                               // 6 planes of RT_VCM_COUNT_PLANE
@@ -1651,7 +1802,7 @@ static int flushPending(RtgpuContext* c)
 static void freeVcm(RtgpuContext* c)
 {
     RtgpuContext::Vcm& v = c->vcm;
-    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue,
+    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue, v.overflowQueue,
                      v.queues[0], v.queues[1], v.queues[2], v.queues[3], v.shadowQueues[0], v.shadowQueues[1], v.shadowQueues[2], v.shadowQueues[3], v.counts,
                      v.passDev, v.seedDev };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1679,6 +1830,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
     HIP_TRY(hipMalloc((void**)&v.arena.photonRaw, (size_t)maxLV * 2 * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.arena.cameraVertex, (size_t)RT_VCM_LV_RECORDS * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.mergeQueue, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.overflowQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMemset(v.arena.photonCount, 0, cap * sizeof(uint32_t)));
@@ -1686,7 +1838,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
     for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));
     for (int k = 2; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.passDev, sizeof(DevPass)));
     HIP_TRY(hipMalloc((void**)&v.seedDev, (size_t)RTGPU_MAX_DIMENSIONS * sizeof(uint32_t)));
     v.requestsPerVertex = requests;
@@ -1695,9 +1847,13 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV)
 }
 
 static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc, uint32_t* cursor,
-                        float shadowOffset = 0.0001f)
+                        float shadowOffset = 0.0001f, uint32_t* overflowQueue = nullptr, uint32_t* overflowCount = nullptr)
 {
     TravTuning tune = c->tune; tune.shadowOffset = shadowOffset;
+    const bool monsters = overflowQueue && tq && !c->countIntersections && c->sceneDev.numObjects == 1u;
+    tune.overflowQueue = monsters ? overflowQueue : nullptr; tune.overflowCount = monsters ? overflowCount : nullptr;
+    static const int abortEnv = getenv("RTGPU_ABORT_CLOSEST_AFTER") ? atoi(getenv("RTGPU_ABORT_CLOSEST_AFTER")) : -1;   // test hook: 0 sends every ray in flight at exhaustion
+    if (abortEnv >= 0) tune.abortClosestAfter = (uint32_t)abortEnv;
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
     const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
@@ -1706,6 +1862,7 @@ static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths,
     else if (stackClass == 32u) { if (c->countIntersections) RT_VCM_TRACE(32, true); else RT_VCM_TRACE(32, false); }
     else { if (c->countIntersections) RT_VCM_TRACE(64, true); else RT_VCM_TRACE(64, false); }
 #undef RT_VCM_TRACE
+    if (monsters) hipLaunchKernelGGL(k_trace_monster, dim3(64), dim3(RT_MONSTER_BLOCK), 0, stream, c->sceneDev, paths, overflowQueue, overflowCount);
 }
 
 // One VertexConnectionAndMerging pass: PreRender (.cpp:84-170) on the host, then the launch sequence of rt_vcm.inl
@@ -1772,7 +1929,7 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions) HIP_TRY(hipMemcpyAsync(v.seedDev, p->seed, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v.passDev, &pass, sizeof(pass), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));   // `pass` and the caller's seed array are host temporaries
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE; uint32_t* csc = v.counts + 4 * RT_VCM_COUNT_PLANE; uint32_t* ccur = v.counts + 5 * RT_VCM_COUNT_PLANE;
     uint32_t* cmc = v.counts + 6 * RT_VCM_COUNT_PLANE;
@@ -1791,7 +1948,8 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
     for (uint32_t b = 0; b < maxLV; ++b)
     {
         const bool haveShadow = b > 0 && vp.useVertexConnection;
-        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b);
+        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0001f,
+                    v.overflowQueue, v.counts + 7 * RT_VCM_COUNT_PLANE + b);
         LaunchTimer t(c, stream, KC_SHADE);
         hipLaunchKernelGGL(k_vcm_light_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
                            lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);
@@ -1807,7 +1965,8 @@ static int vcmRenderPass(RtgpuContext* c, const RtPassParams* p)
     for (uint32_t d = 0; d < vp.maxPathLength; ++d)
     {
         const bool haveShadow = d > 0;
-        launchTrace(c, stream, v.cameraPaths, cq[d & 1u], cpc + d, haveShadow ? csq[(d - 1u) & 1u] : nullptr, haveShadow ? csc + (d - 1u) : nullptr, ccur + d);
+        launchTrace(c, stream, v.cameraPaths, cq[d & 1u], cpc + d, haveShadow ? csq[(d - 1u) & 1u] : nullptr, haveShadow ? csc + (d - 1u) : nullptr, ccur + d, 0.0001f,
+                    v.overflowQueue, v.counts + 8 * RT_VCM_COUNT_PLANE + d);
         LaunchTimer t(c, stream, KC_SHADE);
         hipLaunchKernelGGL(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.cameraPaths, v.arena, grid, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
                            csq[d & 1u], csc + d, v.mergeQueue, cmc + d, c->counters);
@@ -1846,7 +2005,7 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions) HIP_TRY(hipMemcpyAsync(v.seedDev, p->seed, p->numDimensions * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(v.passDev, &pass, sizeof(pass), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)7 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE;
     uint32_t** lq = v.queues; uint32_t** lsq = v.shadowQueues;
@@ -1862,7 +2021,8 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
     for (uint32_t b = 0; b <= p->maxRayDepth; ++b)
     {
         const bool haveShadow = b > 0;
-        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0f);
+        launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0f,
+                    v.overflowQueue, v.counts + 7 * RT_VCM_COUNT_PLANE + b);
         LaunchTimer t(c, stream, KC_SHADE);
         hipLaunchKernelGGL(k_lt_shade, grid1, block, 0, stream, c->sceneDev, v.passDev, dev, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
                            lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);

@@ -185,3 +185,43 @@ def test_light_tracer_matches_the_oracle(built):
         ref_counters = {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}
         for n in COMPARED:
             assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
+
+
+def test_degenerate_closest_hit_rays_take_the_cooperative_path(built):
+    """k_trace hands closest-hit rays that outlive the queue by far (exactly axis-parallel directions walk most of the tree) to
+    k_trace_monster, which searches the smallest distance with a whole block and falls back to the sequential order on ties.
+    RTGPU_ABORT_CLOSEST_AFTER=0 sends EVERY closest-hit ray still in flight when the queue runs dry down that path: images,
+    ray / shadow-ray / hit counters must not change (box / triangle test counters are off on this path)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import oracle_lib, scene_zoo, raytracer_amd as ra
+w, h = 96, 54
+scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000, with_analytic=False)
+desc = scene.desc
+bn = ra.load_blue_noise(); desc.contents.blueNoise = bn.ctypes.data
+vp = ra.Viewport(w, h, seed=99)
+vp.set_renderer(scene, name="VCM")
+vp.set_vcm(camera_connecting_weight=0.0)
+ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0)
+cam = np.zeros((h, w, 3), np.float32); light = np.zeros((h, w, 3), np.float32); cnt = np.zeros(16, np.uint64)
+vcm = oracle_lib.Vcm(camera_connecting_weight=0.0)
+for i in range(3):
+    p = vp.next_pass_params(camera)
+    vp.render_pass_with(p)
+    vcm.render_pass(desc, p, w, h, cam, None, light, cnt)
+img = vp.sum_buffer()
+c = vp.counters()
+assert np.array_equal(img.view(np.uint32), cam.view(np.uint32)), int(np.count_nonzero(img.view(np.uint32) != cam.view(np.uint32)))
+for k, n in enumerate(ra.COUNTER_NAMES):
+    if n in ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits"):
+        assert c[n] == int(cnt[k]), (n, c[n], int(cnt[k]))
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_value in ("0", "3"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RTGPU_ABORT_CLOSEST_AFTER=env_value), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
