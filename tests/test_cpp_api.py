@@ -59,3 +59,18 @@ def test_headless_demo_renders_the_ingested_scene(built, tmp_path):
     assert data[:2] == b"BM" and len(data) == 54 + 160 * 3 * 100
     pixels = np.frombuffer(data[54:], dtype=np.uint8)
     assert pixels.max() > 100 and len(np.unique(pixels)) > 50      # an image, not a constant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("renderer", ["Path Tracer", "Light Tracer", "VCM", "Debug"])
+def test_headless_demo_other_renderers(built, tmp_path, renderer):
+    """The reference Demo's --renderer option with every other name of CreateRenderer (Renderer.cpp:45-69)."""
+    scene = os.path.join(ROOT, "tests", "golden", "obj", "scene.json")
+    out = tmp_path / "out.bmp"
+    r = subprocess.run([DEMO, "-s", scene, "--data", os.path.dirname(scene) + "/", "-w", "128", "-h", "80", "--passes", "6", "--depth", "5", "--renderer", renderer,
+                        "--output", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 128 * 3 * 80
+    pixels = np.frombuffer(data[54:], dtype=np.uint8)
+    assert pixels.max() > 60 and len(np.unique(pixels)) > 20
