@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[2]): Sponza-class triangle mesh (~262k triangles
 reference's sponza.obj is not shipped), PathTracerMIS, 8 bounces, 1920x1080, background + delta directional
 light, LightSamplingStrategy::Single.  One "step" = one pass = one sample per pixel of the whole frame.
 
-  python bench.py --gpus 1 --steps 16 --warmup 8
+  python bench.py --gpus 1 --steps 256 --warmup 16        (the defaults: BASELINE config 3 renders 256 samples per pixel)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N > 1: the frame's 64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no
@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=8)   # one full batch of passes
+    ap.add_argument("--steps", type=int, default=256)   # the 256 spp of BASELINE config 3: the whole frame of the metric's configuration
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
