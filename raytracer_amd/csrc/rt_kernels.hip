@@ -1558,6 +1558,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].texture == RT_NO_TEXTURE;
     c->leanScene = lean;
     c->sceneReady = true;
+    c->vcm.havePhotons = false;   // photons of another scene
     return RTGPU_OK;
 }
 
@@ -1615,6 +1616,7 @@ static int rebuildFilm(RtgpuContext* c)
     HIP_TRY(hipMemset(c->sum, 0, n * sizeof(float)));
     HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
     c->activeMask.clear();   // a new film starts with the whole image active
+    c->vcm.havePhotons = false;   // recorded per slot of the old film
     return rebuildSlots(c);
 }
 
