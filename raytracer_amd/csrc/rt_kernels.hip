@@ -1727,7 +1727,8 @@ static int flushPending(RtgpuContext* c)
     const DevPass* passesDev = c->passRingDev + firstSlot;
 
     const uint32_t totalSlots = c->numSlots * numPasses;
-    const uint32_t maxBlocks = c->numCUs * 8u;
+    static const uint32_t shadeBlocksPerCU = getenv("RTGPU_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_SHADE_BLOCKS_PER_CU")) : 8u;   // tuning knob
+    const uint32_t maxBlocks = c->numCUs * shadeBlocksPerCU;
     const uint32_t blocksNeeded = (totalSlots + RT_BLOCK - 1) / RT_BLOCK;
     const uint32_t pixelBlocks = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
     const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), pixelGrid(pixelBlocks < maxBlocks ? pixelBlocks : maxBlocks), block(RT_BLOCK);
