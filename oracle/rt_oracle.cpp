@@ -617,8 +617,23 @@ uint32_t rto_vcm_num_photons(void* h) { return (uint32_t)static_cast<VcmRenderer
 
 // One pass over the whole film, pixels in row-major order.  Camera-path radiance goes to sum (+ secondarySum when non-null);
 // light-path splats go to lightSum when it is non-null (so the two estimators can be compared separately), else to sum.
+static int vcmRenderPassImpl(void* h, const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t passNumber,
+                             float* sum, float* secondarySum, float* lightSum, uint64_t* counters, uint32_t shardRank, uint32_t shardWorld);
 int rto_vcm_render_pass(void* h, const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t passNumber,
                         float* sum, float* secondarySum, float* lightSum, uint64_t* counters)
+{
+    return vcmRenderPassImpl(h, scene, params, width, height, passNumber, sum, secondarySum, lightSum, counters, 0, 1);
+}
+// Only the pixels of the 64x64 tiles with tile % shardWorld == shardRank (sampling a large frame).  A pixel's camera-path radiance depends
+// on other pixels only through merging, so with merging off (or in pass 0) the owned pixels get exactly their full-frame values; the
+// light image and the photon set are those of the owned pixels' light paths only.
+int rto_vcm_render_pass_tiles(void* h, const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t passNumber,
+                              float* sum, float* secondarySum, float* lightSum, uint64_t* counters, uint32_t shardRank, uint32_t shardWorld)
+{
+    return vcmRenderPassImpl(h, scene, params, width, height, passNumber, sum, secondarySum, lightSum, counters, shardRank, shardWorld);
+}
+static int vcmRenderPassImpl(void* h, const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t passNumber,
+                             float* sum, float* secondarySum, float* lightSum, uint64_t* counters, uint32_t shardRank, uint32_t shardWorld)
 {
     VcmRenderer* r = static_cast<VcmRenderer*>(h);
     r->preRender(passNumber, width, height);
@@ -634,6 +649,7 @@ int rto_vcm_render_pass(void* h, const RtSceneDesc* scene, const RtPassParams* p
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x)
         {
+            if (shardWorld > 1 && ((y / 64u) * ((width + 63u) / 64u) + (x / 64u)) % shardWorld != shardRank) continue;
             const uint32_t realY = height - 1u - y;
             const V4 coords = (V4((float)(int32_t)x, (float)(int32_t)realY, 0.0f, 0.0f) + sampleOffset) * invSize;
             ctx->sampler.resetPixel(x, y, params->rngKey);

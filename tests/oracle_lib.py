@@ -98,13 +98,15 @@ class Vcm:
     def num_photons(self):
         return int(lib().rto_vcm_num_photons(self._h))
 
-    def render_pass(self, scene_desc_ptr, params, width, height, sum_buf, secondary=None, light_sum=None, counters=None):
+    def render_pass(self, scene_desc_ptr, params, width, height, sum_buf, secondary=None, light_sum=None, counters=None, shard=(0, 1)):
+        """shard = (rank, world): only the pixels of the 64x64 tiles with tile % world == rank (exact for the camera paths with merging off)"""
         if counters is None:
             counters = np.zeros(16, dtype=np.uint64)
         fp = C.POINTER(C.c_float)
-        r = lib().rto_vcm_render_pass(self._h, scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(self.passes),
-                                      sum_buf.ctypes.data_as(fp), secondary.ctypes.data_as(fp) if secondary is not None else None,
-                                      light_sum.ctypes.data_as(fp) if light_sum is not None else None, counters.ctypes.data_as(C.POINTER(C.c_uint64)))
+        r = lib().rto_vcm_render_pass_tiles(self._h, scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(self.passes),
+                                            sum_buf.ctypes.data_as(fp), secondary.ctypes.data_as(fp) if secondary is not None else None,
+                                            light_sum.ctypes.data_as(fp) if light_sum is not None else None, counters.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            C.c_uint32(shard[0]), C.c_uint32(shard[1]))
         if r != 0:
             raise RuntimeError("rto_vcm_render_pass failed")
         self.passes += 1

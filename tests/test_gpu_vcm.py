@@ -225,3 +225,37 @@ print("OK")
     for env_value in ("0", "3"):
         r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RTGPU_ABORT_CLOSEST_AFTER=env_value), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_vcm_full_size_frame_sample_against_the_oracle(built):
+    """1920x1080, the 262 176-triangle mesh, path length 10, vertex connection only (a pixel's camera-path radiance then depends
+    on no other pixel): 1/48 of the frame's 64x64 tiles, spread over the whole image, against the oracle bit for bit; plus
+    size-independent properties of the full bidirectional run (finite, energy in the light image, photons recorded)."""
+    w, h = 1920, 1080
+    scene, camera = scenes.sponza_class(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=77)
+    vp.set_renderer(scene, name="VCM")
+    vp.set_vcm(use_vertex_merging=False, camera_connecting_weight=0.0)
+    ref = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
+    vcm = oracle_lib.Vcm(use_vertex_merging=False, camera_connecting_weight=0.0)
+    shard = (7, 48)
+    for _ in range(2):
+        p = vp.next_pass_params(camera)
+        vp.render_pass_with(p)
+        vcm.render_pass(desc, p, w, h, ref, None, light, shard=shard)
+    img = vp.sum_buffer()
+    ty, tx = np.meshgrid(np.arange(h) // 64, np.arange(w) // 64, indexing="ij")
+    owned = ((ty * ((w + 63) // 64) + tx) % shard[1]) == shard[0]
+    assert owned.sum() > 30000 and float(ref[owned].max()) > 0.0
+    assert np.array_equal(img[owned].view(np.uint32), ref[owned].view(np.uint32))
+    # the full combination at this size
+    vp2 = ra.Viewport(w, h, seed=77)
+    vp2.set_renderer(scene, name="VCM")
+    vp2.render(camera, 3)
+    full = vp2.sum_buffer()
+    assert np.isfinite(full).all() and vp2.vcm_num_photons() > 100000
+    c = vp2.counters()
+    assert c["numPrimaryRays"] == 3 * w * h and c["numShadowRaysHit"] <= c["numShadowRays"] and c["numRays"] > 2 * c["numPrimaryRays"]
