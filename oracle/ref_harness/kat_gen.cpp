@@ -1359,6 +1359,41 @@ static void genDebug()
     k.save();
 }
 
+// Bitmap::Load on the DDS fixtures (tests/golden/dds/*.dds, own data): what Bitmap::LoadDDS (Core/Utils/BitmapDDS.cpp) makes of each
+// header variant.  dds_kat.bin = { count } then per file (sorted by name): { nameHash, ok, format, linearSpace, width, height, dataBytes, byteSum }
+#include <dirent.h>
+#include <algorithm>
+static void genDds()
+{
+    const std::string dir = gOutDir + "/dds";
+    std::vector<std::string> names;
+    if (DIR* d = opendir(dir.c_str()))
+    {
+        while (dirent* e = readdir(d)) { const std::string n = e->d_name; if (n.size() > 4 && n.substr(n.size() - 4) == ".dds") names.push_back(n); }
+        closedir(d);
+    }
+    std::sort(names.begin(), names.end());
+    std::vector<uint32_t> out;
+    out.push_back((uint32_t)names.size());
+    for (const std::string& n : names)
+    {
+        uint32_t nameHash = 2166136261u; for (char ch : n) { nameHash ^= (uint8_t)ch; nameHash *= 16777619u; }
+        Bitmap bitmap("dds");
+        const bool ok = bitmap.Load((dir + "/" + n).c_str());
+        out.push_back(nameHash); out.push_back(ok ? 1u : 0u);
+        if (ok)
+        {
+            const size_t bytes = (size_t)bitmap.GetHeight() * bitmap.GetStride();
+            uint32_t sum = 0; const uint8_t* data = reinterpret_cast<const uint8_t*>(bitmap.GetData());
+            for (size_t i = 0; i < bytes; ++i) sum = sum * 31u + data[i];
+            out.push_back((uint32_t)bitmap.GetFormat()); out.push_back(bitmap.mLinearSpace ? 1u : 0u); out.push_back(bitmap.GetWidth()); out.push_back(bitmap.GetHeight());
+            out.push_back((uint32_t)bytes); out.push_back(sum);
+        }
+        else for (int k = 0; k < 6; ++k) out.push_back(0u);
+    }
+    writeRaw("dds_kat.bin", out.data(), out.size() * 4);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -1380,6 +1415,7 @@ int main(int argc, char** argv)
     genBidirCameraFilm();
     genBloom();
     genDebug();
+    genDds();
     printf("done\n");
     return 0;
 }

@@ -3,6 +3,7 @@
 // BitmapTexture, which the device decodes exactly as Bitmap::GetPixelBlock does (all 23 formats).  Of the file loaders only
 // uncompressed BMP is present (DDS / EXR are outside the hot-path scope).
 #pragma once
+#include <stdio.h>
 
 #include "../Math/Math.h"
 
@@ -39,7 +40,9 @@ public:
     bool Init(uint32 width, uint32 height);      // R32G32B32_Float, zeroed (the Viewport's sum buffers)
     // Uncompressed 24-bit and palette-less 8-bit BMP files, rows as stored, sRGB (Bitmap::LoadBMP, Core/Utils/BitmapBMP.cpp:47-134);
     // the reference's other loaders (DDS, EXR, palettes) are outside the hot-path scope
-    bool Load(const char* path);
+    bool Load(const char* path);                      // BMP, then DDS (reference: Bitmap::Load tries BMP, DDS, EXR; EXR is not read here)
+    bool LoadBMP(FILE* file, const char* path);
+    bool LoadDDS(FILE* file, const char* path);      // reference: Core/Utils/BitmapDDS.cpp
     void Clear();
     const char* GetDebugName() const { return mDebugName.c_str(); }
     uint32 GetWidth() const { return mWidth; }

@@ -149,10 +149,23 @@ bool Bitmap::Init(const InitData& initData)
     return true;
 }
 
-bool Bitmap::Load(const char* path)
+bool Bitmap::Load(const char* path)   // Bitmap::Load, Core/Utils/Bitmap.cpp:297-331
 {
     FILE* file = fopen(path, "rb");
     if (!file) { fprintf(stderr, "[rt] ERROR: Failed to load source image from file '%s'\n", path); return false; }
+    bool ok = LoadBMP(file, path);
+    if (!ok)
+    {
+        fseek(file, 0, SEEK_SET);
+        ok = LoadDDS(file, path);
+        if (!ok) fprintf(stderr, "[rt] ERROR: Failed to load '%s' - unknown format (BMP and DDS are read; EXR is not)\n", path);
+    }
+    fclose(file);
+    return ok;
+}
+
+bool Bitmap::LoadBMP(FILE* file, const char* path)
+{
 #pragma pack(push, 2)
     struct FileHeader { uint16 bfType; uint32 bfSize; uint16 bfReserved1, bfReserved2; uint32 bfOffBits; } fileHeader;
     struct InfoHeader { uint32 biSize; int32 biWidth, biHeight; uint16 biPlanes, biBitCount; uint32 biCompression, biSizeImage; int32 biXPelsPerMeter, biYPelsPerMeter; uint32 biClrUsed, biClrImportant; } infoHeader;
@@ -175,8 +188,102 @@ bool Bitmap::Load(const char* path)
         ok = Init(init) && fseek(file, (long)fileHeader.bfOffBits, SEEK_SET) == 0 && fread(mData.data(), mData.size(), 1, file) == 1;
         if (!ok) fprintf(stderr, "[rt] ERROR: Failed to read bitmap data from file '%s'\n", path);
     }
-    fclose(file);
     return ok;
+}
+
+// Bitmap::LoadDDS, Core/Utils/BitmapDDS.cpp:232-540: the header decides one of the texel formats the device decodes; the payload is
+// taken as is (height x width x bits / 8 bytes -- which is also the size of the 4x4-block formats).
+bool Bitmap::LoadDDS(FILE* file, const char* path)
+{
+    struct PixelFormat { uint32 size, flags, fourCC, rgbBitCount, rBitMask, gBitMask, bBitMask, aBitMask; };
+    struct Header { uint32 magic, size, flags, height, width, pitchOrLinearSize, depth, mipMapCount, reserved1[11]; PixelFormat pixelFormat; uint32 caps[4]; uint32 reserved2; } header;
+    struct HeaderDX10 { uint32 dxgiFormat, resourceDimension, miscFlag, arraySize, miscFlags2; } dx10;
+    static_assert(sizeof(Header) == 128, "DDS header");
+    if (fread(&header, sizeof(header), 1, file) != 1) return false;
+    if (header.magic != 0x20534444u) return false;
+    InitData init;
+    init.linearSpace = true;
+    init.width = header.width; init.height = header.height;
+    if (init.width < 1 || init.height < 1 || init.width >= 65535u || init.height >= 65535u)
+    {
+        fprintf(stderr, "[rt] ERROR: Unsupported DDS format in file '%s': dimensions are out of bounds (%ux%u)\n", path, init.width, init.height);
+        return false;
+    }
+    auto fourCC = [](char a, char b, char c, char d) { return (uint32)(uint8)a | ((uint32)(uint8)b << 8) | ((uint32)(uint8)c << 16) | ((uint32)(uint8)d << 24); };
+    const PixelFormat& pf = header.pixelFormat;
+    if (pf.flags & 0x40u)   // DDPF_RGB
+    {
+        if (pf.rgbBitCount == 32)
+        {
+            if (pf.rBitMask == 0x00FF0000u && pf.gBitMask == 0x0000FF00u && pf.bBitMask == 0x000000FFu && pf.aBitMask == 0xFF000000u) { init.format = Format::B8G8R8A8_UNorm; init.linearSpace = false; }
+            else if (pf.rBitMask == 0x000000FFu && pf.gBitMask == 0x0000FF00u && pf.bBitMask == 0x00FF0000u && pf.aBitMask == 0xFF000000u) { init.format = Format::R8G8B8A8_UNorm; init.linearSpace = false; }
+            else if (pf.rBitMask == 0xFFFFFFFFu && pf.gBitMask == 0 && pf.bBitMask == 0 && pf.aBitMask == 0) init.format = Format::R32_Float;
+            else if (pf.rBitMask == 0xFFFFu && pf.gBitMask == 0xFFFF0000u && pf.bBitMask == 0 && pf.aBitMask == 0) init.format = Format::R16G16_UNorm;
+        }
+        else if (pf.rgbBitCount == 16)
+        {
+            if (pf.rBitMask == 0xF800u && pf.gBitMask == 0x07E0u && pf.bBitMask == 0x001Fu && pf.aBitMask == 0) { init.format = Format::B5G6R5_UNorm; init.linearSpace = false; }
+        }
+    }
+    else if (pf.flags & 0x4u)   // DDPF_FOURCC
+    {
+        if (pf.fourCC == 111u) init.format = Format::R16_Half;                    // D3DFMT_R16F ...
+        else if (pf.fourCC == 112u) init.format = Format::R16G16_Half;
+        else if (pf.fourCC == 113u) init.format = Format::R16G16B16A16_Half;
+        else if (pf.fourCC == 114u) init.format = Format::R32_Float;
+        else if (pf.fourCC == 115u) init.format = Format::R32G32_Float;
+        else if (pf.fourCC == 116u) init.format = Format::R32G32B32A32_Float;
+        else if (pf.fourCC == 36u) init.format = Format::R16G16B16A16_UNorm;      // D3DFMT_A16B16G16R16
+        else if (pf.fourCC == fourCC('D', 'X', 'T', '1')) init.format = Format::BC1;
+        else if (pf.fourCC == fourCC('A', 'T', 'I', '1') || pf.fourCC == fourCC('B', 'C', '4', 'U') || pf.fourCC == fourCC('B', 'C', '4', 'S')) init.format = Format::BC4;
+        else if (pf.fourCC == fourCC('A', 'T', 'I', '2') || pf.fourCC == fourCC('B', 'C', '5', 'U')) init.format = Format::BC5;
+        else if (pf.fourCC == fourCC('D', 'X', '1', '0'))
+        {
+            if (fread(&dx10, sizeof(dx10), 1, file) != 1) { fprintf(stderr, "[rt] ERROR: Failed to read DX10 header '%s'\n", path); return false; }
+            switch (dx10.dxgiFormat)   // DXGI_FORMAT values
+            {
+            case 10: init.format = Format::R16G16B16A16_Half; break;
+            case 34: init.format = Format::R16G16_Half; break;
+            case 54: init.format = Format::R16_Half; break;
+            case 2: init.format = Format::R32G32B32A32_Float; break;
+            case 6: init.format = Format::R32G32B32_Float; break;
+            case 16: init.format = Format::R32G32_Float; break;
+            case 41: init.format = Format::R32_Float; break;
+            case 67: init.format = Format::R9G9B9E5_SharedExp; break;
+            case 26: init.format = Format::R11G11B10_Float; break;
+            case 87: init.format = Format::B8G8R8A8_UNorm; break;
+            case 91: init.format = Format::B8G8R8A8_UNorm; init.linearSpace = false; break;
+            case 49: init.format = Format::R8G8_UNorm; break;
+            case 61: init.format = Format::R8_UNorm; break;
+            case 85: init.format = Format::B5G6R5_UNorm; init.linearSpace = false; break;
+            case 11: init.format = Format::R16G16B16A16_UNorm; break;
+            case 35: init.format = Format::R16G16_UNorm; break;
+            case 56: init.format = Format::R16_UNorm; break;
+            case 71: init.format = Format::BC1; break;
+            case 72: init.format = Format::BC1; init.linearSpace = false; break;
+            case 80: init.format = Format::BC4; break;
+            case 83: init.format = Format::BC5; break;
+            default: break;
+            }
+        }
+    }
+    else if (pf.flags & 0x20000u)   // DDPF_LUMINANCE
+    {
+        if (pf.rgbBitCount == 8)
+        {
+            if (pf.rBitMask == 0xFFu && pf.gBitMask == 0 && pf.bBitMask == 0 && pf.aBitMask == 0) { init.format = Format::R8_UNorm; init.linearSpace = false; }
+            else if (pf.rBitMask == 0xFFu && pf.gBitMask == 0 && pf.bBitMask == 0 && pf.aBitMask == 0xFF00u) { init.format = Format::R8G8_UNorm; init.linearSpace = false; }
+        }
+        else if (pf.rgbBitCount == 16)
+        {
+            if (pf.rBitMask == 0xFFFFu && pf.gBitMask == 0 && pf.bBitMask == 0 && pf.aBitMask == 0) init.format = Format::R16_UNorm;
+            else if (pf.rBitMask == 0xFFu && pf.gBitMask == 0 && pf.bBitMask == 0 && pf.aBitMask == 0xFF00u) { init.format = Format::R8G8_UNorm; init.linearSpace = false; }
+        }
+    }
+    if (init.format == Format::Unknown) { fprintf(stderr, "[rt] ERROR: Unsupported DDS format in file '%s'\n", path); return false; }
+    if (!Init(init)) return false;
+    if (fread(mData.data(), mData.size(), 1, file) != 1) { fprintf(stderr, "[rt] ERROR: Failed to read bitmap data from file '%s'\n", path); return false; }
+    return true;
 }
 
 bool Bitmap::Init(uint32 width, uint32 height)

@@ -292,6 +292,17 @@ RTH_API void rth_kat_world_to_screen(const float localToWorld[16], float aspectR
     Matrix4 l; memcpy(&l, localToWorld, 64);
     Camera::ComputeWorldToScreen(l, aspectRatio, tanHalfFoV).Store(out);
 }
+// Bitmap::Load on a file: out = { format, linearSpace, width, height, dataBytes, byteSum (sum * 31 + byte) }; -1 if it does not load
+RTH_API int rth_kat_load_bitmap(const char* path, uint32_t out[6])
+{
+    Bitmap bitmap;
+    if (!bitmap.Load(path)) return -1;
+    const size_t bytes = (size_t)bitmap.GetHeight() * bitmap.GetStride();
+    uint32_t sum = 0; const uint8_t* data = reinterpret_cast<const uint8_t*>(bitmap.GetData());
+    for (size_t i = 0; i < bytes; ++i) sum = sum * 31u + data[i];
+    out[0] = (uint32_t)bitmap.GetFormat(); out[1] = bitmap.IsLinearSpace() ? 1u : 0u; out[2] = bitmap.GetWidth(); out[3] = bitmap.GetHeight(); out[4] = (uint32_t)bytes; out[5] = sum;
+    return 0;
+}
 RTH_API int rth_kat_parse_double(const char* text, double* out) { return helpers::obj::TryParseDouble(text, text + strlen(text), out) ? 0 : -1; }
 
 RTH_API int rth_scene_build(void* sh) { return static_cast<SceneHandle*>(sh)->scene.BuildBVH() ? 0 : -1; }

@@ -146,3 +146,30 @@ def test_camera_world_to_screen_matches_reference(built):
         out = (C.c_float * 16)()
         h.rth_kat_world_to_screen(cam.localToWorld, C.c_float(cam.aspectRatio), C.c_float(cam.tanHalfFoV), out)
         assert np.array_equal(np.frombuffer(out, np.uint32), np.frombuffer(cam.worldToScreen, np.uint32))
+
+
+def test_dds_loader_matches_the_reference(built):
+    """Bitmap::LoadDDS: 45 header variants (tests/golden/dds/, own data) against what the reference's Bitmap::Load made of the same
+    files (dds_kat.bin): texel format, colour space, size, payload -- and the same three files refused (DXT5, BC7, truncated)."""
+    import ctypes as C
+    import glob
+    import kat_io
+    raw = np.fromfile(os.path.join(kat_io.GOLDEN, "dds_kat.bin"), dtype=np.uint32)
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(kat_io.GOLDEN, "dds", "*.dds")))
+    assert raw[0] == len(names) == 45
+    h = ra.host_lib()
+    refused = 0
+    for k, name in enumerate(names):
+        rec = raw[1 + 8 * k:1 + 8 * (k + 1)]
+        fnv = 2166136261
+        for ch in name.encode():
+            fnv = ((fnv ^ ch) * 16777619) & 0xFFFFFFFF
+        assert rec[0] == fnv, name
+        out = (C.c_uint32 * 6)()
+        r = h.rth_kat_load_bitmap(os.path.join(kat_io.GOLDEN, "dds", name).encode(), out)
+        assert (r == 0) == bool(rec[1]), name
+        if r == 0:
+            assert list(out) == [int(v) for v in rec[2:8]], (name, list(out), rec[2:8])
+        else:
+            refused += 1
+    assert refused == 3
