@@ -1137,7 +1137,7 @@ static int fail(int code, const std::string& msg) { gLastError = msg; return cod
 enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_COUNT };
 static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "", "", "", "" };
 
-#define RT_SEED_RING 64
+#define RT_SEED_RING 128
 
 struct CtxPending { DevPass pass; std::vector<uint32_t> seeds; };
 
@@ -1197,6 +1197,10 @@ struct RtgpuContext
     std::vector<CtxPending> pending;
     uint32_t passBatch = 8;
     bool passBatchFromEnv = false;     // otherwise small frames / small shards (< 400 k owned pixels) batch 16 passes
+    // A caller that streams passes (no read-back in between) gets larger batches: after every submitted batch of a full-size frame
+    // the next one grows by 8 passes up to 24 (8 -> 2100, 16 -> 2125-2190, 24 -> 2195-2210 Msamples/s over 256 passes); any
+    // synchronising call starts over at the base size, so a caller that renders few passes between read-backs keeps the small batches.
+    uint32_t passBatchBase = 8;
     DevPass* passRingDev = nullptr;
     DevPass* passRingHost = nullptr;    // pinned
 
@@ -1595,6 +1599,7 @@ static int rebuildSlots(RtgpuContext* c)
     // launches of a batch should stay large enough to fill 256 CUs: a 1/8 shard of a 1080p frame batches 16 passes
     // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
     if (!c->passBatchFromEnv) c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
+    c->passBatchBase = c->passBatch;
     // a shard's launches are shorter, their tails relatively longer: one more lane to overlap them (1/4 and 1/8 of the
     // Sponza-class frame: +1.9 % / +3.6 %; the full frame gains nothing from a fourth lane)
     if (!c->lanesChosen) { c->numLanes = c->numSlots != 0 && c->numSlots < 1100000u ? 4u : 3u; if (c->nextLane >= c->numLanes) c->nextLane = 0; }
@@ -1663,7 +1668,8 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
 static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * c->passBatch;
+    const uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : 24u;   // the largest batch streaming can reach
+    const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * maxBatch;
     if (!l.paths.base || l.paths.capacity < wanted || l.paths.maxLights < maxLights)
     {
         HIP_TRY(hipStreamSynchronize(l.stream));
@@ -1792,6 +1798,7 @@ static int flushPending(RtgpuContext* c)
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
     c->pending.clear();
+    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch && c->passBatch < 24u) c->passBatch += 8u;
     HIP_TRY(hipGetLastError());
     for (uint32_t i = 0; i < numPasses; ++i)
     {
@@ -2148,6 +2155,7 @@ RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
     HIP_TRY(hipSetDevice(c->device));
     { int r = flushPending(c); if (r) return r; }
     HIP_TRY(syncLanes(c));
+    if (!c->passBatchFromEnv) c->passBatch = c->passBatchBase;
     return resolveTimed(c);
 }
 
