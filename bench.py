@@ -154,7 +154,9 @@ def main():
 
     def replay(lanes, intersection_counters, timing):
         """Renders exactly the same passes again (same seed => same rays) on a fresh viewport; returns the counter
-        deltas of the `steps` passes and, if asked, the per-kernel-class HIP-event times."""
+        deltas of the `steps` passes, the counter totals of warm-up + steps and, if asked, the per-kernel-class HIP-event
+        times of warm-up + steps (every launch of the replay: the population `rocprofv3 --kernel-trace --stats` averages over
+        when the same command runs with RTGPU_LANES=1)."""
         v = ra.Viewport(w, h, seed=20260928, max_ray_depth=args.depth)
         v.set_renderer(scene, device=local_rank)
         if world > 1:
@@ -164,22 +166,22 @@ def main():
         vctx = v.device_context()
         lib.rtgpu_set_concurrency(vctx, lanes)
         lib.rtgpu_set_intersection_counters(vctx, 1 if intersection_counters else 0)
+        lib.rtgpu_enable_timing(vctx, 1 if timing else 0)
         v.render(camera, args.warmup)
         a0 = v.counters()
-        lib.rtgpu_enable_timing(vctx, 1 if timing else 0)
         v.render(camera, args.steps)
         a1 = v.counters()
         times = kernel_times(vctx) if timing else None
-        return {k: a1[k] - a0[k] for k in a1}, times
+        return {k: a1[k] - a0[k] for k in a1}, dict(a1), times
 
     # kernel-class times measured with HIP events on the streams the kernels run on, over the timed region: with
     # several batch lanes the kernels of consecutive batches OVERLAP, so these durations include time shared with
     # another kernel.  The roofline therefore uses a lanes=1 replay of the same passes (kernels strictly serial).
     ktimes_overlapped = kernel_times(ctx)
-    serial, ktimes = replay(1, False, True)
+    serial, _, ktimes = replay(1, False, True)
     assert serial["numRays"] == delta["numRays"] and serial["numShadowRays"] == delta["numShadowRays"], "serial replay diverged from the timed run"
     # instrumented replay for the intersection counters (not timed)
-    counted, _ = replay(1, True, False)
+    counted, counted_totals, _ = replay(1, True, False)
     assert counted["numRays"] == delta["numRays"] and counted["numShadowRays"] == delta["numShadowRays"], "replay diverged from the timed run"
     for k in ("numRayBoxTests", "numPassedRayBoxTests", "numRayTriangleTests", "numPassedRayTriangleTests", "numShadowRayBoxTests",
               "numShadowRayTriangleTests"):
@@ -214,9 +216,10 @@ def main():
         }
         # roofline of the dominant kernel class (rank 0's own launches and rank 0's own counters)
         abytes = algorithmic_bytes(own_counts)
+        abytes_replay = algorithmic_bytes(counted_totals)   # warm-up + timed passes: what the replay's launches processed
         dom = max(ktimes, key=lambda k: ktimes[k][0]) if ktimes else None
         if dom and ktimes[dom][0] > 0:
-            per_launch_bytes = abytes[dom] / max(1, ktimes[dom][1])
+            per_launch_bytes = abytes_replay[dom] / max(1, ktimes[dom][1])
             per_launch_s = ktimes[dom][0] / 1000.0 / max(1, ktimes[dom][1])
             achieved = per_launch_bytes / per_launch_s / 1e9
             traffic = None
@@ -230,8 +233,9 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1000.0,
                                "launches": ktimes[dom][1],
-                               "measured": "HIP events around every launch in a lanes=1 replay of the timed passes (serial kernels); "
-                                           "the timed region itself runs 3 batch lanes whose kernels overlap"}
+                               "measured": "HIP events around every launch of a lanes=1 replay of the warm-up and timed passes (serial "
+                                           "kernels; batches of 8, 16, then 24 passes per launch); the timed region itself runs 3 batch "
+                                           "lanes whose kernels overlap"}
             out["kernel_time_ms"] = {k: round(v[0], 3) for k, v in ktimes.items()}
             out["kernel_time_ms_timed_region_overlapped"] = {k: round(v[0], 3) for k, v in ktimes_overlapped.items()}
             tot_bytes = sum(abytes.values())
