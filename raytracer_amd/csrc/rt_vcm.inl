@@ -58,6 +58,10 @@ struct VcmDev   // VertexConnectionAndMerging members after PreRender (.cpp:84-1
     float bsdfSamplingWeight[4], lightSamplingWeight[4], vertexConnectingWeight[4], cameraConnectingWeight[4], vertexMergingWeight[4];
 };
 
+// A batch of passes rides through one launch sequence (slot = passInBatch * slotsPerPass + pixelSlot): every pass has its own constants,
+// its own MIS factors (they depend on the pass number) and its own merge set (the photons of the pass before it).
+struct VcmBatch { const DevPass* passes; const VcmDev* vcms; const HashGridView* grids; uint32_t slotsPerPass; };
+
 RT_DEV float vcmPdfWtoA(float pdfW, float distance, float cosThere) { return pdfW * Abs(cosThere) / Sqr(distance); }   // :25-28
 
 RT_DEV void loadSimd(RandomSimd& r, const VcmArena& a, uint32_t slot)
@@ -107,14 +111,13 @@ RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_
 
 // GenerateLightSample, :428-491.  The scalar generator (Random::GetInt) is the pixel's Sampler::fallback stream, which lives in
 // the CAMERA arena's R_RNG record (k_generate has reset it for this pass).
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const Paths cp,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const Paths cp,
                                                        const VcmArena a, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
                                                        uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
     __shared__ uint32_t sCount, sBase;
     if (threadIdx.x == 0) sCount = 0u;
     __syncthreads();
-    const DevPass& pass = passes[0];
     const uint32_t rounded = (numSlots + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;   // whole blocks iterate together (blockReserve synchronises)
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < rounded; slot += stride)
@@ -122,7 +125,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, 
         bool ok = false;
         if (slot < numSlots)
         {
-            const uint32_t pix = slotPixel[slot];
+            const uint32_t pb = slot / b.slotsPerPass;
+            const DevPass& pass = b.passes[pb];
+            const VcmDev& vcm = b.vcms[pb];
+            const uint32_t pix = slotPixel[slot - pb * b.slotsPerPass];
             const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
             RandomSimd simd; simd.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
             a.lvCount[slot] = 0u; a.photonCount[slot] = 0u;
@@ -224,7 +230,7 @@ RT_DEV bool vcmAdvancePath(const RtSceneDesc& scene, const VcmDev& vcm, const Pa
 }
 
 // One vertex of TraceLightPath's loop, :334-425
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const VcmArena a,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
                                                               const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                               uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -234,8 +240,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
     if (threadIdx.x == 0) sCount = 0u;
     __syncthreads();
     Counters cnt; zeroCounters(cnt);
-    const DevPass& pass = passes[0];
-    const bool evenPass = (pass.passIndex % 2u) == 0u;
     const uint32_t count = *countIn;
     const uint32_t rounded = (count + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -246,6 +250,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
         if (i < count)
         {
             slot = queueIn[i];
+            const uint32_t pb = slot / b.slotsPerPass;
+            const DevPass& pass = b.passes[pb];
+            const VcmDev& vcm = b.vcms[pb];
+            const bool evenPass = (pass.passIndex % 2u) == 0u;
             const float4 rOrigin = prec(lp, R_ORIGIN, slot), rDir = prec(lp, R_DIR, slot), rTp = prec(lp, R_TP, slot);
             const float4 rHit = prec(lp, R_HIT, slot), rSampler = prec(lp, R_SAMPLER, slot), rMis = vrec(a, V_MIS, slot);
             if (ubits(rSampler.w) != 0u) resolveSplat(lp, slot, sum, secondary, evenPass, cnt);
@@ -350,7 +358,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
 // One vertex of LightTracer::RenderPixel's loop (Core/Rendering/LightTracer.cpp:69-181; renderer "Light Tracer"): like k_vcm_light_shade
 // without MIS quantities, light vertices and photons; every vertex below maxRayDepth is connected to the camera with
 // contribution = bsdf * throughput * PdfW / distance^2, and the shadow ray starts at samplePos + normal * 1e-4 (:138).
-__global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths lp, const VcmArena a,
+__global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
                                                        const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                        uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                        uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -360,9 +368,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, 
     if (threadIdx.x == 0) sCount = 0u;
     __syncthreads();
     Counters cnt; zeroCounters(cnt);
-    const DevPass& pass = passes[0];
+    const DevPass& pass = b.passes[0];          // the Light Tracer runs one pass at a time
     const bool evenPass = (pass.passIndex % 2u) == 0u;
-    const uint32_t maxRayDepth = vcm.maxPathLength;
+    const uint32_t maxRayDepth = b.vcms[0].maxPathLength;
     const uint32_t count = *countIn;
     const uint32_t rounded = (count + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -447,14 +455,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, 
     flushCounters(cnt, counters);
 }
 
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_finish(const DevPass* __restrict__ passes, const Paths lp, uint32_t numSlots, float* __restrict__ sum,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_finish(const VcmBatch b, const Paths lp, uint32_t numSlots, float* __restrict__ sum,
                                                                float* __restrict__ secondary, unsigned long long* counters)
 {
     Counters cnt; zeroCounters(cnt);
-    const bool evenPass = (passes[0].passIndex % 2u) == 0u;
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
-        if (ubits(prec(lp, R_SAMPLER, slot).w) != 0u) resolveSplat(lp, slot, sum, secondary, evenPass, cnt);
+        if (ubits(prec(lp, R_SAMPLER, slot).w) != 0u) resolveSplat(lp, slot, sum, secondary, (b.passes[slot / b.slotsPerPass].passIndex % 2u) == 0u, cnt);
     flushCounters(cnt, counters);
 }
 
@@ -532,8 +539,7 @@ RT_DEV V4 vcmEvaluateLight(const RtSceneDesc& scene, const VcmDev& vcm, const Rt
 }
 
 // One vertex of RenderPixel's loop, :201-314
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, const VcmDev vcm, const Paths cp, const VcmArena a,
-                                                               const HashGridView grid,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
                                                                const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                                uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                                uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -543,7 +549,6 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
     if (threadIdx.x == 0) sCount = 0u;
     __syncthreads();
     Counters cnt; zeroCounters(cnt);
-    const DevPass& pass = passes[0];
     const uint32_t count = *countIn;
     const uint32_t rounded = (count + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -555,6 +560,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
         if (i < count)
         {
             slot = queueIn[i];
+            const uint32_t pb = slot / b.slotsPerPass;
+            const DevPass& pass = b.passes[pb];
+            const VcmDev& vcm = b.vcms[pb];
+            const uint32_t gridPhotons = b.grids[pb].numPhotons;
             const float4 rOrigin = prec(cp, R_ORIGIN, slot), rDir = prec(cp, R_DIR, slot), rTp = prec(cp, R_TP, slot);
             const float4 rResult = prec(cp, R_RESULT, slot), rHit = prec(cp, R_HIT, slot), rSampler = prec(cp, R_SAMPLER, slot);
             const uint32_t flags = ubits(rOrigin.w);
@@ -708,7 +717,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
 
                 // MergeVertices, :823-906: the range query runs in k_vcm_merge (wave-cooperative for long photon lists); this
                 // vertex is handed over as a record.  With no photons HashGrid::Process returns at once and the term is +0.
-                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u && grid.numPhotons != 0u)
+                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u && gridPhotons != 0u)
                 {
                     const V4 tg = sd.intersection.frame.r[0], nr = sd.intersection.frame.r[2], og = sd.outgoingDirWorldSpace;
                     cvrec(a, 0, slot) = f4(pos.x, pos.y, pos.z, fbits(sd.intersection.material));
@@ -816,7 +825,7 @@ RT_DEV void loadCameraVertex(const RtSceneDesc& scene, const VcmArena& a, uint32
     throughput = V4(r5.x, r5.y, r5.z, 0.0f);
     dVM = r3.w; dVCM = r5.w;
 }
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene, const VcmDev vcm, const VcmArena a, const HashGridView grid,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene, const VcmBatch b, const VcmArena a,
                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, uint32_t cooperativeMin)
 {
     __shared__ uint32_t sStart[RT_BLOCK][8], sEnd[RT_BLOCK][8];
@@ -831,15 +840,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
         ShadingData sd; V4 throughput = zero4(); float dVM = 0.0f, dVCM = 0.0f;
         MergeRanges r; r.numCells = 0; r.total = 0;
         V4 contribution = zero4();
+        uint32_t pb = 0;
         if (valid)
         {
             slot = queue[i];
+            pb = slot / b.slotsPerPass;
             loadCameraVertex(scene, a, slot, sd, throughput, dVM, dVCM);
-            mergeCellRanges(grid, sd.intersection.frame.r[3], r);
+            mergeCellRanges(b.grids[pb], sd.intersection.frame.r[3], r);
         }
         const bool big = valid && r.total >= cooperativeMin;
         if (valid && !big)
         {
+            const VcmDev& vcm = b.vcms[pb];
+            const HashGridView& grid = b.grids[pb];
             for (uint32_t c = 0; c < r.numCells; ++c)
                 for (uint32_t j = r.start[c]; j < r.end[c]; ++j)
                 {
@@ -857,6 +870,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
             {
                 const int q = __ffsll((long long)mBig) - 1;
                 const uint32_t qSlot = (uint32_t)__shfl((int)slot, q);
+                const uint32_t qpb = qSlot / b.slotsPerPass;
+                const VcmDev& vcm = b.vcms[qpb];
+                const HashGridView& grid = b.grids[qpb];
                 ShadingData qsd; V4 qThroughput; float qVM, qVCM;
                 loadCameraVertex(scene, a, qSlot, qsd, qThroughput, qVM, qVCM);   // same address in all lanes: one broadcast fetch
                 const V4 qPos = qsd.intersection.frame.r[3];
@@ -871,9 +887,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
                         const bool contributes = j < end && mergePhoton(scene, vcm, grid, j, qsd, qPos, qVCM, qVM, term, weight);
                         for (unsigned long long m = __ballot(contributes); m != 0ull; m &= m - 1ull)
                         {
-                            const int b = __ffsll((long long)m) - 1;
-                            const V4 t(__shfl(term.x, b), __shfl(term.y, b), __shfl(term.z, b), __shfl(term.w, b));
-                            acc = mulAdd(t, __shfl(weight, b), acc);
+                            const int src = __ffsll((long long)m) - 1;
+                            const V4 t(__shfl(term.x, src), __shfl(term.y, src), __shfl(term.z, src), __shfl(term.w, src));
+                            acc = mulAdd(t, __shfl(weight, src), acc);
                         }
                     }
                 }
@@ -882,7 +898,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
         }
         if (valid)
         {
-            const V4 vertexMergingColor = contribution * load4(vcm.vertexMergingWeight);
+            const V4 vertexMergingColor = contribution * load4(b.vcms[pb].vertexMergingWeight);
             const V4 m = throughput * vertexMergingColor;
             vrec(a, V_MERGE, slot) = f4(m.x, m.y, m.z, 0.0f);
         }
@@ -890,21 +906,28 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
 }
 
 // the last vertex's pending terms, then Film::AccumulateColor(x, y, color) (Film.cpp:25-39)
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_finish(const DevPass* __restrict__ passes, const VcmDev vcm, const Paths cp, const VcmArena a, uint32_t numSlots,
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_finish(const VcmBatch b, uint32_t numPasses, const Paths cp, const VcmArena a,
                                                                 float* __restrict__ sum, float* __restrict__ secondary, uint32_t width, unsigned long long* counters)
 {
     Counters cnt; zeroCounters(cnt);
-    const bool evenPass = (passes[0].passIndex % 2u) == 0u;
     const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < b.slotsPerPass; pixelSlot += stride)
     {
-        const float4 rResult = prec(cp, R_RESULT, slot);
-        V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-        vcmResolvePending(cp, a, vcm, slot, ubits(prec(cp, R_SAMPLER, slot).w), resultColor, cnt);
-        const uint32_t pix = ubits(rResult.w);
+        const uint32_t pix = ubits(prec(cp, R_RESULT, pixelSlot).w);
         const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
-        sum[idx + 0] = sum[idx + 0] + resultColor.x; sum[idx + 1] = sum[idx + 1] + resultColor.y; sum[idx + 2] = sum[idx + 2] + resultColor.z;
-        if (evenPass) { secondary[idx + 0] = secondary[idx + 0] + resultColor.x; secondary[idx + 1] = secondary[idx + 1] + resultColor.y; secondary[idx + 2] = secondary[idx + 2] + resultColor.z; }
+        float sr = sum[idx + 0], sg = sum[idx + 1], sb = sum[idx + 2];
+        float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
+        for (uint32_t p = 0; p < numPasses; ++p)   // the passes of the batch in pass order, like k_accumulate
+        {
+            const uint32_t slot = p * b.slotsPerPass + pixelSlot;
+            const float4 rResult = prec(cp, R_RESULT, slot);
+            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+            vcmResolvePending(cp, a, b.vcms[p], slot, ubits(prec(cp, R_SAMPLER, slot).w), resultColor, cnt);
+            sr = sr + resultColor.x; sg = sg + resultColor.y; sb = sb + resultColor.z;
+            if ((b.passes[p].passIndex % 2u) == 0u) { tr = tr + resultColor.x; tg = tg + resultColor.y; tb = tb + resultColor.z; }
+        }
+        sum[idx + 0] = sr; sum[idx + 1] = sg; sum[idx + 2] = sb;
+        secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
     flushCounters(cnt, counters);
 }

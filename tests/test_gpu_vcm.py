@@ -23,7 +23,7 @@ COMPARED = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "n
             "numShadowRayTriangleTests")
 
 
-def run_both(scene, camera, w, h, passes, seed=99, **vcm_args):
+def run_both(scene, camera, w, h, passes, seed=99, streamed=False, **vcm_args):
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
@@ -38,7 +38,8 @@ def run_both(scene, camera, w, h, passes, seed=99, **vcm_args):
         p = vp.next_pass_params(camera)
         vp.render_pass_with(p)
         vcm.render_pass(desc, p, w, h, cam, cam2 if i % 2 == 0 else None, light, cnt)
-        photons.append((vp.vcm_num_photons(), vcm.num_photons()))
+        if not streamed or i == passes - 1:     # the query synchronises: without it the passes ride in batches of 8
+            photons.append((vp.vcm_num_photons(), vcm.num_photons()))
     img, img2 = vp.sum_buffer(secondary=True)
     return img, img2, vp.counters(), cam, cam2, light, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, photons
 
@@ -77,6 +78,19 @@ def test_vcm_merging_with_a_large_radius_bit_exact(built):
     assert out[0].sum() > 3.2 * first[0].sum()
     assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, initial_merging_radius=0.4, min_merging_radius=0.25,
                                            merging_radius_multiplier=0.8))
+
+
+def test_vcm_streamed_passes_ride_in_batches_bit_exact(built):
+    """Passes submitted without a synchronising call in between go through the launch sequence 8 at a time (light stages of the
+    batch, the 7 hash grids in between, camera stages): 11 passes = one full batch + a partial one whose first merge set comes from
+    the previous batch.  Same sums, counters and final photon set as the oracle's pass-at-a-time loop, with a shrinking radius."""
+    w, h = 96, 72
+    scene, camera = _two_estimator_scene(w / h)
+    out = run_both(scene, camera, w, h, 11, streamed=True, camera_connecting_weight=0.0, initial_merging_radius=0.4, min_merging_radius=0.2,
+                   merging_radius_multiplier=0.9)
+    assert_camera_paths_identical(out)
+    scene, camera = scenes.cornell_box(w / h)
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 9, streamed=True, camera_connecting_weight=0.0))
 
 
 def test_vcm_camera_paths_bit_exact_all_lights_all_bsdfs(built):
