@@ -612,6 +612,25 @@ void* rto_vcm_create(const uint32_t* settingsWords)
     }
     return r;
 }
+// HashGrid::Build + HashGrid::Process over plain points (the subject of the reference's own Tests/HashGridTest.cpp): for every query the
+// particle indices in visiting order, appended to outIndices (capacity `capacity`); outOffsets[q]..outOffsets[q+1] delimit query q.
+// Returns the total number of indices (which may exceed the capacity: then only the first `capacity` were written).
+uint64_t rto_hash_grid_query(const float* points, uint32_t numPoints, float radius, const float* queries, uint32_t numQueries,
+                             uint64_t* outOffsets, uint32_t* outIndices, uint64_t capacity)
+{
+    std::vector<Photon> particles(numPoints);
+    for (uint32_t i = 0; i < numPoints; ++i) { memset(&particles[i], 0, sizeof(Photon)); particles[i].position[0] = points[3 * i]; particles[i].position[1] = points[3 * i + 1]; particles[i].position[2] = points[3 * i + 2]; }
+    HashGrid grid; grid.build(particles, radius);
+    struct Query { uint32_t* out; uint64_t capacity, total; void operator()(uint32_t index) { if (total < capacity) out[total] = index; total++; } } query = { outIndices, capacity, 0 };
+    for (uint32_t q = 0; q < numQueries; ++q)
+    {
+        outOffsets[q] = query.total;
+        grid.process(V4(queries[3 * q], queries[3 * q + 1], queries[3 * q + 2], 0.0f), particles, query);
+    }
+    outOffsets[numQueries] = query.total;
+    return query.total;
+}
+
 void rto_vcm_destroy(void* h) { delete static_cast<VcmRenderer*>(h); }
 uint32_t rto_vcm_num_photons(void* h) { return (uint32_t)static_cast<VcmRenderer*>(h)->recorded.size(); }
 

@@ -135,3 +135,15 @@ def light_tracer_pass(scene_desc_ptr, params, width, height, sum_buf, secondary=
     if r != 0:
         raise RuntimeError("rto_light_tracer_render_pass failed")
     return counters
+
+
+def hash_grid_query(points, radius, queries, capacity=1 << 22):
+    """HashGrid::Build + Process (Utils/HashGrid.h) over points[n,3] for queries[m,3]: list of index arrays in visiting order."""
+    L = lib()
+    points = np.ascontiguousarray(points, dtype=np.float32); queries = np.ascontiguousarray(queries, dtype=np.float32)
+    offsets = np.zeros(len(queries) + 1, dtype=np.uint64); indices = np.zeros(capacity, dtype=np.uint32)
+    L.rto_hash_grid_query.restype = C.c_uint64
+    L.rto_hash_grid_query.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
+    total = L.rto_hash_grid_query(points.ctypes.data, len(points), radius, queries.ctypes.data, len(queries), offsets.ctypes.data, indices.ctypes.data, capacity)
+    assert total <= capacity
+    return [indices[int(offsets[q]):int(offsets[q + 1])] for q in range(len(queries))]
