@@ -1225,7 +1225,7 @@ struct RtgpuContext
         float mergingRadiusVC = 0.0f, mergingRadiusVM = 0.0f;
         Paths lightPaths = { nullptr, 0, 0 }, cameraPaths = { nullptr, 0, 0 };
         VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
-        uint32_t* mergeQueue = nullptr;
+        uint32_t* mergeQueue = nullptr; uint32_t* connectQueue = nullptr;
         uint32_t* overflowQueue = nullptr;   // closest-hit rays k_trace hands to k_trace_monster
         uint32_t* queues[4] = { nullptr, nullptr, nullptr, nullptr };          // light ping-pong, camera ping-pong
         uint32_t* shadowQueues[4] = { nullptr, nullptr, nullptr, nullptr };
@@ -1825,7 +1825,7 @@ static int flushPending(RtgpuContext* c)
 static void freeVcm(RtgpuContext* c)
 {
     RtgpuContext::Vcm& v = c->vcm;
-    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue, v.overflowQueue,
+    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue, v.connectQueue, v.overflowQueue,
                      v.queues[0], v.queues[1], v.queues[2], v.queues[3], v.shadowQueues[0], v.shadowQueues[1], v.shadowQueues[2], v.shadowQueues[3], v.counts,
                      v.passDev, v.seedDev, v.devsDev, v.gridsDev };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1855,6 +1855,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV, uint32_t batch)
     HIP_TRY(hipMalloc((void**)&v.arena.photonRaw, (size_t)maxLV * 2 * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.arena.cameraVertex, (size_t)RT_VCM_LV_RECORDS * cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&v.mergeQueue, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.connectQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.overflowQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
@@ -1863,7 +1864,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV, uint32_t batch)
     for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));
     for (int k = 2; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.passDev, (size_t)RT_VCM_MAX_BATCH * sizeof(DevPass)));
     HIP_TRY(hipMalloc((void**)&v.seedDev, (size_t)RT_VCM_MAX_BATCH * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.devsDev, (size_t)RT_VCM_MAX_BATCH * sizeof(VcmDev)));
@@ -1996,10 +1997,10 @@ static int vcmFlush(RtgpuContext* c)
     HIP_TRY(hipStreamSynchronize(stream));   // the host vectors and the pending seeds are temporaries
     const VcmBatch batch = { v.passDev, v.devsDev, v.gridsDev, c->numSlots };
 
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE; uint32_t* csc = v.counts + 4 * RT_VCM_COUNT_PLANE; uint32_t* ccur = v.counts + 5 * RT_VCM_COUNT_PLANE;
-    uint32_t* cmc = v.counts + 6 * RT_VCM_COUNT_PLANE;
+    uint32_t* cmc = v.counts + 6 * RT_VCM_COUNT_PLANE; uint32_t* ccc = v.counts + 9 * RT_VCM_COUNT_PLANE;
     uint32_t** lq = v.queues; uint32_t** cq = v.queues + 2; uint32_t** lsq = v.shadowQueues; uint32_t** csq = v.shadowQueues + 2;
 
     const uint32_t totalSlots = c->numSlots * numPasses;
@@ -2048,7 +2049,9 @@ static int vcmFlush(RtgpuContext* c)
                     v.overflowQueue, v.counts + 8 * RT_VCM_COUNT_PLANE + d);
         LaunchTimer t(c, stream, KC_SHADE);
         hipLaunchKernelGGL(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, batch, v.cameraPaths, v.arena, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
-                           csq[d & 1u], csc + d, v.mergeQueue, cmc + d, c->counters);
+                           csq[d & 1u], csc + d, v.mergeQueue, cmc + d, v.connectQueue, ccc + d, c->counters);
+        if (vp.useVertexConnection && maxLV > 0u && d + 1u < vp.maxPathLength)
+            hipLaunchKernelGGL(k_vcm_connect, grid1, block, 0, stream, c->sceneDev, batch, v.cameraPaths, v.arena, v.connectQueue, ccc + d, csq[d & 1u], csc + d);
         if (anyPhotons && vp.useVertexMerging)
             hipLaunchKernelGGL(k_vcm_merge, grid1, block, 0, stream, c->sceneDev, batch, v.arena, v.mergeQueue, cmc + d, mergeCooperativeMin);
     }
@@ -2114,7 +2117,7 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
     HIP_TRY(hipMemcpyAsync(v.gridsDev, &noGrid, sizeof(noGrid), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const VcmBatch batch = { v.passDev, v.devsDev, v.gridsDev, c->numSlots };
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)9 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE;
     uint32_t** lq = v.queues; uint32_t** lsq = v.shadowQueues;

@@ -543,7 +543,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                                                                const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                                uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                                uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
-                                                               uint32_t* __restrict__ mergeQueue, uint32_t* __restrict__ mergeCount, unsigned long long* counters)
+                                                               uint32_t* __restrict__ mergeQueue, uint32_t* __restrict__ mergeCount,
+                                                               uint32_t* __restrict__ connectQueue, uint32_t* __restrict__ connectCount, unsigned long long* counters)
 {
     __shared__ uint32_t sCount, sBase;
     if (threadIdx.x == 0) sCount = 0u;
@@ -554,7 +555,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
     {
-        bool alive = false, wantMerge = false;
+        bool alive = false, wantMerge = false, wantConnect = false;
         uint32_t slot = 0;
         unsigned long long rayMask = 0ull;   // requests of this vertex that need a shadow ray (at most 64 per vertex, checked by the host)
         if (i < count)
@@ -665,59 +666,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                     pendingBits |= 0x1000000u;
                 }
 
-                // ConnectVertices to the light vertices of this pixel, :262-283 and :746-821
-                uint32_t numConnections = 0u;
-                const uint32_t numLightVertices = a.lvCount[slot];
-                if (!isDeltaBsdf && vcm.useVertexConnection && numLightVertices > 0u)
-                {
-                    for (uint32_t v = 0; v < numLightVertices; ++v)
-                    {
-                        ShadingData lsd; V4 lvThroughput; float lvVC, lvVCM; uint32_t lvLength;
-                        loadLightVertex(scene, a, v, slot, lsd, lvThroughput, lvVC, lvVCM, lvLength);
-                        if (lvLength + length + 1u > vcm.maxPathLength) break;
-                        V4 lightDir = lsd.intersection.frame.r[3] - pos;
-                        const float distanceSqr = sqrLength3(lightDir);
-                        const float distance = sqrtf(distanceSqr);
-                        lightDir = lightDir / distance;
-                        const float cosCameraVertex = dot3(sd.intersection.frame.r[2], lightDir);
-                        const float cosLightVertex = dot3(lsd.intersection.frame.r[2], neg(lightDir));
-                        float tmax = -1.0f; V4 contribution = zero4();
-                        if (!(cosCameraVertex <= 0.0f || cosLightVertex <= 0.0f))
-                        {
-                            const float geometryTerm = 1.0f / distanceSqr;
-                            float cameraBsdfPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
-                            const V4 cameraFactor = materialEvaluate<false>(mat, sd, neg(lightDir), cameraBsdfPdfW, &cameraBsdfRevPdfW);
-                            if (!almostZero4(cameraFactor))
-                            {
-                                float lightBsdfPdfW = 0.0f, lightBsdfRevPdfW = 0.0f;
-                                const V4 lightFactor = materialEvaluate<false>(scene.materials[lsd.intersection.material], lsd, lightDir, lightBsdfPdfW, &lightBsdfRevPdfW);
-                                if (!almostZero4(lightFactor))
-                                {
-                                    tmax = distance * 0.999f;
-                                    const float continuationProbability = 1.0f;
-                                    lightBsdfPdfW *= continuationProbability;
-                                    lightBsdfRevPdfW *= continuationProbability;
-                                    const float cameraBsdfPdfA = vcmPdfWtoA(cameraBsdfPdfW, distance, cosLightVertex);
-                                    const float lightBsdfPdfA = vcmPdfWtoA(lightBsdfPdfW, distance, cosCameraVertex);
-                                    const float wLight = cameraBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + lvVCM + lvVC * lightBsdfRevPdfW);
-                                    const float wCamera = lightBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + dVCM + dVC * cameraBsdfRevPdfW);
-                                    const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
-                                    contribution = (cameraFactor * lightFactor) * (geometryTerm * misWeight);
-                                }
-                            }
-                        }
-                        const uint32_t r = numLightRequests + numConnections;
-                        pshadow(cp, r, 0, slot) = f4(lightDir.x, lightDir.y, lightDir.z, tmax);
-                        pshadow(cp, r, 1, slot) = f4(contribution.x, contribution.y, contribution.z, fbits(v));
-                        if (tmax >= 0.0f) rayMask |= 1ull << r;
-                        numConnections++;
-                    }
-                    pendingBits |= 0x2000000u;
-                }
+                // ConnectVertices to the light vertices of this pixel, :262-283 and :746-821: k_vcm_connect, from the vertex record below
+                // (two BSDF evaluations per light vertex: kept out of this kernel's register budget)
+                wantConnect = !isDeltaBsdf && vcm.useVertexConnection && a.lvCount[slot] > 0u;
 
                 // MergeVertices, :823-906: the range query runs in k_vcm_merge (wave-cooperative for long photon lists); this
                 // vertex is handed over as a record.  With no photons HashGrid::Process returns at once and the term is +0.
-                if (!isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u && gridPhotons != 0u)
+                const bool mergeHere = !isDeltaBsdf && vcm.useVertexMerging && vcm.iteration > 0u && gridPhotons != 0u;
+                if (mergeHere || wantConnect)
                 {
                     const V4 tg = sd.intersection.frame.r[0], nr = sd.intersection.frame.r[2], og = sd.outgoingDirWorldSpace;
                     cvrec(a, 0, slot) = f4(pos.x, pos.y, pos.z, fbits(sd.intersection.material));
@@ -726,14 +682,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                     cvrec(a, 3, slot) = f4(og.x, og.y, og.z, dVM);
                     cvrec(a, 4, slot) = f4(sd.mp.baseColor.x, sd.mp.baseColor.y, sd.mp.baseColor.z, sd.mp.baseColor.w);
                     cvrec(a, 5, slot) = f4(throughput.x, throughput.y, throughput.z, dVCM);
-                    wantMerge = true;
-                    pendingBits |= 0x10000u;
                 }
-                pendingBits |= numLightRequests | (numConnections << 8);
-                if (pendingBits != 0u)
+                if (mergeHere) { wantMerge = true; pendingBits |= 0x10000u; }
+                pendingBits |= numLightRequests;
+                if (pendingBits != 0u || wantConnect)
                 {
-                    prec(cp, R_SH_P, slot) = f4(pos.x, pos.y, pos.z, 0.0f);
-                    prec(cp, R_SH_TP, slot) = f4(throughput.x, throughput.y, throughput.z, 0.0f);
+                    prec(cp, R_SH_P, slot) = f4(pos.x, pos.y, pos.z, dVC);                                         // .w: for k_vcm_connect
+                    prec(cp, R_SH_TP, slot) = f4(throughput.x, throughput.y, throughput.z, fbits(length));
                 }
 
                 // AdvancePath, :493-578 (length > maxPathLength cannot hold here, :308-311)
@@ -755,6 +710,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
         if (alive) queueOut[pathAt] = slot;
         const uint32_t mergeAt = blockReserve(wantMerge ? 1u : 0u, mergeCount, &sCount, &sBase);
         if (wantMerge) mergeQueue[mergeAt] = slot;
+        const uint32_t connectAt = blockReserve(wantConnect ? 1u : 0u, connectCount, &sCount, &sBase);
+        if (wantConnect) connectQueue[connectAt] = slot;
     }
     flushCounters(cnt, counters);
 }
@@ -825,6 +782,89 @@ RT_DEV void loadCameraVertex(const RtSceneDesc& scene, const VcmArena& a, uint32
     throughput = V4(r5.x, r5.y, r5.z, 0.0f);
     dVM = r3.w; dVCM = r5.w;
 }
+// ConnectVertices, :746-821, for the camera vertices k_vcm_camera_shade queued: every light vertex of the pixel's light path is one
+// request (direction | tmax, contribution | vertex) after the vertex's next-event requests; the visibility rays ride in the next k_trace
+// launch and vcmResolvePending folds the visible ones in.  Reads the 96-byte vertex record the merge kernel uses, plus dVC and the path
+// length from the spare lanes of R_SH_P / R_SH_TP.
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_connect(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
+                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                          uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount)
+{
+    __shared__ uint32_t sCount, sBase;
+    if (threadIdx.x == 0) sCount = 0u;
+    __syncthreads();
+    const uint32_t count = *queueCount;
+    const uint32_t rounded = (count + RT_BLOCK - 1u) / RT_BLOCK * RT_BLOCK;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        uint32_t slot = 0;
+        unsigned long long rayMask = 0ull;
+        if (i < count)
+        {
+            slot = queue[i];
+            const VcmDev& vcm = b.vcms[slot / b.slotsPerPass];
+            ShadingData sd; V4 throughput; float dVM, dVCM;
+            loadCameraVertex(scene, a, slot, sd, throughput, dVM, dVCM);
+            const float dVC = prec(cp, R_SH_P, slot).w;
+            const uint32_t length = ubits(prec(cp, R_SH_TP, slot).w);
+            uint32_t pendingBits = ubits(prec(cp, R_SAMPLER, slot).w);
+            const uint32_t numLightRequests = pendingBits & 0xFFu;
+            const RtMaterial& mat = scene.materials[sd.intersection.material];
+            const V4 pos = sd.intersection.frame.r[3];
+            uint32_t numConnections = 0u;
+            const uint32_t numLightVertices = a.lvCount[slot];
+            for (uint32_t v = 0; v < numLightVertices; ++v)
+            {
+                ShadingData lsd; V4 lvThroughput; float lvVC, lvVCM; uint32_t lvLength;
+                loadLightVertex(scene, a, v, slot, lsd, lvThroughput, lvVC, lvVCM, lvLength);
+                if (lvLength + length + 1u > vcm.maxPathLength) break;
+                V4 lightDir = lsd.intersection.frame.r[3] - pos;
+                const float distanceSqr = sqrLength3(lightDir);
+                const float distance = sqrtf(distanceSqr);
+                lightDir = lightDir / distance;
+                const float cosCameraVertex = dot3(sd.intersection.frame.r[2], lightDir);
+                const float cosLightVertex = dot3(lsd.intersection.frame.r[2], neg(lightDir));
+                float tmax = -1.0f; V4 contribution = zero4();
+                if (!(cosCameraVertex <= 0.0f || cosLightVertex <= 0.0f))
+                {
+                    const float geometryTerm = 1.0f / distanceSqr;
+                    float cameraBsdfPdfW = 0.0f, cameraBsdfRevPdfW = 0.0f;
+                    const V4 cameraFactor = materialEvaluate<false>(mat, sd, neg(lightDir), cameraBsdfPdfW, &cameraBsdfRevPdfW);
+                    if (!almostZero4(cameraFactor))
+                    {
+                        float lightBsdfPdfW = 0.0f, lightBsdfRevPdfW = 0.0f;
+                        const V4 lightFactor = materialEvaluate<false>(scene.materials[lsd.intersection.material], lsd, lightDir, lightBsdfPdfW, &lightBsdfRevPdfW);
+                        if (!almostZero4(lightFactor))
+                        {
+                            tmax = distance * 0.999f;
+                            const float continuationProbability = 1.0f;
+                            lightBsdfPdfW *= continuationProbability;
+                            lightBsdfRevPdfW *= continuationProbability;
+                            const float cameraBsdfPdfA = vcmPdfWtoA(cameraBsdfPdfW, distance, cosLightVertex);
+                            const float lightBsdfPdfA = vcmPdfWtoA(lightBsdfPdfW, distance, cosCameraVertex);
+                            const float wLight = cameraBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + lvVCM + lvVC * lightBsdfRevPdfW);
+                            const float wCamera = lightBsdfPdfA * (vcm.misVertexMergingWeightFactorVC + dVCM + dVC * cameraBsdfRevPdfW);
+                            const float misWeight = 1.0f / (wLight + 1.0f + wCamera);
+                            contribution = (cameraFactor * lightFactor) * (geometryTerm * misWeight);
+                        }
+                    }
+                }
+                const uint32_t r = numLightRequests + numConnections;
+                pshadow(cp, r, 0, slot) = f4(lightDir.x, lightDir.y, lightDir.z, tmax);
+                pshadow(cp, r, 1, slot) = f4(contribution.x, contribution.y, contribution.z, fbits(v));
+                if (tmax >= 0.0f) rayMask |= 1ull << r;
+                numConnections++;
+            }
+            pendingBits |= (numConnections << 8) | 0x2000000u;
+            prec(cp, R_SAMPLER, slot).w = fbits(pendingBits);
+        }
+        uint32_t shadowAt = blockReserve((uint32_t)__popcll(rayMask), shadowCount, &sCount, &sBase);
+        for (unsigned long long pendingMask = rayMask; pendingMask != 0ull; pendingMask &= pendingMask - 1ull)
+            shadowQueue[shadowAt++] = (uint32_t)(__ffsll((long long)pendingMask) - 1) * cp.capacity + slot;
+    }
+}
+
 __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene, const VcmBatch b, const VcmArena a,
                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, uint32_t cooperativeMin)
 {
