@@ -721,6 +721,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
 // a query with few candidate photons is one lane's loop; a query with many (a caustic, the footprint of a spot light:
 // thousands of photons per cell) is taken by the whole wave -- 64 photons are tested and their BSDF terms evaluated at a time,
 // then every lane replays the fma chain over the contributing lanes in order (shuffles), so the sum is the sequential one.
+#define RT_VCM_SCAN_UNROLL 4u
 #define RT_VCM_COOPERATIVE_MERGE_MIN 64u   // measured plateau 48-96 (profiles/r01_tuning_sweep.txt)
 struct MergeRanges { uint32_t start[8], end[8]; uint32_t numCells, total; };
 RT_DEV void mergeCellRanges(const HashGridView& g, V4 queryPos, MergeRanges& r)
@@ -747,12 +748,17 @@ RT_DEV void mergeCellRanges(const HashGridView& g, V4 queryPos, MergeRanges& r)
         }
     }
 }
+RT_DEV bool photonInRadius(const HashGridView& g, uint32_t j, V4 pos)   // HashGrid::Process's test, HashGrid.h:131-137
+{
+    const Photon& photon = g.photons[j];
+    const float distSqr = sqrLength3(pos - V4(photon.px, photon.py, photon.pz, 0.0f));
+    return distSqr <= g.radiusSqr;
+}
 // one photon against one camera vertex: false = no contribution; else term = cameraBsdfFactor * photon throughput, weight = misWeight / cosToLight
 RT_DEV bool mergePhoton(const RtSceneDesc& scene, const VcmDev& vcm, const HashGridView& g, uint32_t j, const ShadingData& sd, V4 pos, float dVCM, float dVM, V4& term, float& weight)
 {
     const Photon& photon = g.photons[j];
-    const float distSqr = sqrLength3(pos - V4(photon.px, photon.py, photon.pz, 0.0f));
-    if (!(distSqr <= g.radiusSqr)) return false;
+    if (!photonInRadius(g, j, pos)) return false;
     const V4 lightDirection = unpackUnitVector(photon.direction);
     const float cosToLight = dot3(sd.intersection.frame.r[2], lightDirection);
     if (cosToLight < FLT_EPSILON) return false;
@@ -767,6 +773,8 @@ RT_DEV bool mergePhoton(const RtSceneDesc& scene, const VcmDev& vcm, const HashG
     term = cameraBsdfFactor * photonThroughput;
     return true;
 }
+RT_DEV float laneValue(float v, int lane) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane)); }   // lane: wave-uniform
+RT_DEV V4 shfl3(V4 v, int lane) { return V4(__shfl(v.x, lane), __shfl(v.y, lane), __shfl(v.z, lane), 0.0f); }
 RT_DEV void loadCameraVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_t slot, ShadingData& sd, V4& throughput, float& dVM, float& dVCM)
 {
     const float4 r0 = cvrec(a, 0, slot), r1 = cvrec(a, 1, slot), r2 = cvrec(a, 2, slot), r3 = cvrec(a, 3, slot), r4 = cvrec(a, 4, slot), r5 = cvrec(a, 5, slot);
@@ -869,6 +877,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, uint32_t cooperativeMin)
 {
     __shared__ uint32_t sStart[RT_BLOCK][8], sEnd[RT_BLOCK][8];
+    __shared__ uint32_t sCand[RT_BLOCK / 64][128], sOwner[RT_BLOCK / 64][128];
     const uint32_t count = *queueCount;
     const uint32_t rounded = (count + 63u) & ~63u;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -889,23 +898,99 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
             mergeCellRanges(b.grids[pb], sd.intersection.frame.r[3], r);
         }
         const bool big = valid && r.total >= cooperativeMin;
-        if (valid && !big)
+        // (a wave only reads what its own lanes wrote: no block barrier needed, the LDS writes are ordered before the reads of the same wave)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sStart[threadIdx.x][c] = c < (int)r.numCells ? r.start[c] : 0u; sEnd[threadIdx.x][c] = c < (int)r.numCells ? r.end[c] : 0u; }
+        uint32_t* cand = sCand[threadIdx.x >> 6];
+        uint32_t* owners = sOwner[threadIdx.x >> 6];
+        const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+        // SHORT photon lists: every lane scans its own candidates with the distance test only (one in five passes on a surface); the
+        // photons inside the radius go, in scan order, to a wave-wide list of (owner lane, photon).  64 entries at a time are then
+        // evaluated one per lane -- the owner's vertex comes through the crossbar -- and each owner adds its entries' terms in list
+        // order, which is its own scan order: the reference's fma chain.  (A lane's own loop had 16 % of the lanes busy: different
+        // list lengths, and a BSDF evaluation behind a branch one lane in five takes.)
+        if (__ballot(valid && !big && r.total != 0u) != 0ull)
         {
-            const VcmDev& vcm = b.vcms[pb];
-            const HashGridView& grid = b.grids[pb];
-            for (uint32_t c = 0; c < r.numCells; ++c)
-                for (uint32_t j = r.start[c]; j < r.end[c]; ++j)
+            uint32_t numList = 0u;   // wave-uniform
+            auto flush = [&](uint32_t n)
+            {
+                __builtin_amdgcn_wave_barrier();
+                const int o = lane < n ? (int)owners[lane] : (int)lane;
+                const uint32_t pj = lane < n ? cand[lane] : 0u;
+                ShadingData osd;
+                osd.intersection.frame.r[0] = shfl3(sd.intersection.frame.r[0], o);
+                osd.intersection.frame.r[2] = shfl3(sd.intersection.frame.r[2], o);
+                osd.intersection.frame.r[1] = cross3(osd.intersection.frame.r[0], osd.intersection.frame.r[2]);
+                osd.intersection.frame.r[3] = shfl3(sd.intersection.frame.r[3], o);
+                osd.intersection.texCoord = zero4();
+                osd.intersection.material = (uint32_t)__shfl((int)sd.intersection.material, o);
+                osd.outgoingDirWorldSpace = shfl3(sd.outgoingDirWorldSpace, o);
+                osd.mp.baseColor = shfl3(sd.mp.baseColor, o); osd.mp.baseColor.w = __shfl(sd.mp.baseColor.w, o);
+                osd.mp.emission = zero4();
+                osd.mp.roughness = __shfl(sd.mp.roughness, o); osd.mp.metalness = __shfl(sd.mp.metalness, o); osd.mp.IoR = __shfl(sd.mp.IoR, o);
+                const float oVM = __shfl(dVM, o), oVCM = __shfl(dVCM, o);
+                const uint32_t opb = (uint32_t)__shfl((int)pb, o);
+                V4 term = zero4(); float weight = 0.0f;
+                const bool contributes = lane < n && mergePhoton(scene, b.vcms[opb], b.grids[opb], pj, osd, osd.intersection.frame.r[3], oVCM, oVM, term, weight);
+                for (unsigned long long m = __ballot(contributes); m != 0ull; m &= m - 1ull)
                 {
-                    V4 term; float weight;
-                    if (mergePhoton(scene, vcm, grid, j, sd, sd.intersection.frame.r[3], dVCM, dVM, term, weight)) contribution = mulAdd(term, weight, contribution);
+                    const int e = __ffsll((long long)m) - 1;
+                    const int owner = __builtin_amdgcn_readlane(o, e);
+                    const V4 t(laneValue(term.x, e), laneValue(term.y, e), laneValue(term.z, e), laneValue(term.w, e));
+                    const float w = laneValue(weight, e);
+                    if ((int)lane == owner) contribution = mulAdd(t, w, contribution);
                 }
+                __builtin_amdgcn_wave_barrier();
+            };
+            bool scanning = valid && !big && r.total != 0u;
+            uint32_t c = 0u, j = sStart[threadIdx.x][0], endJ = sEnd[threadIdx.x][0];
+            auto skipEmptyCells = [&]()
+            {
+                while (scanning && j >= endJ)
+                {
+                    if (++c >= r.numCells) scanning = false;
+                    else { j = sStart[threadIdx.x][c]; endJ = sEnd[threadIdx.x][c]; }
+                }
+            };
+            skipEmptyCells();
+            while (__ballot(scanning) != 0ull)
+            {
+                // four consecutive photons of the cell per step: the loads are independent (the scan is bound by their latency)
+                bool inside[RT_VCM_SCAN_UNROLL]; uint32_t myJ = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < RT_VCM_SCAN_UNROLL; ++k) inside[k] = false;
+                if (scanning)
+                {
+                    const HashGridView& grid = b.grids[pb];
+                    const uint32_t n = endJ - j < RT_VCM_SCAN_UNROLL ? endJ - j : RT_VCM_SCAN_UNROLL;
+                    myJ = j;
+#pragma unroll
+                    for (uint32_t k = 0; k < RT_VCM_SCAN_UNROLL; ++k) inside[k] = photonInRadius(grid, j + (k < n ? k : n - 1u), sd.intersection.frame.r[3]) && k < n;
+                    j += n;
+                    skipEmptyCells();
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < RT_VCM_SCAN_UNROLL; ++k)
+                {
+                    const unsigned long long m = __ballot(inside[k]);
+                    if (m == 0ull) continue;
+                    if (inside[k]) { const uint32_t at = numList + (uint32_t)__popcll(m & lanesBelow); cand[at] = myJ + k; owners[at] = lane; }
+                    numList += (uint32_t)__popcll(m);
+                    if (numList >= 64u)
+                    {
+                        flush(64u);
+                        const uint32_t restJ = lane < numList - 64u ? cand[64u + lane] : 0u, restOwner = lane < numList - 64u ? owners[64u + lane] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        cand[lane] = restJ; owners[lane] = restOwner;
+                        numList -= 64u;
+                    }
+                }
+            }
+            if (numList != 0u) flush(numList);
         }
         unsigned long long mBig = __ballot(big);
         if (mBig != 0ull)
         {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { sStart[threadIdx.x][c] = c < (int)r.numCells ? r.start[c] : 0u; sEnd[threadIdx.x][c] = c < (int)r.numCells ? r.end[c] : 0u; }
-            // (a wave only reads what its own lanes wrote: no block barrier needed, the LDS writes are ordered before the reads of the same wave)
             for (; mBig != 0ull; mBig &= mBig - 1ull)
             {
                 const int q = __ffsll((long long)mBig) - 1;
@@ -917,22 +1002,45 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene,
                 loadCameraVertex(scene, a, qSlot, qsd, qThroughput, qVM, qVCM);   // same address in all lanes: one broadcast fetch
                 const V4 qPos = qsd.intersection.frame.r[3];
                 V4 acc = zero4();
+                // The photons inside the radius (one in five of a cell block's on a surface) are compacted, in order, into a wave-wide
+                // list; 64 of them are evaluated at a time, then every lane replays the fma chain over the contributing lanes in order.
+                uint32_t numCand = 0u;   // wave-uniform
+                auto evaluate = [&](uint32_t n)
+                {
+                    __builtin_amdgcn_wave_barrier();
+                    V4 term = zero4(); float weight = 0.0f;
+                    const bool contributes = lane < n && mergePhoton(scene, vcm, grid, cand[lane], qsd, qPos, qVCM, qVM, term, weight);
+                    for (unsigned long long m = __ballot(contributes); m != 0ull; m &= m - 1ull)
+                    {
+                        const int src = __ffsll((long long)m) - 1;
+                        // (src is wave-uniform: v_readlane broadcasts through an SGPR instead of a trip through the LDS crossbar)
+                        const V4 t(laneValue(term.x, src), laneValue(term.y, src), laneValue(term.z, src), laneValue(term.w, src));
+                        acc = mulAdd(t, laneValue(weight, src), acc);
+                    }
+                };
                 for (uint32_t c = 0; c < 8u; ++c)
                 {
                     const uint32_t start = sStart[waveBase + (uint32_t)q][c], end = sEnd[waveBase + (uint32_t)q][c];
                     for (uint32_t base = start; base < end; base += 64u)
                     {
                         const uint32_t j = base + lane;
-                        V4 term = zero4(); float weight = 0.0f;
-                        const bool contributes = j < end && mergePhoton(scene, vcm, grid, j, qsd, qPos, qVCM, qVM, term, weight);
-                        for (unsigned long long m = __ballot(contributes); m != 0ull; m &= m - 1ull)
+                        const bool inside = j < end && photonInRadius(grid, j, qPos);
+                        const unsigned long long m = __ballot(inside);
+                        if (inside) cand[numCand + (uint32_t)__popcll(m & lanesBelow)] = j;
+                        numCand += (uint32_t)__popcll(m);
+                        if (numCand >= 64u)
                         {
-                            const int src = __ffsll((long long)m) - 1;
-                            const V4 t(__shfl(term.x, src), __shfl(term.y, src), __shfl(term.z, src), __shfl(term.w, src));
-                            acc = mulAdd(t, __shfl(weight, src), acc);
+                            evaluate(64u);
+                            __builtin_amdgcn_wave_barrier();
+                            const uint32_t rest = lane < numCand - 64u ? cand[64u + lane] : 0u;
+                            __builtin_amdgcn_wave_barrier();
+                            cand[lane] = rest;
+                            numCand -= 64u;
                         }
                     }
                 }
+                if (numCand != 0u) evaluate(numCand);
+                __builtin_amdgcn_wave_barrier();
                 if ((int)lane == q) contribution = acc;
             }
         }
