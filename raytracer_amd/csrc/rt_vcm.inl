@@ -722,7 +722,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
 // thousands of photons per cell) is taken by the whole wave -- 64 photons are tested and their BSDF terms evaluated at a time,
 // then every lane replays the fma chain over the contributing lanes in order (shuffles), so the sum is the sequential one.
 #define RT_VCM_SCAN_UNROLL 4u
-#define RT_VCM_COOPERATIVE_MERGE_MIN 64u   // measured plateau 48-96 (profiles/r01_tuning_sweep.txt)
+#define RT_VCM_COOPERATIVE_MERGE_MIN 128u   // measured plateau 128-256 (profiles/r01_tuning_sweep.txt)
 struct MergeRanges { uint32_t start[8], end[8]; uint32_t numCells, total; };
 RT_DEV void mergeCellRanges(const HashGridView& g, V4 queryPos, MergeRanges& r)
 {
