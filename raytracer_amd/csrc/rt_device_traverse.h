@@ -144,10 +144,15 @@ RT_DEV void travStepOther(TravState& s, const RtSceneDesc& d, const LdsStack& st
             const uint32_t first = s.cur & RT_NODE_CHILD_MASK;
             if (kCount) { cnt.c[C_TRI_SHADOW] += s.shadow ? numLeaves : 0u; cnt.c[C_TRI] += s.shadow ? 0u : numLeaves; }
             const RtTriangle* tris = d.triangles + s.triBase;
+            // the second triangle of the leaf (adjacent in memory) is fetched with the first: one memory round trip per leaf
+            V4 v0, e1, e2, nv0, ne1, ne2;
+            loadTriangle(tris + first, v0, e1, e2);
+            loadTriangle(tris + first + (numLeaves > 1u ? 1u : 0u), nv0, ne1, ne2);
             for (uint32_t i = 0; i < numLeaves; ++i)
             {
                 const uint32_t triangleIndex = first + i;
-                V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
+                if (i == 1u) { v0 = nv0; e1 = ne1; e2 = ne2; }
+                else if (i > 1u) loadTriangle(tris + triangleIndex, v0, e1, e2);
                 float u, v, dist;
                 if (intersectTriangleRay(s.ray, v0, e1, e2, u, v, dist))
                 {
