@@ -344,12 +344,16 @@ RT_DEV bool lightTestRayHit(const RtLight& L, const Ray& ray, float& outDistance
 }
 
 // MeshShape::EvaluateIntersection, MeshShape.cpp:283-328
+// The device copy of the scene holds the shading data DE-INDEXED: one 128-byte record per triangle (its three VertexShadingData and
+// its material), in triangle order, where the C ABI's vertexIndices[] would be (vertexShading[] is not uploaded).  A hit then costs
+// one memory round trip to one aligned 128-byte line instead of the index record followed by three scattered 32-byte vertices.
+struct __attribute__((aligned(16))) TriangleShading { RtVertexShading v[3]; uint32_t materialIndex; uint32_t _pad[7]; };
+static_assert(sizeof(TriangleShading) == 128, "TriangleShading");
 RT_DEV void meshEvaluateIntersection(const RtSceneDesc& d, const RtMesh& mesh, const Hit& hit, Intersection& out)
 {
-    const RtVertexIndices& idx = d.vertexIndices[mesh.firstTriangle + hit.subObjectId];
-    if (idx.materialIndex != RT_NO_MATERIAL) out.material = idx.materialIndex;
-    const RtVertexShading* vs = d.vertexShading + mesh.firstVertex;
-    const RtVertexShading& a = vs[idx.i0]; const RtVertexShading& b = vs[idx.i1]; const RtVertexShading& c = vs[idx.i2];
+    const TriangleShading& tri = reinterpret_cast<const TriangleShading*>(d.vertexIndices)[mesh.firstTriangle + hit.subObjectId];
+    if (tri.materialIndex != RT_NO_MATERIAL) out.material = tri.materialIndex;
+    const RtVertexShading& a = tri.v[0]; const RtVertexShading& b = tri.v[1]; const RtVertexShading& c = tri.v[2];
     const V4 coeff1 = splat(hit.u), coeff2 = splat(hit.v);
     const V4 coeff0 = splat(1.0f) - (coeff1 + coeff2);
     V4 texCoord = coeff1 * V4(b.texCoord[0], b.texCoord[1], 0.0f, 0.0f);

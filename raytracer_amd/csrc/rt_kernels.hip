@@ -1457,6 +1457,11 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         const RtMesh& m = s->meshes[i];
         if ((uint64_t)m.firstNode + m.numNodes > s->numMeshNodes || (uint64_t)m.firstTriangle + m.numTriangles > s->numTriangles || (uint64_t)m.firstVertex + m.numVertices > s->numVertices)
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "mesh ranges out of bounds");
+        for (uint32_t t = 0; t < m.numTriangles; ++t)
+        {
+            const RtVertexIndices& idx = s->vertexIndices[m.firstTriangle + t];
+            if (idx.i0 >= m.numVertices || idx.i1 >= m.numVertices || idx.i2 >= m.numVertices) return fail(RTGPU_ERR_INVALID_ARGUMENT, "triangle vertex index out of range");
+        }
         const uint32_t md = bvhDepth(s->meshNodes + m.firstNode, m.numNodes);
         if (md == 0xFFFFFFFFu) return fail(RTGPU_ERR_INVALID_ARGUMENT, "malformed mesh BVH");
         if (md > maxMeshDepth) maxMeshDepth = md;
@@ -1554,8 +1559,27 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->meshes, s->numMeshes, &d.meshes))) return r;
     if ((r = uploadArray(c, s->meshNodes, s->numMeshNodes, &d.meshNodes))) return r;
     if ((r = uploadArray(c, s->triangles, s->numTriangles, &d.triangles))) return r;
-    if ((r = uploadArray(c, s->vertexIndices, s->numTriangles, &d.vertexIndices))) return r;
-    if ((r = uploadArray(c, s->vertexShading, s->numVertices, &d.vertexShading))) return r;
+    {
+        // de-indexed shading records (rt_device_core.h, TriangleShading), built once here
+        std::vector<TriangleShading> records(s->numTriangles);
+        if (!records.empty()) memset(records.data(), 0, records.size() * sizeof(TriangleShading));
+        for (uint32_t m = 0; m < s->numMeshes; ++m)
+        {
+            const RtMesh& mesh = s->meshes[m];
+            const RtVertexShading* vs = s->vertexShading + mesh.firstVertex;
+            for (uint32_t t = 0; t < mesh.numTriangles; ++t)
+            {
+                const RtVertexIndices& idx = s->vertexIndices[mesh.firstTriangle + t];
+                TriangleShading& out = records[mesh.firstTriangle + t];
+                out.v[0] = vs[idx.i0]; out.v[1] = vs[idx.i1]; out.v[2] = vs[idx.i2];
+                out.materialIndex = idx.materialIndex;
+            }
+        }
+        const TriangleShading* dev = nullptr;
+        if ((r = uploadArray(c, records.data(), records.size(), &dev))) return r;
+        d.vertexIndices = reinterpret_cast<const RtVertexIndices*>(dev);
+        d.vertexShading = nullptr;
+    }
     if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
     if ((r = uploadArray(c, s->textures, s->numTextures, &d.textures))) return r;
     if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
