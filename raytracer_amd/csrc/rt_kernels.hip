@@ -1631,7 +1631,12 @@ static int rebuildSlots(RtgpuContext* c)
     c->numSlots = (uint32_t)slots.size();
     // launches of a batch should stay large enough to fill 256 CUs: a 1/8 shard of a 1080p frame batches 16 passes
     // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
-    if (!c->passBatchFromEnv) c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
+    if (!c->passBatchFromEnv)
+    {
+        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
+        // (very large frames: fewer passes per launch, an arena of 8 passes of an 8K frame would be 47 GB)
+        while (c->passBatch > 1u && (size_t)c->numSlots * c->passBatch * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4) > ((size_t)24 << 30)) c->passBatch /= 2u;
+    }
     c->passBatchBase = c->passBatch;
     // a shard's launches are shorter, their tails relatively longer: one more lane to overlap them (1/4 and 1/8 of the
     // Sponza-class frame: +1.9 % / +3.6 %; the full frame gains nothing from a fourth lane)
@@ -1698,10 +1703,20 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
     return RTGPU_OK;
 }
 
+// Streaming grows the batch 8 -> 16 -> 24 passes; frames beyond full HD stop earlier so that an arena stays below ~24 GB
+// (176 bytes per slot with one NEE request per vertex: 4K frames reach 16 passes, 8K frames stay at 8 and below)
+static uint32_t maxStreamingBatch(const RtgpuContext* c)
+{
+    const size_t perPass = (size_t)(c->numSlots ? c->numSlots : 1) * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4);
+    uint32_t batch = 24u;
+    while (batch > 8u && perPass * batch > ((size_t)24 << 30)) batch -= 8u;
+    return batch;
+}
+
 static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    const uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : 24u;   // the largest batch streaming can reach
+    const uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
     const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * maxBatch;
     if (!l.paths.base || l.paths.capacity < wanted || l.paths.maxLights < maxLights)
     {
@@ -1831,7 +1846,7 @@ static int flushPending(RtgpuContext* c)
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
     c->pending.clear();
-    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch && c->passBatch < 24u) c->passBatch += 8u;
+    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch && c->passBatch + 8u <= maxStreamingBatch(c)) c->passBatch += 8u;
     HIP_TRY(hipGetLastError());
     for (uint32_t i = 0; i < numPasses; ++i)
     {

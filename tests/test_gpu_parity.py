@@ -555,3 +555,28 @@ def test_debug_renderer_all_modes_bit_exact(built):
             assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), mode
             images.append(img.copy())
         assert len({im.tobytes() for im in images}) >= 11   # the modes really differ (two material parameters may coincide)
+
+
+def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
+    """3840x2160 (8.3 M pixels): streaming grows the pass batch only to 16 (an arena stays below ~24 GB), and the shard-sampled
+    pixels of the full frame equal the oracle bit for bit after 20 streamed passes' worth of batching logic (8 + 12: two launch
+    sequences, the second one larger).  Cornell box, depth 4."""
+    w, h, depth, passes = 3840, 2160, 4, 20
+    scene, camera = scenes.cornell_box(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    full = ra.Viewport(w, h, seed=77, max_ray_depth=depth)
+    full.set_renderer(scene)
+    params = [full.next_pass_params(camera) for _ in range(passes)]
+    for p in params:
+        full.render_pass_with(p)          # no synchronising call in between
+    whole = full.sum_buffer()
+    cw = full.counters()
+    assert cw["numPrimaryRays"] == w * h * passes and np.isfinite(whole).all()
+    ref = np.zeros((h, w, 3), dtype=np.float32)
+    for p in params:
+        oracle_lib.render_pass(desc, p, w, h, ref, None, None, shard=(5, 256), threads=16)
+    owned = ref != 0
+    assert owned.any()
+    assert np.array_equal(whole[owned].view(np.uint32), ref[owned].view(np.uint32))
