@@ -88,11 +88,18 @@ RT_DEV uint32_t blockReserve(uint32_t n, uint32_t* __restrict__ globalCount, uin
     return *sBase + local;
 }
 
-// ShadingData of a stored light vertex
-RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_t vertex, uint32_t slot, ShadingData& sd, V4& throughput, float& dVC, float& dVCM, uint32_t& pathLength)
+// ShadingData of a stored light vertex: fetch and decode are separate so that a loop can fetch the next vertex while it works on this one
+struct LightVertexRecords { float4 r0, r1, r2, r3, r4, r5; };
+RT_DEV LightVertexRecords fetchLightVertex(const VcmArena& a, uint32_t vertex, uint32_t slot)
 {
-    const float4 r0 = lvrec(a, vertex, 0, slot), r1 = lvrec(a, vertex, 1, slot), r2 = lvrec(a, vertex, 2, slot), r3 = lvrec(a, vertex, 3, slot);
-    const float4 r4 = lvrec(a, vertex, 4, slot), r5 = lvrec(a, vertex, 5, slot);
+    LightVertexRecords v;
+    v.r0 = lvrec(a, vertex, 0, slot); v.r1 = lvrec(a, vertex, 1, slot); v.r2 = lvrec(a, vertex, 2, slot);
+    v.r3 = lvrec(a, vertex, 3, slot); v.r4 = lvrec(a, vertex, 4, slot); v.r5 = lvrec(a, vertex, 5, slot);
+    return v;
+}
+RT_DEV void decodeLightVertex(const RtSceneDesc& scene, const LightVertexRecords& v, ShadingData& sd, V4& throughput, float& dVC, float& dVCM, uint32_t& pathLength)
+{
+    const float4 r0 = v.r0, r1 = v.r1, r2 = v.r2, r3 = v.r3, r4 = v.r4, r5 = v.r5;
     sd.intersection.frame.r[0] = V4(r1.x, r1.y, r1.z, 0.0f);
     sd.intersection.frame.r[2] = V4(r2.x, r2.y, r2.z, 0.0f);
     sd.intersection.frame.r[1] = cross3(sd.intersection.frame.r[0], sd.intersection.frame.r[2]);   // as Scene::EvaluateIntersection left it (Scene.cpp:345)
@@ -105,6 +112,10 @@ RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_
     sd.mp.roughness = r1.w; sd.mp.metalness = r2.w; sd.mp.IoR = scene.materials[sd.intersection.material].IoR;
     throughput = V4(r5.x, r5.y, r5.z, 0.0f);
     dVC = r3.w; dVCM = r5.w;
+}
+RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_t vertex, uint32_t slot, ShadingData& sd, V4& throughput, float& dVC, float& dVCM, uint32_t& pathLength)
+{
+    decodeLightVertex(scene, fetchLightVertex(a, vertex, slot), sd, throughput, dVC, dVCM, pathLength);
 }
 
 // ---- light stage ---------------------------------------------------------------------------------------------------------
@@ -476,28 +487,51 @@ RT_DEV void vcmResolvePending(const Paths& cp, const VcmArena& a, const VcmDev& 
     const V4 tp(tp4.x, tp4.y, tp4.z, 0.0f);
     if (pendingBits & 0x1000000u)   // SampleLights ran for this vertex, :719-731 and :254-259
     {
+        // (the records of four requests are fetched together, unconditionally: the loop is bound by memory round trips, and a
+        // fetch behind the visibility test would double them)
         V4 accumulatedColor = zero4();
-        for (uint32_t l = 0; l < numLightRequests; ++l)
+        for (uint32_t base = 0; base < numLightRequests; base += 4u)
         {
-            if (pshadow(cp, l, 0, slot).w < 0.0f) continue;
-            cnt.c[C_SHADOW_HIT]++;
-            const float4 c = pshadow(cp, l, 1, slot);
-            accumulatedColor = accumulatedColor + V4(c.x, c.y, c.z, 0.0f);
+            float tmax[4]; float4 c[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+            {
+                const uint32_t l = base + k < numLightRequests ? base + k : numLightRequests - 1u;
+                tmax[k] = pshadow(cp, l, 0, slot).w; c[k] = pshadow(cp, l, 1, slot);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+            {
+                if (base + k >= numLightRequests || tmax[k] < 0.0f) continue;
+                cnt.c[C_SHADOW_HIT]++;
+                accumulatedColor = accumulatedColor + V4(c[k].x, c[k].y, c[k].z, 0.0f);
+            }
         }
         accumulatedColor = accumulatedColor * load4(vcm.lightSamplingWeight);
         resultColor = mulAdd(tp, accumulatedColor, resultColor);
     }
     if (pendingBits & 0x2000000u)   // vertex connections, :262-283
     {
+        // (request j connects light vertex j: k_vcm_connect numbers them together, so the vertex's throughput record does not
+        // have to wait for the request's)
         V4 vertexConnectionColor = zero4();
-        for (uint32_t j = 0; j < numConnections; ++j)
+        for (uint32_t base = 0; base < numConnections; base += 4u)
         {
-            const uint32_t r = numLightRequests + j;
-            if (pshadow(cp, r, 0, slot).w < 0.0f) continue;
-            cnt.c[C_SHADOW_HIT]++;
-            const float4 c = pshadow(cp, r, 1, slot);
-            const float4 lvTp = lvrec(a, ubits(c.w), 5, slot);
-            vertexConnectionColor = mulAdd(V4(lvTp.x, lvTp.y, lvTp.z, 0.0f), V4(c.x, c.y, c.z, 0.0f), vertexConnectionColor);
+            float tmax[4]; float4 c[4], lvTp[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+            {
+                const uint32_t j = base + k < numConnections ? base + k : numConnections - 1u;
+                tmax[k] = pshadow(cp, numLightRequests + j, 0, slot).w; c[k] = pshadow(cp, numLightRequests + j, 1, slot);
+                lvTp[k] = lvrec(a, j, 5, slot);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+            {
+                if (base + k >= numConnections || tmax[k] < 0.0f) continue;
+                cnt.c[C_SHADOW_HIT]++;
+                vertexConnectionColor = mulAdd(V4(lvTp[k].x, lvTp[k].y, lvTp[k].z, 0.0f), V4(c[k].x, c[k].y, c[k].z, 0.0f), vertexConnectionColor);
+            }
         }
         vertexConnectionColor = vertexConnectionColor * load4(vcm.vertexConnectingWeight);
         resultColor = mulAdd(tp, vertexConnectionColor, resultColor);
@@ -822,10 +856,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_connect(const RtSceneDesc scen
             const V4 pos = sd.intersection.frame.r[3];
             uint32_t numConnections = 0u;
             const uint32_t numLightVertices = a.lvCount[slot];
+            LightVertexRecords next = fetchLightVertex(a, 0u, slot);   // (numLightVertices >= 1 for a queued vertex)
             for (uint32_t v = 0; v < numLightVertices; ++v)
             {
                 ShadingData lsd; V4 lvThroughput; float lvVC, lvVCM; uint32_t lvLength;
-                loadLightVertex(scene, a, v, slot, lsd, lvThroughput, lvVC, lvVCM, lvLength);
+                const LightVertexRecords cur = next;
+                next = fetchLightVertex(a, v + 1u < numLightVertices ? v + 1u : v, slot);   // in flight during this vertex's two BSDF evaluations
+                decodeLightVertex(scene, cur, lsd, lvThroughput, lvVC, lvVCM, lvLength);
                 if (lvLength + length + 1u > vcm.maxPathLength) break;
                 V4 lightDir = lsd.intersection.frame.r[3] - pos;
                 const float distanceSqr = sqrLength3(lightDir);
