@@ -234,7 +234,7 @@ def main():
                                "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1000.0,
                                "launches": ktimes[dom][1],
                                "measured": "HIP events around every launch of a lanes=1 replay of the warm-up and timed passes (serial "
-                                           "kernels; batches of 8, 16, then 24 passes per launch); the timed region itself runs 3 batch "
+                                           "kernels; batches growing 2, 4, 8, 16, then 24 passes per launch); the timed region itself runs 3 batch "
                                            "lanes whose kernels overlap"}
             out["kernel_time_ms"] = {k: round(v[0], 3) for k, v in ktimes.items()}
             out["kernel_time_ms_timed_region_overlapped"] = {k: round(v[0], 3) for k, v in ktimes_overlapped.items()}

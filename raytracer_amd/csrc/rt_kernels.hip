@@ -1633,7 +1633,7 @@ static int rebuildSlots(RtgpuContext* c)
     // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
     if (!c->passBatchFromEnv)
     {
-        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 8u;
+        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 2u;   // full frames: 2 -> 4 -> 8 -> 16 -> 24 while streaming (flushPending)
         // (very large frames: fewer passes per launch, an arena of 8 passes of an 8K frame would be 47 GB)
         while (c->passBatch > 1u && (size_t)c->numSlots * c->passBatch * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4) > ((size_t)24 << 30)) c->passBatch /= 2u;
     }
@@ -1846,7 +1846,13 @@ static int flushPending(RtgpuContext* c)
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
     c->pending.clear();
-    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch && c->passBatch + 8u <= maxStreamingBatch(c)) c->passBatch += 8u;
+    // a stream starts with small batches (a caller that renders 4 or 8 passes and reads back gets two or three overlapping launch
+    // sequences instead of one: +7 %) and grows while the caller keeps streaming
+    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch)
+    {
+        const uint32_t next = c->passBatch < 8u ? c->passBatch * 2u : c->passBatch + 8u;
+        if (next <= maxStreamingBatch(c)) c->passBatch = next;
+    }
     HIP_TRY(hipGetLastError());
     for (uint32_t i = 0; i < numPasses; ++i)
     {
