@@ -243,10 +243,14 @@ def main():
 
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, camera, ra)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        print(line, flush=True)   # after the process group is gone: nothing the communication library prints can follow it
 
 
 def cpu_baseline(args, scene, camera, ra):
