@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- Msamples/s (paths x bounces = RayTracingCounters::numRays) of the MI355X PathTracerMIS core.
+"""bench.py -- Msamples/s (paths x bounces = RayTracingCounters::numRays) of the MI355X path-tracing core.
 
 Workload (BASELINE.json configs[2]): Sponza-class triangle mesh (~262k triangles, procedural stand-in: the
 reference's sponza.obj is not shipped), PathTracerMIS, 8 bounces, 1920x1080, background + delta directional
@@ -7,18 +7,27 @@ light, LightSamplingStrategy::Single.  One "step" = one pass = one sample per pi
 
   python bench.py --gpus 1 --steps 256 --warmup 16        (the defaults: BASELINE config 3 renders 256 samples per pixel)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --workload bdpt-glass                   (BASELINE configs[4]: rough-glass slab, renderer "VCM" without merging)
 
-N > 1: the frame's 64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no
-data-path collective); after the K timed passes the float3 sum buffers (disjoint support) are sum-reduced to
-rank 0 over RCCL, inside the timed region.  Total work is fixed => "scaling": "strong".
+Timed region: the K passes AND the final read-back of the float3 sum buffer to host memory.  N > 1: the frame's
+64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no data-path collective); the
+read-back is preceded by ONE gather of the owned tiles to rank 0 over RCCL (packed tile pixels, 24.9 MB / N per peer; the
+collective is warmed up before the timed region).  Total work is fixed => "scaling": "strong".
 
-Prints ONE JSON line on rank 0.
+The roofline block is measured in the run itself: HIP-event launch times from a serial (one batch lane) replay of the same
+passes, and HBM-side traffic from two `rocprofv3 --pmc` child runs of the same passes (FETCH_SIZE, WRITE_SIZE; separate
+passes, kernel-trace only).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import shutil
+import sqlite3
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,6 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide
+SEED = 20260928
 
 
 def parse_args():
@@ -38,9 +49,11 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--triangles", type=int, default=262144)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "sponza-textured", "cornell", "sphere"])
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "sponza-textured", "cornell", "sphere", "bdpt-glass"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of a bench run
     return ap.parse_args()
 
 
@@ -50,16 +63,60 @@ def build_scene(args, aspect):
         return scenes.sponza_class(aspect, args.triangles, textured=args.workload == "sponza-textured")
     if args.workload == "cornell":
         return scenes.cornell_box(aspect)
+    if args.workload == "bdpt-glass":
+        return scenes.rough_glass_slab(aspect)
     return scenes.sphere_area_light(aspect)
 
 
+def make_viewport(ra, args, scene, device, shard=None):
+    from raytracer_amd import scenes
+    vp = ra.Viewport(args.width, args.height, seed=SEED, max_ray_depth=args.depth)
+    if args.workload == "bdpt-glass":
+        vp.set_renderer(scene, name="VCM", device=device)
+        vp.set_vcm(**scenes.ROUGH_GLASS_SLAB_VCM)
+    else:
+        vp.set_renderer(scene, device=device)
+    if shard is not None and shard[1] > 1:
+        vp.set_shard(*shard)
+    return vp
+
+
 def device_tensor(ptr, num_floats, torch):
-    """torch view of a hipMalloc'ed float buffer owned by librtgpu (plumbing for the RCCL reduce)."""
+    """torch view of a hipMalloc'ed float buffer owned by librtgpu (plumbing for the RCCL gather)."""
     class _Buf:
         pass
     b = _Buf()
     b.__cuda_array_interface__ = {"shape": (int(num_floats),), "typestr": "<f4", "data": (int(ptr), False), "version": 3}
     return torch.as_tensor(b, device="cuda")
+
+
+def owned_pixel_indices(width, height, rank, world):
+    """Row-major pixel indices of the 64x64 tiles rank `rank` of `world` owns (rtgpu_set_shard: tile % world == rank)."""
+    ty, tx = np.meshgrid(np.arange(height) // 64, np.arange(width) // 64, indexing="ij")
+    owned = ((ty * ((width + 63) // 64) + tx) % world) == rank
+    return np.nonzero(owned.reshape(-1))[0].astype(np.int64)
+
+
+class TileGather:
+    """The final exchange of the multi-GPU path: every peer sends the pixels of its own tiles (packed float3) to rank 0, which
+    writes them into its sum buffer -- bit-identical to the 1-GPU image because each pixel was accumulated by exactly one rank."""
+
+    def __init__(self, torch, dist, width, height, rank, world, sum_tensor):
+        self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
+        self.image = sum_tensor.view(-1, 3)
+        counts = [len(owned_pixel_indices(width, height, r, world)) for r in range(world)]
+        self.pad = max(counts)
+        self.own = torch.from_numpy(owned_pixel_indices(width, height, rank, world)).cuda()
+        self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device="cuda")
+        self.recv = [torch.zeros((self.pad, 3), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
+        self.peers = [torch.from_numpy(owned_pixel_indices(width, height, r, world)).cuda() for r in range(world)] if rank == 0 else None
+
+    def run(self):
+        self.send[:len(self.own)] = self.image.index_select(0, self.own)
+        self.dist.gather(self.send, self.recv, dst=0)
+        if self.rank == 0:
+            for r in range(1, self.world):
+                self.image.index_copy_(0, self.peers[r], self.recv[r][:len(self.peers[r])])
 
 
 def algorithmic_bytes(c):
@@ -72,6 +129,83 @@ def algorithmic_bytes(c):
     return {"trace": trace_closest + trace_shadow, "shade": shade, "accumulate": film, "generate": 0}
 
 
+# kernel-name prefix (as rocprofv3 reports it) -> kernel class of rtgpu_get_kernel_times
+KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_trace", "trace"), ("k_shade", "shade"), ("k_vcm_light_finish", "accumulate"),
+                         ("k_vcm_camera_finish", "accumulate"), ("k_vcm_emit", "generate"), ("k_vcm_", "shade"), ("k_lt_shade", "shade"),
+                         ("k_generate", "generate"), ("k_accumulate", "accumulate"))
+
+
+def kernel_class(name):
+    base = name.replace("void ", "").strip()
+    for prefix, cls in KERNEL_CLASS_PREFIXES:
+        if base.startswith(prefix):
+            return cls
+    return None
+
+
+def pmc_child_sums(args, counter, timeout_s):
+    """Runs THIS command's passes (same workload, size, --steps, --warmup; one batch lane, intersection counters off) in a child
+    process under `rocprofv3 --kernel-trace --pmc <counter>` and returns {kernel class: (sum of the counter, launches, ns)}."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="rtbench_pmc_", dir="/tmp")
+    try:
+        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child",
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--width", str(args.width), "--height", str(args.height),
+               "--depth", str(args.depth), "--triangles", str(args.triangles), "--workload", args.workload]
+        env = dict(os.environ, TMPDIR="/tmp", RTGPU_LANES="1")
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-300:])
+        cur = sqlite3.connect(dbs[0]).cursor()
+        tables = [t[0] for t in cur.execute("select name from sqlite_master where type in ('table', 'view')").fetchall()]
+        rows = None
+        if "pmc_events" in tables and "kernels" in tables:
+            rows = cur.execute("select k.name, count(*), sum(p.value), sum(k.duration) from pmc_events p join kernels k on p.event_id = k.id "
+                               "where p.counter_name = ? group by k.name", (counter,)).fetchall()
+        elif "counters_collection" in tables:
+            rows = [(n, c, s, 0) for n, c, s in cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                                                            "group by kernel_name", (counter,)).fetchall()]
+        if not rows:
+            return None, "no %s rows in the rocprofv3 database" % counter
+        out = {}
+        for name, launches, total, ns in rows:
+            cls = kernel_class(name)
+            if cls:
+                a = out.setdefault(cls, [0.0, 0, 0])
+                a[0] += float(total); a[1] += int(launches); a[2] += int(ns or 0)
+        return out, None
+    except subprocess.TimeoutExpired:
+        return None, "rocprofv3 --pmc %s timed out" % counter
+    except Exception as e:   # a profiler problem must not take the benchmark down
+        return None, "rocprofv3 --pmc %s: %r" % (counter, e)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(args):
+    """HBM-side bytes per launch of every kernel class from two separate --pmc child runs (the guide's recipe: FETCH_SIZE and
+    WRITE_SIZE do not fit one pass).  rocprofv3 reports both in KiB.  gfx950 correction: FETCH_SIZE counts a 128-byte request of
+    16-byte-per-lane loads as 64 bytes, so the fetched bytes are 2 x FETCH_SIZE for such loads -- every record / node / triangle
+    load of these kernels is a 16-byte load, so the doubled figure is used (an upper bound where narrower loads are mixed in).
+    Infinity-Cache hits are included in both counters (fabric requests)."""
+    budget = max(120.0, 6.0 * (args.steps + args.warmup))
+    fetch, err_f = pmc_child_sums(args, "FETCH_SIZE", budget)
+    write, err_w = pmc_child_sums(args, "WRITE_SIZE", budget)
+    if fetch is None or write is None:
+        return None, err_f or err_w
+    out = {}
+    for cls in fetch:
+        if cls in write and fetch[cls][1] == write[cls][1] and fetch[cls][1] > 0:
+            n = fetch[cls][1]
+            out[cls] = {"launches": n, "fetch_size_bytes": 1024.0 * fetch[cls][0] / n, "write_size_bytes": 1024.0 * write[cls][0] / n,
+                        "hbm_bytes": (2.0 * 1024.0 * fetch[cls][0] + 1024.0 * write[cls][0]) / n,
+                        "profiled_avg_launch_ms": fetch[cls][2] / n / 1e6 if fetch[cls][2] else None}
+    return out, None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -80,10 +214,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.workload == "bdpt-glass" and world > 1:
+        raise SystemExit("the bidirectional integrator needs the whole frame on one device (light paths splat anywhere): replicas only, run with --gpus 1")
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
-    if rank == 0:
+    if rank == 0 and not args.pmc_child:
         entry.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -103,15 +239,21 @@ def main():
 
     w, h = args.width, args.height
     scene, camera = build_scene(args, w / h)
-    vp = ra.Viewport(w, h, seed=20260928, max_ray_depth=args.depth)
-    vp.set_renderer(scene, device=local_rank)
-    if world > 1:
-        vp.set_shard(rank, world)
-    elif os.environ.get("BENCH_EMULATE_SHARD"):
-        # tuning aid on a 1-GPU box: render only the tiles rank 0 of N would own ("value" is then that rank's share)
-        vp.set_shard(0, int(os.environ["BENCH_EMULATE_SHARD"]))
+    emulate = int(os.environ.get("BENCH_EMULATE_SHARD", "0"))   # tuning aid on a 1-GPU box: only the tiles rank 0 of N would own
+    shard = (rank, world) if world > 1 else ((0, emulate) if emulate > 1 else None)
+    vp = make_viewport(ra, args, scene, local_rank, shard)
     lib = ra.rtgpu_lib()
+    host = ra.host_lib()
     ctx = vp.device_context()
+
+    if args.pmc_child:
+        # the profiled child: exactly the parent's passes, strictly serial kernels, nothing else
+        lib.rtgpu_set_concurrency(ctx, 1)
+        lib.rtgpu_set_intersection_counters(ctx, 0)
+        vp.render(camera, args.warmup)
+        vp.render(camera, args.steps)
+        lib.rtgpu_synchronize(ctx)
+        return
 
     def sync_all():
         lib.rtgpu_synchronize(ctx)
@@ -123,29 +265,36 @@ def main():
     # every rank draws the same per-pass constants (same seed => same Halton / AA offsets).
     # The box / triangle test counters are instrumentation (a compile-time debug switch in the reference,
     # RT_ENABLE_INTERSECTION_COUNTERS, off by default): they are OFF in the timed region and collected afterwards
-    # by replaying exactly the same passes (same seed => same rays) with the counters on.
+    # by replaying exactly the same passes (same seed => same rays) with the counters on.  Per-kernel event timing is off too.
     lib.rtgpu_set_intersection_counters(ctx, 0)
     vp.render(camera, args.warmup)
+    host_sum = np.zeros((h, w, 3), dtype=np.float32)
+    gather = None
+    if world > 1:
+        sum_ptr, sec_ptr, nfl = C.c_void_p(), C.c_void_p(), C.c_size_t()
+        lib.rtgpu_get_device_sum(ctx, C.byref(sum_ptr), C.byref(sec_ptr), C.byref(nfl))
+        gather = TileGather(torch, dist, w, h, rank, world, device_tensor(sum_ptr.value, nfl.value, torch))
+        sync_all()
+        gather.run()            # warm-up of the collective (channel set-up) outside the timed region; it moves the warm-up image
     sync_all()
     c0 = vp.counters()
-    lib.rtgpu_enable_timing(ctx, 1)
-
-    sum_ptr, sec_ptr, nfl = C.c_void_p(), C.c_void_p(), C.c_size_t()
-    lib.rtgpu_get_device_sum(ctx, C.byref(sum_ptr), C.byref(sec_ptr), C.byref(nfl))
 
     sync_all()
     t0 = time.perf_counter()
     vp.render(camera, args.steps)
-    lib.rtgpu_synchronize(ctx)
     if world > 1:
-        t_sum = device_tensor(sum_ptr.value, nfl.value, torch)
-        dist.reduce(t_sum, dst=0, op=dist.ReduceOp.SUM)   # disjoint tile support => exact gather
+        lib.rtgpu_synchronize(ctx)
+        gather.run()
+        torch.cuda.synchronize()
+    if rank == 0:
+        host.rth_viewport_read_sum(vp._h, host_sum.ctypes.data_as(C.POINTER(C.c_float)), None)   # synchronises: Viewport::GetSumBuffer
     sync_all()
     elapsed = time.perf_counter() - t0
 
     c1 = vp.counters()
     delta = {k: c1[k] - c0[k] for k in c1}
-    lib.rtgpu_enable_timing(ctx, 0)
+    image_ok = bool(np.isfinite(host_sum).all()) if rank == 0 else True
+    image_mean = float(host_sum.mean()) / max(1, args.steps + args.warmup) if rank == 0 else 0.0
 
     def kernel_times(context):
         ms = (C.c_double * 8)(); launches = (C.c_uint64 * 8)(); names = (C.c_char_p * 8)()
@@ -155,14 +304,9 @@ def main():
     def replay(lanes, intersection_counters, timing):
         """Renders exactly the same passes again (same seed => same rays) on a fresh viewport; returns the counter
         deltas of the `steps` passes, the counter totals of warm-up + steps and, if asked, the per-kernel-class HIP-event
-        times of warm-up + steps (every launch of the replay: the population `rocprofv3 --kernel-trace --stats` averages over
-        when the same command runs with RTGPU_LANES=1)."""
-        v = ra.Viewport(w, h, seed=20260928, max_ray_depth=args.depth)
-        v.set_renderer(scene, device=local_rank)
-        if world > 1:
-            v.set_shard(rank, world)
-        elif os.environ.get("BENCH_EMULATE_SHARD"):
-            v.set_shard(0, int(os.environ["BENCH_EMULATE_SHARD"]))
+        times of warm-up + steps (every launch of the replay: the population the --pmc children and
+        `RTGPU_LANES=1 rocprofv3 --kernel-trace --stats` average over)."""
+        v = make_viewport(ra, args, scene, local_rank, shard)
         vctx = v.device_context()
         lib.rtgpu_set_concurrency(vctx, lanes)
         lib.rtgpu_set_intersection_counters(vctx, 1 if intersection_counters else 0)
@@ -174,10 +318,6 @@ def main():
         times = kernel_times(vctx) if timing else None
         return {k: a1[k] - a0[k] for k in a1}, dict(a1), times
 
-    # kernel-class times measured with HIP events on the streams the kernels run on, over the timed region: with
-    # several batch lanes the kernels of consecutive batches OVERLAP, so these durations include time shared with
-    # another kernel.  The roofline therefore uses a lanes=1 replay of the same passes (kernels strictly serial).
-    ktimes_overlapped = kernel_times(ctx)
     serial, _, ktimes = replay(1, False, True)
     assert serial["numRays"] == delta["numRays"] and serial["numShadowRays"] == delta["numShadowRays"], "serial replay diverged from the timed run"
     # instrumented replay for the intersection counters (not timed)
@@ -199,45 +339,70 @@ def main():
 
     if rank == 0:
         value = delta["numRays"] / elapsed / 1e6
+        if args.workload == "bdpt-glass":
+            label = "configs[4]: rough-glass slab over a diffuse ground under a rect light (materials_test.json style), renderer VCM with merging off (BDPT), max path length 8, %dx%d" % (w, h)
+            metric = "Msamples/sec (path segments of camera + light sub-paths) at %dx%d, rough-glass BDPT" % (w, h)
+        else:
+            what = ("procedural Sponza-class mesh (%d triangles, 8 diffuse materials)" % scene.desc.contents.numTriangles) if args.workload.startswith("sponza") else args.workload
+            label = "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::Single" % (what, args.depth, w, h)
+            if args.workload == "sponza-textured":
+                label += " + albedo / normal maps on all materials, HDR environment map"
+            metric = "Msamples/sec (paths x bounces) at %dx%d, Sponza-class PT-MIS" % (w, h)
         out = {
-            "metric": "Msamples/sec (paths x bounces) at %dx%d, Sponza-class PT-MIS" % (w, h),
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric, "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::Single" %
-                       ("procedural Sponza-class mesh (%d triangles, 8 diffuse materials)" % scene.desc.contents.numTriangles
-                        if args.workload.startswith("sponza") else args.workload, args.depth, w, h)
-                       + (" + albedo / normal maps on all materials, HDR environment map" if args.workload == "sponza-textured" else ""),
-                       "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world},
+            "config": {"workload": label, "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world,
+                       "timed_region": "K passes + gather of owned tiles (N > 1) + read-back of the float3 sum buffer to host"},
             "counters": {k: delta[k] for k in ("numRays", "numPrimaryRays", "numShadowRays", "numRayBoxTests", "numRayTriangleTests",
                                                "numShadowRayBoxTests", "numShadowRayTriangleTests", "numMeshHits", "numAnalyticHits")},
             "mrays_per_s_incl_shadow": (delta["numRays"] + delta["numShadowRays"]) / elapsed / 1e6,
             "intersection_counters": "off in the timed region (reference default); counts from an identical instrumented replay",
+            "image": {"finite": image_ok, "mean_per_pass": image_mean},
         }
         # roofline of the dominant kernel class (rank 0's own launches and rank 0's own counters)
         abytes = algorithmic_bytes(own_counts)
         abytes_replay = algorithmic_bytes(counted_totals)   # warm-up + timed passes: what the replay's launches processed
         dom = max(ktimes, key=lambda k: ktimes[k][0]) if ktimes else None
         if dom and ktimes[dom][0] > 0:
-            per_launch_bytes = abytes_replay[dom] / max(1, ktimes[dom][1])
-            per_launch_s = ktimes[dom][0] / 1000.0 / max(1, ktimes[dom][1])
-            achieved = per_launch_bytes / per_launch_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch_upper")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": per_launch_bytes, "avg_launch_ms": per_launch_s * 1000.0,
-                               "launches": ktimes[dom][1],
-                               "measured": "HIP events around every launch of a lanes=1 replay of the warm-up and timed passes (serial "
-                                           "kernels; batches growing 2, 4, 8, 16, then 24 passes per launch); the timed region itself runs 3 batch "
-                                           "lanes whose kernels overlap"}
+            traffic, traffic_error = (None, "skipped (--no-pmc)") if (args.no_pmc or world > 1) else measure_traffic(args)
+            launches = ktimes[dom][1]
+            per_launch_bytes = abytes_replay[dom] / max(1, launches)
+            per_launch_s = ktimes[dom][0] / 1000.0 / max(1, launches)
+            algorithmic_gbs = per_launch_bytes / per_launch_s / 1e9
+            roof = {"bound": "hbm", "kernel": "k_" + dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
+                    "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_GBs": algorithmic_gbs,
+                    "algorithmic_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
+                    "measured": "launch time: HIP events around every launch of a one-lane (serial kernels) replay of the warm-up and timed passes; "
+                                "traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the same passes, 2 x FETCH_SIZE + WRITE_SIZE per launch"}
+            t = traffic.get(dom) if traffic else None
+            if t and t["launches"] != launches and t["profiled_avg_launch_ms"]:
+                # a kernel class whose event pairs span several kernels (the bidirectional integrator's shading stages): bytes and time both
+                # from the profiled child, which is one self-consistent population
+                roof["avg_launch_ms"] = t["profiled_avg_launch_ms"]; roof["launches"] = launches = t["launches"]
+                per_launch_s = t["profiled_avg_launch_ms"] / 1000.0
+                per_launch_bytes = abytes_replay[dom] / max(1, launches)
+                roof["algorithmic_bytes_per_launch"] = per_launch_bytes
+                roof["measured"] += "; this class's event pairs span several kernels, so launch time and count are the profiled child's"
+            if t and t["launches"] == launches:
+                # `achieved` is what crossed the L2 <-> fabric boundary per second while the kernel ran: <= peak by construction.  The
+                # algorithmic byte model of SURVEY 8(d) (every node visit fetched from memory) is reported beside it: caches serve most of it.
+                roof.update({"achieved": t["hbm_bytes"] / per_launch_s / 1e9, "traffic": t["hbm_bytes"],
+                             "traffic_fetch_size_bytes": t["fetch_size_bytes"], "traffic_write_size_bytes": t["write_size_bytes"],
+                             "profiled_avg_launch_ms": t["profiled_avg_launch_ms"]})
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+                roof["traffic_over_algorithmic"] = t["hbm_bytes"] / per_launch_bytes if per_launch_bytes else None
+                out["traffic_per_launch"] = {k: {"launches": v["launches"], "hbm_bytes": v["hbm_bytes"],
+                                                 "GBs": (v["hbm_bytes"] / (ktimes[k][0] / 1000.0 / max(1, ktimes[k][1])) / 1e9) if k in ktimes and ktimes[k][0] > 0 else None,
+                                                 "algorithmic_bytes": abytes_replay.get(k, 0) / max(1, v["launches"])}
+                                             for k, v in traffic.items()}
+            else:
+                roof.update({"achieved": None, "traffic": None, "frac": None,
+                             "traffic_error": traffic_error or ("launch population mismatch: %s" % (t,))})
+            out["roofline"] = roof
             out["kernel_time_ms"] = {k: round(v[0], 3) for k, v in ktimes.items()}
-            out["kernel_time_ms_timed_region_overlapped"] = {k: round(v[0], 3) for k, v in ktimes_overlapped.items()}
+            out["kernel_launches"] = {k: v[1] for k, v in ktimes.items()}
             tot_bytes = sum(abytes.values())
             out["whole_pass_algorithmic_GBs"] = tot_bytes / elapsed / 1e9
 
@@ -254,9 +419,13 @@ def main():
 
 
 def cpu_baseline(args, scene, camera, ra):
-    """The scalar CPU oracle ("port" of the reference algorithm -- the reference renderer itself cannot be built
-    in this image) timed on all host cores on a BOUNDED sample of the same workload: rows of the
-    same frame, same scene, same depth, as many whole passes as fit the time budget (at least a band of one)."""
+    """CPU baseline on the GPU box's host cores, on a BOUNDED sample of the same workload.
+    Preferred: oracle/_ref/ref_render -- the reference's own AVX2/FMA translation units (traversal, intersection, shapes, BSDFs, lights,
+    sampler, math: everything a ray does) under a restated pass loop (kind "reference-partial", see oracle/ref_harness).  Otherwise the
+    scalar CPU restatement of the algorithm (kind "port")."""
+    ref = reference_baseline(args, scene, camera, ra)
+    if ref is not None:
+        return ref
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     w, h = args.width, args.height
@@ -264,6 +433,19 @@ def cpu_baseline(args, scene, camera, ra):
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
+    if args.workload == "bdpt-glass":
+        # the oracle's VertexConnectionAndMerging restatement is single-threaded (film splats are ordered): a band of tiles of one pass
+        from raytracer_amd import scenes
+        vp = ra.Viewport(w, h, seed=77)
+        vcm = oracle_lib.Vcm(**scenes.ROUGH_GLASS_SLAB_VCM)
+        img = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
+        cnt = np.zeros(16, dtype=np.uint64)
+        p = vp.next_pass_params(camera)
+        t0 = time.perf_counter()
+        vcm.render_pass(desc, p, w, h, img, None, light, cnt, shard=(0, 64))
+        dt = time.perf_counter() - t0
+        return {"value": int(cnt[0]) / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port", "sample": "1/64 of the tiles of one pass (single thread)",
+                "seconds": round(dt, 2), "numRays": int(cnt[0])}
     vp = ra.Viewport(w, h, seed=77, max_ray_depth=args.depth)
     img = np.zeros((h, w, 3), dtype=np.float32)
     cnt = np.zeros(16, dtype=np.uint64)
@@ -291,6 +473,21 @@ def cpu_baseline(args, scene, camera, ra):
         sample = "%d full pass(es) of the %dx%d frame" % (passes, w, h)
     return {"value": rate / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port", "sample": sample,
             "seconds": round(total_t, 2), "numRays": total_rays}
+
+
+def reference_baseline(args, scene, camera, ra):
+    """oracle/_ref/ref_render (built by oracle/ref_harness from the reference's own sources where /root/reference exists; the binary
+    travels, the sources do not).  Returns None when it is not there or does not support the workload."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_render")
+    if not os.path.exists(exe) or args.workload not in ("sponza", "cornell", "sphere"):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import ref_render
+        return ref_render.timed_baseline(exe, args, scene, camera, ra)
+    except Exception as e:
+        sys.stderr.write("reference baseline unavailable: %r\n" % (e,))
+        return None
 
 
 if __name__ == "__main__":

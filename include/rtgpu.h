@@ -339,7 +339,9 @@ typedef struct RtCounters
     uint64_t numAnalyticHits;    /* EvaluateIntersection on sphere/box/rect (incl. area lights) */
     uint64_t numShadowRayBoxTests;      /* box tests done by shadow rays (not counted by the reference) */
     uint64_t numShadowRayTriangleTests; /* triangle tests done by shadow rays */
-    uint64_t _reserved[4];
+    uint64_t numRetracedRays;    /* rays the 4-wide traversal kernel did not trust (runner-up hit within its tolerance, NaN slab tests) and
+                                  * handed to the binary-tree kernel, which walks the reference's order (performance statistic) */
+    uint64_t _reserved[3];
 } RtCounters;
 
 typedef struct RtgpuContext RtgpuContext;
@@ -504,6 +506,27 @@ int rtgpu_set_active_blocks(RtgpuContext* ctx, uint32_t numBlocks, const RtBlock
  * (uv[2*i], uv[2*i+1])).  Host pointers; synchronous.  Exists so that the device decode of every texel format can be
  * checked against the reference's vectors directly (tests/golden/texture_kat.bin). */
 int rtgpu_evaluate_textures(RtgpuContext* ctx, uint32_t count, const uint32_t* textureIndex, const float* uv, float* out);
+
+/* Known-answer-test hooks.  They evaluate the DEVICE implementation of one hot-path function (the code the traversal and shading
+ * kernels call, rt_device_*.h) on caller-provided records, so that tests can hold the HIP functions directly against vectors produced
+ * by the reference's own translation units (tests/golden/) without going through any CPU
+ * restatement.  Host pointers, synchronous, not performance relevant.
+ *   rtgpu_kat         func = function id of the .kat fixture header (tests/golden/README.md: Sin/SinCos/FastLog/FastACos/FastATan2,
+ *                     SamplingHelpers, BuildOrthonormalBasis, Fresnel*, Refract3/Reflect3, Ray::Ray, TransformRay_Unsafe,
+ *                     FastInverseNoScale, Intersect_BoxRay(_TwoSided), Intersect_TriangleRay, shape Intersect/Sample/Pdf/
+ *                     EvaluateIntersection, ILight::Illuminate/GetRadiance/Emit, BSDF::Sample/Evaluate/Pdf, Camera::GenerateRay/
+ *                     WorldToFilm/PdfW, Film splat pixel, Packed* photons, DebugRenderer triangle colour); in: n records of inStride
+ *                     floats (integers bit-cast), out: n records of outStride floats.
+ *   rtgpu_kat_sampler GenericSampler::ResetPixel + GetInt/GetFloat (Core/Sampling/GenericSampler.cpp:69-113): record =
+ *                     {x, y, useBlueNoise, numDims, seed[numDims]}; count draws per record.  blueNoise: 128*128*4 uint16 or NULL.
+ *   rtgpu_kat_mesh    MeshShape::Traverse / Traverse_Shadow / EvaluateIntersection (Core/Shapes/MeshShape.cpp:134-328) through the
+ *                     traversal state machine of the path tracer, on the uploaded scene's single mesh object: rays = n * {origin[3],
+ *                     direction[3], tmax}, out = n * 19 words {objectId (7 on a hit), triangle, distance, u, v, anyHit, tangent[4],
+ *                     normal[4], texCoord[4], material}. */
+int rtgpu_kat(RtgpuContext* ctx, uint32_t func, const float* in, uint32_t inStride, float* out, uint32_t outStride, uint32_t n);
+int rtgpu_kat_sampler(RtgpuContext* ctx, const uint16_t* blueNoise, const uint32_t* in, uint32_t inStride, uint32_t count, uint32_t n,
+                      uint32_t* outInts, float* outFloats);
+int rtgpu_kat_mesh(RtgpuContext* ctx, const float* rays, uint32_t n, uint32_t* out);
 
 /* --- measurement hooks (bench.py) ---------------------------------------------------------------
  * Per-kernel-class GPU time in milliseconds accumulated since rtgpu_reset, measured with HIP events

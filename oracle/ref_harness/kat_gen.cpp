@@ -1394,6 +1394,42 @@ static void genDds()
     writeRaw("dds_kat.bin", out.data(), out.size() * 4);
 }
 
+// Bitmap::Load on the BMP fixtures (tests/golden/bmp/*.bmp, own data): what Bitmap::LoadBMP (Core/Utils/BitmapBMP.cpp) makes of each.
+// bmp_kat.bin = { count } then per file (sorted by name): { nameHash, ok, format, linearSpace, width, height, dataBytes, byteSum,
+// paletteSize, paletteSum }
+static void genBmp()
+{
+    const std::string dir = gOutDir + "/bmp";
+    std::vector<std::string> names;
+    if (DIR* d = opendir(dir.c_str()))
+    {
+        while (dirent* e = readdir(d)) { const std::string n = e->d_name; if (n.size() > 4 && n.substr(n.size() - 4) == ".bmp") names.push_back(n); }
+        closedir(d);
+    }
+    std::sort(names.begin(), names.end());
+    std::vector<uint32_t> out;
+    out.push_back((uint32_t)names.size());
+    for (const std::string& n : names)
+    {
+        uint32_t nameHash = 2166136261u; for (char ch : n) { nameHash ^= (uint8_t)ch; nameHash *= 16777619u; }
+        Bitmap bitmap("bmp");
+        const bool ok = bitmap.Load((dir + "/" + n).c_str());
+        out.push_back(nameHash); out.push_back(ok ? 1u : 0u);
+        if (ok)
+        {
+            const size_t bytes = (size_t)bitmap.GetHeight() * bitmap.GetStride();
+            uint32_t sum = 0; const uint8_t* data = reinterpret_cast<const uint8_t*>(bitmap.GetData());
+            for (size_t i = 0; i < bytes; ++i) sum = sum * 31u + data[i];
+            uint32_t paletteSum = 0;
+            for (size_t i = 0; i < (size_t)bitmap.mPaletteSize * 4u; ++i) paletteSum = paletteSum * 31u + bitmap.mPalette[i];
+            out.push_back((uint32_t)bitmap.GetFormat()); out.push_back(bitmap.mLinearSpace ? 1u : 0u); out.push_back(bitmap.GetWidth()); out.push_back(bitmap.GetHeight());
+            out.push_back((uint32_t)bytes); out.push_back(sum); out.push_back(bitmap.mPaletteSize); out.push_back(paletteSum);
+        }
+        else for (int k = 0; k < 8; ++k) out.push_back(0u);
+    }
+    writeRaw("bmp_kat.bin", out.data(), out.size() * 4);
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1) gOutDir = argv[1];
@@ -1416,6 +1452,7 @@ int main(int argc, char** argv)
     genBloom();
     genDebug();
     genDds();
+    genBmp();
     printf("done\n");
     return 0;
 }

@@ -141,12 +141,12 @@ class RtCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests",
                                           "numPassedRayBoxTests", "numRayTriangleTests", "numPassedRayTriangleTests",
                                           "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
-                                          "numShadowRayTriangleTests")] + [("_reserved", C.c_uint64 * 4)]
+                                          "numShadowRayTriangleTests", "numRetracedRays")] + [("_reserved", C.c_uint64 * 3)]
 
 
 COUNTER_NAMES = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numRayBoxTests", "numPassedRayBoxTests",
                  "numRayTriangleTests", "numPassedRayTriangleTests", "numMeshHits", "numAnalyticHits", "numShadowRayBoxTests",
-                 "numShadowRayTriangleTests")
+                 "numShadowRayTriangleTests", "numRetracedRays")
 
 BSDF_NAMES = ("null", "diffuse", "roughDiffuse", "dielectric", "roughDielectric", "metal", "roughMetal", "plastic", "roughPlastic")
 
@@ -484,7 +484,12 @@ class Viewport:
     def counters(self):
         out = (C.c_uint64 * 16)()
         host_lib().rth_viewport_counters(self._h, out)
-        return {n: int(out[i]) for i, n in enumerate(COUNTER_NAMES)}
+        d = {n: int(out[i]) for i, n in enumerate(COUNTER_NAMES)}
+        if self.has_renderer:   # a statistic of the device library, not part of the reference's RayTracingCounters
+            raw = RtCounters()
+            if rtgpu_lib().rtgpu_get_counters(self.device_context(), C.byref(raw)) == 0:
+                d["numRetracedRays"] = int(raw.numRetracedRays)
+        return d
 
     @property
     def passes_finished(self):

@@ -1182,24 +1182,43 @@ __device__ __forceinline__ static V4 materialSample(const RtMaterial& mat, const
 }
 
 // =====================================================================================================
-// Camera -- Camera::GenerateRay, Core/Scene/Camera.cpp:81-118 (pinhole + circular DOF; no barrel distortion)
+// Camera -- Camera::GenerateRay, Core/Scene/Camera.cpp:81-118: pinhole, barrel distortion (:86-91), thin lens with the three
+// bokeh shapes of Camera::GenerateBokeh (:195-216)
 // =====================================================================================================
-RT_DEV Ray cameraGenerateRay(const RtCamera& cam, V4 coords, Sampler& sampler)
+// Everything up to (not including) the Ray constructor: k_generate stores origin + direction in the path records and every
+// kernel that needs the ray re-runs makeRay from them.
+RT_DEV void cameraGenerateRayParts(const RtCamera& cam, V4 coords, Sampler& sampler, V4& origin, V4& direction)
 {
     const M4 transform = loadM4(cam.localToWorld);
-    const V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));   // UnipolarToBipolar Vector4ImplSSE.h:598-601
-    V4 origin = transform.r[3];
-    V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * cam.aspectRatio, transform.r[1] * offsetedCoords.y), cam.tanHalfFoV, transform.r[2]);
+    V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));   // UnipolarToBipolar Vector4ImplSSE.h:598-601
+    if (cam.barrelDistortionVariableFactor != 0.0f)   // Random::GetFloat, Random.cpp:54-59
+    {
+        V4 radius = splat(dot2(offsetedCoords, offsetedCoords));
+        const float rnd = __uint_as_float((sampler.fallbackInt() & 0x007fffffu) | 0x3f800000u) - 1.0f;
+        radius = radius * (cam.barrelDistortionConstFactor + cam.barrelDistortionVariableFactor * rnd);
+        offsetedCoords = mulAdd(offsetedCoords, radius, offsetedCoords);
+    }
+    origin = transform.r[3];
+    direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * cam.aspectRatio, transform.r[1] * offsetedCoords.y), cam.tanHalfFoV, transform.r[2]);
     if (cam.dofEnable)
     {
         const V4 focusPoint = mulAdd(direction, cam.focalPlaneDistance, origin);
-        const V4 right = transform.r[0], up = transform.r[1];
         const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
-        const V4 randomPointOnCircle = getCircle(sx, sy) * cam.aperture;
-        origin = mulAdd(splat(randomPointOnCircle.x), right, origin);
-        origin = mulAdd(splat(randomPointOnCircle.y), up, origin);
+        // circle, hexagon (the third sample coordinate is always 0: its first rhombus, SamplingHelpers.cpp:40-57), square
+        V4 bokeh;
+        if (cam.bokehShape == 1u) bokeh = V4(sx * -1.0f + sy * 0.5f, sx * 0.0f + sy * 0.8660254f, 0.0f, 0.0f);
+        else if (cam.bokehShape == 2u) bokeh = mulSub(V4(sx, sy, 0.0f, 0.0f), 2.0f, splat(1.0f));
+        else bokeh = getCircle(sx, sy);
+        const V4 randomPointOnCircle = bokeh * cam.aperture;
+        origin = mulAdd(splat(randomPointOnCircle.x), transform.r[0], origin);
+        origin = mulAdd(splat(randomPointOnCircle.y), transform.r[1], origin);
         direction = focusPoint - origin;
     }
+}
+RT_DEV Ray cameraGenerateRay(const RtCamera& cam, V4 coords, Sampler& sampler)
+{
+    V4 origin, direction;
+    cameraGenerateRayParts(cam, coords, sampler, origin, direction);
     return makeRay(origin, direction);
 }
 

@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace rtd;
@@ -163,31 +164,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, 
         sampler.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
 
         // Camera::GenerateRay up to (not including) the Ray constructor, which trace/shade re-run from origin+direction
-        const M4 transform = loadM4(pass.camera.localToWorld);
-        V4 offsetedCoords = mulSub(coords, 2.0f, splat(1.0f));
-        if (pass.camera.barrelDistortionVariableFactor != 0.0f)   // barrel distortion, Camera.cpp:86-91; Random::GetFloat, Random.cpp:54-59
-        {
-            V4 radius = splat(dot2(offsetedCoords, offsetedCoords));
-            const float rnd = fbits((sampler.fallbackInt() & 0x007fffffu) | 0x3f800000u) - 1.0f;
-            radius = radius * (pass.camera.barrelDistortionConstFactor + pass.camera.barrelDistortionVariableFactor * rnd);
-            offsetedCoords = mulAdd(offsetedCoords, radius, offsetedCoords);
-        }
-        V4 origin = transform.r[3];
-        V4 direction = mulAdd(mulAdd(transform.r[0], offsetedCoords.x * pass.camera.aspectRatio, transform.r[1] * offsetedCoords.y), pass.camera.tanHalfFoV, transform.r[2]);
-        if (pass.camera.dofEnable)
-        {
-            const V4 focusPoint = mulAdd(direction, pass.camera.focalPlaneDistance, origin);
-            const float sx = sampler.getFloat(); const float sy = sampler.getFloat();
-            // Camera::GenerateBokeh, Camera.cpp:195-216: circle, hexagon (third sample coordinate always 0: its first rhombus), square
-            V4 bokeh;
-            if (pass.camera.bokehShape == 1u) bokeh = V4(sx * -1.0f + sy * 0.5f, sx * 0.0f + sy * 0.8660254f, 0.0f, 0.0f);
-            else if (pass.camera.bokehShape == 2u) bokeh = mulSub(V4(sx, sy, 0.0f, 0.0f), 2.0f, splat(1.0f));
-            else bokeh = getCircle(sx, sy);
-            const V4 randomPointOnCircle = bokeh * pass.camera.aperture;
-            origin = mulAdd(splat(randomPointOnCircle.x), transform.r[0], origin);
-            origin = mulAdd(splat(randomPointOnCircle.y), transform.r[1], origin);
-            direction = focusPoint - origin;
-        }
+        V4 origin, direction;
+        cameraGenerateRayParts(pass.camera, coords, sampler, origin, direction);
 
         prec(paths, R_ORIGIN, slot) = f4(origin.x, origin.y, origin.z, fbits(0x100u));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
         prec(paths, R_DIR, slot) = f4(direction.x, direction.y, direction.z, 1.0f);        // lastPdfW = 1
@@ -602,6 +580,9 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
     }
 }
 
+#define RT_COUNTER_RETRACED 12   // counters[]: rays the wide kernel handed to the binary-tree kernel (RtCounters::numRetracedRays)
+#include "rt_trace_wide.inl"
+
 RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
 RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
 
@@ -913,6 +894,13 @@ RT_DEV V4 hsvToRgb(float hue, float saturation, float value)   // Core/Color/Col
     else if (h_i == 5) return V4(value, p, q, 0.0f);
     return zero4();
 }
+RT_DEV V4 debugTriangleIdColor(uint32_t objectId, uint32_t subObjectId)   // DebugRenderer.cpp:98-106
+{
+    const uint64_t hash = murmurFmix64((uint64_t)objectId | ((uint64_t)subObjectId << 32));
+    const float hue = (float)(uint32_t)hash / (float)UINT32_MAX;
+    const float saturation = 0.5f + 0.5f * (float)(uint32_t)(hash >> 32) / (float)UINT32_MAX;
+    return hsvToRgb(hue, saturation, 1.0f);
+}
 __global__ void __launch_bounds__(RT_BLOCK) k_debug_shade(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                           uint32_t mode, unsigned long long* counters)
 {
@@ -943,10 +931,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_debug_shade(const RtSceneDesc scen
                 case DBG_DEPTH: { const float invDepth = 1.0f - 1.0f / (1.0f + hit.distance / 10.0f); color = splat(invDepth); break; }
                 case DBG_TRIANGLE_ID:
                 {
-                    const uint64_t hash = murmurFmix64((uint64_t)hit.objectId | ((uint64_t)hit.subObjectId << 32));
-                    const float hue = (float)(uint32_t)hash / (float)UINT32_MAX;
-                    const float saturation = 0.5f + 0.5f * (float)(uint32_t)(hash >> 32) / (float)UINT32_MAX;
-                    color = hsvToRgb(hue, saturation, 1.0f);
+                    color = debugTriangleIdColor(hit.objectId, hit.subObjectId);
                     break;
                 }
                 case DBG_TANGENTS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[0], splat(0.5f), splat(0.5f)))); break;
@@ -999,6 +984,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
 }
 
 #include "rt_vcm.inl"
+#include "rt_kat.inl"
 
 // Viewport::PostProcessTile (Viewport.cpp:495-550): sum buffer -> 0x00RRGGBB front buffer, one thread per pixel
 struct PostScale { float c[3]; };
@@ -1134,8 +1120,8 @@ static int fail(int code, const std::string& msg) { gLastError = msg; return cod
                         std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
-enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_COUNT };
-static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "", "", "", "" };
+enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_RETRACE, KC_COUNT };
+static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "retrace", "", "", "" };
 
 #define RT_SEED_RING 128
 
@@ -1149,8 +1135,11 @@ struct BatchLane
     Paths paths = { nullptr, 0, 0 };
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
-    // per-batch work counters, 4 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
-    // shadow-queue counts, traversal cursors (one of each per bounce, so that no reset ever races with a reader)
+    uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests the wide traversal kernel hands to the binary-tree kernel
+    uint32_t* exactShadowQueue = nullptr;
+    // per-batch work counters, 8 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
+    // shadow-queue counts, traversal cursors, -, exact-queue counts, exact-shadow-queue counts, exact cursors, - (one of each per
+    // bounce, so that no reset ever races with a reader)
     uint32_t* queueCounts = nullptr;
     uint32_t queueCountCapacity = 0;
     hipEvent_t accumulated = nullptr;   // recorded after the lane's k_accumulate
@@ -1187,6 +1176,10 @@ struct RtgpuContext
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
+    WideBvh wide = { nullptr, nullptr, 0, 0, 0, { 0.0f, 0.0f, 0.0f } };   // 4-wide tree of a single-mesh scene (rt_trace_wide.inl); nodes == nullptr: none
+    bool wideAllowed = true;           // RTGPU_NO_WIDE=1: the binary-tree kernel only
+    bool wideLdsTop = true;            // RTGPU_WIDE_NO_LDS=1: top levels from memory like the rest
+    uint32_t wideBlocksPerCU = 0;      // 0 = default
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
@@ -1274,6 +1267,9 @@ static void freePaths(BatchLane& l)
     if (l.queues[1]) (void)hipFree(l.queues[1]);
     if (l.shadowQueues[0]) (void)hipFree(l.shadowQueues[0]);
     if (l.shadowQueues[1]) (void)hipFree(l.shadowQueues[1]);
+    if (l.exactQueue) (void)hipFree(l.exactQueue);
+    if (l.exactShadowQueue) (void)hipFree(l.exactShadowQueue);
+    l.exactQueue = l.exactShadowQueue = nullptr;
     l.paths.base = nullptr; l.paths.capacity = 0; l.paths.maxLights = 0;
     l.queues[0] = l.queues[1] = nullptr; l.shadowQueues[0] = l.shadowQueues[1] = nullptr;
 }
@@ -1357,6 +1353,29 @@ static uint32_t bvhDepth(const RtNode* nodes, uint32_t numNodes)
     return maxDepth;
 }
 
+// round trip of a host buffer through one of the KAT kernels (synchronous, lane 0's stream)
+template <typename Launch>
+static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* out, size_t outBytes, Launch launch)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    void* dIn = nullptr; void* dOut = nullptr;
+    hipError_t e = hipMalloc(&dIn, inBytes ? inBytes : 4);
+    if (e == hipSuccess) e = hipMalloc(&dOut, outBytes ? outBytes : 4);
+    if (e == hipSuccess) e = hipMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dOut, 0, outBytes);
+    if (e == hipSuccess)
+    {
+        launch(dIn, dOut, c->lanes[0].stream);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->lanes[0].stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
+    if (dIn) (void)hipFree(dIn);
+    if (dOut) (void)hipFree(dOut);
+    if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_kat: ") + hipGetErrorString(e));
+    return RTGPU_OK;
+}
+
 extern "C" {
 
 #define RTGPU_API __attribute__((visibility("default")))
@@ -1383,6 +1402,9 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
+    if (const char* e = getenv("RTGPU_NO_WIDE")) c->wideAllowed = atoi(e) == 0;
+    if (const char* e = getenv("RTGPU_WIDE_NO_LDS")) c->wideLdsTop = atoi(e) == 0;
+    if (const char* e = getenv("RTGPU_WIDE_BLOCKS_PER_CU")) c->wideBlocksPerCU = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_PASS_BATCH")) { c->passBatch = (uint32_t)atoi(e); c->passBatchFromEnv = true; }
     if (c->passBatch < 1) c->passBatch = 1;
     if (c->passBatch > RT_SEED_RING / 2) c->passBatch = RT_SEED_RING / 2;
@@ -1583,6 +1605,21 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
     if ((r = uploadArray(c, s->textures, s->numTextures, &d.textures))) return r;
     if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
+    // single-mesh scenes (Scene::Traverse's one-object bypass): the 4-wide tree of the default traversal kernel
+    memset(&c->wide, 0, sizeof(c->wide));
+    if (s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH)
+    {
+        const RtMesh& mesh = s->meshes[s->objects[0].meshIndex];
+        const WideBuild w = buildWideBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, s->triangles + mesh.firstTriangle, mesh.numTriangles);
+        if (w.ok && w.stackNeed <= 64u)
+        {
+            const float4* devNodes = nullptr; const float4* devLeaves = nullptr;
+            if ((r = uploadArray(c, w.nodes.data(), w.nodes.size(), &devNodes))) return r;
+            if ((r = uploadArray(c, w.leaves.data(), w.leaves.size(), &devLeaves))) return r;
+            c->wide.nodes = devNodes; c->wide.leaves = devLeaves; c->wide.numNodes = w.numNodes; c->wide.numLeaves = w.numLeaves;
+            c->wide.stackNeed = w.stackNeed; memcpy(c->wide.bound, w.bound, sizeof(w.bound));
+        }
+    }
     c->sceneDev = d;
     c->numLights = s->numLights;
     c->traversalStackNeed = topDepth + maxMeshDepth;
@@ -1731,6 +1768,8 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
         if ((unsigned long long)cap * maxLights >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x lights exceeds the NEE request index range");
         HIP_TRY(hipMalloc((void**)&l.shadowQueues[0], cap * maxLights * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&l.shadowQueues[1], cap * maxLights * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.exactQueue, cap * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.exactShadowQueue, cap * maxLights * sizeof(uint32_t)));
         l.paths.capacity = (uint32_t)cap; l.paths.maxLights = maxLights;
     }
     if (l.queueCountCapacity < maxDepth + 2)
@@ -1738,9 +1777,28 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
         HIP_TRY(hipStreamSynchronize(l.stream));
         if (l.queueCounts) (void)hipFree(l.queueCounts);
         l.queueCountCapacity = maxDepth + 2;
-        HIP_TRY(hipMalloc((void**)&l.queueCounts, (size_t)4 * l.queueCountCapacity * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.queueCounts, (size_t)8 * l.queueCountCapacity * sizeof(uint32_t)));
     }
     return RTGPU_OK;
+}
+
+// The 4-wide quad-per-ray kernel serves single-mesh scenes unless the reference's box / triangle test counters are wanted (they
+// belong to the binary walk) or it was switched off.
+static bool useWide(const RtgpuContext* c) { return c->wide.nodes != nullptr && c->wideAllowed && !c->countIntersections; }
+
+static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
+                            uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset)
+{
+    WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount };
+    const uint32_t stackClass = c->wide.stackNeed <= 32u ? 32u : (c->wide.stackNeed <= 48u ? 48u : 64u);
+    // LDS per block: stack class x 256 B + 10.9 KB of staged nodes -> 8 / 6 / 5 blocks per CU fit; 6 is where the registers end
+    const uint32_t perCU = c->wideBlocksPerCU ? c->wideBlocksPerCU : (stackClass == 64u ? 5u : 6u);
+    const dim3 grid(c->numCUs * perCU), block(RT_BLOCK);
+    LaunchTimer t(c, stream, KC_TRACE);
+#define RT_LAUNCH_WIDE(S, L) hipLaunchKernelGGL((k_trace_wide<S, L>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
+    if (c->wideLdsTop) { if (stackClass == 32u) RT_LAUNCH_WIDE(32, true); else if (stackClass == 48u) RT_LAUNCH_WIDE(48, true); else RT_LAUNCH_WIDE(64, true); }
+    else { if (stackClass == 32u) RT_LAUNCH_WIDE(32, false); else if (stackClass == 48u) RT_LAUNCH_WIDE(48, false); else RT_LAUNCH_WIDE(64, false); }
+#undef RT_LAUNCH_WIDE
 }
 
 // Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.
@@ -1797,7 +1855,7 @@ static int flushPending(RtgpuContext* c)
     uint32_t* cursors = l.queueCounts + 2 * l.queueCountCapacity;
     const uint32_t maxRayDepth = first.maxRayDepth;
 
-    HIP_TRY(hipMemsetAsync(l.queueCounts, 0, (size_t)4 * l.queueCountCapacity * sizeof(uint32_t), l.stream));
+    HIP_TRY(hipMemsetAsync(l.queueCounts, 0, (size_t)8 * l.queueCountCapacity * sizeof(uint32_t), l.stream));
     {
         LaunchTimer t(c, l.stream, KC_GENERATE);
         hipLaunchKernelGGL(k_generate, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, l.queues[0], pathCounts + 0, c->counters);
@@ -1817,10 +1875,25 @@ static int flushPending(RtgpuContext* c)
             const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
-            LaunchTimer t(c, l.stream, KC_TRACE);
-            if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
-            else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
-            else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
+            if (useWide(c))
+            {
+                // the wide kernel serves the launch; what it does not trust goes through the binary-tree kernel right behind it
+                uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
+                uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
+                uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
+                launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
+                tq = l.exactQueue; tqc = exactCounts + launchIndex; tsq = l.exactShadowQueue; tsc = exactShadowCounts + launchIndex;
+                uint32_t* cursors = exactCursors;
+                LaunchTimer t(c, l.stream, KC_RETRACE);
+                if (stackClass == 24u) RT_LAUNCH_TRACE(24, false); else if (stackClass == 32u) RT_LAUNCH_TRACE(32, false); else RT_LAUNCH_TRACE(64, false);
+            }
+            else
+            {
+                LaunchTimer t(c, l.stream, KC_TRACE);
+                if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
+                else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
+                else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
+            }
         }
         if (haveClosest)
         {
@@ -2336,6 +2409,7 @@ RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
     out->numRayTriangleTests = host[C_TRI]; out->numPassedRayTriangleTests = host[C_TRI_PASS];
     out->numMeshHits = host[C_MESH_HITS]; out->numAnalyticHits = host[C_ANALYTIC_HITS];
     out->numShadowRayBoxTests = host[C_BOX_SHADOW]; out->numShadowRayTriangleTests = host[C_TRI_SHADOW];
+    out->numRetracedRays = host[RT_COUNTER_RETRACED];
     return RTGPU_OK;
 }
 
@@ -2504,6 +2578,69 @@ RTGPU_API int rtgpu_evaluate_textures(RtgpuContext* c, uint32_t count, const uin
     if (dOut) (void)hipFree(dOut);
     if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_evaluate_textures: ") + hipGetErrorString(e));
     return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_kat(RtgpuContext* c, uint32_t func, const float* in, uint32_t inStride, float* out, uint32_t outStride, uint32_t n)
+{
+    if (!c || (n && (!in || !out))) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n == 0) return RTGPU_OK;
+    static const struct { uint32_t func, minIn, minOut; } known[] = {
+        { KAT_SIN_LANE, 1, 1 }, { KAT_SINCOS, 1, 4 }, { KAT_FASTLOG, 1, 1 }, { KAT_FASTACOS, 1, 1 }, { KAT_FASTATAN2, 2, 1 }, { KAT_FLOAT_NORMAL2, 2, 4 },
+        { KAT_HEMISPHERE_COS, 2, 4 }, { KAT_SPHERE, 2, 4 }, { KAT_CIRCLE, 2, 4 }, { KAT_ORTHO_BASIS, 4, 8 }, { KAT_FRESNEL_DIELECTRIC, 2, 1 },
+        { KAT_FRESNEL_METAL, 3, 1 }, { KAT_REFRACT3, 9, 4 }, { KAT_REFLECT3, 8, 4 }, { KAT_BOX_RAY, 14, 2 }, { KAT_BOX_RAY_TWOSIDED, 14, 3 },
+        { KAT_TRIANGLE_RAY, 17, 4 }, { KAT_MAKE_RAY, 8, 12 }, { KAT_TRANSFORM_RAY, 24, 16 }, { KAT_FAST_INVERSE, 16, 16 }, { KAT_SHAPE_INTERSECT, 13, 4 },
+        { KAT_SHAPE_SAMPLE, 12, 8 }, { KAT_SHAPE_PDF, 13, 1 }, { KAT_SHAPE_EVAL, 13, 16 },
+        { KAT_LIGHT_ILLUMINATE, (uint32_t)(sizeof(RtLight) / 4) + 19, 11 }, { KAT_LIGHT_RADIANCE, (uint32_t)(sizeof(RtLight) / 4) + 13, 5 },
+        { KAT_LIGHT_EMIT, (uint32_t)(sizeof(RtLight) / 4) + 5, 15 }, { KAT_LIGHT_ILLUMINATE_BIDIR, (uint32_t)(sizeof(RtLight) / 4) + 19, 12 },
+        { KAT_LIGHT_RADIANCE_BIDIR, (uint32_t)(sizeof(RtLight) / 4) + 13, 6 }, { KAT_BSDF_SAMPLE, 23, 11 }, { KAT_BSDF_EVALUATE, 24, 5 }, { KAT_BSDF_PDFS, 24, 8 },
+        { KAT_CAMERA_RAY, (uint32_t)(sizeof(RtCamera) / 4) + 8, 16 }, { KAT_CAMERA_FILM, (uint32_t)(sizeof(RtCamera) / 4) + 8, 6 }, { KAT_FILM_SPLAT, 12, 10 },
+        { KAT_PACKED_PHOTON, 8, 11 }, { KAT_HSV_TO_RGB, 2, 4 } };
+    bool ok = false;
+    for (const auto& k : known) if (k.func == func) { if (inStride < k.minIn || outStride < k.minOut) return fail(RTGPU_ERR_INVALID_ARGUMENT, "rtgpu_kat: record stride too small for this function"); ok = true; }
+    if (!ok) return fail(RTGPU_ERR_INVALID_ARGUMENT, "rtgpu_kat: unknown function id");
+    RtSceneDesc none; memset(&none, 0, sizeof(none));   // the fixtures' lights and materials carry no textures
+    return katRoundTrip(c, in, (size_t)n * inStride * 4, out, (size_t)n * outStride * 4, [&](void* dIn, void* dOut, hipStream_t st) {
+        hipLaunchKernelGGL(k_kat, dim3((n + 63u) / 64u), dim3(64), 0, st, none, func, (const float*)dIn, inStride, (float*)dOut, outStride, n);
+    });
+}
+
+RTGPU_API int rtgpu_kat_sampler(RtgpuContext* c, const uint16_t* blueNoise, const uint32_t* in, uint32_t inStride, uint32_t count, uint32_t n, uint32_t* outInts, float* outFloats)
+{
+    if (!c || !in || !outInts || !outFloats || n == 0 || count == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (uint32_t r = 0; r < n; ++r) if (inStride < 4u + in[(size_t)r * inStride + 3]) return fail(RTGPU_ERR_INVALID_ARGUMENT, "rtgpu_kat_sampler: record shorter than its seed table");
+    HIP_TRY(hipSetDevice(c->device));
+    uint16_t* dBlue = nullptr;
+    if (blueNoise)
+    {
+        HIP_TRY(hipMalloc((void**)&dBlue, (size_t)128 * 128 * 4 * sizeof(uint16_t)));
+        const hipError_t e = hipMemcpy(dBlue, blueNoise, (size_t)128 * 128 * 4 * sizeof(uint16_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dBlue); return fail(RTGPU_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    std::vector<float> out((size_t)n * 2 * count);
+    const int r = katRoundTrip(c, in, (size_t)n * inStride * 4, out.data(), out.size() * 4, [&](void* dIn, void* dOut, hipStream_t st) {
+        hipLaunchKernelGGL(k_kat_sampler, dim3((n + 63u) / 64u), dim3(64), 0, st, dBlue, (const float*)dIn, inStride, (float*)dOut, count, n);
+    });
+    if (dBlue) (void)hipFree(dBlue);
+    if (r) return r;
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        memcpy(outInts + (size_t)k * count, out.data() + (size_t)k * 2 * count, count * 4);
+        memcpy(outFloats + (size_t)k * count, out.data() + (size_t)k * 2 * count + count, count * 4);
+    }
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_kat_mesh(RtgpuContext* c, const float* rays, uint32_t n, uint32_t* out)
+{
+    if (!c || (n && (!rays || !out))) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!c->sceneReady) return fail(RTGPU_ERR_NOT_READY, "rtgpu_upload_scene has not been called");
+    if (c->sceneDev.numObjects != 1u || c->sceneDev.numMeshes != 1u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "rtgpu_kat_mesh needs a scene made of exactly one mesh object");
+    if (c->traversalStackNeed > RT_KAT_MESH_STACK) return fail(RTGPU_ERR_UNSUPPORTED, "mesh BVH deeper than the KAT kernel's stack");
+    if (n == 0) return RTGPU_OK;
+    { int fr = flushPending(c); if (fr) return fr; }
+    return katRoundTrip(c, rays, (size_t)n * 7 * 4, out, (size_t)n * 19 * 4, [&](void* dIn, void* dOut, hipStream_t st) {
+        hipLaunchKernelGGL(k_kat_mesh, dim3((n + 63u) / 64u), dim3(64), 0, st, c->sceneDev, (const float*)dIn, n, (uint32_t*)dOut);
+    });
 }
 
 RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)

@@ -176,6 +176,7 @@ bool Bitmap::LoadBMP(FILE* file, const char* path)
     if (ok)
     {
         if (infoHeader.biBitCount == 24) init.format = Format::B8G8R8_UNorm;
+        else if (infoHeader.biBitCount == 8 && infoHeader.biClrUsed > 0) init.format = Format::B8G8R8A8_UNorm_Palette;   // BitmapBMP.cpp:79-82
         else if (infoHeader.biBitCount == 8 && infoHeader.biClrUsed == 0) init.format = Format::R8_UNorm;
         else { fprintf(stderr, "[rt] ERROR: Unsupported BMP bit depth (%u): '%s'\n", (uint32)infoHeader.biBitCount, path); ok = false; }
     }
@@ -185,7 +186,15 @@ bool Bitmap::LoadBMP(FILE* file, const char* path)
         init.linearSpace = false;
         init.width = (uint32)infoHeader.biWidth; init.height = (uint32)infoHeader.biHeight;
         init.stride = ((uint32)infoHeader.biWidth * BitsPerPixel(init.format) / 8u + 3u) & ~3u;   // BMP rows are multiples of 4 bytes
-        ok = Init(init) && fseek(file, (long)fileHeader.bfOffBits, SEEK_SET) == 0 && fread(mData.data(), mData.size(), 1, file) == 1;
+        // the colour table follows the info header (BitmapBMP.cpp:104-119); more than 256 entries cannot be indexed by a byte
+        if (init.format == Format::B8G8R8A8_UNorm_Palette) { if (infoHeader.biClrUsed > 256u) { fprintf(stderr, "[rt] ERROR: Unsupported BMP palette size (%u): '%s'\n", infoHeader.biClrUsed, path); return false; } init.paletteSize = infoHeader.biClrUsed; }
+        ok = Init(init);
+        if (ok && init.paletteSize > 0 && fread(mPalette.data(), (size_t)init.paletteSize * 4u, 1, file) != 1)
+        {
+            fprintf(stderr, "[rt] ERROR: Failed to read bitmap palette from file '%s'\n", path);
+            return false;
+        }
+        ok = ok && fseek(file, (long)fileHeader.bfOffBits, SEEK_SET) == 0 && fread(mData.data(), mData.size(), 1, file) == 1;
         if (!ok) fprintf(stderr, "[rt] ERROR: Failed to read bitmap data from file '%s'\n", path);
     }
     return ok;

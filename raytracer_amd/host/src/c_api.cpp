@@ -303,6 +303,15 @@ RTH_API int rth_kat_load_bitmap(const char* path, uint32_t out[6])
     out[0] = (uint32_t)bitmap.GetFormat(); out[1] = bitmap.IsLinearSpace() ? 1u : 0u; out[2] = bitmap.GetWidth(); out[3] = bitmap.GetHeight(); out[4] = (uint32_t)bytes; out[5] = sum;
     return 0;
 }
+RTH_API int rth_kat_load_bitmap_palette(const char* path, uint32_t out[2])   // { palette entries, checksum of the palette bytes }
+{
+    Bitmap bitmap;
+    if (!bitmap.Load(path)) return -1;
+    uint32_t sum = 0;
+    for (size_t i = 0; i < (size_t)bitmap.GetPaletteSize() * 4u; ++i) sum = sum * 31u + bitmap.GetPalette()[i];
+    out[0] = bitmap.GetPaletteSize(); out[1] = sum;
+    return 0;
+}
 RTH_API int rth_kat_parse_double(const char* text, double* out) { return helpers::obj::TryParseDouble(text, text + strlen(text), out) ? 0 : -1; }
 
 RTH_API int rth_scene_build(void* sh) { return static_cast<SceneHandle*>(sh)->scene.BuildBVH() ? 0 : -1; }

@@ -130,6 +130,35 @@ def sphere_area_light(aspect):
     return scene, camera
 
 
+# BASELINE config 5 as SURVEY 8(d) C5 defines it: a Data/TestScenes/materials_test.json-style scene -- that file's ground plane
+# (5x5 at y = -1, diffuse 0.9, textures dropped), its camera and its "glass" recipe (roughDielectric, baseColor 1, default IoR)
+# at roughness 0.1 -- with ONE rough-glass slab (a flat box hovering over the ground) under ONE rect light (Cornell-box style:
+# a plane facing down), so that the ground is lit through the slab: caustics for the bidirectional integrator.
+ROUGH_GLASS_SLAB = {
+    "materials": [
+        {"name": "ground", "bsdf": "diffuse", "baseColor": [0.9, 0.9, 0.9], "metalness": 0.0, "roughness": 0.5},
+        {"name": "glass", "bsdf": "roughDielectric", "baseColor": [1.0, 1.0, 1.0], "metalness": 0.0, "roughness": 0.1},
+    ],
+    "objects": [
+        {"type": "plane", "transform": {"translation": [0.0, -1.0, 0.0], "orientation": [-90.0, 0.0, 0.0]}, "textureScale": [0.2, 0.2],
+         "size": [5.0, 5.0], "material": "ground"},
+        {"type": "box", "size": [1.5, 0.1, 1.0], "transform": {"translation": [0.0, -0.4, 0.0], "orientation": [0.0, 0.2, 0.0]}, "material": "glass"},
+    ],
+    "lights": [
+        {"type": "area", "color": [40.0, 40.0, 40.0], "transform": {"translation": [0.0, 2.5, 0.0], "orientation": [90.0, 0.0, 0.0]},
+         "shape": {"type": "plane", "size": [0.5, 0.5]}},
+    ],
+    "camera": {"transform": {"translation": [-2.4, 4.03, 3.49], "orientation": [40.0, 158.0, 0.0]}, "fieldOfView": 45.0},
+}
+# renderer settings of BASELINE config 5: "VCM" with merging off (= bidirectional path tracing), maximum path length 8
+ROUGH_GLASS_SLAB_VCM = dict(max_path_length=8, use_vertex_connection=True, use_vertex_merging=False)
+
+
+def rough_glass_slab(aspect):
+    """BASELINE config 5 (rough-glass dielectric scene with caustics for the BDPT integrator)."""
+    return load_json_scene(ROUGH_GLASS_SLAB, aspect)
+
+
 def furnace(bsdf, base_color=(0.4, 0.6, 0.8), emission=(0.0, 0.0, 0.0), light_color=(1.0, 2.0, 3.0), ior=1.5, k=4.0, roughness=0.1):
     """The reference's furnace set-up (Tests/RaytracingTests.cpp:317-523): unit sphere inside a uniform
     background light, camera at z = -3 with a 10 degree field of view."""

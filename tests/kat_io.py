@@ -45,3 +45,24 @@ def load_texture_kat():
     off += num_bg * bg.itemsize
     assert off == raw.size
     return dict(textures=textures, texels=texels, evals=evals, materials=mats, backgrounds=bgs)
+
+
+def mesh_fixture_scene():
+    """The mesh the reference's MeshShape::Initialize was fed for mesh_kat.bin (mesh_input.bin), as a one-object scene."""
+    import raytracer_amd as ra
+    raw = open(os.path.join(GOLDEN, "mesh_input.bin"), "rb").read()
+    nv, nt, nmat = (int(v) for v in np.frombuffer(raw[:12], dtype=np.uint32))
+    off = 12
+
+    def take(count, dtype, width):
+        nonlocal off
+        a = np.frombuffer(raw[off:off + count * width * 4], dtype=dtype).reshape(count, width).copy()
+        off += count * width * 4
+        return a
+    pos, nrm, tan, uv = take(nv, np.float32, 3), take(nv, np.float32, 3), take(nv, np.float32, 3), take(nv, np.float32, 2)
+    idx, mat = take(nt, np.uint32, 3), take(nt, np.uint32, 1).reshape(-1)
+    scene = ra.Scene()
+    mats = [scene.add_material("diffuse") for _ in range(nmat)]
+    scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    scene.build()
+    return scene, mats, nt

@@ -58,7 +58,7 @@ def test_product_never_touches_the_oracle():
     for base in ("raytracer_amd", "include"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
             for f in files:
-                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".inl")):
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     if re.search(r"oracle/|oracle_lib|liboracle|rto_", text):
                         offenders.append(os.path.join(dirpath, f))

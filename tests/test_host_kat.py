@@ -103,22 +103,7 @@ def test_bvh_builder_matches_reference(host):
 
 @pytest.fixture(scope="module")
 def mesh_scene(built):
-    import raytracer_amd as ra
-    raw = open(os.path.join(kat_io.GOLDEN, "mesh_input.bin"), "rb").read()
-    nv, nt, nmat = (int(v) for v in np.frombuffer(raw[:12], dtype=np.uint32))
-    off = 12
-    def take(count, dtype, width):
-        nonlocal off
-        a = np.frombuffer(raw[off:off + count * width * 4], dtype=dtype).reshape(count, width).copy()
-        off += count * width * 4
-        return a
-    pos, nrm, tan, uv = take(nv, np.float32, 3), take(nv, np.float32, 3), take(nv, np.float32, 3), take(nv, np.float32, 2)
-    idx, mat = take(nt, np.uint32, 3), take(nt, np.uint32, 1).reshape(-1)
-    scene = ra.Scene()
-    mats = [scene.add_material("diffuse") for _ in range(nmat)]
-    scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
-    scene.build()
-    return scene, mats, nt
+    return kat_io.mesh_fixture_scene()
 
 
 def test_mesh_preprocessing_and_traversal_match_reference(mesh_scene):

@@ -173,3 +173,34 @@ def test_dds_loader_matches_the_reference(built):
         else:
             refused += 1
     assert refused == 3
+
+
+def test_bmp_loader_matches_the_reference(built):
+    """Bitmap::LoadBMP: 24-bit, 8-bit grey, 8-bit with a colour table of 2 / 16 / 256 entries (B8G8R8A8_UNorm_Palette: palette and
+    index bytes), padded rows -- against what the reference's Bitmap::Load made of the same files (tests/golden/bmp/, own data;
+    bmp_kat.bin) -- and the same four files refused (4-bit, RLE, truncated, two planes)."""
+    import ctypes as C
+    import glob
+    import kat_io
+    raw = np.fromfile(os.path.join(kat_io.GOLDEN, "bmp_kat.bin"), dtype=np.uint32)
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(kat_io.GOLDEN, "bmp", "*.bmp")))
+    assert raw[0] == len(names) == 11
+    h = ra.host_lib()
+    refused, palettized = 0, 0
+    for k, name in enumerate(names):
+        rec = raw[1 + 10 * k:1 + 10 * (k + 1)]
+        fnv = 2166136261
+        for ch in name.encode():
+            fnv = ((fnv ^ ch) * 16777619) & 0xFFFFFFFF
+        assert rec[0] == fnv, name
+        out = (C.c_uint32 * 6)(); pal = (C.c_uint32 * 2)()
+        path = os.path.join(kat_io.GOLDEN, "bmp", name).encode()
+        r = h.rth_kat_load_bitmap(path, out)
+        assert (r == 0) == bool(rec[1]), name
+        if r == 0:
+            assert list(out) == [int(v) for v in rec[2:8]], (name, list(out), rec[2:8])
+            assert h.rth_kat_load_bitmap_palette(path, pal) == 0 and list(pal) == [int(v) for v in rec[8:10]], (name, list(pal), rec[8:10])
+            palettized += int(rec[8]) > 0
+        else:
+            refused += 1
+    assert refused == 4 and palettized == 3
