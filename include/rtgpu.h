@@ -339,7 +339,7 @@ typedef struct RtCounters
     uint64_t numAnalyticHits;    /* EvaluateIntersection on sphere/box/rect (incl. area lights) */
     uint64_t numShadowRayBoxTests;      /* box tests done by shadow rays (not counted by the reference) */
     uint64_t numShadowRayTriangleTests; /* triangle tests done by shadow rays */
-    uint64_t numRetracedRays;    /* rays the 4-wide traversal kernel did not trust (runner-up hit within its tolerance, NaN slab tests) and
+    uint64_t numRetracedRays;    /* rays the default traversal kernel of single-mesh scenes did not trust (runner-up hit within its tolerance, NaN slab tests) and
                                   * handed to the binary-tree kernel, which walks the reference's order (performance statistic) */
     uint64_t _reserved[3];
 } RtCounters;

@@ -233,13 +233,15 @@ struct TravTuning
 // Occupancy: 5 waves per SIMD (<= 96 VGPRs; the register allocator gets there without spilling once the world ray and
 // the hit record are not carried) x 24.6 KB of LDS stack per block = 5 blocks per CU.  The interior loop waits ~800 ns
 // per dependent node fetch, so every extra wave is throughput.
-template <int kStack, bool kCount>
+#define RT_LDS_TOP_NODES 224u   // 7 KB: the stack class of 24 entries leaves 7.4 KB per block at five blocks per CU
+template <int kStack, bool kCount, bool kLdsTop = false>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace(const RtSceneDesc scene, const Paths paths,
                                                     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                     const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                     uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    __shared__ float4 sTop[kLdsTop ? RT_LDS_TOP_NODES * 2u : 1u];
     const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
     const uint32_t numClosest = queueCount ? *queueCount : 0u;
@@ -296,6 +298,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             bypassTriBase = mesh.firstTriangle;
             bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
         }
+    }
+    // LDS-staged node packets: the device copy of a mesh tree is in breadth-first order, so its top levels are its first nodes
+    LdsTop top = { sTop, 0u };
+    if (kLdsTop && bypassMesh)
+    {
+        const uint32_t numNodes = scene.meshes[scene.objects[0].meshIndex].numNodes;
+        top.count = numNodes > 2u ? (numNodes - 2u < RT_LDS_TOP_NODES ? numNodes - 2u : RT_LDS_TOP_NODES) : 0u;
+        const float4* src = reinterpret_cast<const float4*>(bypassNodes + 2);
+        for (uint32_t i = threadIdx.x; i < top.count * 2u; i += RT_BLOCK) sTop[i] = src[i];
+        __syncthreads();
     }
     uint32_t drainIterations = 0, closestDrain = 0;
     for (;;)
@@ -414,7 +426,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             {
                 for (;;)
                 {
-                    if (in) travStepInterior<kCount, false>(s, stack, cnt);
+                    if (in) travStepInterior<kCount, false>(s, stack, cnt, top);
                     in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
@@ -424,7 +436,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             {
                 for (;;)
                 {
-                    if (in) travStepInterior<kCount, true>(s, stack, cnt);
+                    if (in) travStepInterior<kCount, true>(s, stack, cnt, top);
                     in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
@@ -580,8 +592,8 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
     }
 }
 
-#define RT_COUNTER_RETRACED 12   // counters[]: rays the wide kernel handed to the binary-tree kernel (RtCounters::numRetracedRays)
-#include "rt_trace_wide.inl"
+#define RT_COUNTER_RETRACED 12   // counters[]: rays k_trace_quant handed to the binary-tree kernel (RtCounters::numRetracedRays)
+#include "rt_trace_quant.inl"
 
 RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
 RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
@@ -1135,7 +1147,7 @@ struct BatchLane
     Paths paths = { nullptr, 0, 0 };
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
-    uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests the wide traversal kernel hands to the binary-tree kernel
+    uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests k_trace_quant hands to the binary-tree kernel
     uint32_t* exactShadowQueue = nullptr;
     // per-batch work counters, 8 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
     // shadow-queue counts, traversal cursors, -, exact-queue counts, exact-shadow-queue counts, exact cursors, - (one of each per
@@ -1176,10 +1188,9 @@ struct RtgpuContext
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
-    WideBvh wide = { nullptr, nullptr, 0, 0, 0, { 0.0f, 0.0f, 0.0f } };   // 4-wide tree of a single-mesh scene (rt_trace_wide.inl); nodes == nullptr: none
-    bool wideAllowed = true;           // RTGPU_NO_WIDE=1: the binary-tree kernel only
-    bool wideLdsTop = true;            // RTGPU_WIDE_NO_LDS=1: top levels from memory like the rest
-    uint32_t wideBlocksPerCU = 0;      // 0 = default
+    QuantBvh quant;                    // 32-byte child pairs of a single-mesh scene (rt_trace_quant.inl); pairs == nullptr: none
+    bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
+    bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
@@ -1402,9 +1413,9 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
-    if (const char* e = getenv("RTGPU_NO_WIDE")) c->wideAllowed = atoi(e) == 0;
-    if (const char* e = getenv("RTGPU_WIDE_NO_LDS")) c->wideLdsTop = atoi(e) == 0;
-    if (const char* e = getenv("RTGPU_WIDE_BLOCKS_PER_CU")) c->wideBlocksPerCU = (uint32_t)atoi(e);
+    if (const char* e = getenv("RTGPU_QUANT")) c->quantAllowed = atoi(e) != 0;
+    if (const char* e = getenv("RTGPU_LDS_TOP")) c->ldsTopAllowed = atoi(e) != 0;
+    memset(&c->quant, 0, sizeof(c->quant));
     if (const char* e = getenv("RTGPU_PASS_BATCH")) { c->passBatch = (uint32_t)atoi(e); c->passBatchFromEnv = true; }
     if (c->passBatch < 1) c->passBatch = 1;
     if (c->passBatch > RT_SEED_RING / 2) c->passBatch = RT_SEED_RING / 2;
@@ -1579,7 +1590,31 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->globalLights, s->numGlobalLights, &d.globalLights))) return r;
     if ((r = uploadArray(c, s->materials, s->numMaterials, &d.materials))) return r;
     if ((r = uploadArray(c, s->meshes, s->numMeshes, &d.meshes))) return r;
-    if ((r = uploadArray(c, s->meshNodes, s->numMeshNodes, &d.meshNodes))) return r;
+    {
+        // mesh trees go to the device in BREADTH-FIRST order (root at 0, node 1 unused, child pairs from 2 on as the reference lays them
+        // out, levels one after the other): the same tree -- a node's childIndex is only a pointer -- with the top levels every ray
+        // walks through contiguous at the front, which k_trace stages in LDS.  Leaves keep their triangle ranges.
+        std::vector<RtNode> ordered(s->meshNodes, s->meshNodes + s->numMeshNodes);
+        for (uint32_t m = 0; m < s->numMeshes; ++m)
+        {
+            const RtMesh& mesh = s->meshes[m];
+            if (mesh.numNodes < 3u) continue;
+            const RtNode* src = s->meshNodes + mesh.firstNode;
+            RtNode* dst = ordered.data() + mesh.firstNode;
+            std::vector<uint32_t> oldIndex; oldIndex.reserve(mesh.numNodes);   // oldIndex[new position]
+            oldIndex.push_back(0u); oldIndex.push_back(1u);
+            for (size_t k = 0; k < oldIndex.size() && oldIndex.size() + 2u <= mesh.numNodes; ++k)
+            {
+                if (k == 1u) continue;
+                const RtNode& n = src[oldIndex[k]];
+                if ((n.leaves & 0x3FFFFFFFu) != 0u) continue;
+                dst[k] = n; dst[k].childIndex = (uint32_t)oldIndex.size();
+                oldIndex.push_back(n.childIndex); oldIndex.push_back(n.childIndex + 1u);
+            }
+            for (size_t k = 0; k < oldIndex.size(); ++k) if (k != 1u && (src[oldIndex[k]].leaves & 0x3FFFFFFFu) != 0u) dst[k] = src[oldIndex[k]];
+        }
+        if ((r = uploadArray(c, ordered.data(), ordered.size(), &d.meshNodes))) return r;
+    }
     if ((r = uploadArray(c, s->triangles, s->numTriangles, &d.triangles))) return r;
     {
         // de-indexed shading records (rt_device_core.h, TriangleShading), built once here
@@ -1605,19 +1640,19 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->blueNoise, s->blueNoise ? (size_t)128 * 128 * 4 : 0, &d.blueNoise))) return r;
     if ((r = uploadArray(c, s->textures, s->numTextures, &d.textures))) return r;
     if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
-    // single-mesh scenes (Scene::Traverse's one-object bypass): the 4-wide tree of the default traversal kernel
-    memset(&c->wide, 0, sizeof(c->wide));
+    // single-mesh scenes (Scene::Traverse's one-object bypass): the re-encoded tree of the default traversal kernel
+    memset(&c->quant, 0, sizeof(c->quant));
     if (s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH)
     {
         const RtMesh& mesh = s->meshes[s->objects[0].meshIndex];
-        const WideBuild w = buildWideBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, s->triangles + mesh.firstTriangle, mesh.numTriangles);
-        if (w.ok && w.stackNeed <= 64u)
+        const QuantBuild q = buildQuantBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, mesh.numTriangles, maxMeshDepth);
+        if (q.ok)
         {
-            const float4* devNodes = nullptr; const float4* devLeaves = nullptr;
-            if ((r = uploadArray(c, w.nodes.data(), w.nodes.size(), &devNodes))) return r;
-            if ((r = uploadArray(c, w.leaves.data(), w.leaves.size(), &devLeaves))) return r;
-            c->wide.nodes = devNodes; c->wide.leaves = devLeaves; c->wide.numNodes = w.numNodes; c->wide.numLeaves = w.numLeaves;
-            c->wide.stackNeed = w.stackNeed; memcpy(c->wide.bound, w.bound, sizeof(w.bound));
+            const float4* devPairs = nullptr; const float4* devGate = nullptr;
+            if ((r = uploadArray(c, q.pairs.data(), q.pairs.size(), &devPairs))) return r;
+            if ((r = uploadArray(c, q.gate.data(), q.gate.size(), &devGate))) return r;
+            c->quant.pairs = devPairs; c->quant.gate = devGate; c->quant.root = q.root; c->quant.stackNeed = q.stackNeed;
+            memcpy(c->quant.base, q.base, sizeof(q.base)); memcpy(c->quant.step, q.step, sizeof(q.step)); memcpy(c->quant.bound, q.bound, sizeof(q.bound));
         }
     }
     c->sceneDev = d;
@@ -1782,23 +1817,20 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
     return RTGPU_OK;
 }
 
-// The 4-wide quad-per-ray kernel serves single-mesh scenes unless the reference's box / triangle test counters are wanted (they
-// belong to the binary walk) or it was switched off.
-static bool useWide(const RtgpuContext* c) { return c->wide.nodes != nullptr && c->wideAllowed && !c->countIntersections; }
+// The re-encoded tree serves single-mesh scenes unless the reference's box / triangle test counters are wanted (they belong to the
+// reference's walk) or it was switched off.
+static bool useQuant(const RtgpuContext* c) { return c->quant.pairs != nullptr && c->quantAllowed && !c->countIntersections; }
 
-static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
-                            uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset)
+static void launchTraceQuant(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
+                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset)
 {
-    WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount };
-    const uint32_t stackClass = c->wide.stackNeed <= 32u ? 32u : (c->wide.stackNeed <= 48u ? 48u : 64u);
-    // LDS per block: stack class x 256 B + 10.9 KB of staged nodes -> 8 / 6 / 5 blocks per CU fit; 6 is where the registers end
-    const uint32_t perCU = c->wideBlocksPerCU ? c->wideBlocksPerCU : (stackClass == 64u ? 5u : 6u);
-    const dim3 grid(c->numCUs * perCU), block(RT_BLOCK);
+    QuantTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount };
+    const uint32_t stackClass = c->quant.stackNeed <= 24u ? 24u : (c->quant.stackNeed <= 32u ? 32u : 64u);
+    const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
-#define RT_LAUNCH_WIDE(S, L) hipLaunchKernelGGL((k_trace_wide<S, L>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
-    if (c->wideLdsTop) { if (stackClass == 32u) RT_LAUNCH_WIDE(32, true); else if (stackClass == 48u) RT_LAUNCH_WIDE(48, true); else RT_LAUNCH_WIDE(64, true); }
-    else { if (stackClass == 32u) RT_LAUNCH_WIDE(32, false); else if (stackClass == 48u) RT_LAUNCH_WIDE(48, false); else RT_LAUNCH_WIDE(64, false); }
-#undef RT_LAUNCH_WIDE
+#define RT_LAUNCH_QUANT(S) hipLaunchKernelGGL((k_trace_quant<S>), grid, block, 0, stream, c->sceneDev, c->quant, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
+    if (stackClass == 24u) RT_LAUNCH_QUANT(24); else if (stackClass == 32u) RT_LAUNCH_QUANT(32); else RT_LAUNCH_QUANT(64);
+#undef RT_LAUNCH_QUANT
 }
 
 // Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.
@@ -1861,6 +1893,7 @@ static int flushPending(RtgpuContext* c)
         hipLaunchKernelGGL(k_generate, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, l.queues[0], pathCounts + 0, c->counters);
     }
 #define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
+    const bool ldsTop = stackClass == 24u && !c->countIntersections && c->ldsTopAllowed && c->sceneDev.numObjects == 1u;
     // bounce k: trace {closest rays of bounce k, NEE rays of bounce k-1} -> shade k; one last trace for the NEE rays of
     // the final bounce
     const uint32_t lastDepth = c->debugMode >= 0 ? 0u : maxRayDepth + 1u;
@@ -1875,13 +1908,13 @@ static int flushPending(RtgpuContext* c)
             const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
-            if (useWide(c))
+            if (useQuant(c))
             {
-                // the wide kernel serves the launch; what it does not trust goes through the binary-tree kernel right behind it
+                // the re-encoded tree serves the launch; what it does not trust goes through the binary-tree kernel right behind it
                 uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
                 uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
                 uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
-                launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
+                launchTraceQuant(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
                 tq = l.exactQueue; tqc = exactCounts + launchIndex; tsq = l.exactShadowQueue; tsc = exactShadowCounts + launchIndex;
                 uint32_t* cursors = exactCursors;
                 LaunchTimer t(c, l.stream, KC_RETRACE);
@@ -1890,7 +1923,8 @@ static int flushPending(RtgpuContext* c)
             else
             {
                 LaunchTimer t(c, l.stream, KC_TRACE);
-                if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
+                if (ldsTop) hipLaunchKernelGGL((k_trace<24, false, true>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune);
+                else if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
                 else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
                 else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
             }

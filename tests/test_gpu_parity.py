@@ -582,13 +582,13 @@ def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
     assert np.array_equal(whole[owned].view(np.uint32), ref[owned].view(np.uint32))
 
 
-# ---- the default traversal of single-mesh scenes: four lanes per ray over the 4-wide tree (rt_trace_wide.inl) ---------------------
+# ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_trace_quant.inl) -------
 NOT_INTERSECTION = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits", "numAnalyticHits")
 
 
-def run_wide(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_args):
-    """Like run_both, with the intersection counters OFF (the reference's default): single-mesh scenes then run k_trace_wide, and
-    what it does not trust is traced again by the binary-tree kernel."""
+def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_args):
+    """Like run_both, with the intersection counters OFF (the reference's default) and RTGPU_QUANT=1 set by the caller: single-mesh
+    scenes then run k_trace_quant, and what it does not trust is traced again by the binary-tree kernel."""
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
@@ -607,7 +607,7 @@ def run_wide(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_a
     return img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}
 
 
-def assert_wide_identical(img, img2, counters, ref, ref2, ref_counters):
+def assert_quant_identical(img, img2, counters, ref, ref2, ref_counters):
     assert np.isfinite(ref).all()
     nbad = int(np.count_nonzero(img.view(np.uint32) != ref.view(np.uint32)))
     assert nbad == 0, "%d of %d sum-buffer values differ (max abs %.3e)" % (nbad, ref.size, float(np.abs(img - ref).max()))
@@ -617,43 +617,59 @@ def assert_wide_identical(img, img2, counters, ref, ref2, ref_counters):
     assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0   # the reference's counters belong to its own walk
 
 
-def test_wide_traversal_bit_exact_on_single_mesh_scenes(built):
-    """The quad-per-ray kernel over the collapsed 4-wide tree gives the reference's hits: images and ray / shadow-ray / hit counters
+def test_quantized_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch):
+    """The walk over the conservatively re-encoded tree (exact leaf gate, runner-up tracking, exact re-trace) gives the reference's hits: images and ray / shadow-ray / hit counters
     identical to the oracle's binary-tree walk on a small and a mid-size mesh, under both light sampling strategies, and only a
     small fraction of the rays needs the exact re-trace."""
+    monkeypatch.setenv("RTGPU_QUANT", "1")
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
-    out = run_wide(scene, camera, w, h, passes=3, max_ray_depth=8)
-    assert_wide_identical(*out)
+    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
+    assert_quant_identical(*out)
     traced = out[2]["numRays"] + out[2]["numShadowRays"]
     assert 0 < out[2]["numRetracedRays"] < 0.02 * traced, (out[2]["numRetracedRays"], traced)
     scene, camera = scenes.sponza_class(w / h, 60000)
-    out = run_wide(scene, camera, w, h, passes=2, max_ray_depth=8, light_sampling_all=True, dimensions=128)
-    assert_wide_identical(*out)
-    out = run_wide(scene, camera, w, h, passes=2, max_ray_depth=3, min_russian_roulette_depth=8)
-    assert_wide_identical(*out)
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=8, light_sampling_all=True, dimensions=128)
+    assert_quant_identical(*out)
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=3, min_russian_roulette_depth=8)
+    assert_quant_identical(*out)
 
 
-def test_wide_and_binary_traversal_agree_at_full_size(built, monkeypatch):
-    """1920x1080, the benchmark's 262 176-triangle mesh, depth 8, counters off: the frame rendered with the wide kernel equals the
-    frame rendered with the binary-tree kernel alone (RTGPU_NO_WIDE=1) bit for bit, ray counters included, and 1/48 of its tiles equal
+def test_quantized_and_exact_traversal_agree_at_full_size(built, monkeypatch):
+    """1920x1080, the benchmark's 262 176-triangle mesh, depth 8, counters off: the frame rendered with the re-encoded tree equals the
+    frame rendered with the binary-tree kernel alone bit for bit, ray counters included, and 1/48 of its tiles equal
     the oracle; the exact re-trace serves well under 1 % of the rays."""
     w, h, depth, passes = 1920, 1080, 8, 2
     scene, camera = scenes.sponza_class(w / h)
     frames = []
-    for no_wide in ("0", "1"):
-        monkeypatch.setenv("RTGPU_NO_WIDE", no_wide)
+    for quant in ("1", "0"):
+        monkeypatch.setenv("RTGPU_QUANT", quant)
         vp = ra.Viewport(w, h, seed=515, max_ray_depth=depth)
         vp.set_renderer(scene)
         assert ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0) == 0
         vp.render(camera, passes)
         frames.append((vp.sum_buffer(), vp.counters()))
-    monkeypatch.delenv("RTGPU_NO_WIDE")
+    monkeypatch.setenv("RTGPU_QUANT", "1")
     (wide, cw), (binary, cb) = frames
     assert np.isfinite(wide).all() and float(wide.max()) > 0.0
     assert np.array_equal(wide.view(np.uint32), binary.view(np.uint32))
     for n in NOT_INTERSECTION:
         assert cw[n] == cb[n], (n, cw[n], cb[n])
     assert cb["numRetracedRays"] == 0 and 0 < cw["numRetracedRays"] < 0.01 * (cw["numRays"] + cw["numShadowRays"]), cw["numRetracedRays"]
-    out = run_wide(scene, camera, w, h, passes=2, seed=515, threads=16, shard=(5, 48), max_ray_depth=depth)
-    assert_wide_identical(*out)
+    out = run_quant(scene, camera, w, h, passes=2, seed=515, threads=16, shard=(5, 48), max_ray_depth=depth)
+    assert_quant_identical(*out)
+
+
+def test_lds_staged_top_levels_bit_exact(built, monkeypatch):
+    """Intersection counters off (the reference's default, what bench.py times) on a single-mesh scene, whose tree the device holds in
+    breadth-first order: same images and ray counters as the oracle -- with the plain k_trace and with the variant that serves the top
+    levels from an LDS copy (RTGPU_LDS_TOP=1; slower than the L1 on this chip, kept as an option)."""
+    w, h = 128, 72
+    scene, camera = scenes.sponza_class(w / h, 60000)
+    a = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
+    assert_quant_identical(*a)
+    assert a[2]["numRetracedRays"] == 0
+    monkeypatch.setenv("RTGPU_LDS_TOP", "1")
+    b = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
+    assert_quant_identical(*b)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
