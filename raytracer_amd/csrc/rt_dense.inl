@@ -1,0 +1,274 @@
+// rt_dense.inl -- PathTracerMIS / PathTracer passes with DENSE path state (LightSamplingStrategy::Single).  Included by rt_kernels.hip.
+//
+// The first layout kept a path in the slot of its pixel for its whole life: after a few bounces the live slots are sparse, every
+// 16-byte record access of k_shade pulls its own 64/128-byte line from HBM (measured: 3.1x the bytes the kernel needs, L2 hit rate
+// 27 %, profiles/r02_diag0_pmc_8.txt) and costs its own L1 access.  Here the state ping-pongs between two arenas: k_shade_dense reads
+// the records of bounce k at consecutive slots and writes the survivors to consecutive slots of the other arena, so that every record
+// access of every kernel is a fully coalesced 1 KB per wave.
+//   * Slot allocation: a block counts its survivors in LDS and takes its range with ONE returning atomic per 256 vertices, on one of
+//     RT_DENSE_SHARDS counters selected by the block index (a single word sustains only ~88 returning atomics per microsecond).  An
+//     arena is therefore RT_DENSE_SHARDS regions; region s holds its live paths upwards from s * shardCapacity.
+//   * A path that ends at a vertex whose next-event request still needs its shadow ray becomes a ZOMBIE: only what the resolution
+//     needs is written, downwards from the top of the region; the next k_shade_dense folds the visibility result in and parks the
+//     radiance.
+//   * Finished paths park their radiance at home[pass * slotsPerPass + pixelSlot]; k_accumulate_home adds the passes of a batch to the
+//     film per pixel in pass order -- the float sums are those of the reference's pass-after-pass accumulation, whatever order the
+//     paths were compacted in.
+// Arithmetic and consumption order of the samples are those of k_shade (same functions, same sequence): the images are bit-identical.
+// k_generate for dense state: slot i = home i; the regions of the first arena are simply filled one after the other
+__global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
+                                                             const uint32_t* __restrict__ slotPixel, uint32_t numSlots, uint32_t shardCapacity, uint32_t* __restrict__ counts,
+                                                             unsigned long long* counters)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
+    {
+        const uint32_t passInBatch = slot / slotsPerPass;
+        const DevPass& pass = passes[passInBatch];
+        const uint32_t pix = slotPixel[slot - passInBatch * slotsPerPass];
+        const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
+        const uint32_t realY = pass.height - 1u - y;
+        const float invW = 1.0f / (float)(int32_t)pass.width, invH = 1.0f / (float)(int32_t)pass.height;
+        const V4 coords(((float)(int32_t)x + pass.sampleOffset[0]) * invW, ((float)(int32_t)realY + pass.sampleOffset[1]) * invH, 0.0f, 0.0f);
+        Sampler sampler;
+        sampler.seed = pass.seed; sampler.numDims = pass.numDimensions; sampler.blueNoiseLayers = pass.blueNoiseLayers; sampler.blueNoise = scene.blueNoise;
+        sampler.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
+        V4 origin, direction;
+        cameraGenerateRayParts(pass.camera, coords, sampler, origin, direction);
+        prec(paths, R_ORIGIN, slot) = f4(origin.x, origin.y, origin.z, fbits(0x100u));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
+        prec(paths, R_DIR, slot) = f4(direction.x, direction.y, direction.z, 1.0f);        // lastPdfW = 1
+        prec(paths, R_TP, slot) = f4(1.0f, 1.0f, 1.0f, 1.0f);
+        prec(paths, R_RESULT, slot) = f4(0.0f, 0.0f, 0.0f, fbits(pix));
+        prec(paths, R_SH_TP, slot) = f4(0.0f, 0.0f, 0.0f, fbits(slot));                    // .w: the path's home
+        storeSampler(sampler, paths, slot, 0.0f, 0u);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < RT_DENSE_SHARDS)
+    {
+        const uint32_t first = threadIdx.x * shardCapacity;
+        counts[threadIdx.x] = first >= numSlots ? 0u : (numSlots - first < shardCapacity ? numSlots - first : shardCapacity);
+        if (threadIdx.x == 0) atomicAdd(&counters[C_PRIMARY], (unsigned long long)numSlots);
+    }
+}
+
+// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395), as k_shade, reading arena `in`
+// and writing the survivors densely into arena `out`.  kPlain: PathTracer::RenderPixel (Core/Rendering/PathTracer.cpp:73-171).
+template <bool kLean, bool kPlain = false>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
+                                                          const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                          float4* __restrict__ home, unsigned long long* counters)
+{
+    __shared__ uint32_t sShadowBuf[RT_APPEND_BUFFER];
+    __shared__ uint32_t sShadowCount, sShadowBase;
+    __shared__ uint32_t sLive, sZombies, sLiveBase, sZombieBase;
+    __shared__ uint32_t sLivePrefix[RT_DENSE_SHARDS + 1u], sZombiePrefix[RT_DENSE_SHARDS + 1u];
+    if (threadIdx.x == 0) { sShadowCount = 0; sLive = 0; sZombies = 0; }
+    denseLoadPrefix(dense.in, sLivePrefix);
+    if (threadIdx.x == 64) { uint32_t sum = 0; for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s) { sZombiePrefix[s] = sum; sum += dense.in[RT_DENSE_SHARDS + s]; } sZombiePrefix[RT_DENSE_SHARDS] = sum; }
+    __syncthreads();
+    Counters cnt; zeroCounters(cnt);
+    const uint32_t numLive = sLivePrefix[RT_DENSE_SHARDS], count = numLive + sZombiePrefix[RT_DENSE_SHARDS];
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t shard = blockIdx.x & (RT_DENSE_SHARDS - 1u);
+    const DevPass pass = passes[0];   // the structural parameters are those of every pass of the batch
+    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
+    const float lightPickProbability = 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172 (Single)
+
+    const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    {
+        // what this vertex leaves behind: 0 nothing (radiance parked), 1 a live path, 2 a zombie (radiance + one pending request)
+        uint32_t outcome = 0;
+        float4 oOrigin, oDir, oTp, oResult, oSampler, oRng, oShP, oShTp, oShadow0, oShadow1;
+        bool rayNeeded = false;
+        if (i < count)
+        {
+            uint32_t slot;
+            const bool zombie = i >= numLive;
+            if (!zombie) slot = denseLiveSlot(sLivePrefix, dense.shardCapacity, i);
+            else { const uint32_t z = i - numLive, s = denseRegionOf(sZombiePrefix, z); slot = (s + 1u) * dense.shardCapacity - 1u - (z - sZombiePrefix[s]); }
+            const float4 rResult = prec(in, R_RESULT, slot), rSampler = prec(in, R_SAMPLER, slot), rShTp = prec(in, R_SH_TP, slot);
+            const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
+            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+            resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
+            if (!zombie)
+            {
+                const float4 rOrigin = prec(in, R_ORIGIN, slot), rDir = prec(in, R_DIR, slot), rTp = prec(in, R_TP, slot), rHit = prec(in, R_HIT, slot);
+                const uint32_t flags = ubits(rOrigin.w);
+                const uint32_t depth = flags & 0xFFu;
+                const bool lastSpecular = (flags & 0x100u) != 0;
+                const float lastPdfW = rDir.w;
+                const Ray ray = makePathRay(rOrigin, rDir, depth);
+                V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+                Hit hit;
+                hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+                uint32_t numRequests = 0;
+                do
+                {
+                    if (hit.objectId == RT_INVALID_OBJECT)
+                    {
+                        // EvaluateGlobalLights, PathTracerMIS.cpp:214-252
+                        V4 result = zero4();
+                        for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
+                        {
+                            const RtLight& light = scene.lights[scene.globalLights[g]];
+                            const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
+                            float directPdfW = 0.0f;
+                            const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+                            if (kPlain) result = result + lightContribution;   // PathTracer::EvaluateGlobalLights, PathTracer.cpp:47-71
+                            else if (!almostZero4(lightContribution))
+                            {
+                                float misWeight = 1.0f;
+                                if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                                result = mulAdd(lightContribution, misWeight, result);
+                            }
+                        }
+                        if (!kPlain) result = result * bsdfSamplingWeight;
+                        resultColor = mulAdd(throughput, result, resultColor);
+                        break;
+                    }
+                    ShadingData sd;
+                    sd.intersection.material = (flags >> 9) - 1u;   // the previous vertex's material (see k_shade)
+                    if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
+                    if (!kLean && hit.subObjectId == RT_LIGHT_OBJECT)
+                    {
+                        // EvaluateLight, PathTracerMIS.cpp:174-212
+                        const RtObject& obj = scene.objects[hit.objectId];
+                        const RtLight& light = scene.lights[obj.lightIndex];
+                        const M4 worldToLight = loadM4(obj.invTransform);
+                        const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+                        const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
+                        const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
+                        float directPdfA = 0.0f;
+                        V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+                        if (kPlain) resultColor = mulAdd(throughput, lightContribution, resultColor);   // PathTracer::EvaluateLight, PathTracer.cpp:26-45
+                        else if (!almostZero4(lightContribution))
+                        {
+                            float misWeight = 1.0f;
+                            if (depth > 0 && !lastSpecular)
+                            {
+                                const float directPdfW = PdfAtoW(directPdfA, hit.distance, cosAtLight);
+                                misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                            }
+                            lightContribution = lightContribution * bsdfSamplingWeight;
+                            resultColor = mulAdd(throughput, lightContribution * misWeight, resultColor);
+                        }
+                        else resultColor = mulAdd(throughput, zero4(), resultColor);
+                        break;
+                    }
+                    sd.outgoingDirWorldSpace = neg(ray.dir);
+                    const RtMaterial& mat = scene.materials[sd.intersection.material];
+                    materialEvaluateShadingData<kLean>(scene, mat, sd);
+                    resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);   // emission, :309-317
+
+                    Sampler sampler; loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise);
+                    sampler.seed = passes[homeIndex / slotsPerPass].seed;
+
+                    // SampleLights (next event estimation, one light), PathTracerMIS.cpp:125-155
+                    if (!kPlain && scene.numLights != 0)
+                    {
+                        uint32_t lightIndex = 0;
+                        if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
+                        rayNeeded = computeLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, oShadow0, oShadow1);
+                        numRequests = rayNeeded ? 1u : 0u;   // a request without a ray contributes nothing (resolvePendingLightSamples skips it): not kept
+                        oShP = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                        oShTp = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                    }
+                    bool cont = depth < pass.maxRayDepth;
+                    if (cont && depth >= pass.minRussianRouletteDepth)   // Russian roulette, :330-347
+                    {
+                        const float minColorValue = 0.125f;
+                        const float threshold = minColorValue + (1.0f - minColorValue) * colorMax(sd.mp.baseColor);
+                        if (sampler.getFloat() > threshold) cont = false;
+                        else throughput = throughput * (1.0f / threshold);
+                    }
+                    if (cont)   // BSDF sampling, :349-395
+                    {
+                        float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
+                        float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
+                        const V4 bsdfValue = materialSample<kLean>(mat, sd, u, incomingDirWorldSpace, pdf, event);
+                        if (event != EV_NULL)
+                        {
+                            throughput = throughput * bsdfValue;
+                            if (!almostZero4(throughput))
+                            {
+                                oOrigin = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
+                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
+                                oDir = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
+                                oTp = f4(throughput.x, throughput.y, throughput.z, throughput.w);
+                                outcome = 1;
+                            }
+                        }
+                    }
+                    if (outcome == 1)
+                    {
+                        oSampler = f4(0.0f, fbits(sampler.salt), fbits(sampler.generated), fbits(numRequests));
+                        oRng = f4(fbits((uint32_t)sampler.fallback.s[0]), fbits((uint32_t)(sampler.fallback.s[0] >> 32)),
+                                  fbits((uint32_t)sampler.fallback.s[1]), fbits((uint32_t)(sampler.fallback.s[1] >> 32)));
+                        if (numRequests == 0u) oShTp = f4(0.0f, 0.0f, 0.0f, fbits(homeIndex));
+                    }
+                    else if (rayNeeded)
+                    {
+                        outcome = 2;   // the path ends here, its last next-event sample still needs its shadow ray
+                        oSampler = f4(0.0f, 0.0f, 0.0f, fbits(numRequests));
+                    }
+                } while (false);
+                if (outcome != 1) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
+            }
+            oResult = f4(resultColor.x, resultColor.y, resultColor.z, fbits(pix));
+            if (outcome == 0) home[homeIndex] = f4(resultColor.x, resultColor.y, resultColor.z, 0.0f);
+        }
+
+        // dense slots of the other arena: ranks from LDS counters, the block's two ranges with one global atomic each
+        uint32_t rank = 0;
+        if (outcome == 1) rank = atomicAdd(&sLive, 1u);
+        else if (outcome == 2) rank = atomicAdd(&sZombies, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && sLive != 0u) sLiveBase = atomicAdd(&dense.out[shard], sLive);
+        if (threadIdx.x == 64 && sZombies != 0u) sZombieBase = atomicAdd(&dense.out[RT_DENSE_SHARDS + shard], sZombies);
+        __syncthreads();
+        if (outcome != 0)
+        {
+            const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);
+            prec(out, R_RESULT, slot) = oResult;
+            prec(out, R_SAMPLER, slot) = oSampler;
+            prec(out, R_SH_TP, slot) = oShTp;
+            if (outcome == 1) { prec(out, R_ORIGIN, slot) = oOrigin; prec(out, R_DIR, slot) = oDir; prec(out, R_TP, slot) = oTp; prec(out, R_RNG, slot) = oRng; }
+            if (ubits(oSampler.w) != 0u)
+            {
+                prec(out, R_SH_P, slot) = oShP;
+                pshadow(out, 0, 0, slot) = oShadow0;
+                pshadow(out, 0, 1, slot) = oShadow1;
+                if (rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { sLive = 0; sZombies = 0; }
+        const bool last = (i - threadIdx.x) + stride >= rounded;
+        if (last || sShadowCount + RT_BLOCK > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
+        else __syncthreads();
+    }
+    flushCounters(cnt, counters);
+}
+
+// Film::AccumulateColor (Film.cpp:25-39) from the parked radiance: the passes of a batch are added per pixel IN PASS ORDER; the
+// secondary sum receives the even passes (Viewport.cpp:303)
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate_home(const float4* __restrict__ home, const uint32_t* __restrict__ slotPixel, uint32_t slotsPerPass, uint32_t numPasses,
+                                                              float* __restrict__ sum, float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < slotsPerPass; pixelSlot += stride)
+    {
+        const uint32_t pix = slotPixel[pixelSlot];
+        const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
+        float sr = sum[idx + 0], sg = sum[idx + 1], sb = sum[idx + 2];
+        float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
+        for (uint32_t b = 0; b < numPasses; ++b)
+        {
+            const float4 c = home[(size_t)b * slotsPerPass + pixelSlot];
+            sr = sr + c.x; sg = sg + c.y; sb = sb + c.z;
+            if ((passes[b].passIndex % 2u) == 0u) { tr = tr + c.x; tg = tg + c.y; tb = tb + c.z; }
+        }
+        sum[idx + 0] = sr; sum[idx + 1] = sg; sum[idx + 2] = sb;
+        secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
+    }
+}

@@ -209,6 +209,41 @@ RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSiz
     if (chunk.end < chunk.next) chunk.end = chunk.next;
 }
 
+// ---- dense path state (rt_dense.inl): an arena is RT_DENSE_SHARDS regions, region s holds its live paths upwards from s * shardCapacity ----
+#define RT_DENSE_SHARDS 16u
+
+struct DenseCounts
+{
+    const uint32_t* in;     // [0, 16): live paths per region of the arena being read; [16, 32): zombies per region
+    uint32_t* out;          // the same for the arena being written (zeroed by the host)
+    uint32_t shardCapacity;
+};
+
+// prefix sums of the 16 region counts into LDS (prefix[16] = total); all threads of the block call it
+RT_DEV void denseLoadPrefix(const uint32_t* __restrict__ counts, uint32_t* sPrefix)
+{
+    if (threadIdx.x == 0)
+    {
+        uint32_t sum = 0;
+        for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s) { sPrefix[s] = sum; sum += counts[s]; }
+        sPrefix[RT_DENSE_SHARDS] = sum;
+    }
+}
+RT_DEV uint32_t denseRegionOf(const uint32_t* sPrefix, uint32_t idx)
+{
+    uint32_t s = idx >= sPrefix[8] ? 8u : 0u;
+    s += idx >= sPrefix[s + 4u] ? 4u : 0u;
+    s += idx >= sPrefix[s + 2u] ? 2u : 0u;
+    s += idx >= sPrefix[s + 1u] ? 1u : 0u;
+    return s;
+}
+// slot of the idx-th live path
+RT_DEV uint32_t denseLiveSlot(const uint32_t* sPrefix, uint32_t shardCapacity, uint32_t idx)
+{
+    const uint32_t s = denseRegionOf(sPrefix, idx);
+    return s * shardCapacity + (idx - sPrefix[s]);
+}
+
 #define RT_SPLIT_AFTER 32u   // drain iterations of a wave before its shadow rays start sharing subtrees
 
 // Wave scheduling knobs of the persistent traversal kernel (wave-uniform, passed as kernel arguments)
@@ -221,6 +256,8 @@ struct TravTuning
     uint32_t* overflowQueue;  // closest-hit rays still running this long after the queue ran dry are handed to k_trace_monster
     uint32_t* overflowCount;  // (null: never)
     uint32_t abortClosestAfter;   // ... measured in scheduling rounds of the wave after its queue is exhausted
+    const uint32_t* denseCounts;  // dense path state: the closest-hit rays are the live paths of the arena's regions (no queue); else null
+    uint32_t denseShardCapacity;
 };
 #define RT_ABORT_CLOSEST_AFTER 768u
 
@@ -242,9 +279,11 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
     __shared__ float4 sTop[kLdsTop ? RT_LDS_TOP_NODES * 2u : 1u];
+    __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
     const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
-    const uint32_t numClosest = queueCount ? *queueCount : 0u;
+    if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
+    const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
     const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
     TravState s; s.mode = TRAV_DONE; s.shadow = false;
     uint32_t slot = 0, light = 0;
@@ -354,7 +393,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 if (idx != 0xFFFFFFFFu)
                 {
                     shadowRequest = idx >= numClosest;
-                    request = shadowRequest ? shadowQueue[idx - numClosest] : queue[idx];
+                    request = shadowRequest ? shadowQueue[idx - numClosest] : (tune.denseCounts ? denseLiveSlot(sDensePrefix, tune.denseShardCapacity, idx) : queue[idx]);
                     if (shadowRequest) cnt.c[C_SHADOW]++;
                 }
             }
@@ -601,9 +640,9 @@ RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDi
 // PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
 // request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
 template <bool kLean>
-__device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
+__device__ __forceinline__ static bool computeLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
                                const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
-                               const Paths& paths, uint32_t slot, uint32_t requestIndex)
+                               float4& outDirTmax, float4& outContribution)
 {
     float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
     float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
@@ -628,9 +667,20 @@ __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& sce
             tmax = ir.distance * 0.999f;
         }
     }
-    pshadow(paths, requestIndex, 0, slot) = f4(dir.x, dir.y, dir.z, tmax);
-    pshadow(paths, requestIndex, 1, slot) = f4(contribution.x, contribution.y, contribution.z, 0.0f);
+    outDirTmax = f4(dir.x, dir.y, dir.z, tmax);
+    outContribution = f4(contribution.x, contribution.y, contribution.z, 0.0f);
     return tmax >= 0.0f;   // a shadow ray has to be traced for this request
+}
+template <bool kLean>
+__device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
+                               const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
+                               const Paths& paths, uint32_t slot, uint32_t requestIndex)
+{
+    float4 dirTmax, contribution;
+    const bool ray = computeLightSample<kLean>(scene, pass, sampler, light, sd, mat, depth, lightPickProbability, dirTmax, contribution);
+    pshadow(paths, requestIndex, 0, slot) = dirTmax;
+    pshadow(paths, requestIndex, 1, slot) = contribution;
+    return ray;
 }
 
 // Folds the finished NEE requests of the path's previous vertex into its radiance:
@@ -995,6 +1045,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
     flushCounters(cnt, counters);
 }
 
+#include "rt_dense.inl"
 #include "rt_vcm.inl"
 #include "rt_kat.inl"
 
@@ -1149,6 +1200,11 @@ struct BatchLane
     uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
     uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests k_trace_quant hands to the binary-tree kernel
     uint32_t* exactShadowQueue = nullptr;
+    // dense path state (rt_dense.inl, LightSamplingStrategy::Single): the second arena of the ping-pong, the parked radiance of
+    // finished paths, per bounce the live / zombie counts of the arena's regions (2 * RT_DENSE_SHARDS words per bounce)
+    Paths paths2 = { nullptr, 0, 0 };
+    float4* home = nullptr;
+    uint32_t* denseCounts = nullptr;
     // per-batch work counters, 8 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
     // shadow-queue counts, traversal cursors, -, exact-queue counts, exact-shadow-queue counts, exact cursors, - (one of each per
     // bounce, so that no reset ever races with a reader)
@@ -1190,8 +1246,9 @@ struct RtgpuContext
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
     QuantBvh quant;                    // 32-byte child pairs of a single-mesh scene (rt_trace_quant.inl); pairs == nullptr: none
     bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
+    bool denseAllowed = true;          // RTGPU_NO_DENSE=1: path state stays in the pixel's slot for the whole path (the first layout)
     bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
-    TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
+    TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
     bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
@@ -1280,7 +1337,9 @@ static void freePaths(BatchLane& l)
     if (l.shadowQueues[1]) (void)hipFree(l.shadowQueues[1]);
     if (l.exactQueue) (void)hipFree(l.exactQueue);
     if (l.exactShadowQueue) (void)hipFree(l.exactShadowQueue);
-    l.exactQueue = l.exactShadowQueue = nullptr;
+    if (l.paths2.base) (void)hipFree(l.paths2.base);
+    if (l.home) (void)hipFree(l.home);
+    l.exactQueue = l.exactShadowQueue = nullptr; l.paths2.base = nullptr; l.paths2.capacity = 0; l.paths2.maxLights = 0; l.home = nullptr;
     l.paths.base = nullptr; l.paths.capacity = 0; l.paths.maxLights = 0;
     l.queues[0] = l.queues[1] = nullptr; l.shadowQueues[0] = l.shadowQueues[1] = nullptr;
 }
@@ -1415,6 +1474,7 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_QUANT")) c->quantAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_LDS_TOP")) c->ldsTopAllowed = atoi(e) != 0;
+    if (const char* e = getenv("RTGPU_NO_DENSE")) c->denseAllowed = atoi(e) == 0;
     memset(&c->quant, 0, sizeof(c->quant));
     if (const char* e = getenv("RTGPU_PASS_BATCH")) { c->passBatch = (uint32_t)atoi(e); c->passBatchFromEnv = true; }
     if (c->passBatch < 1) c->passBatch = 1;
@@ -1458,6 +1518,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
         freePaths(c->lanes[i]);
         if (i == 0) freeVcm(c);
         if (c->lanes[i].queueCounts) (void)hipFree(c->lanes[i].queueCounts);
+        if (c->lanes[i].denseCounts) (void)hipFree(c->lanes[i].denseCounts);
         if (c->lanes[i].accumulated) (void)hipEventDestroy(c->lanes[i].accumulated);
     }
     if (c->counters) (void)hipFree(c->counters);
@@ -1785,17 +1846,38 @@ static uint32_t maxStreamingBatch(const RtgpuContext* c)
     return batch;
 }
 
+// Device bytes one path slot costs a batch lane when a vertex can have `maxLights` next-event requests: the records of both arenas
+// (the second one only exists for one request per vertex), the parked radiance, the queues.  LightSamplingStrategy::All with many
+// lights makes slots fat (64 lights: 2.2 KB), so the batch a lane can hold shrinks with it -- down to one pass.
+static size_t bytesPerSlot(uint32_t maxLights)
+{
+    if (maxLights == 0) maxLights = 1;
+    const size_t arena = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * sizeof(float4);
+    return arena * (maxLights == 1u ? 2u : 1u) + sizeof(float4) + sizeof(uint32_t) * (3u + 3u * (size_t)maxLights);
+}
+static uint32_t maxBatchFor(const RtgpuContext* c, uint32_t maxLights)
+{
+    const size_t perPass = (size_t)(c->numSlots ? c->numSlots : 1) * bytesPerSlot(maxLights);
+    const size_t batch = ((size_t)32 << 30) / perPass;
+    return batch < 1u ? 1u : (batch > RT_SEED_RING / 2 ? RT_SEED_RING / 2 : (uint32_t)batch);
+}
+// slots an arena is allocated for: the regions of dense path state need a margin each (a region's share of a launch is only
+// roughly a sixteenth: blocks take turns)
+static size_t arenaCapacityFor(size_t slots) { return (size_t)RT_DENSE_SHARDS * ((slots + RT_DENSE_SHARDS - 1u) / RT_DENSE_SHARDS + 65536u); }
+
 static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    const uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
+    uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
+    if (maxBatch > maxBatchFor(c, maxLights)) maxBatch = maxBatchFor(c, maxLights);
     const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * maxBatch;
-    if (!l.paths.base || l.paths.capacity < wanted || l.paths.maxLights < maxLights)
+    const bool wantDense = c->denseAllowed && maxLights == 1u;
+    if (!l.paths.base || l.paths.capacity < arenaCapacityFor(wanted) || l.paths.maxLights < maxLights || (wantDense && !l.paths2.base))
     {
         HIP_TRY(hipStreamSynchronize(l.stream));
         freePaths(l);
-        if (wanted >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
-        const size_t cap = wanted;
+        const size_t cap = arenaCapacityFor(wanted);
+        if (cap >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
         const size_t records = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * cap;
         HIP_TRY(hipMalloc((void**)&l.paths.base, records * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&l.queues[0], cap * sizeof(uint32_t)));
@@ -1806,13 +1888,21 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
         HIP_TRY(hipMalloc((void**)&l.exactQueue, cap * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&l.exactShadowQueue, cap * maxLights * sizeof(uint32_t)));
         l.paths.capacity = (uint32_t)cap; l.paths.maxLights = maxLights;
+        if (wantDense)
+        {
+            HIP_TRY(hipMalloc((void**)&l.paths2.base, records * sizeof(float4)));
+            HIP_TRY(hipMalloc((void**)&l.home, wanted * sizeof(float4)));
+            l.paths2.capacity = (uint32_t)cap; l.paths2.maxLights = maxLights;
+        }
     }
     if (l.queueCountCapacity < maxDepth + 2)
     {
         HIP_TRY(hipStreamSynchronize(l.stream));
         if (l.queueCounts) (void)hipFree(l.queueCounts);
+        if (l.denseCounts) (void)hipFree(l.denseCounts);
         l.queueCountCapacity = maxDepth + 2;
         HIP_TRY(hipMalloc((void**)&l.queueCounts, (size_t)8 * l.queueCountCapacity * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&l.denseCounts, (size_t)2 * RT_DENSE_SHARDS * (l.queueCountCapacity + 1u) * sizeof(uint32_t)));
     }
     return RTGPU_OK;
 }
@@ -1888,6 +1978,52 @@ static int flushPending(RtgpuContext* c)
     const uint32_t maxRayDepth = first.maxRayDepth;
 
     HIP_TRY(hipMemsetAsync(l.queueCounts, 0, (size_t)8 * l.queueCountCapacity * sizeof(uint32_t), l.stream));
+    // One next-event request per vertex (LightSamplingStrategy::Single, or none: "Path Tracer"): DENSE path state (rt_dense.inl)
+    const bool dense = c->denseAllowed && c->debugMode < 0 && maxLights <= 1u && l.paths2.base != nullptr;
+    if (dense)
+    {
+        const uint32_t shardCapacity = (totalSlots + RT_DENSE_SHARDS - 1u) / RT_DENSE_SHARDS + 65536u;
+        const uint32_t plane = 2u * RT_DENSE_SHARDS;
+        HIP_TRY(hipMemsetAsync(l.denseCounts, 0, (size_t)plane * (l.queueCountCapacity + 1u) * sizeof(uint32_t), l.stream));
+        {
+            LaunchTimer t(c, l.stream, KC_GENERATE);
+            hipLaunchKernelGGL(k_generate_dense, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters);
+        }
+        const bool haveNee = c->numLights != 0 && !c->plainPathTracer;
+        for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
+        {
+            const Paths& in = (depth & 1u) ? l.paths2 : l.paths;
+            const Paths& out = (depth & 1u) ? l.paths : l.paths2;
+            const bool haveClosest = depth <= maxRayDepth, haveShadow = depth > 0 && haveNee;
+            if (haveClosest || haveShadow)
+            {
+                TravTuning tune = c->tune;
+                tune.denseCounts = haveClosest ? l.denseCounts + (size_t)plane * depth : nullptr; tune.denseShardCapacity = shardCapacity;
+                const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
+                const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
+                LaunchTimer t(c, l.stream, KC_TRACE);
+#define RT_LAUNCH_TRACE_DENSE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, in, (const uint32_t*)nullptr, (const uint32_t*)nullptr, tsq, tsc, cursors + depth, c->counters, tune)
+                if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(24, true); else RT_LAUNCH_TRACE_DENSE(24, false); }
+                else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(32, true); else RT_LAUNCH_TRACE_DENSE(32, false); }
+                else { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(64, true); else RT_LAUNCH_TRACE_DENSE(64, false); }
+#undef RT_LAUNCH_TRACE_DENSE
+            }
+            // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
+            const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity };
+            LaunchTimer t(c, l.stream, KC_SHADE);
+#define RT_LAUNCH_SHADE_DENSE(L, P) hipLaunchKernelGGL((k_shade_dense<L, P>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
+                                                     l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters)
+            if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(false, true); else if (c->leanScene) RT_LAUNCH_SHADE_DENSE(true, false); else RT_LAUNCH_SHADE_DENSE(false, false);
+#undef RT_LAUNCH_SHADE_DENSE
+        }
+        if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
+        {
+            LaunchTimer t(c, l.stream, KC_ACCUMULATE);
+            hipLaunchKernelGGL(k_accumulate_home, pixelGrid, block, 0, l.stream, l.home, c->slotPixel, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
+        }
+    }
+    else
+    {
     {
         LaunchTimer t(c, l.stream, KC_GENERATE);
         hipLaunchKernelGGL(k_generate, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, l.queues[0], pathCounts + 0, c->counters);
@@ -1949,6 +2085,7 @@ static int flushPending(RtgpuContext* c)
     {
         LaunchTimer t(c, l.stream, KC_ACCUMULATE);
         hipLaunchKernelGGL(k_accumulate, pixelGrid, block, 0, l.stream, l.paths, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev, c->counters);
+    }
     }
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
@@ -2395,7 +2532,8 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
         if (!same) { int r = flushPending(c); if (r) return r; }
     }
     c->pending.push_back(std::move(pd));
-    if (c->pending.size() >= c->passBatch) return flushPending(c);
+    const uint32_t lightLimit = maxBatchFor(c, pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u);
+    if (c->pending.size() >= (c->passBatch < lightLimit ? c->passBatch : lightLimit)) return flushPending(c);
     return RTGPU_OK;
 }
 

@@ -622,6 +622,7 @@ def test_quantized_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch)
     identical to the oracle's binary-tree walk on a small and a mid-size mesh, under both light sampling strategies, and only a
     small fraction of the rays needs the exact re-trace."""
     monkeypatch.setenv("RTGPU_QUANT", "1")
+    monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
     out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
@@ -641,6 +642,7 @@ def test_quantized_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     the oracle; the exact re-trace serves well under 1 % of the rays."""
     w, h, depth, passes = 1920, 1080, 8, 2
     scene, camera = scenes.sponza_class(w / h)
+    monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
     frames = []
     for quant in ("1", "0"):
         monkeypatch.setenv("RTGPU_QUANT", quant)
@@ -673,3 +675,23 @@ def test_lds_staged_top_levels_bit_exact(built, monkeypatch):
     b = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
     assert_quant_identical(*b)
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+
+
+def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch):
+    """LightSamplingStrategy::Single runs with dense path state (survivors compacted into a second arena every bounce, finished paths
+    parked per pixel, zombies for the last pending shadow ray); RTGPU_NO_DENSE=1 keeps every path in its pixel's slot.  Same images,
+    same counters -- on the Cornell box (analytic shapes, area light hits, specular chains), a mesh under two lights (light picking
+    from the per-pixel generator), with Russian roulette off and a short depth limit (every path ends as a zombie or at the limit), for
+    the plain "Path Tracer", and with more passes than one batch."""
+    cases = [(scenes.cornell_box, dict(max_ray_depth=6), 5), (lambda a: scene_zoo.mesh_scene(a, triangles=8000), dict(max_ray_depth=8), 3),
+             (lambda a: scenes.sponza_class(a, 20000), dict(max_ray_depth=2, min_russian_roulette_depth=9), 19)]
+    w, h = 96, 54
+    for make, args, passes in cases:
+        scene, camera = make(w / h)
+        outs = []
+        for no_dense in ("0", "1"):
+            monkeypatch.setenv("RTGPU_NO_DENSE", no_dense)
+            outs.append(run_both(scene, camera, w, h, passes, **args))
+        monkeypatch.delenv("RTGPU_NO_DENSE")
+        assert_identical(*outs[0]); assert_identical(*outs[1])
+        assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
