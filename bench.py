@@ -160,14 +160,21 @@ def pmc_child_sums(args, counter, timeout_s):
         if r.returncode != 0 or not dbs:
             return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-300:])
         cur = sqlite3.connect(dbs[0]).cursor()
-        tables = [t[0] for t in cur.execute("select name from sqlite_master where type in ('table', 'view')").fetchall()]
         rows = None
-        if "pmc_events" in tables and "kernels" in tables:
-            rows = cur.execute("select k.name, count(*), sum(p.value), sum(k.duration) from pmc_events p join kernels k on p.event_id = k.id "
-                               "where p.counter_name = ? group by k.name", (counter,)).fetchall()
-        elif "counters_collection" in tables:
-            rows = [(n, c, s, 0) for n, c, s in cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
-                                                            "group by kernel_name", (counter,)).fetchall()]
+        for query in ("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name",
+                      "select k.name, count(*), sum(p.value) from pmc_events p join kernels k on p.event_id = k.id where p.counter_name = ? group by k.name"):
+            try:
+                rows = cur.execute(query, (counter,)).fetchall()
+                if rows:
+                    break
+            except sqlite3.Error:
+                rows = None
+        durations = {}
+        try:
+            durations = {n: (int(c), int(d)) for n, c, d in cur.execute("select name, count(*), sum(duration) from kernels group by name").fetchall()}
+        except sqlite3.Error:
+            pass
+        rows = [(n, c, t, durations.get(n, (0, 0))[1]) for n, c, t in (rows or [])]
         if not rows:
             return None, "no %s rows in the rocprofv3 database" % counter
         out = {}
@@ -251,6 +258,7 @@ def main():
         lib.rtgpu_set_concurrency(ctx, 1)
         lib.rtgpu_set_intersection_counters(ctx, 0)
         vp.render(camera, args.warmup)
+        vp.counters()            # the parent's replay reads the counters here (a synchronising call: the pass batches start over)
         vp.render(camera, args.steps)
         lib.rtgpu_synchronize(ctx)
         return

@@ -5,11 +5,11 @@
 // provided below over posix_memalign/free.  No arithmetic on the hot path depends on them.  They are
 // declared (not defined) in the reference's own header Core/Utils/Memory.h:15-29, which is what is
 // included here.  Likewise Core/Utils/MemoryHelpers.cpp (needs <intrin.h>) would define LargeMemCopy, which
-// Bitmap::Copy references; the KAT generator never copies a bitmap, so the symbol only has to exist for the
-// linker -- it aborts if it is ever called.
+// Bitmap::Copy references: a plain memcpy here.
 #include <stdlib.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <string.h>
 #include <algorithm>
 #include <memory>
 #include <string>
@@ -38,6 +38,6 @@ void* SystemAllocator::Allocate(size_t size, size_t alignment) { return DefaultA
 
 void SystemAllocator::Free(void* ptr) { free(ptr); }
 
-void LargeMemCopy(void* __restrict, const void* __restrict, size_t) { abort(); }   // link-only, see the header comment
+void LargeMemCopy(void* __restrict dest, const void* __restrict src, size_t size) { memcpy(dest, src, size); }   // (the reference's is a non-temporal copy)
 
 } // namespace rt

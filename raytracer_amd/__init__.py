@@ -187,6 +187,7 @@ class Scene:
         self._h = C.c_void_p(host_lib().rth_scene_create())
         self._keep = []
         self.built = False
+        self.calls = []     # what was added, in order: ("material", {...}), ("sphere", {...}), ... (plain data; lets a tool rebuild the scene)
 
     def __del__(self):
         try:
@@ -201,16 +202,20 @@ class Scene:
                                              C.c_float(metalness), C.c_float(ior), C.c_float(k))
         if mid < 0:
             raise ValueError("unknown BSDF name %r" % bsdf)
+        self.calls.append(("material", dict(bsdf=bsdf, base_color=tuple(base_color)[:3], emission=tuple(emission)[:3], roughness=roughness, metalness=metalness, ior=ior, k=k)))
         return mid
 
     def add_sphere(self, radius, transform=None, material=-1):
         host_lib().rth_add_sphere(self._h, C.c_float(radius), transform or _IDENTITY, int(material))
+        self.calls.append(("sphere", dict(radius=radius, transform=list(transform or _IDENTITY), material=int(material))))
 
     def add_box(self, size, transform=None, material=-1):
         host_lib().rth_add_box(self._h, _f(size, 3), transform or _IDENTITY, int(material))
+        self.calls.append(("box", dict(size=tuple(size), transform=list(transform or _IDENTITY), material=int(material))))
 
     def add_rect(self, size, transform=None, material=-1, tex_scale=(1.0, 1.0)):
         host_lib().rth_add_rect(self._h, _f(size, 2), _f(tex_scale, 2), transform or _IDENTITY, int(material))
+        self.calls.append(("rect", dict(size=tuple(size), tex_scale=tuple(tex_scale), transform=list(transform or _IDENTITY), material=int(material))))
 
     def add_mesh(self, positions, indices, normals=None, tangents=None, tex_coords=None, material_indices=None, materials=(),
                  transform=None, default_material=-1):
@@ -238,18 +243,22 @@ class Scene:
                                     transform or _IDENTITY, int(default_material))
         if r != 0:
             raise ValueError("mesh rejected (code %d)" % r)
+        self.calls.append(("mesh", dict(positions=pos, indices=idx, normals=nrm, tangents=tan, tex_coords=uv, material_indices=mi, materials=tuple(materials),
+                                        transform=list(transform or _IDENTITY), material=int(default_material))))
 
     def add_area_light(self, shape, params, color, transform=None):
         kind = {"sphere": 0, "box": 1, "rect": 2, "plane": 2}[shape]
         p = list(params) + [0.0] * (4 - len(params))
         if host_lib().rth_add_light_area(self._h, kind, _f(p, 4), _color(color), transform or _IDENTITY) != 0:
             raise ValueError("bad area light")
+        self.calls.append(("area_light", dict(shape=kind, params=tuple(p), color=tuple(color)[:3], transform=list(transform or _IDENTITY))))
 
     def add_background_light(self, color, texture=None):
         if texture is None:
             host_lib().rth_add_light_background(self._h, _color(color))
         elif host_lib().rth_add_light_background_textured(self._h, _color(color), int(texture)) != 0:
             raise ValueError("bad environment map texture")
+        self.calls.append(("background_light", dict(color=tuple(color)[:3], texture=texture)))
 
     # ---- ingestion (helpers::LoadScene / LoadMesh of the reference's Demo, in the C++ host mirror) ------------------
     def load_json(self, path, data_path="", camera=None):
@@ -309,12 +318,15 @@ class Scene:
 
     def add_directional_light(self, color, angle_rad=0.2, transform=None):
         host_lib().rth_add_light_directional(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)
+        self.calls.append(("directional_light", dict(color=tuple(color)[:3], angle=float(angle_rad), transform=list(transform or _IDENTITY))))
 
     def add_point_light(self, color, transform=None):
         host_lib().rth_add_light_point(self._h, _color(color), transform or _IDENTITY)
+        self.calls.append(("point_light", dict(color=tuple(color)[:3], transform=list(transform or _IDENTITY))))
 
     def add_spot_light(self, color, angle_rad, transform=None):
         host_lib().rth_add_light_spot(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)
+        self.calls.append(("spot_light", dict(color=tuple(color)[:3], angle=float(angle_rad), transform=list(transform or _IDENTITY))))
 
     def build(self):
         if host_lib().rth_scene_build(self._h) != 0:
@@ -333,6 +345,7 @@ class Camera:
 
     def __init__(self, translation=(0.0, 0.0, 0.0), orientation_deg=(0.0, 0.0, 0.0), aspect=1.0, fov_deg=20.0):
         self._h = C.c_void_p(host_lib().rth_camera_create())
+        self.settings = dict(dof=False, focal_plane_distance=2.0, aperture=0.1)
         self.set_transform(translation, orientation_deg)
         self.set_perspective(aspect, np.float32(fov_deg) / np.float32(180.0) * np.float32(3.14159265359))
 
@@ -345,12 +358,15 @@ class Camera:
 
     def set_transform(self, translation, orientation_deg=(0.0, 0.0, 0.0)):
         host_lib().rth_camera_set_transform(self._h, _f(translation, 3), _f(orientation_deg, 3))
+        self.settings.update(translation=tuple(translation), orientation_deg=tuple(orientation_deg))
 
     def set_perspective(self, aspect, fov_rad):
         host_lib().rth_camera_set_perspective(self._h, C.c_float(aspect), C.c_float(fov_rad))
+        self.settings.update(aspect=float(aspect), fov_rad=float(fov_rad))
 
     def set_dof(self, enable, focal_plane_distance=2.0, aperture=0.1):
         host_lib().rth_camera_set_dof(self._h, int(bool(enable)), C.c_float(focal_plane_distance), C.c_float(aperture))
+        self.settings.update(dof=bool(enable), focal_plane_distance=float(focal_plane_distance), aperture=float(aperture))
 
     def set_lens(self, bokeh_shape=0, barrel_const=0.01, barrel_variable=0.0):
         """DOFSettings::bokehShape (0 circle, 1 hexagon, 2 square) and the barrel-distortion factors of rt::Camera."""

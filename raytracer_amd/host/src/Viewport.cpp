@@ -427,6 +427,9 @@ bool Viewport::Resize(uint32 width, uint32 height)
     mSum.Init(width, height);
     mSecondarySum.Init(width, height);
     if (mRenderer && !mRenderer->Resize(width, height)) return false;
+    // The reference fills mPixelSalt[width * height] from mRandomGenerator.GetVector4() here (Viewport.cpp:96-102).  Nothing reads the
+    // salts, but the draws advance the generator the anti-aliasing offsets of every pass come from: they are part of the pass sequence.
+    for (uint64 i = 0; i < (uint64)width * height; ++i) (void)mRandomGenerator.GetVector4();
     Reset();
     return true;
 }

@@ -1,0 +1,35 @@
+"""Writes tests/golden/ref_render/<name>.bin: what the REFERENCE'S OWN renderer (Viewport::Render -> PathTracerMIS::RenderPixel, the
+objects of oracle/_ref/libref_partial.a behind oracle/_ref/ref_render; see oracle/ref_harness/ref_render.cpp for the glue) makes of the
+scenes of tests/ref_scenes.py: the float3 sum buffer, the ray counters, the sampler seeds and the anti-aliasing offset of the first
+pass.  Build container only (needs oracle/_ref/ref_render).  Regenerate: python tests/golden/make_ref_render_fixtures.py
+
+File: uint32 magic 'RRF1', width, height, passes, maxRayDepth, samplingAll, dimensions, numSeeds; uint64 numRays, numPrimaryRays,
+numShadowRays, numShadowRaysHit; float32 sampleOffset[2]; uint32 seeds[numSeeds]; float32 image[height][width][3]."""
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import ref_render   # noqa: E402
+import ref_scenes   # noqa: E402
+
+if __name__ == "__main__":
+    for name, (make, w, h, passes, depth, sampling_all, dims) in ref_scenes.FIXTURES.items():
+        scene, camera = make(w / h)
+        path = "/tmp/ref_fixture_%s.bin" % name
+        ref_render.export_scene(path, scene, camera, w, h, passes, 4, depth, dimensions=dims, light_sampling_all=sampling_all, seed=ref_scenes.SEED)
+        stats, out = ref_render.run(path)
+        again, out2 = ref_render.run(path, threads=1)      # the result must not depend on the thread count
+        assert np.array_equal(out["image"], out2["image"]), name
+        os.remove(path)
+        with open(os.path.join(HERE, "ref_render", name + ".bin"), "wb") as f:
+            f.write(struct.pack("<8I", 0x31465252, w, h, passes, depth, int(sampling_all), dims, len(out["first_pass_seeds"])))
+            f.write(struct.pack("<4Q", out["numRays"], out["numPrimaryRays"], out["numShadowRays"], out["numShadowRaysHit"]))
+            f.write(out["first_pass_sample_offset"].astype("<f4").tobytes())
+            f.write(out["first_pass_seeds"].astype("<u4").tobytes())
+            f.write(out["image"].astype("<f4").tobytes())
+        print(name, stats["mean"], out["numRays"], out["numShadowRays"])

@@ -1,0 +1,56 @@
+"""The scenes of the image-level golden fixtures (tests/golden/ref_render/*.bin, produced by the reference's own renderer through
+oracle/_ref/ref_render) -- shared by the generator script and the tests that hold the oracle / the GPU against them."""
+import numpy as np
+
+import raytracer_amd as ra
+from raytracer_amd import scenes
+
+
+def cornell(aspect):
+    return scenes.cornell_box(aspect)
+
+
+def sphere_area(aspect):
+    return scenes.sphere_area_light(aspect)
+
+
+def cornell_two_lights(aspect):
+    d = dict(scenes.CORNELL_BOX)
+    d["lights"] = list(d["lights"]) + [{"type": "background", "color": [0.3, 0.4, 0.6]}]
+    d["objects"] = [o for o in d["objects"] if o["transform"]["translation"] != [0.0, 5.0, 0.0]]   # open the ceiling: the sky gets in
+    return scenes.load_json_scene(d, aspect)
+
+
+def box_mesh(aspect):
+    pos, idx, nrm, tan, uv, mat = scenes.box_mesh(1.0)
+    s = ra.Scene()
+    a = s.add_material("diffuse", (0.8, 0.3, 0.2)); b = s.add_material("roughMetal", (0.9, 0.8, 0.6), roughness=0.3)
+    ground = s.add_material("diffuse", (0.7, 0.7, 0.7))
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, [a, b], transform=ra.transform_from_euler((0.0, 0.0, 0.0), (0.0, 30.0, 0.0)))
+    s.add_rect((6.0, 6.0), ra.transform_from_euler((0.0, -1.0, 0.0), (-90.0, 0.0, 0.0)), ground)
+    s.add_area_light("rect", [1.0, 1.0], (12.0, 11.0, 10.0), ra.transform_from_euler((0.5, 4.0, 0.5), (90.0, 0.0, 0.0)))
+    s.build()
+    return s, ra.Camera((0.0, 2.5, 6.0), (20.0, 180.0, 0.0), aspect, 45.0)
+
+
+def mesh_2k(aspect):
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(2000, seed=5)
+    s = ra.Scene()
+    mats = [s.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    s.add_background_light((1.0, 1.5, 2.0))
+    s.add_directional_light((20000.0, 19000.0, 18000.0), np.float32(1.0) / np.float32(180.0) * np.float32(3.14159265359),
+                            ra.transform_from_euler((0.0, 0.0, 0.0), (80.0, 20.0, 0.0)))
+    s.build()
+    return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+
+
+# name -> (scene function, width, height, passes, maxRayDepth, lightSamplingAll, dimensions)
+FIXTURES = {
+    "cornell": (cornell, 64, 48, 16, 4, False, 64),
+    "sphere_area": (sphere_area, 64, 36, 16, 4, False, 64),
+    "cornell_two_lights_all": (cornell_two_lights, 64, 48, 8, 4, True, 128),
+    "box_mesh": (box_mesh, 64, 48, 8, 5, False, 64),
+    "mesh_2k_all": (mesh_2k, 64, 36, 8, 6, True, 128),
+}
+SEED = 1234

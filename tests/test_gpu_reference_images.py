@@ -1,0 +1,23 @@
+"""The DEVICE against what the reference's own renderer produced (tests/golden/ref_render/*.bin, see test_reference_images.py): the
+rt::Viewport mirror drives the HIP path tracer with the same seed through the same call sequence; tolerance as stated there (the
+reference's _mm_rcp_ss / _mm_rsqrt_ps sites are exact operations on the device)."""
+import numpy as np
+import pytest
+
+import ref_scenes
+import raytracer_amd as ra
+from test_reference_images import compare_with_reference, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(ref_scenes.FIXTURES))
+def test_device_image_matches_the_reference_renderer(built, name):
+    fx = load_fixture(name)
+    scene, camera = ref_scenes.FIXTURES[name][0](fx["w"] / fx["h"])
+    vp = ra.Viewport(fx["w"], fx["h"], seed=ref_scenes.SEED, max_ray_depth=fx["depth"], dimensions=fx["dims"], light_sampling_all=fx["sampling_all"])
+    vp.set_renderer(scene)     # CreateRenderer + SetRenderer + Reset, like the reference's callers
+    vp.render(camera, fx["passes"])
+    img = vp.sum_buffer()
+    frac = compare_with_reference(fx, img, vp.counters())
+    assert frac >= 0.96

@@ -1,0 +1,98 @@
+"""Image-level parity against the REFERENCE'S OWN renderer.  tests/golden/ref_render/*.bin hold what rt::Viewport::Render ->
+rt::PathTracerMIS::RenderPixel -> the reference's traversal / shading object code rendered for five small scenes
+(tests/golden/make_ref_render_fixtures.py; oracle/ref_harness/ref_render.cpp says which few functions around them are glue): the float3
+sum buffer, the ray counters, and the first pass's sampler seeds and anti-aliasing offset.
+
+* The host mirror (rt::Viewport / HaltonSequence / Random of raytracer_amd/host) must reproduce the per-pass constants BIT FOR BIT after
+  the same call sequence (Viewport(), SetRenderingParams, Resize, SetRenderer, Reset): the integer sample streams are then identical.
+* The oracle (and, in test_gpu_reference_images.py, the device) then walks the same paths.  Stated tolerance: the reference evaluates
+  its MIS weights with _mm_rcp_ss (FastDivide, 12 bits) and normalises sphere frames / mesh tangents with _mm_rsqrt_ps, exact operations
+  here; a 2^-12 difference is harmless until it flips a Russian-roulette or hit decision, after which that path is another path.  So:
+  >= 96 % of the pixels within 1e-3 relative (+1e-3 absolute) per channel, mean image within 0.5 %, ray counters within 0.1 %."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import ref_scenes
+import raytracer_amd as ra
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_render")
+
+
+def load_fixture(name):
+    raw = open(os.path.join(GOLDEN, name + ".bin"), "rb").read()
+    magic, w, h, passes, depth, sampling_all, dims, num_seeds = struct.unpack_from("<8I", raw, 0)
+    assert magic == 0x31465252
+    counters = struct.unpack_from("<4Q", raw, 32)
+    off = 64
+    offset = np.frombuffer(raw, np.float32, 2, off); off += 8
+    seeds = np.frombuffer(raw, np.uint32, num_seeds, off); off += 4 * num_seeds
+    image = np.frombuffer(raw, np.float32, w * h * 3, off).reshape(h, w, 3)
+    return dict(w=w, h=h, passes=passes, depth=depth, sampling_all=bool(sampling_all), dims=dims, seeds=seeds, offset=offset, image=image,
+                numRays=counters[0], numPrimaryRays=counters[1], numShadowRays=counters[2], numShadowRaysHit=counters[3])
+
+
+def mirror_viewport(fx):
+    vp = ra.Viewport(fx["w"], fx["h"], seed=ref_scenes.SEED, max_ray_depth=fx["depth"], dimensions=fx["dims"], light_sampling_all=fx["sampling_all"])
+    vp.reset()     # Viewport::SetRenderer is followed by Reset() in every caller (here there is no device to set a renderer on)
+    return vp
+
+
+def compare_with_reference(fx, img, counters):
+    ref = fx["image"]
+    close = np.abs(img - ref) <= 1e-3 * np.abs(ref) + 1e-3
+    frac = float(close.all(axis=2).mean())
+    mean_ref, mean_img = ref.mean(axis=(0, 1)), img.mean(axis=(0, 1))
+    assert frac >= 0.96, "only %.2f %% of the pixels agree with the reference renderer" % (100 * frac)
+    assert np.all(np.abs(mean_img - mean_ref) <= 0.005 * mean_ref + 1e-6), (mean_img, mean_ref)
+    for k in ("numRays", "numShadowRays", "numShadowRaysHit"):
+        assert abs(int(counters[k]) - fx[k]) <= 0.001 * fx[k] + 2, (k, int(counters[k]), fx[k])
+    assert int(counters["numPrimaryRays"]) == fx["numPrimaryRays"]
+    return frac
+
+
+@pytest.mark.parametrize("name", sorted(ref_scenes.FIXTURES))
+def test_pass_constants_and_oracle_image_match_the_reference_renderer(built, name):
+    fx = load_fixture(name)
+    make = ref_scenes.FIXTURES[name][0]
+    scene, camera = make(fx["w"] / fx["h"])
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = mirror_viewport(fx)
+    img = np.zeros((fx["h"], fx["w"], 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for i in range(fx["passes"]):
+        p = vp.next_pass_params(camera)
+        if i == 0:
+            seeds = np.ctypeslib.as_array(p.seed, shape=(p.numDimensions,))
+            assert np.array_equal(seeds, fx["seeds"]), "Halton seeds of the first pass differ from the reference's"
+            assert np.array_equal(np.array([p.sampleOffset[0], p.sampleOffset[1]], np.float32).view(np.uint32), fx["offset"].view(np.uint32)), "anti-aliasing offset differs"
+        oracle_lib.render_pass(desc, p, fx["w"], fx["h"], img, None, cnt, threads=8)
+    counters = {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:12])}
+    frac = compare_with_reference(fx, img, counters)
+    assert frac >= 0.96
+
+
+def test_cornell_statistics_of_the_survey(built):
+    """SURVEY section 6 measured the real reference on the Cornell box (640x480, 16 passes, depth 4): mean RGB 0.268601 / 0.220071 /
+    0.262727, 3.1358 rays per path, 1.5628 shadow rays per path.  Different seed, same estimator: the oracle at 320x240 must land within
+    1.5 % of those means and 1 % of those ratios."""
+    from raytracer_amd import scenes
+    w, h, passes = 320, 240, 16
+    scene, camera = scenes.cornell_box(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=7, max_ray_depth=4)
+    img = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for _ in range(passes):
+        oracle_lib.render_pass(desc, vp.next_pass_params(camera), w, h, img, None, cnt, threads=16)
+    mean = img.mean(axis=(0, 1)) / passes
+    assert np.all(np.abs(mean - np.array([0.268601, 0.220071, 0.262727])) <= 0.015 * mean), mean
+    paths = w * h * passes
+    assert abs(int(cnt[0]) / paths - 3.1358) <= 0.0314 and abs(int(cnt[1]) / paths - 1.5628) <= 0.0157, (int(cnt[0]) / paths, int(cnt[1]) / paths)
