@@ -1432,7 +1432,7 @@ static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* o
     hipError_t e = hipMalloc(&dIn, inBytes ? inBytes : 4);
     if (e == hipSuccess) e = hipMalloc(&dOut, outBytes ? outBytes : 4);
     if (e == hipSuccess) e = hipMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(dOut, 0, outBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, outBytes, c->lanes[0].stream);   // on the kernel's stream: the lanes do not synchronise with the null stream
     if (e == hipSuccess)
     {
         launch(dIn, dOut, c->lanes[0].stream);
@@ -1492,6 +1492,7 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&c->seedRingDev, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->seedRingHost, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&c->passRingDev, (size_t)RT_SEED_RING * sizeof(DevPass));
@@ -1791,6 +1792,7 @@ static int rebuildFilm(RtgpuContext* c)
     HIP_TRY(hipMalloc((void**)&c->secondary, n * sizeof(float)));
     HIP_TRY(hipMemset(c->sum, 0, n * sizeof(float)));
     HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // the batch lanes are non-blocking streams: they do not wait for the null stream's memsets
     c->activeMask.clear();   // a new film starts with the whole image active
     c->vcm.havePhotons = false;   // recorded per slot of the old film
     return rebuildSlots(c);
@@ -1831,6 +1833,7 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
         HIP_TRY(hipMemset(c->secondary, 0, n * sizeof(float)));
     }
     HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // (see rebuildFilm)
     int r = resolveTimed(c); if (r) return r;
     memset(c->kernelMs, 0, sizeof(c->kernelMs)); memset(c->kernelLaunches, 0, sizeof(c->kernelLaunches));
     return RTGPU_OK;
@@ -2149,6 +2152,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV, uint32_t batch)
     HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMemset(v.arena.photonCount, 0, cap * sizeof(uint32_t)));
+    HIP_TRY(hipStreamSynchronize(nullptr));
     v.arena.capacity = (uint32_t)cap; v.arena.maxLV = maxLV;
     for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));

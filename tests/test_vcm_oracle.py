@@ -120,3 +120,18 @@ def test_reference_hash_grid_acceptance_test(built):
             assert len(np.unique(have)) == len(have)      # no cell is visited twice
             nonempty += len(have) > 0
         assert nonempty > min_nonempty     # (the reference's sizes give 0.026 points per query on average)
+
+
+def test_baseline_config5_scene_on_the_oracle(built):
+    """BASELINE configs[4] (scenes.rough_glass_slab, BDPT = "VCM" with merging off, path length 8) through the oracle at reduced size: finite,
+    reproducible, both estimators contribute, and the ground under the slab -- which next event estimation cannot reach through the glass --
+    is lit by the light paths."""
+    w, h = 48, 27
+    scene, camera = scenes.rough_glass_slab(w / h)
+    a = render_vcm(scene, camera, w, h, 8, **scenes.ROUGH_GLASS_SLAB_VCM)
+    b = render_vcm(scene, camera, w, h, 8, **scenes.ROUGH_GLASS_SLAB_VCM)
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    cam, light = a[0], a[1]
+    assert np.isfinite(cam).all() and np.isfinite(light).all()
+    assert cam.mean() > 0.0 and light.mean() > 0.02 * (cam.mean() + light.mean())
+    assert a[3].num_photons() == 0

@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+python -m pytest tests -q -m gpu 2>&1 | grep -v "^$" | tail -30
