@@ -315,7 +315,7 @@ def test_adaptive_rendering_follows_the_reference_block_logic(built):
     scene, camera = scenes.cornell_box(w / h)
     desc = scene.desc
     bn = ra.load_blue_noise(); desc.contents.blueNoise = bn.ctypes.data
-    vp = ra.Viewport(w, h, seed=11, max_ray_depth=3)
+    vp = ra.Viewport(w, h, seed=14, max_ray_depth=3)      # (a seed whose 12 passes show both a split and a drop)
     vp.set_renderer(scene)
     settings = dict(num_initial_passes=4, min_block_size=8, max_block_size=64, subdivision_treshold=0.35, convergence_treshold=0.12)
     vp.set_adaptive(True, **settings)
