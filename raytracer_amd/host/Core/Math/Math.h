@@ -6,6 +6,8 @@
 #pragma once
 
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include <float.h>
 #include <string.h>
@@ -15,6 +17,8 @@
 #include <vector>
 
 #define RAYLIB_API __attribute__((visibility("default")))
+// reference: Core/Common.h:95-103 (a no-op in its FINAL configuration; here a failed check reports and aborts)
+#define RT_ASSERT(expression, ...) do { if (!(expression)) { fprintf(stderr, "[rt] assertion failed: %s (%s:%d)\n", #expression, __FILE__, __LINE__); abort(); } } while (0)
 #define RT_EPSILON (0.000001f)
 #define RT_PI (3.14159265359f)
 #define RT_INV_PI (0.31830988618f)
@@ -30,6 +34,11 @@ using int32 = int32_t;
 using int64 = int64_t;
 
 namespace math {
+
+// Flush-to-zero / denormals-are-zero of the CALLING THREAD's SSE unit (reference: Core/Math/Math.cpp:27-43; its Demo and Tests mains
+// enable it).  The host side here only runs scene construction and the pass prologue; the device keeps IEEE denormals.
+RAYLIB_API void SetFlushDenormalsToZero(bool enable = true);
+RAYLIB_API bool GetFlushDenormalsToZero();
 
 constexpr float DegToRad(const float x) { return x / 180.0f * RT_PI; }   // reference: Core/Math/Math.h:49-52
 constexpr float RadToDeg(const float x) { return x / RT_PI * 180.0f; }

@@ -61,6 +61,10 @@ public:
     // R32G32B32_Float only (the sum buffers): what the rendering tests read
     const math::Vector4 GetPixel(uint32 x, uint32 y, const bool forceLinearSpace = false) const;
     bool Scale(const math::Vector4& factor);
+    // Writes an R32G32B32_Float bitmap (the sum buffers) as an OpenEXR file: channels B, G, R as 32-bit floats, scan lines, no
+    // compression (the reference goes through tinyexr with PIZ compression, Core/Utils/BitmapEXR.cpp:196-279; any EXR reader opens
+    // either).  false for other formats and when the file cannot be created.
+    bool SaveEXR(const char* path, const float exposure = 1.0f) const;
     // raw little-endian dump: "RTF3" magic, width, height (uint32 each), then width*height*3 floats
     bool SaveRaw(const char* path) const;
 private:

@@ -244,6 +244,25 @@ uint32 Entropy::GetInt()
 
 Random::Random() { Reset(); }
 
+void SetFlushDenormalsToZero(bool enable)
+{
+#if defined(__SSE__)
+    unsigned int csr = __builtin_ia32_stmxcsr();
+    csr = enable ? (csr | 0x8040u) : (csr & ~0x8040u);   // FTZ (bit 15) + DAZ (bit 6)
+    __builtin_ia32_ldmxcsr(csr);
+#else
+    (void)enable;
+#endif
+}
+bool GetFlushDenormalsToZero()
+{
+#if defined(__SSE__)
+    return (__builtin_ia32_stmxcsr() & 0x8040u) == 0x8040u;
+#else
+    return true;
+#endif
+}
+
 void Random::Reset()
 {
     Entropy entropy;

@@ -323,6 +323,53 @@ bool Bitmap::Scale(const Vector4& factor)
     return true;
 }
 
+bool Bitmap::SaveEXR(const char* path, const float exposure) const
+{
+    if (mFormat != Format::R32G32B32_Float)
+    {
+        fprintf(stderr, "[rt] ERROR: Bitmap::SaveEXR: Unsupported format\n");
+        return false;
+    }
+    FILE* file = fopen(path, "wb");
+    if (!file)
+    {
+        fprintf(stderr, "[rt] ERROR: Failed to save EXR file '%s'\n", path);
+        return false;
+    }
+    std::vector<uint8> head;
+    auto bytes = [&](const void* p, size_t n) { const uint8* b = static_cast<const uint8*>(p); head.insert(head.end(), b, b + n); };
+    auto text = [&](const char* t) { bytes(t, strlen(t) + 1); };
+    auto i32 = [&](int32 v) { bytes(&v, 4); };
+    auto f32 = [&](float v) { bytes(&v, 4); };
+    auto attribute = [&](const char* name, const char* type, int32 size) { text(name); text(type); i32(size); };
+    i32(20000630); i32(2);                                   // magic, version 2 (scan lines, single part)
+    attribute("channels", "chlist", 3 * 18 + 1);
+    for (const char* channel : { "B", "G", "R" }) { text(channel); i32(2); head.push_back(0); head.push_back(0); head.push_back(0); head.push_back(0); i32(1); i32(1); }   // FLOAT, linear, sampling 1 x 1
+    head.push_back(0);
+    attribute("compression", "compression", 1); head.push_back(0);
+    attribute("dataWindow", "box2i", 16); i32(0); i32(0); i32((int32)mWidth - 1); i32((int32)mHeight - 1);
+    attribute("displayWindow", "box2i", 16); i32(0); i32(0); i32((int32)mWidth - 1); i32((int32)mHeight - 1);
+    attribute("lineOrder", "lineOrder", 1); head.push_back(0);
+    attribute("pixelAspectRatio", "float", 4); f32(1.0f);
+    attribute("screenWindowCenter", "v2f", 8); f32(0.0f); f32(0.0f);
+    attribute("screenWindowWidth", "float", 4); f32(1.0f);
+    head.push_back(0);
+    const size_t lineBytes = 8 + (size_t)mWidth * 12;
+    bool ok = fwrite(head.data(), 1, head.size(), file) == head.size();
+    for (uint32 y = 0; y < mHeight && ok; ++y) { const uint64 offset = head.size() + (uint64)mHeight * 8 + (uint64)y * lineBytes; ok = fwrite(&offset, 8, 1, file) == 1; }
+    std::vector<float> line((size_t)mWidth * 3);
+    for (uint32 y = 0; y < mHeight && ok; ++y)
+    {
+        const float* row = reinterpret_cast<const float*>(mData.data() + (size_t)mStride * y);
+        for (uint32 x = 0; x < mWidth; ++x) for (uint32 c = 0; c < 3; ++c) line[(size_t)c * mWidth + x] = exposure * row[3 * x + (2 - c)];   // planes B, G, R
+        const int32 header[2] = { (int32)y, (int32)(mWidth * 12) };
+        ok = fwrite(header, 4, 2, file) == 2 && fwrite(line.data(), 4, line.size(), file) == line.size();
+    }
+    fclose(file);
+    if (!ok) fprintf(stderr, "[rt] ERROR: Failed to save EXR file '%s'\n", path);
+    return ok;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Textures: device descriptors
 // ---------------------------------------------------------------------------------------------------
