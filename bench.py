@@ -101,15 +101,15 @@ class TileGather:
     """The final exchange of the multi-GPU path: every peer sends the pixels of its own tiles (packed float3) to rank 0, which
     writes them into its sum buffer -- bit-identical to the 1-GPU image because each pixel was accumulated by exactly one rank."""
 
-    def __init__(self, torch, dist, width, height, rank, world, sum_tensor):
+    def __init__(self, torch, dist, width, height, rank, world, sum_tensor, device="cuda"):
         self.torch, self.dist, self.rank, self.world = torch, dist, rank, world
         self.image = sum_tensor.view(-1, 3)
         counts = [len(owned_pixel_indices(width, height, r, world)) for r in range(world)]
         self.pad = max(counts)
-        self.own = torch.from_numpy(owned_pixel_indices(width, height, rank, world)).cuda()
-        self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device="cuda")
-        self.recv = [torch.zeros((self.pad, 3), dtype=torch.float32, device="cuda") for _ in range(world)] if rank == 0 else None
-        self.peers = [torch.from_numpy(owned_pixel_indices(width, height, r, world)).cuda() for r in range(world)] if rank == 0 else None
+        self.own = torch.from_numpy(owned_pixel_indices(width, height, rank, world)).to(device)
+        self.send = torch.zeros((self.pad, 3), dtype=torch.float32, device=device)
+        self.recv = [torch.zeros((self.pad, 3), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+        self.peers = [torch.from_numpy(owned_pixel_indices(width, height, r, world)).to(device) for r in range(world)] if rank == 0 else None
 
     def run(self):
         self.send[:len(self.own)] = self.image.index_select(0, self.own)

@@ -358,6 +358,17 @@ typedef struct RtgpuShard
 /* --- lifetime --------------------------------------------------------------------------------*/
 /* Creates a context on HIP device `deviceIndex` (one context = one device = one host thread at a time). */
 int  rtgpu_create(int deviceIndex, RtgpuContext** outCtx);
+/* One context over several devices of a node: what the reference's ThreadPool does with the tiles of a frame across the cores of a
+ * machine (Viewport.cpp:244-262, ThreadPool.cpp:176-260).  The frame's 64x64 tiles are dealt round-robin to the devices (RtgpuShard),
+ * the scene is replicated by rtgpu_upload_scene, rtgpu_render_pass queues the pass on every device asynchronously, and the read-back
+ * calls (rtgpu_read_sum, rtgpu_get_device_sum, rtgpu_postprocess, rtgpu_compute_block_errors) first gather the peers' tiles into the
+ * first device's buffers (a kernel that reads the peers' HBM over xGMI; hipMemcpyPeerAsync staging without peer access or with
+ * RTGPU_MULTI_STAGED=1).  Results are bit-identical to a one-device context; counters are summed.  deviceIndices == NULL: the first
+ * numDevices visible devices (0 = all).  An index may repeat (two shards on one device: how the path is tested on a 1-GPU box).
+ * Unsupported on such a context: rtgpu_set_shard, RT_INTEGRATOR_VCM / _LIGHT_TRACER (they splat over the whole frame);
+ * rtgpu_get_kernel_times reports the first device. */
+int  rtgpu_create_multi(const int* deviceIndices, uint32_t numDevices, RtgpuContext** outCtx);
+int  rtgpu_num_devices(RtgpuContext* ctx, uint32_t* outCount);
 void rtgpu_destroy(RtgpuContext* ctx);
 const char* rtgpu_last_error(void);
 uint32_t rtgpu_abi_version(void);

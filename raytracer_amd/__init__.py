@@ -397,10 +397,18 @@ class Viewport:
         except Exception:
             pass
 
-    def set_renderer(self, scene, name="Path Tracer MIS", device=-1):
-        """CreateRenderer(name, scene) + SetRenderer.  Raises when the GPU renderer cannot be created."""
+    def set_renderer(self, scene, name="Path Tracer MIS", device=-1, devices=None):
+        """CreateRenderer(name, scene) + SetRenderer.  Raises when the GPU renderer cannot be created.  `devices`: a list of HIP device indices
+        for ONE renderer over several GPUs of the node (SetRendererDevices -> rtgpu_create_multi; an index may repeat)."""
         self._scene = scene
-        r = host_lib().rth_viewport_set_renderer(self._h, scene._h, name.encode(), int(device))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            host_lib().rth_set_renderer_devices(arr, C.c_uint32(len(devices)))
+        try:
+            r = host_lib().rth_viewport_set_renderer(self._h, scene._h, name.encode(), int(device))
+        finally:
+            if devices is not None:
+                host_lib().rth_set_renderer_devices(None, C.c_uint32(0))
         if r != 0:
             err = rtgpu_lib().rtgpu_last_error()
             raise RuntimeError("CreateRenderer(%r) failed (%d): %s" % (name, r, err.decode() if err else ""))

@@ -1227,6 +1227,12 @@ struct RtgpuContext
     // film
     uint32_t width = 0, height = 0;
     RtgpuShard shard = { 0, 1 };
+    // rtgpu_create_multi: the context the caller holds renders shard 0 and owns one more context per further device (shards 1..);
+    // every call fans out, the read-back calls gather the peers' tiles into this context's sum buffers first (rt_multi.inl)
+    std::vector<RtgpuContext*> peers;
+    bool isPeer = false;
+    bool stagedGather = false;         // no peer access between the devices (or RTGPU_MULTI_STAGED=1): hipMemcpyPeerAsync into staging buffers, then the gather
+    float* gatherStage = nullptr; size_t gatherStageFloats = 0;
     float* sum = nullptr;
     float* secondary = nullptr;
     uint32_t* slotPixel = nullptr;
@@ -1446,6 +1452,8 @@ static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* o
     return RTGPU_OK;
 }
 
+#include "rt_multi.inl"
+
 extern "C" {
 
 #define RTGPU_API __attribute__((visibility("default")))
@@ -1508,11 +1516,63 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     return RTGPU_OK;
 }
 
+RTGPU_API int rtgpu_create_multi(const int* deviceIndices, uint32_t numDevices, RtgpuContext** outCtx)
+{
+    if (!outCtx) return fail(RTGPU_ERR_INVALID_ARGUMENT, "outCtx is NULL");
+    *outCtx = nullptr;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) return fail(RTGPU_ERR_NO_DEVICE, "no HIP device available");
+    std::vector<int> devices;
+    if (deviceIndices) devices.assign(deviceIndices, deviceIndices + numDevices);
+    else for (int d = 0; d < (numDevices ? (int)numDevices : visible); ++d) devices.push_back(d);   // NULL: the first numDevices (0: all) visible ones
+    if (devices.empty() || devices.size() > RTGPU_MAX_DEVICES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "1..16 devices");
+    for (int d : devices) if (d < 0 || d >= visible) return fail(RTGPU_ERR_INVALID_ARGUMENT, "device index out of range");
+    RtgpuContext* c = nullptr;
+    int r = rtgpu_create(devices[0], &c); if (r) return r;
+    const uint32_t world = (uint32_t)devices.size();
+    c->shard = { 0u, world };
+    if (const char* e = getenv("RTGPU_MULTI_STAGED")) c->stagedGather = atoi(e) != 0;
+    for (uint32_t k = 1; k < world; ++k)
+    {
+        RtgpuContext* p = nullptr;
+        r = rtgpu_create(devices[k], &p);
+        if (r) { rtgpu_destroy(c); return r; }
+        p->shard = { k, world }; p->isPeer = true;
+        c->peers.push_back(p);
+        if (devices[k] != devices[0] && !c->stagedGather)
+        {
+            // the gather kernel on device 0 reads the peers' sum buffers in place
+            int can = 0;
+            (void)hipSetDevice(devices[0]);
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) != hipSuccess || !can) c->stagedGather = true;
+            else
+            {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) c->stagedGather = true;
+                (void)hipGetLastError();
+            }
+        }
+    }
+    (void)hipSetDevice(devices[0]);
+    *outCtx = c;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_num_devices(RtgpuContext* c, uint32_t* outCount)
+{
+    if (!c || !outCount) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    *outCount = (uint32_t)c->peers.size() + 1u;
+    return RTGPU_OK;
+}
+
 RTGPU_API void rtgpu_destroy(RtgpuContext* c)
 {
     if (!c) return;
+    for (RtgpuContext* p : c->peers) rtgpu_destroy(p);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
     (void)syncLanes(c);
+    if (c->gatherStage) (void)hipFree(c->gatherStage);
     freeScene(c); freeFilm(c);
     for (uint32_t i = 0; i < RT_MAX_LANES; ++i)
     {
@@ -1537,6 +1597,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
 RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
 {
     if (!c || !s) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    RT_FAN_OUT(c, rtgpu_upload_scene(peer, s));   // the scene is replicated: every device traverses its own copy
     if (s->abiVersion != RTGPU_ABI_VERSION) return fail(RTGPU_ERR_INVALID_ARGUMENT, "RtSceneDesc::abiVersion mismatch");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
@@ -1802,6 +1863,7 @@ RTGPU_API int rtgpu_resize(RtgpuContext* c, uint32_t width, uint32_t height)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (width == 0 || height == 0 || width > 65536u || height > 65536u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid viewport size");
+    RT_FAN_OUT(c, rtgpu_resize(peer, width, height));
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(syncLanes(c));
@@ -1813,6 +1875,7 @@ RTGPU_API int rtgpu_set_shard(RtgpuContext* c, RtgpuShard shard)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (shard.worldSize == 0 || shard.rank >= shard.worldSize) return fail(RTGPU_ERR_INVALID_ARGUMENT, "invalid shard");
+    if (!c->peers.empty() || c->isPeer) return fail(RTGPU_ERR_UNSUPPORTED, "a multi-device context shards the frame itself (rtgpu_create_multi)");
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(syncLanes(c));
@@ -1823,6 +1886,7 @@ RTGPU_API int rtgpu_set_shard(RtgpuContext* c, RtgpuShard shard)
 RTGPU_API int rtgpu_reset(RtgpuContext* c)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    RT_FAN_OUT(c, rtgpu_reset(peer));
     HIP_TRY(hipSetDevice(c->device));
     { int fr = flushPending(c); if (fr) return fr; }
     HIP_TRY(syncLanes(c));
@@ -2454,6 +2518,9 @@ RTGPU_API int rtgpu_set_integrator(RtgpuContext* c, uint32_t integrator, const R
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (integrator > RT_INTEGRATOR_LIGHT_TRACER) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown integrator");
+    if ((!c->peers.empty() || c->isPeer) && (integrator == RT_INTEGRATOR_VCM || integrator == RT_INTEGRATOR_LIGHT_TRACER))
+        return fail(RTGPU_ERR_UNSUPPORTED, "VCM and the Light Tracer splat over the whole frame: they need a single-device context (rtgpu_create)");
+    RT_FAN_OUT(c, rtgpu_set_integrator(peer, integrator, vcm));
     int r = rtgpu_synchronize(c); if (r) return r;
     RtVcmParams vp; defaultVcmParams(vp);
     if (vcm) vp = *vcm;
@@ -2477,6 +2544,7 @@ RTGPU_API int rtgpu_set_debug_rendering_mode(RtgpuContext* c, uint32_t mode)
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (mode >= DBG_NUM_MODES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown DebugRenderingMode");
     if (c->debugMode < 0) return fail(RTGPU_ERR_NOT_READY, "the integrator is not RT_INTEGRATOR_DEBUG");
+    RT_FAN_OUT(c, rtgpu_set_debug_rendering_mode(peer, mode));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->debugMode = (int)mode;
     return RTGPU_OK;
@@ -2504,6 +2572,8 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     if (p->numDimensions > 0 && !p->seed) return fail(RTGPU_ERR_INVALID_ARGUMENT, "seed is NULL");
     if (p->maxRayDepth >= 255u) return fail(RTGPU_ERR_INVALID_ARGUMENT, "maxRayDepth must be < 255");
     if (p->camera.dofEnable && p->camera.bokehShape > 2u) return fail(RTGPU_ERR_UNSUPPORTED, "bokeh shapes: circle, hexagon, square (NGon is a TODO in the reference, texture-shaped bokeh is not implemented)");
+    RT_FAN_OUT(c, rtgpu_render_pass(peer, p));   // asynchronous on every device: the shards render side by side
+    HIP_TRY(hipSetDevice(c->device));
     if (c->numSlots == 0) return RTGPU_OK;   // this shard owns no pixels
     if (c->vcm.enabled) return vcmRenderPass(c, p);
     if (c->lightTracer) return lightTracerRenderPass(c, p);
@@ -2544,6 +2614,9 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
 RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    // every device's queued passes are submitted before the first wait, so that the tails run side by side
+    for (RtgpuContext* peer : c->peers) { HIP_TRY(hipSetDevice(peer->device)); int r = flushPending(peer); if (r) return r; }
+    RT_FAN_OUT(c, rtgpu_synchronize(peer));
     HIP_TRY(hipSetDevice(c->device));
     { int r = vcmFlush(c); if (r) return r; }
     { int r = flushPending(c); if (r) return r; }
@@ -2557,6 +2630,7 @@ RTGPU_API int rtgpu_read_sum(RtgpuContext* c, float* sumRGB, float* secondaryRGB
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
     int r = rtgpu_synchronize(c); if (r) return r;
+    r = gatherPeers(c); if (r) return r;
     const size_t bytes = (size_t)c->width * c->height * 3 * sizeof(float);
     if (sumRGB) HIP_TRY(hipMemcpy(sumRGB, c->sum, bytes, hipMemcpyDeviceToHost));
     if (secondaryRGB) HIP_TRY(hipMemcpy(secondaryRGB, c->secondary, bytes, hipMemcpyDeviceToHost));
@@ -2567,6 +2641,8 @@ RTGPU_API int rtgpu_get_device_sum(RtgpuContext* c, void** sumDevice, void** sec
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
+    int r = rtgpu_synchronize(c); if (r) return r;   // the pointers are handed out with every queued pass accumulated
+    r = gatherPeers(c); if (r) return r;
     if (sumDevice) *sumDevice = c->sum;
     if (secondaryDevice) *secondaryDevice = c->secondary;
     if (numFloats) *numFloats = (size_t)c->width * c->height * 3;
@@ -2586,12 +2662,21 @@ RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
     out->numMeshHits = host[C_MESH_HITS]; out->numAnalyticHits = host[C_ANALYTIC_HITS];
     out->numShadowRayBoxTests = host[C_BOX_SHADOW]; out->numShadowRayTriangleTests = host[C_TRI_SHADOW];
     out->numRetracedRays = host[RT_COUNTER_RETRACED];
+    for (RtgpuContext* peer : c->peers)
+    {
+        RtCounters pc;
+        r = rtgpu_get_counters(peer, &pc); if (r) return r;
+        uint64_t* a = (uint64_t*)out; const uint64_t* b = (const uint64_t*)&pc;
+        for (size_t i = 0; i < sizeof(RtCounters) / sizeof(uint64_t); ++i) a[i] += b[i];
+    }
+    HIP_TRY(hipSetDevice(c->device));
     return RTGPU_OK;
 }
 
 RTGPU_API int rtgpu_set_intersection_counters(RtgpuContext* c, int enable)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    RT_FAN_OUT(c, rtgpu_set_intersection_counters(peer, enable));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->countIntersections = enable != 0;
     return RTGPU_OK;
@@ -2614,6 +2699,7 @@ RTGPU_API int rtgpu_compute_block_errors(RtgpuContext* c, uint32_t numPasses, ui
     int r = checkBlocks(c, numBlocks, blocks); if (r) return r;
     if (numBlocks == 0) return RTGPU_OK;
     r = rtgpu_synchronize(c); if (r) return r;
+    r = gatherPeers(c); if (r) return r;
     std::vector<ErrorRow> rows; std::vector<uint32_t> firstRow(numBlocks);
     for (uint32_t i = 0; i < numBlocks; ++i)
     {
@@ -2649,6 +2735,7 @@ RTGPU_API int rtgpu_set_active_blocks(RtgpuContext* c, uint32_t numBlocks, const
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (!c->sum) return fail(RTGPU_ERR_NOT_READY, "rtgpu_resize has not been called");
     int r = checkBlocks(c, numBlocks, blocks); if (r) return r;
+    RT_FAN_OUT(c, rtgpu_set_active_blocks(peer, numBlocks, blocks));
     r = rtgpu_synchronize(c); if (r) return r;
     c->activeMask.clear();
     if (numBlocks)
@@ -2695,6 +2782,7 @@ RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, u
     if (p->tonemapper > RT_TONEMAPPER_ACES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown tonemapper");
     if (p->numPasses == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "numPasses must be > 0");
     int r = rtgpu_synchronize(c); if (r) return r;
+    r = gatherPeers(c); if (r) return r;
     const size_t pixels = (size_t)c->width * c->height;
     uint32_t* dFront = nullptr;
     HIP_TRY(hipMalloc((void**)&dFront, pixels * sizeof(uint32_t)));
@@ -2823,6 +2911,7 @@ RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
     if (lanes < 1 || lanes > RT_MAX_LANES) return fail(RTGPU_ERR_INVALID_ARGUMENT, "lanes must be 1..6");
+    RT_FAN_OUT(c, rtgpu_set_concurrency(peer, lanes));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->numLanes = lanes; c->nextLane = 0; c->lanesChosen = true;
     return RTGPU_OK;
@@ -2831,6 +2920,7 @@ RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)
 RTGPU_API int rtgpu_enable_timing(RtgpuContext* c, int enable)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    RT_FAN_OUT(c, rtgpu_enable_timing(peer, enable));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->timing = enable != 0;
     return RTGPU_OK;

@@ -29,6 +29,10 @@ public:
     RtgpuContext* GetDeviceContext() const { return mCtx; }
     bool SetShard(uint32 rank, uint32 worldSize);
 
+protected:
+    // wholeFrameOnOneDevice: integrators that splat over the frame (Light Tracer, VCM) ignore SetRendererDevices
+    PathTracerMIS(const Scene& scene, bool wholeFrameOnOneDevice);
+
 private:
     bool EnsureSceneUploaded();
     RtgpuContext* mCtx = nullptr;

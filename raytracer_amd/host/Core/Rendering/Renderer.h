@@ -5,6 +5,8 @@
 // (Renderer.h:33 "TODO batch & multisample rendering") is the one implemented here: RenderPass().
 #pragma once
 
+#include <vector>
+
 #include "Context.h"
 #include "../Scene/Scene.h"
 #include "../Scene/Camera.h"
@@ -40,11 +42,15 @@ private:
 };
 using RendererPtr = std::shared_ptr<IRenderer>;
 
-// "Path Tracer MIS" -> the MI355X path tracer.  Every other name of the reference's factory
-// ("Path Tracer", "Light Tracer", "Debug", "VCM") is outside the hot-path scope: returns nullptr and logs.
+// The reference's factory (Core/Rendering/Renderer.cpp:20-46): "Path Tracer MIS" (the hot path), "Path Tracer", "Light Tracer",
+// "Debug" and "VCM", all on the device; an unknown name logs and returns nullptr.
 RAYLIB_API RendererPtr CreateRenderer(const std::string& name, const Scene& scene);
 
 // Device selection for renderers created afterwards (default 0, or LOCAL_RANK when set).
 RAYLIB_API void SetRendererDevice(int deviceIndex);
+RAYLIB_API int GetRendererDevice();   // -1: the default
+// Several devices of the node for ONE renderer (rtgpu_create_multi: the frame's 64x64 tiles are dealt to them, the read-back calls gather);
+// an empty list goes back to one device.  The environment variable RTGPU_DEVICES ("0,1,2,3", or "all") does the same without a code change.
+RAYLIB_API void SetRendererDevices(const std::vector<int>& deviceIndices);
 
 } // namespace rt

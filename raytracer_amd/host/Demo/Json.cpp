@@ -50,10 +50,17 @@ struct Parser
         return true;
     }
 
+    // objects / arrays nest by recursion: a bounded depth keeps a hostile file from running the stack out (scene files nest 4 deep)
+    static constexpr int MaxDepth = 128;
+    int depth = 0;
+    struct DepthGuard { int& d; explicit DepthGuard(int& d_) : d(d_) { ++d; } ~DepthGuard() { --d; } };
+
     bool ParseValue(Value& v)
     {
         SkipWs();
         if (p >= end) return Fail("The document is empty.");
+        DepthGuard guard(depth);
+        if (depth > MaxDepth) return Fail("The document nests too deeply.");
         if (*p == '{')
         {
             v.type = Value::Type::Object; ++p; SkipWs();

@@ -160,8 +160,19 @@ bool LoadMeshStreams(const std::string& filePath, MaterialsMap& outMaterials, co
     for (size_t faceIndex = 0; faceIndex < numFaces; faceIndex++)
     {
         const obj::Index idx[3] = { model.indices[3 * faceIndex + 0], model.indices[3 * faceIndex + 1], model.indices[3 * faceIndex + 2] };
-        const bool hasNormals = idx[0].normal_index >= 0 && idx[1].normal_index >= 0 && idx[2].normal_index >= 0;
-        const bool hasTexCoords = idx[0].texcoord_index >= 0 && idx[1].texcoord_index >= 0 && idx[2].texcoord_index >= 0;
+        // a face that names a vertex the file never defined is a load error; a normal / uv out of range counts as missing
+        const int numVertices = (int)(model.vertices.size() / 3), numNormals = (int)(model.normals.size() / 3), numTexCoords = (int)(model.texcoords.size() / 2);
+        bool hasNormals = true, hasTexCoords = true;
+        for (size_t i = 0; i < 3; i++)
+        {
+            if (idx[i].vertex_index < 0 || idx[i].vertex_index >= numVertices)
+            {
+                fprintf(stderr, "[rt] ERROR: Mesh '%s': face %zu references vertex %d of %d\n", filePath.c_str(), faceIndex, idx[i].vertex_index + 1, numVertices);
+                return false;
+            }
+            hasNormals = hasNormals && idx[i].normal_index >= 0 && idx[i].normal_index < numNormals;
+            hasTexCoords = hasTexCoords && idx[i].texcoord_index >= 0 && idx[i].texcoord_index < numTexCoords;
+        }
         Vector4 verts[3];
         for (size_t i = 0; i < 3; i++)
             verts[i] = scale * Vector4(model.vertices[3 * idx[i].vertex_index + 0], model.vertices[3 * idx[i].vertex_index + 1], model.vertices[3 * idx[i].vertex_index + 2]);

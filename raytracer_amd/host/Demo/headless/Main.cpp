@@ -1,7 +1,8 @@
 // Headless counterpart of the reference's Demo (Demo/Main.cpp:6-40 takes -w/--width, -h/--height, -s/--scene, --renderer,
 // --data and opens a window): loads a JSON scene with helpers::LoadScene, renders N passes with the device "Path Tracer MIS"
 // through the same rt::Viewport API the window loop uses (Demo.cpp: Resize -> SetRenderer -> Render per frame ->
-// GetFrontBuffer) and writes the tone-mapped front buffer as a BMP.  The extra options are --passes, --depth, --output.
+// GetFrontBuffer) and writes the tone-mapped front buffer as a BMP.  The extra options are --passes, --depth, --output, --seed;
+// the environment variable RTGPU_DEVICES ("0,1,2,3" / "all") spreads the frame over several GPUs (Core/Rendering/Renderer.h).
 #include "../Demo.h"
 #include "../SceneLoader.h"
 #include "../../Core/Rendering/Viewport.h"
@@ -40,6 +41,7 @@ int main(int argc, char* argv[])
 {
     uint32 width = 1280, height = 720, passes = 64, depth = 20;
     std::string scenePath, rendererName = "Path Tracer MIS", output = "out.bmp";
+    unsigned long long seed = 0; bool haveSeed = false;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -52,7 +54,8 @@ int main(int argc, char* argv[])
         else if (a == "--passes") passes = (uint32)atoi(value("--passes"));
         else if (a == "--depth") depth = (uint32)atoi(value("--depth"));
         else if (a == "--output") output = value("--output");
-        else { fprintf(stderr, "usage: rt_demo -s scene.json [--data dir/] [-w W] [-h H] [--passes N] [--depth D] [--renderer name] [--output out.bmp]\n"); return 2; }
+        else if (a == "--seed") { seed = strtoull(value("--seed"), nullptr, 10); haveSeed = true; }
+        else { fprintf(stderr, "usage: rt_demo -s scene.json [--data dir/] [-w W] [-h H] [--passes N] [--depth D] [--renderer name] [--output out.bmp] [--seed N]\n"); return 2; }
     }
     if (scenePath.empty()) { fprintf(stderr, "no scene given (-s scene.json)\n"); return 2; }
 
@@ -65,6 +68,7 @@ int main(int argc, char* argv[])
     Viewport viewport;
     RenderingParams params;
     params.maxRayDepth = depth;
+    if (haveSeed) viewport.SetSeed(seed);   // reproducible frames (the reference seeds its generators from the clock)
     if (!viewport.SetRenderingParams(params) || !viewport.Resize(width, height)) return 1;
     RendererPtr renderer = CreateRenderer(rendererName, scene);
     if (!renderer) { fprintf(stderr, "renderer '%s' is not available (no GPU?)\n", rendererName.c_str()); return 1; }

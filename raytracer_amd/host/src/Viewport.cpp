@@ -11,6 +11,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace rt {
 
@@ -696,8 +697,32 @@ const RayTracingCounters& Viewport::GetCounters()
 IRenderer::~IRenderer() = default;
 
 static int gRendererDevice = -1;
+static std::vector<int> gRendererDevices;
 
-void SetRendererDevice(int deviceIndex) { gRendererDevice = deviceIndex; }
+void SetRendererDevice(int deviceIndex) { gRendererDevice = deviceIndex; gRendererDevices.clear(); }
+int GetRendererDevice() { return gRendererDevice; }
+void SetRendererDevices(const std::vector<int>& deviceIndices) { gRendererDevices = deviceIndices; }
+
+// the devices of the next multi-device renderer: SetRendererDevices, else RTGPU_DEVICES ("0,1,2,3" / "all"); empty: one device
+static bool MultiDeviceList(std::vector<int>& out, bool& all)
+{
+    out = gRendererDevices; all = false;
+    if (out.empty())
+        if (const char* e = getenv("RTGPU_DEVICES"))
+        {
+            if (strcmp(e, "all") == 0) { all = true; return true; }
+            for (const char* p = e; *p;)
+            {
+                char* end = nullptr;
+                const long d = strtol(p, &end, 10);
+                if (end == p) break;
+                out.push_back((int)d);
+                p = (*end == ',') ? end + 1 : end;
+                if (*end != ',' ) break;
+            }
+        }
+    return out.size() > 1;
+}
 
 static int DefaultDevice()
 {
@@ -765,12 +790,17 @@ static bool LoadBlueNoise(std::vector<uint16>& out)
     return false;
 }
 
-PathTracerMIS::PathTracerMIS(const Scene& scene)
+PathTracerMIS::PathTracerMIS(const Scene& scene) : PathTracerMIS(scene, false) {}
+
+PathTracerMIS::PathTracerMIS(const Scene& scene, bool wholeFrameOnOneDevice)
     : IRenderer(scene)
     , mLightSamplingWeight(1.0f)
     , mBSDFSamplingWeight(1.0f)
 {
-    if (rtgpu_create(DefaultDevice(), &mCtx) != RTGPU_OK)
+    std::vector<int> devices; bool all = false;
+    const bool multi = !wholeFrameOnOneDevice && MultiDeviceList(devices, all);
+    const int r = multi ? rtgpu_create_multi(all ? nullptr : devices.data(), all ? 0u : (uint32_t)devices.size(), &mCtx) : rtgpu_create(DefaultDevice(), &mCtx);
+    if (r != RTGPU_OK)
     {
         fprintf(stderr, "[rt] ERROR: cannot create device context: %s\n", rtgpu_last_error());
         mCtx = nullptr;
@@ -822,7 +852,7 @@ PathTracer::PathTracer(const Scene& scene) : PathTracerMIS(scene)
 }
 const char* PathTracer::GetName() const { return "Path Tracer"; }
 
-LightTracer::LightTracer(const Scene& scene) : PathTracerMIS(scene)
+LightTracer::LightTracer(const Scene& scene) : PathTracerMIS(scene, true)
 {
     if (GetDeviceContext() && rtgpu_set_integrator(GetDeviceContext(), RT_INTEGRATOR_LIGHT_TRACER, nullptr) != RTGPU_OK)
         fprintf(stderr, "[rt] ERROR: cannot select the light tracer: %s\n", rtgpu_last_error());
@@ -846,7 +876,7 @@ bool DebugRenderer::RenderPass(const RtPassParams& params)
 }
 
 VertexConnectionAndMerging::VertexConnectionAndMerging(const Scene& scene)
-    : PathTracerMIS(scene)
+    : PathTracerMIS(scene, true)
     , mVertexConnectingWeight(1.0f), mVertexMergingWeight(1.0f), mCameraConnectingWeight(1.0f)
     , mMaxPathLength(10), mInitialMergingRadius(0.02f), mMinMergingRadius(0.02f), mMergingRadiusMultiplier(1.0f)   // VertexConnectionAndMerging.cpp:53-71
     , mUseVertexConnection(true), mUseVertexMerging(true)

@@ -361,11 +361,16 @@ RTH_API void rth_viewport_set_seed(void* v, uint64_t seed) { static_cast<Viewpor
 RTH_API int rth_viewport_set_renderer(void* v, void* sh, const char* name, int device)
 {
     ViewportHandle* vh = static_cast<ViewportHandle*>(v);
+    // the device applies to THIS renderer only: the process-wide default is put back afterwards
+    const int previous = GetRendererDevice();
     if (device >= 0) SetRendererDevice(device);
     vh->renderer = CreateRenderer(name, static_cast<SceneHandle*>(sh)->scene);
+    if (device >= 0) SetRendererDevice(previous);
     if (!vh->renderer) return -2;
     return vh->viewport.SetRenderer(vh->renderer) ? 0 : -1;
 }
+// the devices of renderers created afterwards (SetRendererDevices); n == 0: back to one device
+RTH_API void rth_set_renderer_devices(const int* devices, uint32_t n) { SetRendererDevices(std::vector<int>(devices, devices + n)); }
 // the public knobs of the "VCM" renderer (no-op with -3 when the viewport's renderer is not VCM); weights = 5 scalars:
 // bsdf, light, vertexConnecting, cameraConnecting, vertexMerging
 RTH_API int rth_viewport_set_vcm(void* v, uint32_t maxPathLength, int useVertexConnection, int useVertexMerging, float initialMergingRadius,
@@ -438,7 +443,9 @@ RTH_API int rth_viewport_set_shard(void* v, uint32_t rank, uint32_t world)
 {
     ViewportHandle* vh = static_cast<ViewportHandle*>(v);
     PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(vh->renderer.get());
-    return (pt && pt->SetShard(rank, world)) ? 0 : -1;
+    if (!pt || !pt->SetShard(rank, world)) return -1;
+    vh->viewport.Reset();   // the device film was cleared with the ownership change: the host's sums, pass count and block list start over with it
+    return 0;
 }
 RTH_API uint32_t rth_viewport_passes_finished(void* v) { return static_cast<ViewportHandle*>(v)->viewport.GetPassesFinished(); }
 // adaptive rendering (RenderingParams::adaptiveSettings) and progress

@@ -132,6 +132,28 @@ def test_json_loader_rejects_what_the_reference_rejects(built, tmp_path):
         ra.Scene().load_json(bad)
 
 
+def test_malformed_inputs_fail_to_load_instead_of_reading_out_of_bounds(built, tmp_path):
+    scene_file = tmp_path / "mesh.json"
+    scene_file.write_text(json.dumps({"objects": [{"type": "mesh", "path": "broken.obj", "scale": 1.0}]}))
+    # a face that references vertex 9 of a file that defines 3: a load error
+    (tmp_path / "broken.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(ValueError):
+        ra.Scene().load_json(scene_file, data_path=str(tmp_path) + "/")
+    # normal / uv indices beyond what the file defines count as missing: the face normal and zero uv are used
+    (tmp_path / "broken.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nvt 0.5 0.5\nf 1/7/5 2/1/1 3/1/1\n")
+    scene = ra.Scene().load_json(scene_file, data_path=str(tmp_path) + "/")
+    scene.build()
+    d = scene.desc.contents
+    assert d.numTriangles == 1
+    shading = np.ctypeslib.as_array(C.cast(d.vertexShading, C.POINTER(C.c_float)), shape=(d.numVertices, 8))
+    assert np.isfinite(shading).all()
+    # 100 000 nested arrays: an error, not a stack overflow
+    deep = tmp_path / "deep.json"
+    deep.write_text('{"objects": ' + "[" * 100000 + "]" * 100000 + "}")
+    with pytest.raises(ValueError):
+        ra.Scene().load_json(deep)
+
+
 def test_camera_world_to_screen_matches_reference(built):
     """Camera::SetPerspective's mWorldToScreen (FastInverseNoScale x MakePerspective, with the reference's operation
     order and its stray w lanes) recomputed by the host mirror from the camera_film.kat inputs: bit-exact."""

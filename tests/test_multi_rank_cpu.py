@@ -1,7 +1,7 @@
 """N > 1 path on CPU: two gloo ranks each render the tiles they own (with the CPU oracle standing in for the
-device pass -- same shard arithmetic, same per-pass constants from the same seed), the float3 sum buffers
-(disjoint support) are sum-reduced to rank 0 exactly like bench.py does over RCCL, and the result must equal the
-unsharded image bit for bit."""
+device pass -- same shard arithmetic, same per-pass constants from the same seed), rank 0 gathers the peers' owned
+tiles with bench.py's own TileGather (the class the RCCL run uses, on CPU tensors here), and the result must equal
+the unsharded image bit for bit -- including -0.0 and the untouched pixels of rank 0."""
 import os
 import subprocess
 import sys
@@ -31,8 +31,14 @@ cnt = np.zeros(16, dtype=np.uint64)
 for _ in range(2):
     p = vp.next_pass_params(camera)
     oracle_lib.render_pass(scene.desc, p, w, h, img, None, cnt, shard=(rank, world), threads=2)
+import bench
 t = torch.from_numpy(img)
-dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+own = bench.owned_pixel_indices(w, h, rank, world)
+others = np.setdiff1d(np.arange(w * h), own)
+assert not img.reshape(-1, 3)[others].any()            # a shard never touches a pixel it does not own
+gather = bench.TileGather(torch, dist, w, h, rank, world, t.view(-1), device="cpu")
+gather.run()
+gather.run()                                           # idempotent: the bench warms the collective with one extra call
 rays = torch.tensor([int(cnt[0])], dtype=torch.int64)
 dist.all_reduce(rays)
 if rank == 0:
