@@ -72,10 +72,10 @@ def make_viewport(ra, args, scene, device, shard=None):
     from raytracer_amd import scenes
     vp = ra.Viewport(args.width, args.height, seed=SEED, max_ray_depth=args.depth)
     if args.workload == "bdpt-glass":
-        vp.set_renderer(scene, name="VCM", device=device)
+        vp.set_renderer(scene, name="VCM", device=device, intersection_counters=False)
         vp.set_vcm(**scenes.ROUGH_GLASS_SLAB_VCM)
     else:
-        vp.set_renderer(scene, device=device)
+        vp.set_renderer(scene, device=device, intersection_counters=False)   # the library's default (the reference's): counters off
     if shard is not None and shard[1] > 1:
         vp.set_shard(*shard)
     return vp
@@ -130,15 +130,19 @@ def algorithmic_bytes(c):
 
 
 # kernel-name prefix (as rocprofv3 reports it) -> kernel class of rtgpu_get_kernel_times
-KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_trace", "trace"), ("k_shade", "shade"), ("k_vcm_light_finish", "accumulate"),
-                         ("k_vcm_camera_finish", "accumulate"), ("k_vcm_emit", "generate"), ("k_vcm_", "shade"), ("k_lt_shade", "shade"),
-                         ("k_generate", "generate"), ("k_accumulate", "accumulate"))
+KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_trace_wide", "trace"), ("k_trace_quant", "trace"), ("k_trace", "trace"), ("k_shade", "shade"),
+                         ("k_vcm_light_finish", "accumulate"), ("k_vcm_camera_finish", "accumulate"), ("k_vcm_emit", "generate"), ("k_vcm_", "shade"),
+                         ("k_lt_shade", "shade"), ("k_generate", "generate"), ("k_accumulate", "accumulate"))
 
 
-def kernel_class(name):
+def kernel_class(name, reencoded_walk=False):
+    """reencoded_walk: the run's traversal kernel is k_trace_wide / k_trace_quant; the binary-tree k_trace then only re-traces the few rays
+    those hand over (the library's class "retrace")."""
     base = name.replace("void ", "").strip()
     for prefix, cls in KERNEL_CLASS_PREFIXES:
         if base.startswith(prefix):
+            if prefix == "k_trace" and reencoded_walk:
+                return "retrace"
             return cls
     return None
 
@@ -178,8 +182,9 @@ def pmc_child_sums(args, counter, timeout_s):
         if not rows:
             return None, "no %s rows in the rocprofv3 database" % counter
         out = {}
+        reencoded = any(n.replace("void ", "").strip().startswith(("k_trace_wide", "k_trace_quant")) for n, _, _, _ in rows)
         for name, launches, total, ns in rows:
-            cls = kernel_class(name)
+            cls = kernel_class(name, reencoded)
             if cls:
                 a = out.setdefault(cls, [0.0, 0, 0])
                 a[0] += float(total); a[1] += int(launches); a[2] += int(ns or 0)
@@ -295,9 +300,11 @@ def main():
         gather.run()
         torch.cuda.synchronize()
     if rank == 0:
-        host.rth_viewport_read_sum(vp._h, host_sum.ctypes.data_as(C.POINTER(C.c_float)), None)   # synchronises: Viewport::GetSumBuffer
+        host.rth_viewport_fetch_sum(vp._h)   # Viewport::GetSumBuffer: synchronises, the frame is in the viewport's (page-locked) host bitmap afterwards
     sync_all()
     elapsed = time.perf_counter() - t0
+    if rank == 0:
+        host.rth_viewport_read_sum(vp._h, host_sum.ctypes.data_as(C.POINTER(C.c_float)), None)   # a copy of that bitmap for the checks below
 
     c1 = vp.counters()
     delta = {k: c1[k] - c0[k] for k in c1}

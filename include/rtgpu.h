@@ -394,7 +394,14 @@ int rtgpu_synchronize(RtgpuContext* ctx);
  *     NULL.  Synchronises. */
 int rtgpu_read_sum(RtgpuContext* ctx, float* sumRGB, float* secondaryRGB);
 
-/* Device pointers of the float3 sum buffers (for RCCL gather/reduce by the caller). */
+/* Optional: page-locks (hipHostRegister) a host buffer the caller passes to rtgpu_read_sum / rtgpu_postprocess again and again, so
+ * that the copies run at the PCIe link's rate (a 1080p float3 frame: ~0.6 ms instead of ~3 ms).  Unregister before freeing the
+ * buffer.  RTGPU_ERR_NO_DEVICE / RTGPU_ERR_DEVICE when it cannot be done: the buffer then simply stays pageable. */
+int rtgpu_host_register(RtgpuContext* ctx, void* ptr, size_t bytes);
+int rtgpu_host_unregister(RtgpuContext* ctx, void* ptr);
+
+/* Device pointers of the float3 sum buffers (for RCCL gather/reduce by the caller).  Synchronises first (and gathers, on a
+ * multi-device context): the buffers hold every pass queued so far. */
 int rtgpu_get_device_sum(RtgpuContext* ctx, void** sumDevice, void** secondaryDevice, size_t* numFloats);
 
 /* Counters accumulated since the last rtgpu_reset (Viewport::GetCounters is per pass; callers
@@ -403,8 +410,11 @@ int rtgpu_get_counters(RtgpuContext* ctx, RtCounters* out);
 
 /* Box / triangle test counters (numRayBoxTests ... numShadowRayTriangleTests).  In the reference they exist only
  * under the compile-time switch RT_ENABLE_INTERSECTION_COUNTERS (Core/Config.h:4, off by default); here they are a
- * run-time switch, ON by default.  numRays / numShadowRays / numShadowRaysHit / numPrimaryRays / hit counts are
- * always maintained.  Synchronises. */
+ * run-time switch, OFF by default like there (the environment variable RTGPU_INTERSECTION_COUNTERS=1 turns them on for
+ * contexts created afterwards).  They are the counters of the REFERENCE'S walk: with the switch on, every ray walks the binary
+ * tree in the reference's order (k_trace); with it off, single-mesh scenes walk the 4-wide collapse of the same tree
+ * (k_trace_wide: same hits, another visiting order; RTGPU_WIDE=0 keeps the binary walk).  numRays / numShadowRays /
+ * numShadowRaysHit / numPrimaryRays / hit counts are always maintained.  Synchronises. */
 int rtgpu_set_intersection_counters(RtgpuContext* ctx, int enable);
 
 /* ---------------------------------------------------------------------------------------------

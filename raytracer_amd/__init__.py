@@ -397,9 +397,11 @@ class Viewport:
         except Exception:
             pass
 
-    def set_renderer(self, scene, name="Path Tracer MIS", device=-1, devices=None):
+    def set_renderer(self, scene, name="Path Tracer MIS", device=-1, devices=None, intersection_counters=True):
         """CreateRenderer(name, scene) + SetRenderer.  Raises when the GPU renderer cannot be created.  `devices`: a list of HIP device indices
-        for ONE renderer over several GPUs of the node (SetRendererDevices -> rtgpu_create_multi; an index may repeat)."""
+        for ONE renderer over several GPUs of the node (SetRendererDevices -> rtgpu_create_multi; an index may repeat).
+        `intersection_counters`: this wrapper is test / bench plumbing and turns the box / triangle test counters ON (the library's default is
+        the reference's: off) so that parity tests can compare them; pass False for the library's default walk (bench.py does)."""
         self._scene = scene
         if devices is not None:
             arr = (C.c_int * len(devices))(*[int(d) for d in devices])
@@ -413,6 +415,8 @@ class Viewport:
             err = rtgpu_lib().rtgpu_last_error()
             raise RuntimeError("CreateRenderer(%r) failed (%d): %s" % (name, r, err.decode() if err else ""))
         self.has_renderer = True
+        if intersection_counters:
+            rtgpu_lib().rtgpu_set_intersection_counters(self.device_context(), 1)
         self.reset()
 
     def set_vcm(self, max_path_length=10, use_vertex_connection=True, use_vertex_merging=True, initial_merging_radius=0.02,
@@ -513,6 +517,7 @@ class Viewport:
             raw = RtCounters()
             if rtgpu_lib().rtgpu_get_counters(self.device_context(), C.byref(raw)) == 0:
                 d["numRetracedRays"] = int(raw.numRetracedRays)
+                d["numUntrustedRays"], d["numStackOverflowRays"], d["diag2"] = int(raw._reserved[0]), int(raw._reserved[1]), int(raw._reserved[2])
         return d
 
     @property

@@ -633,6 +633,7 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
 
 #define RT_COUNTER_RETRACED 12   // counters[]: rays k_trace_quant handed to the binary-tree kernel (RtCounters::numRetracedRays)
 #include "rt_trace_quant.inl"
+#include "rt_trace_wide.inl"
 
 RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
 RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
@@ -1245,19 +1246,22 @@ struct RtgpuContext
     // a plane of box faces can take 30 000) overlaps with the next batch's kernels instead of idling the chip.
     // Only k_accumulate is ordered across lanes (an event): the film is summed in pass order.
     BatchLane lanes[RT_MAX_LANES];
-    uint32_t numLanes = 3;
+    uint32_t numLanes = 4;
     bool lanesChosen = false;          // by RTGPU_LANES or rtgpu_set_concurrency; otherwise shards (< 1.1 M owned pixels) run 4 lanes
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
     QuantBvh quant;                    // 32-byte child pairs of a single-mesh scene (rt_trace_quant.inl); pairs == nullptr: none
+    WideBvh wide;                      // 4-wide collapse of the same tree (rt_trace_wide.inl); nodes == nullptr: none
+    bool wideAllowed = true;           // RTGPU_WIDE=0: single-mesh scenes walk the binary tree (k_trace) even with the intersection counters off
     bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
     bool denseAllowed = true;          // RTGPU_NO_DENSE=1: path state stays in the pixel's slot for the whole path (the first layout)
     bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
-    bool countIntersections = true;    // box / triangle test counters (RT_ENABLE_INTERSECTION_COUNTERS of the reference)
+    bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
+                                       // rtgpu_set_intersection_counters, or RTGPU_INTERSECTION_COUNTERS=1 for the default of new contexts
     unsigned long long* counters = nullptr;   // 16 x u64
 
     // passes queued by rtgpu_render_pass and not yet submitted: up to passBatch of them ride through ONE launch
@@ -1269,6 +1273,8 @@ struct RtgpuContext
     // the next one grows by 8 passes up to 24 (8 -> 2100, 16 -> 2125-2190, 24 -> 2195-2210 Msamples/s over 256 passes); any
     // synchronising call starts over at the base size, so a caller that renders few passes between read-backs keeps the small batches.
     uint32_t passBatchBase = 8;
+    uint32_t batchesAtThisSize = 0;    // full batches submitted at the current passBatch
+    uint32_t batchesSinceSync = 0;     // batches submitted since the last synchronising call (their lanes are busy)
     DevPass* passRingDev = nullptr;
     DevPass* passRingHost = nullptr;    // pinned
 
@@ -1481,6 +1487,9 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_QUANT")) c->quantAllowed = atoi(e) != 0;
+    if (const char* e = getenv("RTGPU_WIDE")) c->wideAllowed = atoi(e) != 0;
+    if (const char* e = getenv("RTGPU_INTERSECTION_COUNTERS")) c->countIntersections = atoi(e) != 0;
+    memset(&c->wide, 0, sizeof(c->wide));
     if (const char* e = getenv("RTGPU_LDS_TOP")) c->ldsTopAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_NO_DENSE")) c->denseAllowed = atoi(e) == 0;
     memset(&c->quant, 0, sizeof(c->quant));
@@ -1765,6 +1774,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
     // single-mesh scenes (Scene::Traverse's one-object bypass): the re-encoded tree of the default traversal kernel
     memset(&c->quant, 0, sizeof(c->quant));
+    memset(&c->wide, 0, sizeof(c->wide));
     if (s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH)
     {
         const RtMesh& mesh = s->meshes[s->objects[0].meshIndex];
@@ -1776,6 +1786,14 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
             if ((r = uploadArray(c, q.gate.data(), q.gate.size(), &devGate))) return r;
             c->quant.pairs = devPairs; c->quant.gate = devGate; c->quant.root = q.root; c->quant.stackNeed = q.stackNeed;
             memcpy(c->quant.base, q.base, sizeof(q.base)); memcpy(c->quant.step, q.step, sizeof(q.step)); memcpy(c->quant.bound, q.bound, sizeof(q.bound));
+            const WideBuild w = buildWideBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, q);
+            if (w.ok)
+            {
+                const float4* devWide = nullptr;
+                if ((r = uploadArray(c, w.nodes.data(), w.nodes.size(), &devWide))) return r;
+                c->wide.nodes = devWide; c->wide.gate = devGate; c->wide.numNodes = (uint32_t)(w.nodes.size() / 4u);
+                memcpy(c->wide.base, q.base, sizeof(q.base)); memcpy(c->wide.step, q.step, sizeof(q.step)); memcpy(c->wide.bound, q.bound, sizeof(q.bound));
+            }
         }
     }
     c->sceneDev = d;
@@ -1828,14 +1846,15 @@ static int rebuildSlots(RtgpuContext* c)
     // (measured on 1/8 of the Sponza-class frame: 0.57 -> 0.50 ms per pass), a full frame 8
     if (!c->passBatchFromEnv)
     {
-        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : 2u;   // full frames: 2 -> 4 -> 8 -> 16 -> 24 while streaming (flushPending)
+        static const uint32_t streamBase = getenv("RTGPU_PASS_BATCH_BASE") ? (uint32_t)atoi(getenv("RTGPU_PASS_BATCH_BASE")) : 5u;
+        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : (streamBase ? streamBase : 1u);   // full frames: 5 -> 10 -> 20 -> 24 while streaming, one size per round of the lanes (flushBatch)
         // (very large frames: fewer passes per launch, an arena of 8 passes of an 8K frame would be 47 GB)
         while (c->passBatch > 1u && (size_t)c->numSlots * c->passBatch * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4) > ((size_t)24 << 30)) c->passBatch /= 2u;
     }
     c->passBatchBase = c->passBatch;
-    // a shard's launches are shorter, their tails relatively longer: one more lane to overlap them (1/4 and 1/8 of the
-    // Sponza-class frame: +1.9 % / +3.6 %; the full frame gains nothing from a fourth lane)
-    if (!c->lanesChosen) { c->numLanes = c->numSlots != 0 && c->numSlots < 1100000u ? 4u : 3u; if (c->nextLane >= c->numLanes) c->nextLane = 0; }
+    // four batch lanes: with the short re-trace launches behind k_trace_wide and streams that start with small batches, a fourth
+    // concurrent launch sequence pays on full frames too (20 passes between read-backs: +4.6 %; 64 and 256 passes: unchanged)
+    if (!c->lanesChosen) { c->numLanes = 4u; if (c->nextLane >= c->numLanes) c->nextLane = 0; }
     if (c->numSlots)
     {
         HIP_TRY(hipMalloc((void**)&c->slotPixel, slots.size() * sizeof(uint32_t)));
@@ -1990,12 +2009,32 @@ static void launchTraceQuant(RtgpuContext* c, hipStream_t stream, const Paths& p
 #undef RT_LAUNCH_QUANT
 }
 
+// The 4-wide tree: single-mesh scenes, intersection counters off (they belong to the reference's walk).  Stack: 24 entries per lane, a
+// ray that would need more goes to the binary-tree kernel.
+static bool useWide(const RtgpuContext* c) { return c->wide.nodes != nullptr && c->wideAllowed && !c->countIntersections; }
+
+static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
+                            uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset,
+                            const uint32_t* denseCounts, uint32_t denseShardCapacity)
+{
+    WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity };
+    const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
+    LaunchTimer t(c, stream, KC_TRACE);
+    static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)
+    static const bool unsorted = getenv("RTGPU_WIDE_UNSORTED") != nullptr; // experiments: deferred children in slot order / no leaf set aside
+    static const bool eager = getenv("RTGPU_WIDE_POSTPONE_LEAVES") == nullptr;
+#define RT_LAUNCH_WIDE(D, S, P) hipLaunchKernelGGL((k_trace_wide<24, D, S, P>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
+    if (diag) { if (unsorted) { if (eager) RT_LAUNCH_WIDE(true, false, false); else RT_LAUNCH_WIDE(true, false, true); } else { if (eager) RT_LAUNCH_WIDE(true, true, false); else RT_LAUNCH_WIDE(true, true, true); } }
+    else { if (unsorted) { if (eager) RT_LAUNCH_WIDE(false, false, false); else RT_LAUNCH_WIDE(false, false, true); } else { if (eager) RT_LAUNCH_WIDE(false, true, false); else RT_LAUNCH_WIDE(false, true, true); } }
+#undef RT_LAUNCH_WIDE
+}
+
 // Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.
-static int flushPending(RtgpuContext* c)
+static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 {
     if (c->pending.empty()) return RTGPU_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t numPasses = (uint32_t)c->pending.size();
+    const uint32_t numPasses = maxPasses && maxPasses < c->pending.size() ? maxPasses : (uint32_t)c->pending.size();
     const DevPass& first = c->pending[0].pass;
     const uint32_t maxLights = first.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
     BatchLane& l = c->lanes[c->nextLane];
@@ -2068,11 +2107,29 @@ static int flushPending(RtgpuContext* c)
                 tune.denseCounts = haveClosest ? l.denseCounts + (size_t)plane * depth : nullptr; tune.denseShardCapacity = shardCapacity;
                 const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
                 const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
-                LaunchTimer t(c, l.stream, KC_TRACE);
 #define RT_LAUNCH_TRACE_DENSE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, in, (const uint32_t*)nullptr, (const uint32_t*)nullptr, tsq, tsc, cursors + depth, c->counters, tune)
+                if (useWide(c))
+                {
+                    // the 4-wide tree serves the launch; what it does not trust goes through the binary-tree kernel right behind it (a small grid: few rays)
+                    uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
+                    uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
+                    uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
+                    launchTraceWide(c, l.stream, in, nullptr, nullptr, tsq, tsc, cursors + depth, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, 0.0001f,
+                                    tune.denseCounts, shardCapacity);
+                    TravTuning exactTune = c->tune;
+                    LaunchTimer t(c, l.stream, KC_RETRACE);
+                    const dim3 retraceGrid(c->numCUs);
+                    if (stackClass == 24u) hipLaunchKernelGGL((k_trace<24, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
+                    else if (stackClass == 32u) hipLaunchKernelGGL((k_trace<32, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
+                    else hipLaunchKernelGGL((k_trace<64, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
+                }
+                else
+                {
+                LaunchTimer t(c, l.stream, KC_TRACE);
                 if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(24, true); else RT_LAUNCH_TRACE_DENSE(24, false); }
                 else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(32, true); else RT_LAUNCH_TRACE_DENSE(32, false); }
                 else { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(64, true); else RT_LAUNCH_TRACE_DENSE(64, false); }
+                }
 #undef RT_LAUNCH_TRACE_DENSE
             }
             // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
@@ -2111,12 +2168,14 @@ static int flushPending(RtgpuContext* c)
             const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
-            if (useQuant(c))
+            if (useWide(c) || useQuant(c))
             {
                 // the re-encoded tree serves the launch; what it does not trust goes through the binary-tree kernel right behind it
                 uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
                 uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
                 uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
+                if (useWide(c)) launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f, nullptr, 0u);
+                else
                 launchTraceQuant(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
                 tq = l.exactQueue; tqc = exactCounts + launchIndex; tsq = l.exactShadowQueue; tsc = exactShadowCounts + launchIndex;
                 uint32_t* cursors = exactCursors;
@@ -2156,13 +2215,16 @@ static int flushPending(RtgpuContext* c)
     }
     HIP_TRY(hipEventRecord(l.accumulated, l.stream));
     c->lastAccumulateLane = laneIndex;
-    c->pending.clear();
+    c->pending.erase(c->pending.begin(), c->pending.begin() + numPasses);
+    c->batchesSinceSync++;
     // a stream starts with small batches (a caller that renders 4 or 8 passes and reads back gets two or three overlapping launch
     // sequences instead of one: +7 %) and grows while the caller keeps streaming
-    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch)
+    if (!c->passBatchFromEnv && c->numSlots >= 400000u && numPasses == c->passBatch && ++c->batchesAtThisSize >= c->numLanes)
     {
-        const uint32_t next = c->passBatch < 8u ? c->passBatch * 2u : c->passBatch + 8u;
-        if (next <= maxStreamingBatch(c)) c->passBatch = next;
+        // every lane has one batch of this size in flight: the next round of the lanes carries twice as many passes
+        uint32_t next = c->passBatch * 2u;
+        if (next > maxStreamingBatch(c)) next = maxStreamingBatch(c);
+        if (next > c->passBatch) { c->passBatch = next; c->batchesAtThisSize = 0; }
     }
     HIP_TRY(hipGetLastError());
     for (uint32_t i = 0; i < numPasses; ++i)
@@ -2170,6 +2232,25 @@ static int flushPending(RtgpuContext* c)
         HIP_TRY(hipEventRecord(c->seedEvents[firstSlot + i], l.stream));
         c->seedEventUsed[firstSlot + i] = true;
     }
+    return RTGPU_OK;
+}
+
+// Submits everything that is queued.  What is left when the caller stops streaming (a synchronising call, a parameter change) goes out
+// as one batch per free lane instead of one batch: the launch sequences of the parts overlap, which hides the tails of their persistent
+// launches (20 passes between read-backs: 8 + 12 -> 8 + 6 + 6 on three lanes).  Results do not depend on the split.
+static int flushPending(RtgpuContext* c)
+{
+    if (c->pending.empty()) return RTGPU_OK;
+    uint32_t parts = 1;
+    if (c->numSlots >= 400000u && !c->passBatchFromEnv && !c->vcm.enabled)
+    {
+        const uint32_t lanesFree = c->batchesSinceSync ? c->numLanes - 1u : c->numLanes;
+        parts = (uint32_t)c->pending.size() / 2u;
+        if (parts > lanesFree) parts = lanesFree;
+        if (parts < 1u) parts = 1u;
+    }
+    const uint32_t each = ((uint32_t)c->pending.size() + parts - 1u) / parts;
+    while (!c->pending.empty()) { const int r = flushBatch(c, each); if (r) return r; }
     return RTGPU_OK;
 }
 
@@ -2607,7 +2688,7 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
     }
     c->pending.push_back(std::move(pd));
     const uint32_t lightLimit = maxBatchFor(c, pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u);
-    if (c->pending.size() >= (c->passBatch < lightLimit ? c->passBatch : lightLimit)) return flushPending(c);
+    if (c->pending.size() >= (c->passBatch < lightLimit ? c->passBatch : lightLimit)) return flushBatch(c, 0u);
     return RTGPU_OK;
 }
 
@@ -2621,6 +2702,7 @@ RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
     { int r = vcmFlush(c); if (r) return r; }
     { int r = flushPending(c); if (r) return r; }
     HIP_TRY(syncLanes(c));
+    c->batchesSinceSync = 0; c->batchesAtThisSize = 0;
     if (!c->passBatchFromEnv) c->passBatch = c->passBatchBase;
     return resolveTimed(c);
 }
@@ -2634,6 +2716,25 @@ RTGPU_API int rtgpu_read_sum(RtgpuContext* c, float* sumRGB, float* secondaryRGB
     const size_t bytes = (size_t)c->width * c->height * 3 * sizeof(float);
     if (sumRGB) HIP_TRY(hipMemcpy(sumRGB, c->sum, bytes, hipMemcpyDeviceToHost));
     if (secondaryRGB) HIP_TRY(hipMemcpy(secondaryRGB, c->secondary, bytes, hipMemcpyDeviceToHost));
+    return RTGPU_OK;
+}
+
+// page-locked host memory for the read-back calls: hipMemcpy into registered memory runs at the PCIe link's rate
+RTGPU_API int rtgpu_host_register(RtgpuContext* c, void* ptr, size_t bytes)
+{
+    if (!c || !ptr || !bytes) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? RTGPU_ERR_NO_DEVICE : RTGPU_ERR_DEVICE, std::string("hipHostRegister: ") + hipGetErrorString(e)); }
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_host_unregister(RtgpuContext* c, void* ptr)
+{
+    if (!c || !ptr) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const hipError_t e = hipHostUnregister(ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(RTGPU_ERR_DEVICE, std::string("hipHostUnregister: ") + hipGetErrorString(e)); }
     return RTGPU_OK;
 }
 
@@ -2662,6 +2763,7 @@ RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
     out->numMeshHits = host[C_MESH_HITS]; out->numAnalyticHits = host[C_ANALYTIC_HITS];
     out->numShadowRayBoxTests = host[C_BOX_SHADOW]; out->numShadowRayTriangleTests = host[C_TRI_SHADOW];
     out->numRetracedRays = host[RT_COUNTER_RETRACED];
+    out->_reserved[0] = host[RT_COUNTER_RETRACED + 1]; out->_reserved[1] = host[RT_COUNTER_RETRACED + 2]; out->_reserved[2] = host[RT_COUNTER_RETRACED + 3];   // diagnostics of the re-encoded walks: untrusted rays, stack overflows
     for (RtgpuContext* peer : c->peers)
     {
         RtCounters pc;

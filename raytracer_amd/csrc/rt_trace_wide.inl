@@ -1,0 +1,392 @@
+// rt_trace_wide.inl -- traversal of single-mesh scenes over a 4-WIDE tree collapsed from the reference's binary tree (same SAH splits,
+// same leaves), one ray per lane.  Included by rt_kernels.hip after rt_trace_quant.inl, whose grid, leaf gates and exactness argument it
+// shares.
+//
+// Why.  k_trace waits ~0.8 us per dependent node fetch with 20 waves per CU to hide it: the walk is a chain of ~33 round
+// trips per ray.  Two earlier attempts changed what a round trip moves -- half the bytes (k_trace_quant: no gain, the conversions ate
+// it), a quad of lanes per ray (1.7x slower, instruction bound) -- not how many there are.  A 4-wide node halves the chain: one round
+// trip fetches four children (64 bytes: four of k_trace_quant's 16-byte records), i.e. two levels of the binary tree at once, and the
+// per-step overhead (stack, loop, scheduling ballots) is paid half as often.
+//
+// Node n = records nodes[4 n .. 4 n + 3], one per child: {min.xyz, max.xyz as 16-bit grid coordinates (rounded outwards, QuantBvh's
+// grid), reference}.  A reference is an interior node's index, a leaf (first triangle | count << 30, the binary tree's own leaves of
+// one or two triangles), or RT_WIDE_EMPTY behind a degenerate box for the unused slots of a node with two or three children.
+//
+// Exactness: k_trace_quant's argument word for word (conservative boxes visit a superset of the reference's leaves in another order;
+// a leaf's triangles count only behind the leaf's exact box; runner-up within tol, zero direction components, far origins -> the
+// binary-tree kernel decides), plus one more hand-over: a ray whose stack would overflow.
+
+#define RT_WIDE_EMPTY 0xC0000000u    // leaf count 3 never occurs in the reference's trees (BVHBuilder.h:16): "no child"
+
+struct WideBvh
+{
+    const float4* nodes;
+    const float4* gate;      // QuantBvh::gate
+    uint32_t numNodes;
+    float base[3], step[3], bound[3];
+};
+
+struct WideTuning
+{
+    uint32_t refillMinIdle, otherMinLanes;
+    float shadowOffset;
+    uint32_t* exactQueue; uint32_t* exactCount;               // closest-hit rays handed to the binary-tree kernel
+    uint32_t* exactShadowQueue; uint32_t* exactShadowCount;   // any-hit requests handed to it
+    const uint32_t* denseCounts; uint32_t denseShardCapacity; // dense path state (TravTuning)
+};
+
+// slab test of one child record against the ray's folded constants; near is clamped to >= 0 (a sort key).  (One packed fma per axis,
+// v_pk_fma_f32 over {min plane, max plane}, measured 2 % slower than six scalar fmas: the operands have to be paired up first.)
+#define RT_WIDE_SLAB(q, nearOut, farOut)                                                                                                          \
+    {                                                                                                                                             \
+        const uint32_t w0 = ubits(q.x), w1 = ubits(q.y), w2 = ubits(q.z);                                                                         \
+        const float nx = __fmaf_rn((float)(w0 & 0xFFFFu), ax, bx), ny = __fmaf_rn((float)(w0 >> 16), ay, by), nz = __fmaf_rn((float)(w1 & 0xFFFFu), az, bz); \
+        const float xx = __fmaf_rn((float)(w1 >> 16), ax, bx), xy = __fmaf_rn((float)(w2 & 0xFFFFu), ay, by), xz = __fmaf_rn((float)(w2 >> 16), az, bz);     \
+        nearOut = fmaxf(fmaxf(fminf(nx, xx), fminf(ny, xy)), fmaxf(fminf(nz, xz), 0.0f));                                                          \
+        farOut = fminf(fminf(fmaxf(nx, xx), fmaxf(ny, xy)), fmaxf(nz, xz));                                                                       \
+    }
+#define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
+
+template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
+                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                         const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
+                                                         uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
+{
+    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
+    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
+    if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
+    const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
+    const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
+    const M4 invTransform = loadM4(scene.objects[0].invTransform);
+    const RtTriangle* const tris = scene.triangles + scene.meshes[scene.objects[0].meshIndex].firstTriangle;
+    const float inf = __uint_as_float(0x7f800000u);
+
+    // per-lane ray state
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;     // local ray (triangle tests, leaf gate)
+    float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;     // folded slab constants: t(q) = fma(q, a, b)
+    float best = 0, second = 0, tol = 0;
+    uint32_t cur = RT_QUANT_DONE, pend = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;   // pend: a leaf set aside while the lane keeps walking interior nodes
+    bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
+    uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
+    uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
+
+    uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
+    chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
+    WaveChunk chunk = { 0u, 0u };
+
+    // kDiag: wave clock per phase (0 refill, 1 interior loop, 2 leaf / finish) and the number of times each ran
+    unsigned long long diagClock[3] = { 0ull, 0ull, 0ull }, diagPrev = kDiag ? (unsigned long long)clock64() : 0ull, diagStart = diagPrev;
+    uint32_t diagRuns[3] = { 0u, 0u, 0u }, diagPhase = 0u;
+    for (;;)
+    {
+        if (kDiag) { const unsigned long long now = (unsigned long long)clock64(); diagClock[diagPhase] += now - diagPrev; diagPrev = now; }
+        const bool interior = have && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
+        const bool other = have && !interior;      // at a leaf, or finished
+        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
+        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
+        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
+        {
+            // ---- refill ----
+            if (kDiag) { diagPhase = 0u; diagRuns[0]++; }
+            if (chunk.next >= chunk.end)
+            {
+                waveClaimChunk(chunk, cursor, chunkSize, count);
+                if (chunk.next >= chunk.end) { exhausted = true; continue; }
+            }
+            const uint32_t idx = waveTake(!have, chunk);
+            if (idx != 0xFFFFFFFFu)
+            {
+                shadow = idx >= numClosest;
+                const uint32_t request = shadow ? shadowQueue[idx - numClosest]
+                                                : (tune.denseCounts ? denseLiveSlot(sDensePrefix, tune.denseShardCapacity, idx) : (queue ? queue[idx] : idx));
+                Ray world;
+                float maxDistance = inf;
+                if (shadow)
+                {
+                    light = request / paths.capacity; slot = request - light * paths.capacity;
+                    const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
+                    world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
+                    world.origin = world.origin + world.dir * tune.shadowOffset;   // PathTracerMIS.cpp:86
+                    maxDistance = dirTmax.w;                                       // hitPoint.distance = illuminateResult.distance * 0.999f
+                }
+                else
+                {
+                    slot = request; light = 0u;
+                    const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
+                    world = makePathRay(origin, dir, ubits(origin.w) & 0xFFu);
+                }
+                const Ray local = transformRayUnsafe(invTransform, world);   // MeshShape is entered in object space, Scene.cpp:128-145
+                // largest magnitude a slab test of this ray can produce, per axis; 2^-21 of it bounds the folded test's rounding
+                const float mx = fabsf(local.originDivDir.x) + bvh.bound[0] * fabsf(local.invDir.x);
+                const float my = fabsf(local.originDivDir.y) + bvh.bound[1] * fabsf(local.invDir.y);
+                const float mz = fabsf(local.originDivDir.z) + bvh.bound[2] * fabsf(local.invDir.z);
+                const float fold = 4.76837158203125e-07f;   // 2^-21
+                const bool trusted = rayIsNaNFree(local) &&
+                                     mx * fold < bvh.step[0] * fabsf(local.invDir.x) && my * fold < bvh.step[1] * fabsf(local.invDir.y) && mz * fold < bvh.step[2] * fabsf(local.invDir.z);
+                if (!trusted)
+                {
+                    // a zero direction component (NaNs in the reference's slab test) or an origin far outside the mesh: the reference's walk only
+                    if (shadow) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
+                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
+                    numRetraced++; numUntrusted++;
+                }
+                else
+                {
+                    ox = local.origin.x; oy = local.origin.y; oz = local.origin.z; dx = local.dir.x; dy = local.dir.y; dz = local.dir.z;
+                    ax = bvh.step[0] * local.invDir.x; ay = bvh.step[1] * local.invDir.y; az = bvh.step[2] * local.invDir.z;
+                    bx = __fmaf_rn(bvh.base[0], local.invDir.x, -local.originDivDir.x);
+                    by = __fmaf_rn(bvh.base[1], local.invDir.y, -local.originDivDir.y);
+                    bz = __fmaf_rn(bvh.base[2], local.invDir.z, -local.originDivDir.z);
+                    tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
+                    best = maxDistance; second = inf; occluded = false; overflow = false;
+                    sp = 0u; cur = 0u; pend = RT_QUANT_DONE;   // node 0 holds the children of the binary tree's root
+                    have = true;
+                    if (shadow) numShadowRays++;   // (a request handed to the binary-tree kernel is counted there)
+                }
+            }
+            continue;
+        }
+        if ((mI | mO) == 0ull) break;
+        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
+        {
+            // ---- interior phase: four conservative slab tests per step, until enough lanes wait at a leaf or are finished ----
+            if (kDiag) { diagPhase = 1u; diagRuns[1]++; }
+            bool in = interior;
+            const float limit = best + (tol + tol);   // box occlusion with the slack that keeps every candidate within tol of the final hit in the walk
+            for (;;)
+            {
+                if (kDiag) { diagSlots++; if (in) diagVisits++; }
+                if (in)
+                {
+                    const float4* p = bvh.nodes + 4u * cur;
+                    const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                    float n0, f0, n1, f1, n2, f2, n3, f3;
+                    RT_WIDE_SLAB(q0, n0, f0); RT_WIDE_SLAB(q1, n1, f1); RT_WIDE_SLAB(q2, n2, f2); RT_WIDE_SLAB(q3, n3, f3);
+                    if (kSort)
+                    {
+                        // sort keys: entry distance (>= 0, so its bits order like the float) with the child's slot in the two low bits; a miss sorts last
+                        const uint32_t miss = 0xFFFFFFFFu;
+                        uint32_t k0 = (f0 >= n0 && n0 < limit) ? ((ubits(n0) & ~3u) | 0u) : miss;
+                        uint32_t k1 = (f1 >= n1 && n1 < limit) ? ((ubits(n1) & ~3u) | 1u) : miss;
+                        uint32_t k2 = (f2 >= n2 && n2 < limit) ? ((ubits(n2) & ~3u) | 2u) : miss;
+                        uint32_t k3 = (f3 >= n3 && n3 < limit) ? ((ubits(n3) & ~3u) | 3u) : miss;
+                        // five compare-exchanges: (0,1) (2,3) (0,2) (1,3) (1,2)
+                        uint32_t t;
+                        t = min(k0, k1); k1 = max(k0, k1); k0 = t;
+                        t = min(k2, k3); k3 = max(k2, k3); k2 = t;
+                        t = min(k0, k2); k2 = max(k0, k2); k0 = t;
+                        t = min(k1, k3); k3 = max(k1, k3); k1 = t;
+                        t = min(k1, k2); k2 = max(k1, k2); k1 = t;
+                        const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
+#define RT_WIDE_REF(k) (((k) & 2u) ? (((k) & 1u) ? r3 : r2) : (((k) & 1u) ? r1 : r0))
+                        // farthest first, so that the nearest child is walked next
+                        if (k3 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k3); ++sp; }
+                        if (k2 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k2); ++sp; }
+                        if (k1 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k1); ++sp; }
+                        if (k0 != miss) cur = RT_WIDE_REF(k0);
+                        else if (sp == 0u) cur = RT_QUANT_DONE;
+                        else { --sp; cur = stack[sp * RT_BLOCK]; }
+#undef RT_WIDE_REF
+                    }
+                    else
+                    {
+                    // the nearest child is walked next; the other children the ray enters are deferred (in slot order: any order gives the
+                    // same candidates, and a full sort costs more instructions than the occasional later cull saves)
+                    const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
+                    const uint32_t miss = 0xFFFFFFFFu;
+                    const uint32_t k0 = h0 ? ((ubits(n0) & ~3u) | 0u) : miss, k1 = h1 ? ((ubits(n1) & ~3u) | 1u) : miss;   // entry distance >= 0: its bits order like the float
+                    const uint32_t k2 = h2 ? ((ubits(n2) & ~3u) | 2u) : miss, k3 = h3 ? ((ubits(n3) & ~3u) | 3u) : miss;
+                    const uint32_t kMin = min(min(k0, k1), min(k2, k3));
+                    const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
+                    if (h0 && k0 != kMin) { stack[sp * RT_BLOCK] = r0; ++sp; }
+                    if (h1 && k1 != kMin) { stack[sp * RT_BLOCK] = r1; ++sp; }
+                    if (h2 && k2 != kMin) { stack[sp * RT_BLOCK] = r2; ++sp; }
+                    if (h3 && k3 != kMin) { stack[sp * RT_BLOCK] = r3; ++sp; }
+                    if (kMin != miss) cur = (kMin & 2u) ? ((kMin & 1u) ? r3 : r2) : ((kMin & 1u) ? r1 : r0);
+                    else if (sp == 0u) cur = RT_QUANT_DONE;
+                    else { --sp; cur = stack[sp * RT_BLOCK]; }
+                    }
+                    if (sp + 3u > (uint32_t)kStack) { overflow = true; cur = RT_QUANT_DONE; }   // the next step could not push: the binary-tree kernel takes the ray
+                    // kPostpone (an experiment that did not pay: interior-loop lane utilisation 0.52 -> 0.55, 4 % more visits from the later culling,
+                    // and a leaf phase twice as long: k_trace_wide 156 -> 171 ms): the first leaf a lane reaches is set aside and the lane goes on
+                    // with its next deferred node, so that it stays in this loop.  Any order gives the same candidates.
+                    if (kPostpone && RT_WIDE_IS_LEAF(cur) && pend == RT_QUANT_DONE && sp != 0u) { pend = cur; --sp; cur = stack[sp * RT_BLOCK]; }
+                }
+                in = in && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
+                const unsigned long long m = __ballot(in);
+                if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
+            }
+        }
+        else if (kDiag && (diagPhase = 2u, diagRuns[2]++, false)) {}
+        else if (other)
+        {
+            // ---- leaves (the current one and the one set aside): MeshShape::Traverse_Leaf(_Shadow), MeshShape.cpp:134-207 ----
+#pragma unroll 1
+            for (int which = 0; which < (kPostpone ? 2 : 1); ++which)
+            {
+                const uint32_t leaf = which == 0 ? cur : pend;
+                if (!RT_WIDE_IS_LEAF(leaf) || occluded) continue;
+                if (kDiag) diagLeaves++;
+                const uint32_t numLeaves = leaf >> RT_NODE_LEAVES_SHIFT, first = leaf & RT_NODE_CHILD_MASK;
+                Ray ray; ray.origin = V4(ox, oy, oz, 0.0f); ray.dir = V4(dx, dy, dz, 0.0f);
+                V4 v0, e1, e2, nv0, ne1, ne2;
+                loadTriangle(tris + first, v0, e1, e2);
+                loadTriangle(tris + first + (numLeaves > 1u ? 1u : 0u), nv0, ne1, ne2);   // the second triangle of the leaf rides in the same round trip
+                float u0, v0_, t0, u1 = 0.0f, v1 = 0.0f, t1 = inf;
+                if (!intersectTriangleRay(ray, v0, e1, e2, u0, v0_, t0)) t0 = inf;
+                if (numLeaves > 1u && !intersectTriangleRay(ray, nv0, ne1, ne2, u1, v1, t1)) t1 = inf;
+                const float lo = fminf(t0, t1);
+                if (lo < best + tol)
+                {
+                    // a hit that matters: it counts only if the ray passes the leaf's exact box, as in the reference's walk
+                    const float4 gmin = bvh.gate[2u * first], gmax = bvh.gate[2u * first + 1u];
+                    const Ray gateRay = makeRayUnsafe(ray.origin, ray.dir);   // = the ray transformRayUnsafe built
+                    float nearD;
+                    const bool pass = intersectBoxRayNoNaN(gateRay, gmin.x, gmin.y, gmin.z, gmax.x, gmax.y, gmax.z, nearD) && (!shadow || nearD < best);
+                    if (pass)
+                    {
+                        if (shadow) { if (lo < best) occluded = true; }
+                        else
+                        {
+                            const float hi = fmaxf(t0, t1);
+                            if (lo < best)
+                            {
+                                second = fminf(best, hi);
+                                best = lo;
+                                const bool firstWins = t0 <= t1;   // HitPoint written through (an exact tie is retraced anyway)
+                                prec(paths, R_HIT, slot) = f4(fbits(0u), fbits(first + (firstWins ? 0u : 1u)), lo, firstWins ? u0 : u1);
+                                prec(paths, R_SAMPLER, slot).x = firstWins ? v0_ : v1;
+                            }
+                            else second = fminf(second, lo);
+                        }
+                    }
+                }
+            }
+            pend = RT_QUANT_DONE;
+            if (occluded) cur = RT_QUANT_DONE;
+            if (cur != RT_QUANT_DONE)
+            {
+                if (sp == 0u) cur = RT_QUANT_DONE;
+                else { --sp; cur = stack[sp * RT_BLOCK]; }
+            }
+            if (cur == RT_QUANT_DONE)
+            {
+                // ---- finished ----
+                if (overflow)
+                {
+                    if (shadow) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = light * paths.capacity + slot;
+                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
+                    numRetraced++; numOverflow++;
+                    if (shadow) numShadowRays--;   // counted by the kernel that resolves it
+                }
+                else if (shadow)
+                {
+                    if (occluded) pshadow(paths, light, 0, slot).w = -1.0f;   // unoccluded requests are tallied when they are resolved
+                }
+                else if (best == inf) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), inf, 0.0f);   // HitPoint.h:14-51
+                else if (second <= best + tol)
+                {
+                    tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;   // a runner-up too close to call: the reference's own walk decides
+                    numRetraced++;
+                }
+                have = false;
+            }
+        }
+    }
+    // counters: shadow rays traced here, rays handed to the binary-tree kernel
+    __shared__ uint32_t sTally[4];
+    if (threadIdx.x < 4u) sTally[threadIdx.x] = 0u;
+    __syncthreads();
+    if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
+    if (numRetraced) atomicAdd(&sTally[1], numRetraced);
+    if (numUntrusted) atomicAdd(&sTally[2], numUntrusted);
+    if (numOverflow) atomicAdd(&sTally[3], numOverflow);
+    __syncthreads();
+    if (threadIdx.x == 0u && sTally[0]) atomicAdd(&counters[C_SHADOW], (unsigned long long)sTally[0]);
+    if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
+    if (!kDiag)
+    {
+        if (threadIdx.x == 2u && sTally[2]) atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)sTally[2]);   // diagnostics: untrusted at refill ...
+        if (threadIdx.x == 3u && sTally[3]) atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)sTally[3]);   // ... and stack overflows
+    }
+    else
+    {
+        // RTGPU_WIDE_DIAG=1: the three spare counters hold the walk's statistics instead
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)diagVisits);
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)diagSlots);
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 3], (unsigned long long)diagLeaves);
+        if ((threadIdx.x & 63u) == 0u)
+        {
+            // the reference's intersection counters are not used by this walk: per-wave clocks and phase counts ride in their slots
+            atomicAdd(&counters[C_BOX], diagClock[0]); atomicAdd(&counters[C_BOX_PASS], diagClock[1]); atomicAdd(&counters[C_TRI], diagClock[2]);
+            atomicAdd(&counters[C_TRI_PASS], (unsigned long long)clock64() - diagStart);
+            atomicAdd(&counters[C_BOX_SHADOW], (unsigned long long)diagRuns[1]); atomicAdd(&counters[C_TRI_SHADOW], (unsigned long long)diagRuns[2]);
+            atomicAdd(&counters[C_MESH_HITS], (unsigned long long)diagRuns[0]);
+        }
+    }
+}
+
+// ---- host: collapse of the reference's binary tree.  A wide node starts as the two children of a binary node; while it has a free
+// slot, its interior child with the largest surface area is replaced by that child's own two children.  Node indices are breadth first.
+struct WideBuild
+{
+    std::vector<float4> nodes;
+    bool ok = false;
+};
+
+static WideBuild buildWideBvh(const RtNode* nodes, uint32_t numNodes, const QuantBuild& q)
+{
+    WideBuild w;
+    if (!q.ok) return w;
+    auto isLeaf = [&](uint32_t n) { return (nodes[n].leaves & 0x3FFFFFFFu) != 0u; };
+    auto area = [&](uint32_t n)
+    {
+        const double ex = (double)nodes[n].max[0] - nodes[n].min[0], ey = (double)nodes[n].max[1] - nodes[n].min[1], ez = (double)nodes[n].max[2] - nodes[n].min[2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    std::vector<uint32_t> wideOf(numNodes, 0xFFFFFFFFu);   // binary interior node -> wide node
+    std::vector<uint32_t> order;                            // wide node -> binary node
+    order.push_back(0u); wideOf[0] = 0u;
+    std::vector<uint32_t> children;                         // 4 binary node indices per wide node (0xFFFFFFFF: empty)
+    for (size_t i = 0; i < order.size(); ++i)
+    {
+        const uint32_t n = order[i];
+        uint32_t list[4]; uint32_t num = 2;
+        list[0] = nodes[n].childIndex; list[1] = nodes[n].childIndex + 1u;
+        while (num < 4u)
+        {
+            int pick = -1; double bestArea = -1.0;
+            for (uint32_t k = 0; k < num; ++k) if (!isLeaf(list[k]) && area(list[k]) > bestArea) { bestArea = area(list[k]); pick = (int)k; }
+            if (pick < 0) break;
+            const uint32_t c = nodes[list[pick]].childIndex;
+            list[pick] = c; list[num++] = c + 1u;
+        }
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            const uint32_t child = k < num ? list[k] : 0xFFFFFFFFu;
+            children.push_back(child);
+            if (child != 0xFFFFFFFFu && !isLeaf(child))
+            {
+                if (order.size() >= RT_NODE_CHILD_MASK) return w;
+                wideOf[child] = (uint32_t)order.size(); order.push_back(child);
+            }
+        }
+    }
+    w.nodes.resize(order.size() * 4u);
+    for (size_t i = 0; i < order.size(); ++i)
+        for (uint32_t k = 0; k < 4u; ++k)
+        {
+            const uint32_t child = children[i * 4u + k];
+            float4 rec = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, (uint32_t)RT_WIDE_EMPTY));   // a point at the grid's corner, outside the mesh's bounds
+            if (child != 0xFFFFFFFFu)
+            {
+                rec = q.pairs[child];   // the child's box on the grid; its packed reference is replaced for interior children
+                if (!isLeaf(child)) rec.w = __builtin_bit_cast(float, wideOf[child]);
+            }
+            w.nodes[i * 4u + k] = rec;
+        }
+    w.ok = true;
+    return w;
+}

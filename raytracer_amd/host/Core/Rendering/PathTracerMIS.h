@@ -17,6 +17,8 @@ public:
     bool Reset() override;
     bool RenderPass(const RtPassParams& params) override;
     bool ReadSum(float* sumRGB, float* secondaryRGB) override;
+    bool PinHostBuffer(void* data, size_t bytes) override;
+    void UnpinHostBuffer(void* data) override;
     bool GetCounters(RayTracingCounters& outTotals) override;
     bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) override;
     bool ComputeBlockErrors(uint32 numPasses, const std::vector<RtBlock>& blocks, std::vector<float>& outErrors) override;

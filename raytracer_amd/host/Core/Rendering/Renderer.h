@@ -5,6 +5,8 @@
 // (Renderer.h:33 "TODO batch & multisample rendering") is the one implemented here: RenderPass().
 #pragma once
 
+#include <stddef.h>
+
 #include <vector>
 
 #include "Context.h"
@@ -27,6 +29,8 @@ public:
     virtual bool Reset() = 0;
     virtual bool RenderPass(const RtPassParams& params) = 0;                 // asynchronous
     virtual bool ReadSum(float* sumRGB, float* secondaryRGB) = 0;            // synchronises
+    virtual bool PinHostBuffer(void* /*data*/, size_t /*bytes*/) { return false; }   // page-locks a buffer ReadSum is given repeatedly
+    virtual void UnpinHostBuffer(void* /*data*/) {}
     virtual bool GetCounters(RayTracingCounters& outTotals) = 0;             // totals since Reset; synchronises
     // Viewport::PostProcessTile over the whole sum buffer -> 0x00RRGGBB pixels; synchronises
     virtual bool PostProcess(const PostprocessParams& params, uint32 numPasses, uint32* outBGRA) = 0;

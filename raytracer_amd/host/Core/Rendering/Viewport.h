@@ -73,7 +73,9 @@ private:
     Bitmap mSum, mSecondarySum, mFrontBuffer;
     PostprocessParams mPostprocessParams;
     uint32 mWidth = 0, mHeight = 0;
-    bool mSumDirty = false;
+    bool mSumDirty = false, mSecondarySumDirty = false;   // the device holds passes the host bitmaps have not seen
+    bool mSumPinned = false;
+    void PinSumBuffers(bool pin);   // page-locks the two sum bitmaps for the read-back (IRenderer::PinHostBuffer)
     std::vector<uint32> mSeedStorage;
     uint64 mRngKey[2];
     RayTracingCounters mCounters, mTotalsAtLastPass, mTotalsBeforeLastPass;

@@ -415,13 +415,14 @@ RTH_API int rth_viewport_render_pass_with(void* v, const RtPassParams* params)
     return 0;
 }
 RTH_API void rth_viewport_finish_pass(void* v) { static_cast<ViewportHandle*>(v)->viewport.FinishPass(); }
+// Viewport::GetSumBuffer() alone: the accumulated frame is in the viewport's host bitmap when this returns (what bench.py times);
+// rth_viewport_read_sum then only copies it out.
+RTH_API int rth_viewport_fetch_sum(void* v) { (void)static_cast<ViewportHandle*>(v)->viewport.GetSumBuffer(); return 0; }
 RTH_API int rth_viewport_read_sum(void* v, float* sum, float* secondary)
 {
     ViewportHandle* vh = static_cast<ViewportHandle*>(v);
-    const Bitmap& s = vh->viewport.GetSumBuffer();
-    const Bitmap& s2 = vh->viewport.GetSecondarySumBuffer();
-    if (sum) memcpy(sum, s.GetData(), s.GetDataSize());
-    if (secondary) memcpy(secondary, s2.GetData(), s2.GetDataSize());
+    if (sum) { const Bitmap& s = vh->viewport.GetSumBuffer(); memcpy(sum, s.GetData(), s.GetDataSize()); }
+    if (secondary) { const Bitmap& s2 = vh->viewport.GetSecondarySumBuffer(); memcpy(secondary, s2.GetData(), s2.GetDataSize()); }
     return 0;
 }
 RTH_API int rth_viewport_counters(void* v, uint64_t out[16])

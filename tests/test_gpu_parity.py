@@ -622,6 +622,7 @@ def test_quantized_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch)
     identical to the oracle's binary-tree walk on a small and a mid-size mesh, under both light sampling strategies, and only a
     small fraction of the rays needs the exact re-trace."""
     monkeypatch.setenv("RTGPU_QUANT", "1")
+    monkeypatch.setenv("RTGPU_WIDE", "0")
     monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
@@ -636,6 +637,56 @@ def test_quantized_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch)
     assert_quant_identical(*out)
 
 
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dense):
+    """k_trace_wide (4-wide collapse of the same tree, conservative 16-bit boxes, exact leaf gate, runner-up tracking, exact re-trace,
+    stack-overflow hand-over) gives the reference's hits: images and ray / shadow-ray / hit counters identical to the oracle's binary-tree
+    walk, with the dense and with the slot-per-pixel path state, and only a small fraction of the rays needs the exact re-trace."""
+    monkeypatch.setenv("RTGPU_WIDE", "1")
+    monkeypatch.setenv("RTGPU_NO_DENSE", "0" if dense == "1" else "1")
+    w, h = 128, 72
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
+    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
+    assert_quant_identical(*out)
+    traced = out[2]["numRays"] + out[2]["numShadowRays"]
+    assert 0 < out[2]["numRetracedRays"] < 0.02 * traced, (out[2]["numRetracedRays"], traced)
+    scene, camera = scenes.sponza_class(w / h, 60000)
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=8, light_sampling_all=True, dimensions=128)
+    assert_quant_identical(*out)
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=3, min_russian_roulette_depth=8)
+    assert_quant_identical(*out)
+    # a tree of a handful of nodes (a 12-triangle box, seen from inside and lit by the background through nothing): wide nodes with empty slots
+    pos, idx, nrm, tan, uv, mat = scenes.box_mesh(1.0)
+    box = ra.Scene()
+    box.add_mesh(pos, idx, nrm, tan, uv, mat, [box.add_material("diffuse", (0.8, 0.3, 0.2)), box.add_material("diffuse", (0.3, 0.8, 0.2))])
+    box.add_background_light((1.0, 1.5, 2.0))
+    box.build()
+    assert_quant_identical(*run_quant(box, ra.Camera((0.0, 2.5, 6.0), (20.0, 180.0, 0.0), w / h, 45.0), w, h, passes=2, max_ray_depth=4))
+
+
+def test_wide_and_exact_traversal_agree_at_full_size(built, monkeypatch):
+    """1920x1080, the benchmark's mesh, depth 8: the frame of the 4-wide walk equals the frame of the binary-tree kernel bit for bit, ray
+    counters included; the exact re-trace serves well under 1 % of the rays."""
+    w, h, depth, passes = 1920, 1080, 8, 2
+    scene, camera = scenes.sponza_class(w / h)
+    frames = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("RTGPU_WIDE", wide)
+        vp = ra.Viewport(w, h, seed=515, max_ray_depth=depth)
+        vp.set_renderer(scene)
+        assert ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0) == 0
+        vp.render(camera, passes)
+        frames.append((vp.sum_buffer(secondary=True), vp.counters()))
+    (a, a2), ca = frames[0]
+    (b, b2), cb = frames[1]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a2.view(np.uint32), b2.view(np.uint32))
+    for n in NOT_INTERSECTION:
+        assert ca[n] == cb[n], n
+    traced = ca["numRays"] + ca["numShadowRays"]
+    assert 0 < ca["numRetracedRays"] < 0.01 * traced and cb["numRetracedRays"] == 0
+    print("retraced %d of %d rays" % (ca["numRetracedRays"], traced))
+
+
 def test_quantized_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     """1920x1080, the benchmark's 262 176-triangle mesh, depth 8, counters off: the frame rendered with the re-encoded tree equals the
     frame rendered with the binary-tree kernel alone bit for bit, ray counters included, and 1/48 of its tiles equal
@@ -643,6 +694,7 @@ def test_quantized_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     w, h, depth, passes = 1920, 1080, 8, 2
     scene, camera = scenes.sponza_class(w / h)
     monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
+    monkeypatch.setenv("RTGPU_WIDE", "0")
     frames = []
     for quant in ("1", "0"):
         monkeypatch.setenv("RTGPU_QUANT", quant)
@@ -667,6 +719,7 @@ def test_lds_staged_top_levels_bit_exact(built, monkeypatch):
     breadth-first order: same images and ray counters as the oracle -- with the plain k_trace and with the variant that serves the top
     levels from an LDS copy (RTGPU_LDS_TOP=1; slower than the L1 on this chip, kept as an option)."""
     w, h = 128, 72
+    monkeypatch.setenv("RTGPU_WIDE", "0")      # the binary-tree walk, not the 4-wide one
     scene, camera = scenes.sponza_class(w / h, 60000)
     a = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
     assert_quant_identical(*a)
