@@ -1273,6 +1273,7 @@ struct RtgpuContext
     // the next one grows by 8 passes up to 24 (8 -> 2100, 16 -> 2125-2190, 24 -> 2195-2210 Msamples/s over 256 passes); any
     // synchronising call starts over at the base size, so a caller that renders few passes between read-backs keeps the small batches.
     uint32_t passBatchBase = 8;
+    size_t laneBudgetBytes = (size_t)32 << 30;   // device memory one batch lane may take: 32 GB, less on a device that could not hold four such lanes
     uint32_t batchesAtThisSize = 0;    // full batches submitted at the current passBatch
     uint32_t batchesSinceSync = 0;     // batches submitted since the last synchronising call (their lanes are busy)
     DevPass* passRingDev = nullptr;
@@ -1482,6 +1483,11 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     for (int i = 0; i < RT_SEED_RING; ++i) { c->seedEvents[i] = nullptr; c->seedEventUsed[i] = false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, deviceIndex) == hipSuccess) c->numCUs = (uint32_t)prop.multiProcessorCount;
+    {
+        // six lanes (the most rtgpu_set_concurrency allows) plus scene, film and the bidirectional integrator's arenas must fit what is free now
+        size_t freeBytes = 0, totalBytes = 0;
+        if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes / 8u < c->laneBudgetBytes) c->laneBudgetBytes = freeBytes / 8u > ((size_t)64 << 20) ? freeBytes / 8u : ((size_t)64 << 20);
+    }
     // scheduling knobs (performance only; results do not depend on them)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
@@ -1944,7 +1950,7 @@ static size_t bytesPerSlot(uint32_t maxLights)
 static uint32_t maxBatchFor(const RtgpuContext* c, uint32_t maxLights)
 {
     const size_t perPass = (size_t)(c->numSlots ? c->numSlots : 1) * bytesPerSlot(maxLights);
-    const size_t batch = ((size_t)32 << 30) / perPass;
+    const size_t batch = c->laneBudgetBytes / perPass;
     return batch < 1u ? 1u : (batch > RT_SEED_RING / 2 ? RT_SEED_RING / 2 : (uint32_t)batch);
 }
 // slots an arena is allocated for: the regions of dense path state need a margin each (a region's share of a launch is only

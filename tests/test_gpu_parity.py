@@ -664,6 +664,39 @@ def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dens
     assert_quant_identical(*run_quant(box, ra.Camera((0.0, 2.5, 6.0), (20.0, 180.0, 0.0), w / h, 45.0), w, h, passes=2, max_ray_depth=4))
 
 
+def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
+    """A pathological mesh -- 64 nested sheets around the camera axis, sizes and distances growing by 1.6 from one to the next: the SAH
+    builder peels them off a few at a time (a tree 22 levels deep for 128 triangles), and a ray through the stack of sheets enters every
+    child on its way down and defers more of them than a 24-entry stack holds (17 000 of 30 000 rays from the near side).  Such rays
+    go to the binary-tree kernel (the uploaded depth picks its stack class); images and ray counters stay the oracle's, from both sides."""
+    n = 64
+    pos, idx = [], []
+    for k in range(n):
+        r, z = 0.5 * 1.6 ** k, -2.0 - 1.6 ** k
+        base = len(pos)
+        pos += [(-r, -r, z), (r, -r, z), (r, r, z), (-r, r, z)]
+        idx += [(base, base + 1, base + 2), (base, base + 2, base + 3)]
+    pos = np.asarray(pos, dtype=np.float32); idx = np.asarray(idx, dtype=np.uint32)
+    nrm = np.tile(np.asarray([[0.0, 0.0, 1.0]], dtype=np.float32), (len(pos), 1))
+    tan = np.tile(np.asarray([[1.0, 0.0, 0.0]], dtype=np.float32), (len(pos), 1))
+    uv = np.zeros((len(pos), 2), dtype=np.float32)
+    scene = ra.Scene()
+    m = scene.add_material("diffuse", (0.7, 0.6, 0.5))
+    scene.add_mesh(pos, idx, nrm, tan, uv, np.zeros(len(idx), dtype=np.uint32), [m])
+    scene.add_background_light((1.0, 1.5, 2.0))
+    scene.build()
+    w, h = 96, 64
+    far = float(1.6 ** n)
+    overflows = 0
+    for camera in (ra.Camera((0.0, 0.0, 3.0), (0.0, 180.0, 0.0), w / h, 50.0), ra.Camera((0.0, 0.0, -3.0 * far), (0.0, 0.0, 0.0), w / h, 50.0)):
+        out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=4)
+        assert_quant_identical(*out)
+        print("stack overflows: %d, untrusted: %d, re-traced: %d of %d rays" % (out[2]["numStackOverflowRays"], out[2]["numUntrustedRays"], out[2]["numRetracedRays"],
+                                                                                 out[2]["numRays"] + out[2]["numShadowRays"]))
+        overflows += out[2]["numStackOverflowRays"]
+    assert overflows > 0
+
+
 def test_wide_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     """1920x1080, the benchmark's mesh, depth 8: the frame of the 4-wide walk equals the frame of the binary-tree kernel bit for bit, ray
     counters included; the exact re-trace serves well under 1 % of the rays."""
