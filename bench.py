@@ -385,7 +385,10 @@ def main():
             per_launch_bytes = abytes_replay[dom] / max(1, launches)
             per_launch_s = ktimes[dom][0] / 1000.0 / max(1, launches)
             algorithmic_gbs = per_launch_bytes / per_launch_s / 1e9
-            roof = {"bound": "hbm", "kernel": "k_" + dom, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kernel_name = "k_" + dom
+            if dom == "trace" and c1.get("numRetracedRays", 0) > 0:
+                kernel_name = "k_trace_wide"   # the 4-wide walk served the launches (it hands a few rays to k_trace: class "retrace")
+            roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
                     "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_GBs": algorithmic_gbs,
                     "algorithmic_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,

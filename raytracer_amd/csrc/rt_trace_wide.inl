@@ -47,15 +47,15 @@ struct WideTuning
     }
 #define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
 
-template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
+template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false, int kBlock = RT_BLOCK>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                          uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
 {
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    __shared__ uint32_t sStack[kStack * kBlock];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
+    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * kBlock]: bank = lane, conflict free at any depth
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
     const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
     const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
 
-    uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
+    uint32_t chunkSize = count / (gridDim.x * ((uint32_t)kBlock / 64u) * 4u);
     chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
     WaveChunk chunk = { 0u, 0u };
 
@@ -182,12 +182,12 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                         const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
 #define RT_WIDE_REF(k) (((k) & 2u) ? (((k) & 1u) ? r3 : r2) : (((k) & 1u) ? r1 : r0))
                         // farthest first, so that the nearest child is walked next
-                        if (k3 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k3); ++sp; }
-                        if (k2 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k2); ++sp; }
-                        if (k1 != miss) { stack[sp * RT_BLOCK] = RT_WIDE_REF(k1); ++sp; }
+                        if (k3 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k3); ++sp; }
+                        if (k2 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k2); ++sp; }
+                        if (k1 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k1); ++sp; }
                         if (k0 != miss) cur = RT_WIDE_REF(k0);
                         else if (sp == 0u) cur = RT_QUANT_DONE;
-                        else { --sp; cur = stack[sp * RT_BLOCK]; }
+                        else { --sp; cur = stack[sp * kBlock]; }
 #undef RT_WIDE_REF
                     }
                     else
@@ -200,19 +200,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     const uint32_t k2 = h2 ? ((ubits(n2) & ~3u) | 2u) : miss, k3 = h3 ? ((ubits(n3) & ~3u) | 3u) : miss;
                     const uint32_t kMin = min(min(k0, k1), min(k2, k3));
                     const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
-                    if (h0 && k0 != kMin) { stack[sp * RT_BLOCK] = r0; ++sp; }
-                    if (h1 && k1 != kMin) { stack[sp * RT_BLOCK] = r1; ++sp; }
-                    if (h2 && k2 != kMin) { stack[sp * RT_BLOCK] = r2; ++sp; }
-                    if (h3 && k3 != kMin) { stack[sp * RT_BLOCK] = r3; ++sp; }
+                    if (h0 && k0 != kMin) { stack[sp * kBlock] = r0; ++sp; }
+                    if (h1 && k1 != kMin) { stack[sp * kBlock] = r1; ++sp; }
+                    if (h2 && k2 != kMin) { stack[sp * kBlock] = r2; ++sp; }
+                    if (h3 && k3 != kMin) { stack[sp * kBlock] = r3; ++sp; }
                     if (kMin != miss) cur = (kMin & 2u) ? ((kMin & 1u) ? r3 : r2) : ((kMin & 1u) ? r1 : r0);
                     else if (sp == 0u) cur = RT_QUANT_DONE;
-                    else { --sp; cur = stack[sp * RT_BLOCK]; }
+                    else { --sp; cur = stack[sp * kBlock]; }
                     }
                     if (sp + 3u > (uint32_t)kStack) { overflow = true; cur = RT_QUANT_DONE; }   // the next step could not push: the binary-tree kernel takes the ray
                     // kPostpone (an experiment that did not pay: interior-loop lane utilisation 0.52 -> 0.55, 4 % more visits from the later culling,
                     // and a leaf phase twice as long: k_trace_wide 156 -> 171 ms): the first leaf a lane reaches is set aside and the lane goes on
                     // with its next deferred node, so that it stays in this loop.  Any order gives the same candidates.
-                    if (kPostpone && RT_WIDE_IS_LEAF(cur) && pend == RT_QUANT_DONE && sp != 0u) { pend = cur; --sp; cur = stack[sp * RT_BLOCK]; }
+                    if (kPostpone && RT_WIDE_IS_LEAF(cur) && pend == RT_QUANT_DONE && sp != 0u) { pend = cur; --sp; cur = stack[sp * kBlock]; }
                 }
                 in = in && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
                 const unsigned long long m = __ballot(in);
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             if (cur != RT_QUANT_DONE)
             {
                 if (sp == 0u) cur = RT_QUANT_DONE;
-                else { --sp; cur = stack[sp * RT_BLOCK]; }
+                else { --sp; cur = stack[sp * kBlock]; }
             }
             if (cur == RT_QUANT_DONE)
             {
