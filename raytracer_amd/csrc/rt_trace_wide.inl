@@ -35,15 +35,26 @@ struct WideTuning
     const uint32_t* denseCounts; uint32_t denseShardCapacity; // dense path state (TravTuning)
 };
 
-// slab test of one child record against the ray's folded constants; near is clamped to >= 0 (a sort key).  (One packed fma per axis,
-// v_pk_fma_f32 over {min plane, max plane}, measured 2 % slower than six scalar fmas: the operands have to be paired up first.)
+// slab test of one child record against the ray's folded constants; near is clamped to >= 0 (its bits then order like the float).
+// Which of an axis's two planes the ray meets first is a property of the RAY (the sign of its direction), so three byte permutes with
+// per-ray selectors (v_perm_b32) put {near plane, far plane} of every axis into one word and the six min / max of the textbook slab
+// test disappear: 3 perm + 6 cvt (sub-word select) + 6 fma + max + max3 + min3 per child.
+// Record words: w0 = minx | miny << 16, w1 = minz | maxx << 16, w2 = maxy | maxz << 16.  __builtin_amdgcn_perm(hi, lo, sel): byte i of
+// the result is byte sel[i] of {lo = bytes 0-3, hi = bytes 4-7}.
+#define RT_WIDE_SEL_X_POS 0x07060100u   // perm(w1, w0): minx (bytes 0,1) first, maxx (bytes 6,7) second
+#define RT_WIDE_SEL_X_NEG 0x01000706u
+#define RT_WIDE_SEL_Y_POS 0x05040302u   // perm(w2, w0): miny (bytes 2,3) first, maxy (bytes 4,5) second
+#define RT_WIDE_SEL_Y_NEG 0x03020504u
+#define RT_WIDE_SEL_Z_POS 0x07060100u   // perm(w2, w1): minz (bytes 0,1) first, maxz (bytes 6,7) second
+#define RT_WIDE_SEL_Z_NEG 0x01000706u
 #define RT_WIDE_SLAB(q, nearOut, farOut)                                                                                                          \
     {                                                                                                                                             \
         const uint32_t w0 = ubits(q.x), w1 = ubits(q.y), w2 = ubits(q.z);                                                                         \
-        const float nx = __fmaf_rn((float)(w0 & 0xFFFFu), ax, bx), ny = __fmaf_rn((float)(w0 >> 16), ay, by), nz = __fmaf_rn((float)(w1 & 0xFFFFu), az, bz); \
-        const float xx = __fmaf_rn((float)(w1 >> 16), ax, bx), xy = __fmaf_rn((float)(w2 & 0xFFFFu), ay, by), xz = __fmaf_rn((float)(w2 >> 16), az, bz);     \
-        nearOut = fmaxf(fmaxf(fminf(nx, xx), fminf(ny, xy)), fmaxf(fminf(nz, xz), 0.0f));                                                          \
-        farOut = fminf(fminf(fmaxf(nx, xx), fmaxf(ny, xy)), fmaxf(nz, xz));                                                                       \
+        const uint32_t px = __builtin_amdgcn_perm(w1, w0, selX), py = __builtin_amdgcn_perm(w2, w0, selY), pz = __builtin_amdgcn_perm(w2, w1, selZ); \
+        const float nx = __fmaf_rn((float)(px & 0xFFFFu), ax, bx), ny = __fmaf_rn((float)(py & 0xFFFFu), ay, by), nz = __fmaf_rn((float)(pz & 0xFFFFu), az, bz); \
+        const float xx = __fmaf_rn((float)(px >> 16), ax, bx), xy = __fmaf_rn((float)(py >> 16), ay, by), xz = __fmaf_rn((float)(pz >> 16), az, bz);            \
+        nearOut = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));                                                                                           \
+        farOut = fminf(fminf(xx, xy), xz);                                                                                                        \
     }
 #define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
 
@@ -67,6 +78,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;     // local ray (triangle tests, leaf gate)
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;     // folded slab constants: t(q) = fma(q, a, b)
     float best = 0, second = 0, tol = 0;
+    uint32_t selX = RT_WIDE_SEL_X_POS, selY = RT_WIDE_SEL_Y_POS, selZ = RT_WIDE_SEL_Z_POS;   // which plane of an axis the ray meets first
     uint32_t cur = RT_QUANT_DONE, pend = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;   // pend: a leaf set aside while the lane keeps walking interior nodes
     bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
@@ -139,6 +151,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                     bx = __fmaf_rn(bvh.base[0], local.invDir.x, -local.originDivDir.x);
                     by = __fmaf_rn(bvh.base[1], local.invDir.y, -local.originDivDir.y);
                     bz = __fmaf_rn(bvh.base[2], local.invDir.z, -local.originDivDir.z);
+                    selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
                     tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
                     best = maxDistance; second = inf; occluded = false; overflow = false;
                     sp = 0u; cur = 0u; pend = RT_QUANT_DONE;   // node 0 holds the children of the binary tree's root
@@ -166,29 +179,23 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                     RT_WIDE_SLAB(q0, n0, f0); RT_WIDE_SLAB(q1, n1, f1); RT_WIDE_SLAB(q2, n2, f2); RT_WIDE_SLAB(q3, n3, f3);
                     if (kSort)
                     {
-                        // sort keys: entry distance (>= 0, so its bits order like the float) with the child's slot in the two low bits; a miss sorts last
-                        const uint32_t miss = 0xFFFFFFFFu;
-                        uint32_t k0 = (f0 >= n0 && n0 < limit) ? ((ubits(n0) & ~3u) | 0u) : miss;
-                        uint32_t k1 = (f1 >= n1 && n1 < limit) ? ((ubits(n1) & ~3u) | 1u) : miss;
-                        uint32_t k2 = (f2 >= n2 && n2 < limit) ? ((ubits(n2) & ~3u) | 2u) : miss;
-                        uint32_t k3 = (f3 >= n3 && n3 < limit) ? ((ubits(n3) & ~3u) | 3u) : miss;
-                        // five compare-exchanges: (0,1) (2,3) (0,2) (1,3) (1,2)
-                        uint32_t t;
-                        t = min(k0, k1); k1 = max(k0, k1); k0 = t;
-                        t = min(k2, k3); k3 = max(k2, k3); k2 = t;
-                        t = min(k0, k2); k2 = max(k0, k2); k0 = t;
-                        t = min(k1, k3); k3 = max(k1, k3); k1 = t;
-                        t = min(k1, k2); k2 = max(k1, k2); k1 = t;
-                        const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
-#define RT_WIDE_REF(k) (((k) & 2u) ? (((k) & 1u) ? r3 : r2) : (((k) & 1u) ? r1 : r0))
-                        // farthest first, so that the nearest child is walked next
-                        if (k3 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k3); ++sp; }
-                        if (k2 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k2); ++sp; }
-                        if (k1 != miss) { stack[sp * kBlock] = RT_WIDE_REF(k1); ++sp; }
-                        if (k0 != miss) cur = RT_WIDE_REF(k0);
+                        // (key, reference) pairs sorted so that the children the ray enters come first, farthest first, and the ones it misses
+                        // last: key = 0x7FFFFFFF - bits(entry distance) (the distance is >= 0, so its bits order like the float), miss = all ones
+                        const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
+                        uint32_t k0 = h0 ? 0x7FFFFFFFu - ubits(n0) : 0xFFFFFFFFu, k1 = h1 ? 0x7FFFFFFFu - ubits(n1) : 0xFFFFFFFFu;
+                        uint32_t k2 = h2 ? 0x7FFFFFFFu - ubits(n2) : 0xFFFFFFFFu, k3 = h3 ? 0x7FFFFFFFu - ubits(n3) : 0xFFFFFFFFu;
+                        uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
+#define RT_WIDE_CE(ka, ra, kb, rb) { const bool c_ = ka > kb; const uint32_t lo_ = min(ka, kb), hi_ = max(ka, kb), rl_ = c_ ? rb : ra, rh_ = c_ ? ra : rb; ka = lo_; kb = hi_; ra = rl_; rb = rh_; }
+                        RT_WIDE_CE(k0, r0, k1, r1) RT_WIDE_CE(k2, r2, k3, r3) RT_WIDE_CE(k0, r0, k2, r2) RT_WIDE_CE(k1, r1, k3, r3) RT_WIDE_CE(k1, r1, k2, r2)
+#undef RT_WIDE_CE
+                        const uint32_t numHit = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
+                        // the first numHit - 1 references are deferred, the last one (the nearest child) is walked next.  The three stores are
+                        // unconditional (what lands above the new top is free space; the overflow check keeps three entries in reserve)
+                        uint32_t* const top = stack + sp * kBlock;
+                        top[0] = r0; top[kBlock] = r1; top[2 * kBlock] = r2;
+                        if (numHit != 0u) { cur = numHit == 1u ? r0 : (numHit == 2u ? r1 : (numHit == 3u ? r2 : r3)); sp += numHit - 1u; }
                         else if (sp == 0u) cur = RT_QUANT_DONE;
                         else { --sp; cur = stack[sp * kBlock]; }
-#undef RT_WIDE_REF
                     }
                     else
                     {
