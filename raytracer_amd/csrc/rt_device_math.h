@@ -192,6 +192,14 @@ RT_DEV Ray makeRayUnsafe(V4 origin, V4 direction)  // Ray::BuildUnsafe Ray.h:31-
     r.originDivDir = origin * r.invDir;
     return r;
 }
+// the same with the three lanes a slab test reads (the w lanes of invDir / originDivDir are never used by the traversal)
+RT_DEV Ray makeRayUnsafe3(V4 origin, V4 direction)
+{
+    Ray r; r.origin = origin; r.dir = direction;
+    r.invDir = V4(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z, 0.0f);
+    r.originDivDir = V4(origin.x * r.invDir.x, origin.y * r.invDir.y, origin.z * r.invDir.z, 0.0f);
+    return r;
+}
 RT_DEV V4 rayAt(const Ray& r, float t) { return mulAdd(r.dir, t, r.origin); }  // Ray.h:41-44
 RT_DEV Ray transformRayUnsafe(const M4& m, const Ray& ray)   // Matrix4.h:245-250
 {

@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
 
     // kDiag: wave clock per phase (0 refill, 1 interior loop, 2 leaf / finish) and the number of times each ran
     unsigned long long diagClock[3] = { 0ull, 0ull, 0ull }, diagPrev = kDiag ? (unsigned long long)clock64() : 0ull, diagStart = diagPrev;
-    uint32_t diagRuns[3] = { 0u, 0u, 0u }, diagPhase = 0u;
+    uint32_t diagRuns[3] = { 0u, 0u, 0u }, diagPhase = 0u, diagClaims = 0u;
+    unsigned long long diagClaimClock = 0ull;   // inside the refill phase: waiting for the work cursor's atomic
     for (;;)
     {
         if (kDiag) { const unsigned long long now = (unsigned long long)clock64(); diagClock[diagPhase] += now - diagPrev; diagPrev = now; }
@@ -104,7 +105,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
             if (kDiag) { diagPhase = 0u; diagRuns[0]++; }
             if (chunk.next >= chunk.end)
             {
+                const unsigned long long claim0 = kDiag ? (unsigned long long)clock64() : 0ull;
                 waveClaimChunk(chunk, cursor, chunkSize, count);
+                if (kDiag) { diagClaimClock += (unsigned long long)clock64() - claim0; diagClaims++; }
                 if (chunk.next >= chunk.end) { exhausted = true; continue; }
             }
             const uint32_t idx = waveTake(!have, chunk);
@@ -113,23 +116,27 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                 shadow = idx >= numClosest;
                 const uint32_t request = shadow ? shadowQueue[idx - numClosest]
                                                 : (tune.denseCounts ? denseLiveSlot(sDensePrefix, tune.denseShardCapacity, idx) : (queue ? queue[idx] : idx));
-                Ray world;
-                float maxDistance = inf;
+                // one ray construction for both kinds of request (a wave usually refills both at once): Ray::Ray normalises the direction
+                // (PathTracerMIS.cpp:86 / :392), then the origin moves along it -- 1e-4 for an any-hit ray, 1e-3 for a bounce, not at all for
+                // a primary ray
+                float maxDistance = inf, offset;
+                float4 origin, dir;
                 if (shadow)
                 {
                     light = request / paths.capacity; slot = request - light * paths.capacity;
-                    const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
-                    world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
-                    world.origin = world.origin + world.dir * tune.shadowOffset;   // PathTracerMIS.cpp:86
-                    maxDistance = dirTmax.w;                                       // hitPoint.distance = illuminateResult.distance * 0.999f
+                    origin = prec(paths, R_SH_P, slot); dir = pshadow(paths, light, 0, slot);
+                    maxDistance = dir.w;           // hitPoint.distance = illuminateResult.distance * 0.999f
+                    offset = tune.shadowOffset;
                 }
                 else
                 {
                     slot = request; light = 0u;
-                    const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
-                    world = makePathRay(origin, dir, ubits(origin.w) & 0xFFu);
+                    origin = prec(paths, R_ORIGIN, slot); dir = prec(paths, R_DIR, slot);
+                    offset = 0.001f;
                 }
-                const Ray local = transformRayUnsafe(invTransform, world);   // MeshShape is entered in object space, Scene.cpp:128-145
+                Ray world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));
+                if (shadow || (ubits(origin.w) & 0xFFu) != 0u) world.origin = world.origin + world.dir * offset;
+                const Ray local = makeRayUnsafe3(transformPoint(invTransform, world.origin), transformVector(invTransform, world.dir));   // = transformRayUnsafe: MeshShape is entered in object space, Scene.cpp:128-145
                 // largest magnitude a slab test of this ray can produce, per axis; 2^-21 of it bounds the folded test's rounding
                 const float mx = fabsf(local.originDivDir.x) + bvh.bound[0] * fabsf(local.invDir.x);
                 const float my = fabsf(local.originDivDir.y) + bvh.bound[1] * fabsf(local.invDir.y);
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                 {
                     // a hit that matters: it counts only if the ray passes the leaf's exact box, as in the reference's walk
                     const float4 gmin = bvh.gate[2u * first], gmax = bvh.gate[2u * first + 1u];
-                    const Ray gateRay = makeRayUnsafe(ray.origin, ray.dir);   // = the ray transformRayUnsafe built
+                    const Ray gateRay = makeRayUnsafe3(ray.origin, ray.dir);   // = the ray transformRayUnsafe built
                     float nearD;
                     const bool pass = intersectBoxRayNoNaN(gateRay, gmin.x, gmin.y, gmin.z, gmax.x, gmax.y, gmax.z, nearD) && (!shadow || nearD < best);
                     if (pass)
@@ -330,7 +337,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
             atomicAdd(&counters[C_BOX], diagClock[0]); atomicAdd(&counters[C_BOX_PASS], diagClock[1]); atomicAdd(&counters[C_TRI], diagClock[2]);
             atomicAdd(&counters[C_TRI_PASS], (unsigned long long)clock64() - diagStart);
             atomicAdd(&counters[C_BOX_SHADOW], (unsigned long long)diagRuns[1]); atomicAdd(&counters[C_TRI_SHADOW], (unsigned long long)diagRuns[2]);
-            atomicAdd(&counters[C_MESH_HITS], (unsigned long long)diagRuns[0]);
+            atomicAdd(&counters[C_ANALYTIC_HITS], (unsigned long long)diagRuns[0]);   // (free in a mesh-only scene)
+            atomicAdd(&counters[C_PRIMARY], diagClaimClock); atomicAdd(&counters[C_SHADOW_HIT], (unsigned long long)diagClaims);   // (k_shade adds to these two as well: subtract a run without RTGPU_WIDE_DIAG)
         }
     }
 }

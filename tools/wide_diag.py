@@ -9,7 +9,7 @@ vp=ra.Viewport(w,h,seed=515,max_ray_depth=8); vp.set_renderer(scene)
 ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 1 if os.environ.get("COUNT") else 0)
 vp.render(camera,4); c=vp.counters()
 rays=c["numRays"]+c["numShadowRays"]
-print({k:c[k] for k in ("numPassedRayBoxTests","numPassedRayTriangleTests","numMeshHits","numRays","numShadowRays","numRetracedRays","numUntrustedRays","numStackOverflowRays","diag2","numRayBoxTests","numShadowRayBoxTests","numRayTriangleTests","numShadowRayTriangleTests")})
+print({k:c[k] for k in ("numPassedRayBoxTests","numPassedRayTriangleTests","numMeshHits","numAnalyticHits","numPrimaryRays","numShadowRaysHit","numRays","numShadowRays","numRetracedRays","numUntrustedRays","numStackOverflowRays","diag2","numRayBoxTests","numShadowRayBoxTests","numRayTriangleTests","numShadowRayTriangleTests")})
 if os.environ.get("RTGPU_WIDE_DIAG"):
     print("interior visits/ray %.2f  interior-loop lane utilisation %.3f  leaf visits/ray %.2f" % (c["numUntrustedRays"]/rays, c["numUntrustedRays"]/max(1,c["numStackOverflowRays"]), c["diag2"]/rays))
     tot = c["numPassedRayTriangleTests"]
@@ -17,5 +17,9 @@ if os.environ.get("RTGPU_WIDE_DIAG"):
     print("phase runs per wave-lifetime: refill %d interior %d leaf %d; clocks per run: refill %.0f interior %.0f leaf %.0f; interior wave-steps per run %.2f, clocks per interior wave-step %.0f" % (
         c["numMeshHits"], c["numShadowRayBoxTests"], c["numShadowRayTriangleTests"], c["numRayBoxTests"]/max(1,c["numMeshHits"]), c["numPassedRayBoxTests"]/max(1,c["numShadowRayBoxTests"]), c["numRayTriangleTests"]/max(1,c["numShadowRayTriangleTests"]),
         c["numStackOverflowRays"]/64/max(1,c["numShadowRayBoxTests"]), c["numPassedRayBoxTests"]/max(1,c["numStackOverflowRays"]/64)))
+    base_primary, base_shadow_hit = w * h * 4, int(os.environ.get("BASE_SHADOW_HIT", "0"))
+    print("refill runs %d (%.0f clocks each); cursor claims %d, %.0f clocks each = %.1f %% of the wave time (needs BASE_SHADOW_HIT = numShadowRaysHit of a plain run; raw %d)" % (
+        c["numAnalyticHits"], c["numRayBoxTests"] / max(1, c["numAnalyticHits"]), c["numShadowRaysHit"] - base_shadow_hit,
+        (c["numPrimaryRays"] - base_primary) / max(1, c["numShadowRaysHit"] - base_shadow_hit), 100.0 * (c["numPrimaryRays"] - base_primary) / tot, c["numShadowRaysHit"]))
 if os.environ.get("COUNT"):
     print("binary: visits/ray %.2f  triangle tests/ray %.2f" % ((c["numRayBoxTests"]+c["numShadowRayBoxTests"])/2/rays, (c["numRayTriangleTests"]+c["numShadowRayTriangleTests"])/rays))
