@@ -113,7 +113,15 @@ class TileGather:
 
     def run(self):
         self.send[:len(self.own)] = self.image.index_select(0, self.own)
-        self.dist.gather(self.send, self.recv, dst=0)
+        if self.send.is_cuda and self.dist.get_backend() != "nccl":
+            # BENCH_DIST_BACKEND=gloo (the N > 1 code path exercised on a 1-GPU box): gloo gathers host tensors
+            recv = [t.cpu() for t in self.recv] if self.rank == 0 else None
+            self.dist.gather(self.send.cpu(), recv, dst=0)
+            if self.rank == 0:
+                for r in range(1, self.world):
+                    self.recv[r].copy_(recv[r])
+        else:
+            self.dist.gather(self.send, self.recv, dst=0)
         if self.rank == 0:
             for r in range(1, self.world):
                 self.image.index_copy_(0, self.peers[r], self.recv[r][:len(self.peers[r])])

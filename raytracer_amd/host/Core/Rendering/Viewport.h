@@ -54,6 +54,7 @@ public:
 
     // Extension (the reference has no seed API): re-seed the Viewport's generators.
     void SetSeed(uint64 seed);
+    void ClearAccumulation();   // sums, progress, counters, block list start over; the sample sequence goes on
 
     // The per-pass constants Render() would use next; advances the Halton sequence and the generator
     // exactly like Render().  Exposed so parity tests can feed identical constants to the CPU oracle.

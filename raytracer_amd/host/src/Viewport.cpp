@@ -500,8 +500,15 @@ bool Viewport::Resize(uint32 width, uint32 height)
 
 void Viewport::Reset()
 {
-    mProgress = RenderingProgress();
     mHaltonSequence.Initialize(mParams.samplingParams.dimensions);
+    ClearAccumulation();
+}
+
+// What Reset does to the accumulated frame, without re-drawing the Halton permutations: used when the renderer's film was cleared behind
+// the viewport's back (a change of tile ownership), so that a sharded viewport draws the same per-pass constants as an unsharded one.
+void Viewport::ClearAccumulation()
+{
+    mProgress = RenderingProgress();
     mSum.Clear();
     mSecondarySum.Clear();
     mSumDirty = false; mSecondarySumDirty = false;

@@ -445,7 +445,7 @@ RTH_API int rth_viewport_set_shard(void* v, uint32_t rank, uint32_t world)
     ViewportHandle* vh = static_cast<ViewportHandle*>(v);
     PathTracerMIS* pt = dynamic_cast<PathTracerMIS*>(vh->renderer.get());
     if (!pt || !pt->SetShard(rank, world)) return -1;
-    vh->viewport.Reset();   // the device film was cleared with the ownership change: the host's sums, pass count and block list start over with it
+    vh->viewport.ClearAccumulation();   // the device film was cleared with the ownership change: the host's sums, pass count and block list start over with it (the sample sequence does not)
     return 0;
 }
 RTH_API uint32_t rth_viewport_passes_finished(void* v) { return static_cast<ViewportHandle*>(v)->viewport.GetPassesFinished(); }

@@ -33,3 +33,28 @@ def test_device_tensor_view_and_rccl_reduce(built):
         assert float(x[0]) == 1.0      # a view of the same memory, not a copy
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_two_ranks_on_one_device(built, tmp_path):
+    """bench.py's N > 1 path end to end on the 1-GPU box: two gloo ranks share the device (RCCL refuses two ranks on one device), each
+    renders its own tiles, rank 0 gathers the peer's tiles and reads the frame back.  One JSON line, both ranks' samples counted, image
+    finite; the gathered frame's mean equals the one-rank run's (same seed => same frame)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_DIST_BACKEND="gloo")
+    common = ["--steps", "6", "--warmup", "2", "--width", "640", "--height", "360", "--triangles", "20000", "--no-pmc", "--no-cpu-baseline"]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d2 = json.loads(lines[0])
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env=dict(os.environ), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d2["n_gpus"] == 2 and d2["image"]["finite"] and d2["value"] > 0
+    assert d2["counters"]["numRays"] == d1["counters"]["numRays"] and d2["counters"]["numShadowRays"] == d1["counters"]["numShadowRays"]
+    assert d2["image"]["mean_per_pass"] == d1["image"]["mean_per_pass"]

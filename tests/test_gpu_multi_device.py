@@ -123,6 +123,31 @@ def test_rt_demo_scales_through_the_environment(built, tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > 200 * 136 * 3
 
 
+def test_sharded_viewports_reproduce_the_unsharded_frame(built):
+    """The one-process-per-GPU front end (bench.py --gpus N): separate viewports with the same seed, each owning a shard.  Their frames
+    add up to the unsharded viewport's frame bit for bit -- set_shard must not disturb the sample sequence -- with the library's default
+    walk (intersection counters off: the 4-wide tree) and with the binary one."""
+    w, h, passes = 320, 200, 5
+    scene, camera = scenes.sponza_class(w / h, 20000)
+
+    def run(shard=None, counters=False):
+        vp = ra.Viewport(w, h, seed=77, max_ray_depth=6)
+        vp.set_renderer(scene, intersection_counters=counters)
+        if shard:
+            vp.set_shard(*shard)
+        vp.render(camera, passes)
+        return vp.sum_buffer(), vp.counters()
+
+    for counters in (False, True):
+        whole, cw = run(counters=counters)
+        parts = [run((r, 3), counters) for r in range(3)]
+        total = parts[0][0] + parts[1][0] + parts[2][0]        # disjoint support: adding zeros is exact
+        assert np.array_equal(total.view(np.uint32), whole.view(np.uint32))
+        for k in ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays"):
+            assert sum(p[1][k] for p in parts) == cw[k], k
+    assert cw["numRayBoxTests"] > 0
+
+
 def test_two_physical_devices(built):
     import torch
     if torch.cuda.device_count() < 2:
