@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 
 import oracle_lib
+import ref_render
 import ref_scenes
 import raytracer_amd as ra
 
@@ -96,3 +97,20 @@ def test_cornell_statistics_of_the_survey(built):
     assert np.all(np.abs(mean - np.array([0.268601, 0.220071, 0.262727])) <= 0.015 * mean), mean
     paths = w * h * passes
     assert abs(int(cnt[0]) / paths - 3.1358) <= 0.0314 and abs(int(cnt[1]) / paths - 1.5628) <= 0.0157, (int(cnt[0]) / paths, int(cnt[1]) / paths)
+
+
+@pytest.mark.skipif(not ref_render.available(), reason="oracle/_ref/ref_render is built in the container that has /root/reference")
+def test_flush_denormals_setting_does_not_change_the_reference_frames(tmp_path, monkeypatch):
+    """The reference's Demo / Tests run with FTZ / DAZ on (Core/Math/Math.cpp:27-34); the oracle and the device keep denormals.  Quantified
+    with the reference's own renderer: with the setting on and off, two of the fixture scenes render bit-identical frames."""
+    for name in ("cornell", "mesh_2k_all"):
+        make, w, h, passes, depth, sampling_all, dims = ref_scenes.FIXTURES[name]
+        scene, camera = make(w / h)
+        path = str(tmp_path / (name + ".bin"))
+        ref_render.export_scene(path, scene, camera, w, h, passes, 4, depth, dimensions=dims, light_sampling_all=sampling_all, seed=ref_scenes.SEED)
+        monkeypatch.delenv("RT_REF_KEEP_DENORMALS", raising=False)
+        _, flushed = ref_render.run(path)
+        monkeypatch.setenv("RT_REF_KEEP_DENORMALS", "1")
+        _, kept = ref_render.run(path)
+        assert np.array_equal(flushed["image"].view(np.uint32), kept["image"].view(np.uint32))
+        assert flushed["numRays"] == kept["numRays"] and flushed["numShadowRays"] == kept["numShadowRays"]
