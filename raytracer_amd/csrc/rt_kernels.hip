@@ -320,7 +320,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     // and searches it as a ray of its own with the same request id; whoever finds an occluder marks the request.
     // Closest-hit rays are never split (their box culling and tie-breaking depend on the visiting order), and the
     // counting variant does not split at all, so the intersection counters stay those of the serial traversal.
-    const bool splitShadowRays = !kCount && scene.numObjects == 1u;   // bypass scenes: a mesh level is all a ray has
+    const bool splitShadowRays = !kCount;
+    const bool singleMeshLevel = scene.numObjects == 1u;   // bypass scenes: a mesh level is all a ray has (degenerate closest-hit rays can be handed over)
     // Single-mesh scenes (Scene::Traverse's one-object bypass, Scene.cpp:231-235, into MeshShape::Traverse): everything a ray
     // needs to enter the mesh is the same for all rays, so it is fetched ONCE per wave (uniform -> scalar registers) instead
     // of through three dependent loads (object -> mesh -> root node) behind every refill.
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         // direction turns two of three slab tests into inf - inf, and the ray walks most of the tree alone -- tens of
         // milliseconds).  Such rays cannot be split like any-hit rays (the visiting order decides ties), so they are handed
         // to k_trace_monster, which finds the same hit cooperatively.  Single-mesh scenes, counters off.
-        if (splitShadowRays && tune.overflowQueue && exhausted && ++closestDrain > tune.abortClosestAfter)
+        if (splitShadowRays && singleMeshLevel && tune.overflowQueue && exhausted && ++closestDrain > tune.abortClosestAfter)
         {
             const bool abortLane = have && !s.shadow;
             const unsigned long long mAbort = __ballot(abortLane);
@@ -380,7 +381,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         if (splitShadowRays && exhausted && nIdle != 0u && ++drainIterations > RT_SPLIT_AFTER) mDonors = __ballot(canDonate);
         if (refill || mDonors != 0ull)
         {
-            uint32_t request = 0xFFFFFFFFu, donated = 0u;
+            uint32_t request = 0xFFFFFFFFu, donated = 0u, meshContextObject = 0u;
             bool shadowRequest = true;
             if (refill)
             {
@@ -416,10 +417,19 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     src = (uint32_t)__ffsll((long long)m) - 1u;
                 }
                 uint32_t entry = 0u;
-                if (donate) { entry = stack.base[s.levelBase * stack.stride]; s.levelBase++; }
+                if (donate)
+                {
+                    // the oldest entry of the mesh level leaves the donor's stack; the newest one takes its place (any-hit rays: the order
+                    // of the remaining subtrees is free), so that nothing stale is left for the level below in a two-level scene
+                    entry = stack.base[s.levelBase * stack.stride];
+                    --s.stackSize;
+                    stack.base[s.levelBase * stack.stride] = stack.base[s.stackSize * stack.stride];
+                }
                 const uint32_t donorRequest = (uint32_t)__shfl((int)(light * paths.capacity + slot), (int)src);
                 donated = (uint32_t)__shfl((int)entry, (int)src);
                 if (take) request = donorRequest;
+                // two-level scenes: the taker continues inside the DONOR'S mesh (it rebuilds the local ray from the request like a mesh entry does)
+                if (!bypassMesh) meshContextObject = (uint32_t)__shfl((int)s.objectId, (int)src);
             }
             if (request != 0xFFFFFFFFu)
             {
@@ -441,7 +451,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     s.stackSize = 0; s.levelBase = 0; s.leafNext = 1; s.leafEnd = 1; s.objectId = 0; s.triBase = bypassTriBase;
                     s.occluded = false; s.nodes = bypassNodes; s.cur = bypassRoot; s.mode = TRAV_MESH;
                 }
-                else
+                else if (refill)
                 {
                     travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
                     // other single-object scenes start at the object loop (BVH bypass): enter the object right away instead
@@ -449,7 +459,17 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
                 }
                 // a taken subtree: same ray, same mesh, but only the donated node instead of the root
-                if (!refill && s.mode == TRAV_MESH) s.cur = donated;
+                if (!refill && bypassMesh) { if (s.mode == TRAV_MESH) s.cur = donated; }
+                else if (!refill)
+                {
+                    const RtObject& obj = scene.objects[meshContextObject];
+                    const RtMesh& mesh = scene.meshes[obj.meshIndex];
+                    s.ray = transformRayUnsafe(loadM4(obj.invTransform), loadWorldRay());   // = the donor's local ray (Scene::Traverse_Object_Shadow's)
+                    s.nanFree = rayIsNaNFree(s.ray); s.hitDistance = maxDistance;
+                    s.stackSize = 0; s.levelBase = 0; s.leafNext = 0; s.leafEnd = 0;   // nothing above the mesh: when its level is exhausted the ray is done
+                    s.objectId = meshContextObject; s.triBase = mesh.firstTriangle; s.nodes = scene.meshNodes + mesh.firstNode;
+                    s.occluded = false; s.cur = donated; s.mode = TRAV_MESH;
+                }
             }
             continue;
         }

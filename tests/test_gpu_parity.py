@@ -697,6 +697,22 @@ def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
     assert overflows > 0
 
 
+def test_two_level_scenes_with_the_counters_off(built):
+    """The library's default (intersection counters off) on scenes the 4-wide walk does not serve -- a mesh among analytic shapes and an
+    area light, the Cornell box: k_trace without the counting code, where a wave's idle lanes take over subtrees of its longest any-hit
+    rays at the end of a launch (two-level scenes: inside the donor's mesh, with the local ray rebuilt from the request).  Images and ray
+    counters are the oracle's."""
+    w, h = 192, 108
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
+    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=6)
+    assert_quant_identical(*out)
+    assert out[2]["numRetracedRays"] == 0 and out[2]["numAnalyticHits"] > 0 and out[2]["numMeshHits"] > 0
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=6, light_sampling_all=True)
+    assert_quant_identical(*out)
+    scene, camera = scenes.cornell_box(w / h)
+    assert_quant_identical(*run_quant(scene, camera, w, h, passes=3, max_ray_depth=6))
+
+
 def test_wide_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     """1920x1080, the benchmark's mesh, depth 8: the frame of the 4-wide walk equals the frame of the binary-tree kernel bit for bit, ray
     counters included; the exact re-trace serves well under 1 % of the rays."""

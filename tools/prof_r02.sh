@@ -30,7 +30,7 @@ for group in \
   rm -rf $T/p$i $T/err_p$i.txt
 done
 # 5. the GPU test suite
-python -m pytest tests -q -m gpu 2>&1 | tail -4 > $T/pytest_gpu.log
+python -m pytest tests -q -m gpu 2>&1 | grep -v "^$" | grep "passed\|failed\|error\|^\." > $T/pytest_gpu.log
 for f in $T/bench_*.json; do echo "$f: $(tail -1 $f | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), d['unit'], d['config']['workload'][:60])")"; done
 head -9 $T/kernel_stats_serial.txt; cat $T/pytest_gpu.log
 grep "k_trace_wide" $T/wide_pmc_*.txt | head -40
