@@ -77,6 +77,7 @@
 #include "Rendering/Viewport.h"
 #include "Rendering/Renderer.h"
 #include "Rendering/PathTracerMIS.h"
+#include "Rendering/PathDebugging.h"
 #include "Rendering/ShadingData.h"
 #include "Rendering/Context.h"
 #include "BVH/BVHBuilder.h"
@@ -382,6 +383,13 @@ int main(int argc, char** argv)
     if (!viewport.SetRenderer(renderer)) return 2;
     viewport.Reset();
 
+#ifdef RT_REF_PATH_DEBUG
+    // ref_paths: PathTracerMIS.cpp built WITHOUT RT_CONFIGURATION_FINAL records every vertex of every path (PathDebugData, the hook the
+    // reference's Demo uses for its path inspector, PathTracerMIS.cpp:377-410 / Demo.cpp:288-291).  One thread, so one context sees all.
+    PathDebugData pathDebug;
+    if (threads != 1) { fprintf(stderr, "ref_paths needs one thread\n"); return 2; }
+    viewport.mThreadData[0].pathDebugData = &pathDebug;
+#endif
     RayTracingCounters total; total.Reset();
     std::vector<uint32> firstSeeds;
     float firstOffset[2] = { 0.0f, 0.0f };
@@ -429,6 +437,26 @@ int main(int argc, char** argv)
         fwrite(firstOffset, 4, 2, f);
         if (!firstSeeds.empty()) fwrite(firstSeeds.data(), 4, firstSeeds.size(), f);
         if (dumpImage) for (uint32 y = 0; y < height; ++y) fwrite(reinterpret_cast<const uint8_t*>(sum.GetData()) + (size_t)y * sum.GetStride(), 4, (size_t)width * 3, f);
+#ifdef RT_REF_PATH_DEBUG
+        // every recorded vertex in the order the pixels were rendered: 28 floats each -- ray origin xyz, ray direction xyz, hit objectId,
+        // subObjectId (bit-cast), distance, u, v, frame position xyz, normal xyz, tangent xyz, texCoord xy, throughput xyzw, bsdfEvent
+        const uint32 numVertices = pathDebug.data.Size();
+        fwrite(&numVertices, 4, 1, f);
+        for (uint32 i = 0; i < numVertices; ++i)
+        {
+            const PathDebugData::HitPointData& d = pathDebug.data[i];
+            float rec[28]; uint32 bits;
+            rec[0] = d.rayOrigin.x; rec[1] = d.rayOrigin.y; rec[2] = d.rayOrigin.z; rec[3] = d.rayDir.x; rec[4] = d.rayDir.y; rec[5] = d.rayDir.z;
+            bits = d.hitPoint.objectId; memcpy(&rec[6], &bits, 4); bits = d.hitPoint.subObjectId; memcpy(&rec[7], &bits, 4);
+            rec[8] = d.hitPoint.distance; rec[9] = d.hitPoint.u; rec[10] = d.hitPoint.v;
+            const Matrix4& fr = d.shadingData.intersection.frame;
+            rec[11] = fr[3].x; rec[12] = fr[3].y; rec[13] = fr[3].z; rec[14] = fr[2].x; rec[15] = fr[2].y; rec[16] = fr[2].z; rec[17] = fr[0].x; rec[18] = fr[0].y; rec[19] = fr[0].z;
+            rec[20] = d.shadingData.intersection.texCoord.x; rec[21] = d.shadingData.intersection.texCoord.y;
+            rec[22] = d.throughput.value.x; rec[23] = d.throughput.value.y; rec[24] = d.throughput.value.z; rec[25] = d.throughput.value.w;
+            bits = (uint32)d.bsdfEvent; memcpy(&rec[26], &bits, 4); rec[27] = 0.0f;
+            fwrite(rec, 4, 28, f);
+        }
+#endif
         fclose(f);
     }
     return 0;

@@ -377,12 +377,26 @@ int rto_kat_xoroshiro(uint64_t s0, uint64_t s1, uint32_t count, uint64_t* outLon
     return 0;
 }
 
-// Per-pixel debug trace: renders ONE pixel and returns its radiance (for path-level parity debugging).
+// Per-pixel debug trace: renders ONE pixel and returns its radiance (for path-level parity debugging).  rto_render_pixel_paths also
+// records the path's vertices like the reference's PathDebugData hook does (28 floats per vertex, see RenderCtx); *numVertices = how many
+// the path has (only the first `capacity` are stored).
+static float* gPathDump = nullptr; static uint32_t gPathDumpCapacity = 0; static uint32_t* gPathDumpCount = nullptr;
+int rto_render_pixel(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
+                     uint32_t x, uint32_t y, float outRGBA[4], uint64_t* counters);
+int rto_render_pixel_paths(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height, uint32_t x, uint32_t y,
+                           float outRGBA[4], uint64_t* counters, float* vertices, uint32_t capacity, uint32_t* numVertices)
+{
+    gPathDump = vertices; gPathDumpCapacity = capacity; gPathDumpCount = numVertices;
+    const int r = rto_render_pixel(scene, params, width, height, x, y, outRGBA, counters);
+    gPathDump = nullptr; gPathDumpCapacity = 0; gPathDumpCount = nullptr;
+    return r;
+}
 int rto_render_pixel(const RtSceneDesc* scene, const RtPassParams* params, uint32_t width, uint32_t height,
                      uint32_t x, uint32_t y, float outRGBA[4], uint64_t* counters)
 {
     Counters c; memset(&c, 0, sizeof(c));
     RenderCtx ctx;
+    ctx.pathDump = gPathDump; ctx.pathDumpCapacity = gPathDumpCapacity;
     ctx.scene = scene; ctx.params = params; ctx.counters = &c;
     ctx.lightSamplingWeight = load4(params->lightSamplingWeight);
     ctx.bsdfSamplingWeight = load4(params->bsdfSamplingWeight);
@@ -395,6 +409,7 @@ int rto_render_pixel(const RtSceneDesc* scene, const RtPassParams* params, uint3
     ctx.sampler.resetPixel(x, y, params->rngKey);
     const Ray ray = cameraGenerateRay(params->camera, coords, ctx.sampler);
     const V4 color = renderPixel(ctx, ray);
+    if (gPathDumpCount) *gPathDumpCount = ctx.pathDumpCount;
     outRGBA[0] = color.x; outRGBA[1] = color.y; outRGBA[2] = color.z; outRGBA[3] = color.w;
     if (counters) for (int i = 0; i < 16; ++i) counters[i] += c.c[i];
     return 0;

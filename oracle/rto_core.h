@@ -1521,6 +1521,10 @@ struct RenderCtx
 {
     const RtSceneDesc* scene; const RtPassParams* params; Sampler sampler; Counters* counters;
     V4 lightSamplingWeight, bsdfSamplingWeight;
+    // the reference's PathDebugData hook (PathDebugging.h:27-53, filled at PathTracerMIS.cpp:377-410): when pathDump is set, renderPixel
+    // records every vertex -- 28 floats: ray origin xyz, ray direction xyz, hit objectId, subObjectId (bit-cast), distance, u, v, frame
+    // position xyz, normal xyz, tangent xyz, texCoord xy, throughput xyzw, bsdfEvent, 0
+    float* pathDump = nullptr; uint32_t pathDumpCapacity = 0, pathDumpCount = 0;
 };
 
 // PathTracerMIS::SampleLight, :43-123
@@ -1621,6 +1625,25 @@ static inline V4 evaluateGlobalLights(RenderCtx& ctx, const Ray& ray, const Path
     return result;
 }
 
+static inline void pathDumpRecord(RenderCtx& ctx, const Ray& ray, const Hit& hit, const ShadingData& sd, V4 throughput, uint32_t bsdfEvent)
+{
+    if (!ctx.pathDump) return;
+    if (ctx.pathDumpCount < ctx.pathDumpCapacity)
+    {
+        float* rec = ctx.pathDump + (size_t)ctx.pathDumpCount * 28u;
+        rec[0] = ray.origin.x; rec[1] = ray.origin.y; rec[2] = ray.origin.z; rec[3] = ray.dir.x; rec[4] = ray.dir.y; rec[5] = ray.dir.z;
+        memcpy(&rec[6], &hit.objectId, 4); memcpy(&rec[7], &hit.subObjectId, 4);
+        rec[8] = hit.distance; rec[9] = hit.u; rec[10] = hit.v;
+        const M4& fr = sd.intersection.frame;
+        rec[11] = fr.r[3].x; rec[12] = fr.r[3].y; rec[13] = fr.r[3].z; rec[14] = fr.r[2].x; rec[15] = fr.r[2].y; rec[16] = fr.r[2].z;
+        rec[17] = fr.r[0].x; rec[18] = fr.r[0].y; rec[19] = fr.r[0].z;
+        rec[20] = sd.intersection.texCoord.x; rec[21] = sd.intersection.texCoord.y;
+        rec[22] = throughput.x; rec[23] = throughput.y; rec[24] = throughput.z; rec[25] = throughput.w;
+        memcpy(&rec[26], &bsdfEvent, 4); rec[27] = 0.0f;
+    }
+    ctx.pathDumpCount++;
+}
+
 // PathTracerMIS::RenderPixel, :254-415
 static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
 {
@@ -1685,11 +1708,13 @@ static inline V4 renderPixel(RenderCtx& ctx, const Ray& primaryRay)
         if (almostZero4(throughput)) break;
         pathState.lastSpecular = (lastSampledBsdfEvent & EV_SPECULAR) != 0;
         pathState.lastPdfW = pdf;
+        pathDumpRecord(ctx, ray, hitPoint, shadingData, throughput, lastSampledBsdfEvent);   // :377-388
 
         ray = makeRay(shadingData.intersection.frame.r[3], incomingDirWorldSpace);
         ray.origin = ray.origin + ray.dir * 0.001f;
         pathState.depth++;
     }
+    pathDumpRecord(ctx, ray, hitPoint, shadingData, throughput, 0u);   // :398-409 (the reference leaves bsdfEvent unset here)
 
     ctx.counters->c[C_RAYS] += (uint64_t)pathState.depth + 1;
     return resultColor;

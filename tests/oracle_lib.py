@@ -45,6 +45,17 @@ def render_pixel(scene_desc_ptr, params, width, height, x, y):
     return np.array(out[:], dtype=np.float32)
 
 
+def render_pixel_paths(scene_desc_ptr, params, width, height, x, y, capacity=64):
+    """The vertices of ONE pixel's path as the reference's PathDebugData hook records them: (numVertices, 28) float32 (see RenderCtx)."""
+    out = (C.c_float * 4)()
+    vertices = np.zeros((capacity, 28), dtype=np.float32)
+    n = C.c_uint32(0)
+    lib().rto_render_pixel_paths(scene_desc_ptr, C.byref(params), C.c_uint32(width), C.c_uint32(height), C.c_uint32(x), C.c_uint32(y), out, None,
+                                 vertices.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(capacity), C.byref(n))
+    assert n.value <= capacity
+    return vertices[:n.value]
+
+
 def kat(func, inputs, out_stride):
     inputs = np.ascontiguousarray(inputs, dtype=np.float32)
     n, in_stride = inputs.shape
