@@ -25,11 +25,11 @@ class Shard(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("worldSize", C.c_uint32)]
 
 
-def render(scene, camera, w, h, passes, devices=None, name="Path Tracer MIS", all_lights=False, depth=6, adaptive=False):
+def render(scene, camera, w, h, passes, devices=None, name="Path Tracer MIS", all_lights=False, depth=6, adaptive=False, counters=True):
     vp = ra.Viewport(w, h, seed=21, max_ray_depth=depth, light_sampling_all=all_lights)
     if adaptive:
         vp.set_adaptive(True, num_initial_passes=2, min_block_size=8, max_block_size=64, subdivision_treshold=0.05, convergence_treshold=0.01)
-    vp.set_renderer(scene, name, devices=devices)
+    vp.set_renderer(scene, name, devices=devices, intersection_counters=counters)
     vp.render(camera, passes)
     s, s2 = vp.sum_buffer(secondary=True)
     n = C.c_uint32(0)
@@ -72,6 +72,11 @@ def test_mesh_scene_and_the_other_per_pixel_integrators(built):
         one = render(scene, camera, w, h, 4, name=name)
         many = render(scene, camera, w, h, 4, devices=[0, 0], name=name)
         assert_same(one, many)
+    # the library's default walk (intersection counters off: the 4-wide tree and its re-trace launches on every shard)
+    one = render(scene, camera, w, h, 6, counters=False)
+    many = render(scene, camera, w, h, 6, devices=[0, 0, 0], counters=False)
+    assert_same(one, many)
+    assert one["counters"]["numRetracedRays"] > 0 and many["counters"]["numRetracedRays"] == one["counters"]["numRetracedRays"]
 
 
 def test_adaptive_rendering_over_shards(built):

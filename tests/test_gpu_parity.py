@@ -697,6 +697,30 @@ def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
     assert overflows > 0
 
 
+def test_page_locked_read_back_buffers(built):
+    """rtgpu_host_register / rtgpu_host_unregister: a registered buffer receives the same frame as a pageable one; unregistering an unknown
+    pointer is an error code, not a crash; NULL arguments are refused."""
+    lib = ra.rtgpu_lib()
+    w, h = 160, 96
+    scene, camera = scenes.cornell_box(w / h)
+    vp = ra.Viewport(w, h, seed=3, max_ray_depth=4)
+    vp.set_renderer(scene)
+    vp.render(camera, 3)
+    ctx = vp.device_context()
+    plain = np.zeros((h, w, 3), dtype=np.float32)
+    pinned = np.zeros((h, w, 3), dtype=np.float32)
+    assert lib.rtgpu_host_register(ctx, pinned.ctypes.data_as(C.c_void_p), C.c_size_t(pinned.nbytes)) == 0
+    try:
+        assert lib.rtgpu_read_sum(ctx, plain.ctypes.data_as(C.POINTER(C.c_float)), None) == 0
+        assert lib.rtgpu_read_sum(ctx, pinned.ctypes.data_as(C.POINTER(C.c_float)), None) == 0
+        assert plain.any() and np.array_equal(plain.view(np.uint32), pinned.view(np.uint32))
+        assert np.array_equal(plain.view(np.uint32), vp.sum_buffer().view(np.uint32))        # the mirror's own (registered) bitmap
+    finally:
+        assert lib.rtgpu_host_unregister(ctx, pinned.ctypes.data_as(C.c_void_p)) == 0
+    assert lib.rtgpu_host_unregister(ctx, plain.ctypes.data_as(C.c_void_p)) != 0              # never registered
+    assert lib.rtgpu_host_register(ctx, None, C.c_size_t(16)) == -1 and lib.rtgpu_host_register(None, plain.ctypes.data_as(C.c_void_p), C.c_size_t(16)) == -1
+
+
 def test_two_level_scenes_with_the_counters_off(built):
     """The library's default (intersection counters off) on scenes the 4-wide walk does not serve -- a mesh among analytic shapes and an
     area light, the Cornell box: k_trace without the counting code, where a wave's idle lanes take over subtrees of its longest any-hit
