@@ -2056,6 +2056,12 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
         hipLaunchKernelGGL((k_trace_wide<24, false, true, false, 64>), grid64, block64, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
         return;
     }
+    static const bool share = getenv("RTGPU_WIDE_SHARE") != nullptr;   // experiment: idle lanes take subtrees of busy any-hit rays in the drain phase
+    if (share && !diag && !unsorted && eager)
+    {
+        hipLaunchKernelGGL((k_trace_wide<24, false, true, false, RT_BLOCK, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+        return;
+    }
 #define RT_LAUNCH_WIDE(D, S, P) hipLaunchKernelGGL((k_trace_wide<24, D, S, P>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
     if (diag) { if (unsorted) { if (eager) RT_LAUNCH_WIDE(true, false, false); else RT_LAUNCH_WIDE(true, false, true); } else { if (eager) RT_LAUNCH_WIDE(true, true, false); else RT_LAUNCH_WIDE(true, true, true); } }
     else { if (unsorted) { if (eager) RT_LAUNCH_WIDE(false, false, false); else RT_LAUNCH_WIDE(false, false, true); } else { if (eager) RT_LAUNCH_WIDE(false, true, false); else RT_LAUNCH_WIDE(false, true, true); } }

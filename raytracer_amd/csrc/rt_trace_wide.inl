@@ -58,7 +58,7 @@ struct WideTuning
     }
 #define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
 
-template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false, int kBlock = RT_BLOCK>
+template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false, int kBlock = RT_BLOCK, bool kShare = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
     uint32_t selX = RT_WIDE_SEL_X_POS, selY = RT_WIDE_SEL_Y_POS, selZ = RT_WIDE_SEL_Z_POS;   // which plane of an axis the ray meets first
     uint32_t cur = RT_QUANT_DONE, pend = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;   // pend: a leaf set aside while the lane keeps walking interior nodes
     bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
-    uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
+    uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0, drainIterations = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
 
     uint32_t chunkSize = count / (gridDim.x * ((uint32_t)kBlock / 64u) * 4u);
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
     // kDiag: wave clock per phase (0 refill, 1 interior loop, 2 leaf / finish) and the number of times each ran
     unsigned long long diagClock[3] = { 0ull, 0ull, 0ull }, diagPrev = kDiag ? (unsigned long long)clock64() : 0ull, diagStart = diagPrev;
     uint32_t diagRuns[3] = { 0u, 0u, 0u }, diagPhase = 0u, diagClaims = 0u;
-    unsigned long long diagClaimClock = 0ull;   // inside the refill phase: waiting for the work cursor's atomic
+    unsigned long long diagClaimClock = 0ull, diagExhausted = 0ull;   // when this wave found the work queue empty   // inside the refill phase: waiting for the work cursor's atomic
     for (;;)
     {
         if (kDiag) { const unsigned long long now = (unsigned long long)clock64(); diagClock[diagPhase] += now - diagPrev; diagPrev = now; }
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                 const unsigned long long claim0 = kDiag ? (unsigned long long)clock64() : 0ull;
                 waveClaimChunk(chunk, cursor, chunkSize, count);
                 if (kDiag) { diagClaimClock += (unsigned long long)clock64() - claim0; diagClaims++; }
-                if (chunk.next >= chunk.end) { exhausted = true; continue; }
+                if (chunk.next >= chunk.end) { exhausted = true; if (kDiag) diagExhausted = (unsigned long long)clock64(); continue; }
             }
             const uint32_t idx = waveTake(!have, chunk);
             if (idx != 0xFFFFFFFFu)
@@ -167,6 +167,56 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                 }
             }
             continue;
+        }
+        // kShare (an experiment that did not pay: 147 -> 159 ms, the extra live state spills seven registers and the drain phase stays at
+        // 17 % of the wave time -- its length is the lifetime of the rays started last, not a few long ones).  Drain phase: the queue is
+        // empty and the wave lasts as long as its longest ray; occlusion is an OR over subtrees, so a lane with nothing to do takes the
+        // OLDEST deferred node of a busy any-hit ray of its wave and searches it as a ray of its own for the same request.
+        if (kShare && exhausted && nIdle != 0u && nIdle != 64u && ++drainIterations > RT_SPLIT_AFTER)
+        {
+            const bool canDonate = have && shadow && sp != 0u && cur != RT_QUANT_DONE;
+            const unsigned long long mDonors = __ballot(canDonate);
+            if (mDonors != 0ull)
+            {
+                const unsigned long long mIdle = __ballot(!have);
+                const uint32_t lane = threadIdx.x & 63u;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t nDonors = (uint32_t)__popcll(mDonors), nTakers = (uint32_t)__popcll(mIdle);
+                const uint32_t pairs = nDonors < nTakers ? nDonors : nTakers;
+                const bool donate = canDonate && (uint32_t)__popcll(mDonors & below) < pairs;
+                const uint32_t takerRank = (uint32_t)__popcll(mIdle & below);
+                const bool take = !have && takerRank < pairs;
+                uint32_t src = lane;
+                if (take)
+                {
+                    unsigned long long m = mDonors;
+                    for (uint32_t k = 0; k < takerRank; ++k) m &= m - 1ull;
+                    src = (uint32_t)__ffsll((long long)m) - 1u;
+                }
+                uint32_t entry = 0u;
+                if (donate)
+                {
+                    entry = stack[0];                    // the oldest deferred node leaves the donor's stack, the newest takes its place
+                    --sp;
+                    stack[0] = stack[sp * kBlock];
+                }
+                // the donor's ray travels with the node (shuffles are evaluated by every lane; one value at a time: the kernel sits on a
+                // register cliff).  A taker is never a donor, so the sources do not change underneath.
+#define RT_WIDE_TAKE_F(x) { const float t_ = __shfl(x, (int)src); if (take) x = t_; }
+#define RT_WIDE_TAKE_U(x) { const uint32_t t_ = (uint32_t)__shfl((int)x, (int)src); if (take) x = t_; }
+                RT_WIDE_TAKE_F(ox) RT_WIDE_TAKE_F(oy) RT_WIDE_TAKE_F(oz) RT_WIDE_TAKE_F(dx) RT_WIDE_TAKE_F(dy) RT_WIDE_TAKE_F(dz)
+                RT_WIDE_TAKE_F(ax) RT_WIDE_TAKE_F(ay) RT_WIDE_TAKE_F(az) RT_WIDE_TAKE_F(bx) RT_WIDE_TAKE_F(by) RT_WIDE_TAKE_F(bz)
+                RT_WIDE_TAKE_F(best) RT_WIDE_TAKE_U(selX) RT_WIDE_TAKE_U(selY) RT_WIDE_TAKE_U(selZ) RT_WIDE_TAKE_U(slot) RT_WIDE_TAKE_U(light)
+#undef RT_WIDE_TAKE_F
+#undef RT_WIDE_TAKE_U
+                const uint32_t tentry = (uint32_t)__shfl((int)entry, (int)src);
+                if (take)
+                {
+                    second = inf; tol = 0.0f; occluded = false; overflow = false; shadow = true;
+                    sp = 0u; cur = tentry; pend = RT_QUANT_DONE; have = true;
+                }
+                continue;
+            }
         }
         if ((mI | mO) == 0ull) break;
         if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
@@ -336,7 +386,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
             // the reference's intersection counters are not used by this walk: per-wave clocks and phase counts ride in their slots
             atomicAdd(&counters[C_BOX], diagClock[0]); atomicAdd(&counters[C_BOX_PASS], diagClock[1]); atomicAdd(&counters[C_TRI], diagClock[2]);
             atomicAdd(&counters[C_TRI_PASS], (unsigned long long)clock64() - diagStart);
-            atomicAdd(&counters[C_BOX_SHADOW], (unsigned long long)diagRuns[1]); atomicAdd(&counters[C_TRI_SHADOW], (unsigned long long)diagRuns[2]);
+            atomicAdd(&counters[C_BOX_SHADOW], (unsigned long long)diagRuns[1]);
+            atomicAdd(&counters[C_TRI_SHADOW], diagExhausted ? diagPrev - diagExhausted : 0ull);   // the wave's drain phase: from the empty queue to its last ray
             atomicAdd(&counters[C_ANALYTIC_HITS], (unsigned long long)diagRuns[0]);   // (free in a mesh-only scene)
             atomicAdd(&counters[C_PRIMARY], diagClaimClock); atomicAdd(&counters[C_SHADOW_HIT], (unsigned long long)diagClaims);   // (k_shade adds to these two as well: subtract a run without RTGPU_WIDE_DIAG)
         }

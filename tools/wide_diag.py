@@ -17,6 +17,7 @@ if os.environ.get("RTGPU_WIDE_DIAG"):
     print("phase runs per wave-lifetime: refill %d interior %d leaf %d; clocks per run: refill %.0f interior %.0f leaf %.0f; interior wave-steps per run %.2f, clocks per interior wave-step %.0f" % (
         c["numMeshHits"], c["numShadowRayBoxTests"], c["numShadowRayTriangleTests"], c["numRayBoxTests"]/max(1,c["numMeshHits"]), c["numPassedRayBoxTests"]/max(1,c["numShadowRayBoxTests"]), c["numRayTriangleTests"]/max(1,c["numShadowRayTriangleTests"]),
         c["numStackOverflowRays"]/64/max(1,c["numShadowRayBoxTests"]), c["numPassedRayBoxTests"]/max(1,c["numStackOverflowRays"]/64)))
+    print("drain phase (queue empty -> the wave's last ray done): %.1f %% of the wave time" % (100.0 * c["numShadowRayTriangleTests"] / tot))
     base_primary, base_shadow_hit = w * h * 4, int(os.environ.get("BASE_SHADOW_HIT", "0"))
     print("refill runs %d (%.0f clocks each); cursor claims %d, %.0f clocks each = %.1f %% of the wave time (needs BASE_SHADOW_HIT = numShadowRaysHit of a plain run; raw %d)" % (
         c["numAnalyticHits"], c["numRayBoxTests"] / max(1, c["numAnalyticHits"]), c["numShadowRaysHit"] - base_shadow_hit,
