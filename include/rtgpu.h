@@ -470,7 +470,7 @@ int rtgpu_set_debug_rendering_mode(RtgpuContext* ctx, uint32_t mode);
 /* number of photons recorded by the last VCM pass (the merge set of the next one).  Synchronises. */
 int rtgpu_vcm_num_photons(RtgpuContext* ctx, uint32_t* outCount);
 
-/* Batch lanes (1..6, default 3).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
+/* Batch lanes (1..6, default 4).  rtgpu_render_pass gathers passes into batches; consecutive batches run on
  * alternating HIP streams with their own path-state arenas, so the drain of one batch's traversal launches (a few
  * very long rays) overlaps with the next batch's kernels.  The film is still summed in pass order.  Performance
  * only: results do not depend on it.  1 = strictly serial kernels (what per-kernel timing wants).  Synchronises.

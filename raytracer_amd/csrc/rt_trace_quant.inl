@@ -1,5 +1,7 @@
-// rt_trace_quant.inl -- the default traversal kernel of single-mesh scenes: the binary tree of the reference with its child pairs
-// re-encoded in 32 bytes.  Included by rt_kernels.hip.
+// rt_trace_quant.inl -- an EXPERIMENT (RTGPU_QUANT=1; measured no faster than k_trace: 182 vs 183 ms) and the home of what the default
+// walk of single-mesh scenes, k_trace_wide (rt_trace_wide.inl), shares with it: the 16-bit grid, the per-leaf exact boxes and the
+// exactness argument below.  The kernel here walks the binary tree of the reference with its child pairs re-encoded in 32 bytes.
+// Included by rt_kernels.hip.
 //
 // Why.  k_trace (rt_device_traverse.h) is bound by the vector L1: a lane fetches its 64-byte node pair with four 16-byte loads, and a
 // divergent 16-byte access occupies the texture-cache pipeline for a cycle whatever it uses of the line -- 0.71 accesses per clock and
