@@ -258,6 +258,33 @@ def test_many_lights_all_strategy_and_degenerate_sizes(built):
         assert out[2]["numShadowRays"] > 0
 
 
+def test_sixty_four_lights_at_full_hd_under_the_all_strategy(built):
+    """LightSamplingStrategy::All makes path slots fat (two records per light): 64 lights at 1920x1080 would be ~109 GB per batch lane at the
+    streaming batch size.  The lane budget knows the light count (bytesPerSlot / maxBatchFor): the passes run in smaller batches instead
+    of failing to allocate, and 1/48 of the frame's tiles equal the oracle bit for bit."""
+    w, h = 1920, 1080
+    scene, camera = scene_zoo.many_lights_scene(w / h, num_point_lights=62)
+    assert scene.desc.contents.numLights == 64
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=8, max_ray_depth=3, light_sampling_all=True, dimensions=512)
+    vp.set_renderer(scene)
+    ref = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    shard = (5, 48)
+    for _ in range(3):
+        p = vp.next_pass_params(camera)
+        vp.render_pass_with(p)
+        oracle_lib.render_pass(desc, p, w, h, ref, None, cnt, shard=shard, threads=32)
+    img = vp.sum_buffer()
+    c = vp.counters()
+    assert np.isfinite(img).all() and c["numShadowRays"] > 10 * c["numPrimaryRays"]
+    owned = ref.any(axis=2)
+    assert owned.sum() > 20000
+    assert np.array_equal(img[owned].view(np.uint32), ref[owned].view(np.uint32))
+
+
 def test_reset_restarts_the_accumulation(built):
     """rtgpu_reset (Viewport::Reset) zeroes sums and counters; the passes rendered afterwards with the same constants give
     the bits a fresh viewport gives."""
