@@ -748,6 +748,26 @@ def test_page_locked_read_back_buffers(built):
     assert lib.rtgpu_host_register(ctx, None, C.c_size_t(16)) == -1 and lib.rtgpu_host_register(None, plain.ctypes.data_as(C.c_void_p), C.c_size_t(16)) == -1
 
 
+def test_adaptive_rendering_with_the_default_walk(built):
+    """Adaptive rendering (active blocks: a subset of the pixels, re-chosen every second pass) over the library's default pipeline --
+    dense path state + the 4-wide walk (intersection counters off) -- gives the frame, the block list and the error of the binary walk
+    with the counters on."""
+    w, h = 256, 192
+    scene, camera = scenes.sponza_class(w / h, 8000)
+    results = []
+    for counters in (False, True):
+        vp = ra.Viewport(w, h, seed=14, max_ray_depth=5)
+        vp.set_adaptive(True, num_initial_passes=2, min_block_size=8, max_block_size=64, subdivision_treshold=0.05, convergence_treshold=0.01)
+        vp.set_renderer(scene, intersection_counters=counters)
+        vp.render(camera, 10)
+        results.append((vp.sum_buffer(secondary=True), vp.progress(), vp.counters()))
+    (a, a2), pa, ca = results[0]
+    (b, b2), pb, cb = results[1]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a2.view(np.uint32), b2.view(np.uint32))
+    assert pa["blocks"] == pb["blocks"] and pa["averageError"] == pb["averageError"] and len(pa["blocks"]) > 1
+    assert ca["numRays"] == cb["numRays"] and ca["numRetracedRays"] > 0 and cb["numRetracedRays"] == 0
+
+
 def test_two_level_scenes_with_the_counters_off(built):
     """The library's default (intersection counters off) on scenes the 4-wide walk does not serve -- a mesh among analytic shapes and an
     area light, the Cornell box: k_trace without the counting code, where a wave's idle lanes take over subtrees of its longest any-hit
