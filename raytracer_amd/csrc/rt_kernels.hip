@@ -2043,7 +2043,9 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset,
                             const uint32_t* denseCounts, uint32_t denseShardCapacity)
 {
-    WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity };
+    static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
+    WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
+                        chunkMin < 64u ? 64u : chunkMin };
     const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
     static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)

@@ -33,6 +33,7 @@ struct WideTuning
     uint32_t* exactQueue; uint32_t* exactCount;               // closest-hit rays handed to the binary-tree kernel
     uint32_t* exactShadowQueue; uint32_t* exactShadowCount;   // any-hit requests handed to it
     const uint32_t* denseCounts; uint32_t denseShardCapacity; // dense path state (TravTuning)
+    uint32_t chunkMin;                                        // smallest piece of the work queue a wave claims at once
 };
 
 // slab test of one child record against the ray's folded constants; near is clamped to >= 0 (its bits then order like the float).
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
 
     uint32_t chunkSize = count / (gridDim.x * ((uint32_t)kBlock / 64u) * 4u);
-    chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
+    chunkSize = chunkSize < tune.chunkMin ? tune.chunkMin : (chunkSize > 1024u ? 1024u : chunkSize);
     WaveChunk chunk = { 0u, 0u };
 
     // kDiag: wave clock per phase (0 refill, 1 interior loop, 2 leaf / finish) and the number of times each ran
