@@ -2,11 +2,15 @@
 // same leaves), one ray per lane.  Included by rt_kernels.hip after rt_trace_quant.inl, whose grid, leaf gates and exactness argument it
 // shares.
 //
-// Why.  k_trace waits ~0.8 us per dependent node fetch with 20 waves per CU to hide it: the walk is a chain of ~33 round
+// Why.  k_trace waits ~0.8 us per dependent node fetch with 20 waves per CU to hide it: the walk is a chain of ~29 round
 // trips per ray.  Two earlier attempts changed what a round trip moves -- half the bytes (k_trace_quant: no gain, the conversions ate
-// it), a quad of lanes per ray (1.7x slower, instruction bound) -- not how many there are.  A 4-wide node halves the chain: one round
-// trip fetches four children (64 bytes: four of k_trace_quant's 16-byte records), i.e. two levels of the binary tree at once, and the
-// per-step overhead (stack, loop, scheduling ballots) is paid half as often.
+// it), a quad of lanes per ray (1.7x slower, instruction bound) -- not how many there are.  A 4-wide node shortens the chain to 17: one
+// round trip fetches four children (64 bytes: four of k_trace_quant's 16-byte records), i.e. two levels of the binary tree at once, and
+// the per-step overhead (stack, loop, scheduling ballots) is paid half as often.
+// What came of it (profiles/r02_wide_*): the kernel is no longer latency-bound but ISSUE-bound -- vector ALU busy 90 % at 57 % lane
+// utilisation -- so what counts is instructions per visit (137 after the permute / pair-sort step below, 161 before): 164.5 -> 147 ms
+// per 69 passes of the benchmark against k_trace.  Variants that add live state (a leaf set aside, shared any-hit rays, fat leaves,
+// one gate per ray) spill on the 96-VGPR cliff and lose; they are kept behind template flags with their measurements.
 //
 // Node n = records nodes[4 n .. 4 n + 3], one per child: {min.xyz, max.xyz as 16-bit grid coordinates (rounded outwards, QuantBvh's
 // grid), reference}.  A reference is an interior node's index, a leaf (first triangle | count << 30, the binary tree's own leaves of
