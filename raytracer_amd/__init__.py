@@ -397,11 +397,11 @@ class Viewport:
         except Exception:
             pass
 
-    def set_renderer(self, scene, name="Path Tracer MIS", device=-1, devices=None, intersection_counters=True):
+    def set_renderer(self, scene, name="Path Tracer MIS", device=-1, devices=None, intersection_counters=False):
         """CreateRenderer(name, scene) + SetRenderer.  Raises when the GPU renderer cannot be created.  `devices`: a list of HIP device indices
         for ONE renderer over several GPUs of the node (SetRendererDevices -> rtgpu_create_multi; an index may repeat).
-        `intersection_counters`: this wrapper is test / bench plumbing and turns the box / triangle test counters ON (the library's default is
-        the reference's: off) so that parity tests can compare them; pass False for the library's default walk (bench.py does)."""
+        `intersection_counters`: False = the library's (and the reference's, Core/Config.h:4) default; True turns the box / triangle test
+        counters on, which routes every ray through the reference's binary walk (parity tests compare those counters too)."""
         self._scene = scene
         if devices is not None:
             arr = (C.c_int * len(devices))(*[int(d) for d in devices])

@@ -18,3 +18,11 @@ def built():
     import __graft_entry__ as g
     g.build()
     return True
+
+
+def pytest_generate_tests(metafunc):
+    """`walk`: every GPU parity test that asks for it runs twice -- "default": the library as shipped and as bench.py times it (intersection
+    counters off, the reference's default build, Core/Config.h:4: the 4-wide walks, dense path state, re-trace hand-over); "counting": the
+    reference's binary walk with RT_ENABLE_INTERSECTION_COUNTERS-style box / triangle test counters, which are then compared too."""
+    if "walk" in metafunc.fixturenames:
+        metafunc.parametrize("walk", ["default", "counting"])

@@ -24,7 +24,7 @@ import ref_scenes   # noqa: E402
 
 EXE = ref_render.EXE.replace("ref_render", "ref_paths")
 SIZE = (40, 30)
-SCENES = ("box_mesh", "cornell", "mesh_2k_all")
+SCENES = ("box_mesh", "cornell", "mesh_2k_all", "mesh_single")
 
 
 def run_paths(scene_path, w, h):

@@ -45,6 +45,18 @@ def mesh_2k(aspect):
     return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
 
 
+def mesh_single(aspect):
+    """ONE mesh object, ONE light, LightSamplingStrategy::Single: the scene class the library's default pipeline serves with the 4-wide
+    walk (k_trace_wide) over dense path state -- BASELINE config 3 in small."""
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(3000, seed=7)
+    s = ra.Scene()
+    mats = [s.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    s.add_background_light((1.0, 1.5, 2.0))
+    s.build()
+    return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+
+
 # name -> (scene function, width, height, passes, maxRayDepth, lightSamplingAll, dimensions)
 FIXTURES = {
     "cornell": (cornell, 64, 48, 16, 4, False, 64),
@@ -52,5 +64,6 @@ FIXTURES = {
     "cornell_two_lights_all": (cornell_two_lights, 64, 48, 8, 4, True, 128),
     "box_mesh": (box_mesh, 64, 48, 8, 5, False, 64),
     "mesh_2k_all": (mesh_2k, 64, 36, 8, 6, True, 128),
+    "mesh_single": (mesh_single, 64, 36, 8, 6, False, 64),
 }
 SEED = 1234

@@ -22,12 +22,18 @@ COMPARED = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "n
             "numShadowRayTriangleTests")
 
 
-def run_both(scene, camera, w, h, passes, seed=99, threads=8, **vp_args):
+NOT_INTERSECTION = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits", "numAnalyticHits")
+
+
+def run_both(scene, camera, w, h, passes, seed=99, threads=8, walk="counting", **vp_args):
+    """`walk` (tests/conftest.py): "default" = the library as shipped and as bench.py times it -- intersection counters off (the
+    reference's default build, Core/Config.h:4), i.e. the 4-wide walks with their re-trace hand-over and dense path state; "counting" =
+    the reference's binary walk with the box / triangle test counters on."""
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
     vp = ra.Viewport(w, h, seed=seed, **vp_args)
-    vp.set_renderer(scene)
+    vp.set_renderer(scene, intersection_counters=(walk == "counting"))
     ref = np.zeros((h, w, 3), dtype=np.float32)
     ref2 = np.zeros((h, w, 3), dtype=np.float32)
     cnt = np.zeros(16, dtype=np.uint64)
@@ -36,56 +42,58 @@ def run_both(scene, camera, w, h, passes, seed=99, threads=8, **vp_args):
         vp.render_pass_with(p)
         oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=threads)
     img, img2 = vp.sum_buffer(secondary=True)
-    return img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}
+    return img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, walk
 
 
-def assert_identical(img, img2, counters, ref, ref2, ref_counters):
+def assert_identical(img, img2, counters, ref, ref2, ref_counters, walk="counting"):
     assert np.isfinite(ref).all()
     nbad = int(np.count_nonzero(img.view(np.uint32) != ref.view(np.uint32)))
     assert nbad == 0, "%d of %d sum-buffer values differ (max abs %.3e)" % (nbad, ref.size, float(np.abs(img - ref).max()))
     assert np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
-    for n in COMPARED:
+    for n in (COMPARED if walk == "counting" else NOT_INTERSECTION):
         assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
+    if walk != "counting":   # the reference's intersection counters belong to its own walk: off means untouched
+        assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0
 
 
-def test_cornell_box_bit_exact(built):
+def test_cornell_box_bit_exact(built, walk):
     """BASELINE config 1 geometry (10 instances, top-level BVH, glass/metal/diffuse, rect light), depth 4."""
     w, h = 160, 120
     scene, camera = scenes.cornell_box(w / h)
-    out = run_both(scene, camera, w, h, passes=4, max_ray_depth=4)
+    out = run_both(scene, camera, w, h, walk=walk, passes=4, max_ray_depth=4)
     assert_identical(*out)
     assert out[2]["numRays"] > 4 * w * h * 2
 
 
-def test_sphere_area_light_bit_exact(built):
+def test_sphere_area_light_bit_exact(built, walk):
     """BASELINE config 2 (single sphere + area light: no BVH, fp64 sphere intersection)."""
     w, h = 192, 108
     scene, camera = scenes.sphere_area_light(w / h)
-    assert_identical(*run_both(scene, camera, w, h, passes=4, max_ray_depth=4))
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=4, max_ray_depth=4))
 
 
-def test_every_light_and_bsdf_all_strategy(built):
+def test_every_light_and_bsdf_all_strategy(built, walk):
     """All five light types, all nine BSDFs, LightSamplingStrategy::All with dimensions raised to 128."""
     w, h = 128, 96
     scene, camera = scene_zoo.all_lights_scene(w / h)
-    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=6, dimensions=128, light_sampling_all=True))
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=6, dimensions=128, light_sampling_all=True))
 
 
-def test_single_strategy_many_lights_and_dimension_overflow(built):
+def test_single_strategy_many_lights_and_dimension_overflow(built, walk):
     """Single strategy with 8 lights (per-pixel fallback generator picks the light) and only 16 Halton
     dimensions (samples past them come from the fallback generator, GenericSampler.cpp:106-109)."""
     w, h = 96, 64
     scene, camera = scene_zoo.all_lights_scene(w / h)
-    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=5, dimensions=16, use_blue_noise=False))
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=5, dimensions=16, use_blue_noise=False))
 
 
-def test_mesh_two_level_bvh_bit_exact(built):
+def test_mesh_two_level_bvh_bit_exact(built, walk):
     """Triangle mesh instance + analytic instances: mesh BVH traversal, Moller-Trumbore, barycentric frames."""
     w, h = 160, 90
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
-    out = run_both(scene, camera, w, h, passes=2, max_ray_depth=8)
+    out = run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=8)
     assert_identical(*out)
-    assert out[2]["numRayTriangleTests"] > 0 and out[2]["numMeshHits"] > 0
+    assert (out[2]["numRayTriangleTests"] > 0) == (walk == "counting") and out[2]["numMeshHits"] > 0
 
 
 def test_device_texture_decode_matches_the_reference_vectors(built):
@@ -114,7 +122,7 @@ def test_device_texture_decode_matches_the_reference_vectors(built):
     lib.rtgpu_destroy(ctx)
 
 
-def test_textured_materials_normal_maps_and_environment_map(built):
+def test_textured_materials_normal_maps_and_environment_map(built, walk):
     """bitmap textures (7 texel formats, sRGB and linear, the three filters) on base colour /
     roughness / metalness / emission, bitmap and procedural normal maps, checkerboard / const textures and an HDR
     environment map on the background light -- bit-exact against the oracle, which is itself pinned to the
@@ -123,7 +131,7 @@ def test_textured_materials_normal_maps_and_environment_map(built):
     scene, camera = scene_zoo.textured_scene(w / h)
     d = scene.desc.contents
     assert d.numTextures == 13 and d.texelBytes > 0   # 8 bitmaps (one BC1), checkerboard, const, noise, mix, environment map
-    out = run_both(scene, camera, w, h, passes=3, max_ray_depth=6)
+    out = run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=6)
     assert_identical(*out)
     # the textures are really in play: the same scene without them renders differently
     plain, cam2 = scene_zoo.mesh_scene(w / h, triangles=6000)
@@ -133,7 +141,7 @@ def test_textured_materials_normal_maps_and_environment_map(built):
     assert not np.array_equal(vp.sum_buffer(), out[0])
 
 
-def test_ingested_json_obj_scene_bit_exact(built):
+def test_ingested_json_obj_scene_bit_exact(built, walk):
     """SURVEY 8(f) row 3 end to end: a JSON scene file (helpers::LoadScene) with an OBJ mesh + MTL materials + BMP texture
     (helpers::LoadMesh), textured materials, three light types and a depth-of-field camera, rendered on the GPU and
     by the oracle from the same flattened scene."""
@@ -147,17 +155,17 @@ def test_ingested_json_obj_scene_bit_exact(built):
     camera.set_perspective(w / h, np.float32(48.0) / np.float32(180.0) * np.float32(3.14159265359))
     d = scene.desc.contents
     assert d.numMeshes == 1 and d.numTriangles > 200 and d.numTextures == 3 and d.numLights == 3   # checkerboard + the BMP twice (scene file, MTL)
-    out = run_both(scene, camera, w, h, passes=3, max_ray_depth=5)
+    out = run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=5)
     assert_identical(*out)
     assert out[2]["numMeshHits"] > 0 and out[2]["numAnalyticHits"] > 0
 
 
-def test_single_object_scene_bypasses_top_bvh(built):
+def test_single_object_scene_bypasses_top_bvh(built, walk):
     """Sponza-class configuration: ONE object (Scene::Traverse bypasses the BVH, Scene.cpp:231-235), two global lights."""
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
     assert scene.desc.contents.numObjects == 1
-    assert_identical(*run_both(scene, camera, w, h, passes=2, max_ray_depth=8))
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=8))
 
 
 def test_lean_and_generic_shade_variants_agree(built, monkeypatch):
@@ -245,7 +253,7 @@ def test_front_buffer_postprocess_matches_oracle(built):
     assert ra.rtgpu_lib().rtgpu_postprocess(vp.device_context(), C.byref(p), out.ctypes.data_as(C.c_void_p)) == -6   # RTGPU_ERR_UNSUPPORTED
 
 
-def test_many_lights_all_strategy_and_degenerate_sizes(built):
+def test_many_lights_all_strategy_and_degenerate_sizes(built, walk):
     """Edge cases: 16 lights under LightSamplingStrategy::All (requests past the eighth use the per-lane queue append, black
     lights produce no shadow ray), a one-triangle mesh without normals / tangents / uvs, a 1 x 1 viewport, a viewport that is
     not a multiple of the 64-pixel tiles or the 8 x 8 blocks, maxRayDepth = 0 (direct light only) and Russian roulette
@@ -253,7 +261,7 @@ def test_many_lights_all_strategy_and_degenerate_sizes(built):
     for (w, h, depth, rr) in ((67, 41, 5, 0), (1, 1, 3, 1), (96, 64, 0, 1)):
         scene, camera = scene_zoo.many_lights_scene(w / h)
         assert scene.desc.contents.numLights == 16
-        out = run_both(scene, camera, w, h, passes=2, max_ray_depth=depth, min_russian_roulette_depth=rr, dimensions=256, light_sampling_all=True)
+        out = run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=depth, min_russian_roulette_depth=rr, dimensions=256, light_sampling_all=True)
         assert_identical(*out)
         assert out[2]["numShadowRays"] > 0
 
@@ -385,30 +393,30 @@ def test_adaptive_rendering_follows_the_reference_block_logic(built):
     assert saw_split and saw_drop
 
 
-def test_depth_of_field(built):
+def test_depth_of_field(built, walk):
     w, h = 96, 72
     scene, camera = scenes.cornell_box(w / h)
     camera.set_dof(True, 11.0, 0.3)
-    assert_identical(*run_both(scene, camera, w, h, passes=3, max_ray_depth=3))
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=3))
     # the other bokeh shapes of Camera::GenerateBokeh (hexagon: the reference only ever samples its first rhombus; square) and barrel
     # distortion (its random factor comes from the per-pixel generator); camera_ray.kat pins all of them to the reference
     for shape in (1, 2):
         camera.set_lens(bokeh_shape=shape, barrel_const=0.02, barrel_variable=0.03)
-        out = run_both(scene, camera, w, h, passes=2, max_ray_depth=3)
+        out = run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=3)
         assert_identical(*out)
 
 
-def test_empty_scene_and_background_only(built):
+def test_empty_scene_and_background_only(built, walk):
     """RenderingTest.EmptyScene / BackgroundLightOnly (Tests/RaytracingTests.cpp:263-315) with their tolerances."""
     w = h = 32
     scene = ra.Scene().build()
     cam = ra.Camera((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 90.0)
-    img, _, counters, ref, _, _ = run_both(scene, cam, w, h, passes=1)
+    img, _, counters, ref, _, _, _ = run_both(scene, cam, w, h, walk=walk, passes=1)
     assert np.all(img == 0.0) and np.all(ref == 0.0)
     scene = ra.Scene()
     scene.add_background_light((1.0, 2.0, 3.0))
     scene.build()
-    out = run_both(scene, cam, w, h, passes=1)
+    out = run_both(scene, cam, w, h, walk=walk, passes=1)
     assert_identical(*out)
     assert np.all(np.abs(out[0] - np.array([1.0, 2.0, 3.0], dtype=np.float32)) <= 0.01)
 
@@ -472,9 +480,10 @@ def test_c_abi_error_paths(built):
     assert lib.rtgpu_create(99, C.byref(ctx)) == -1               # device index out of range
 
 
-def test_full_size_sponza_class_properties(built):
+def test_full_size_sponza_class_properties(built, walk):
     """BASELINE config 3 at its full size (1920x1080, Sponza-class mesh of ~262 k triangles, depth 8), through
-    size-independent properties and an oracle-checked sample:
+    size-independent properties and an oracle-checked sample -- with walk = "default" this is exactly the pipeline bench.py times
+    (k_trace_wide + its re-trace hand-over, dense path state, four batch lanes, intersection counters off):
       * the tiles one shard owns (1/32 of the frame, spread over the whole image) equal the CPU oracle bit for bit,
         with identical counters -- the GPU renders exactly those tiles via rtgpu_set_shard;
       * the 2-shard images are disjoint and add up to the unsharded image bit for bit;
@@ -488,7 +497,7 @@ def test_full_size_sponza_class_properties(built):
     desc.contents.blueNoise = bn.ctypes.data
 
     full = ra.Viewport(w, h, seed=4242, max_ray_depth=depth)
-    full.set_renderer(scene)
+    full.set_renderer(scene, intersection_counters=(walk == "counting"))
     params = [full.next_pass_params(camera) for _ in range(passes)]
     for p in params:
         full.render_pass_with(p)
@@ -501,7 +510,7 @@ def test_full_size_sponza_class_properties(built):
 
     # oracle-checked sample: shard 0 of 32
     part_vp = ra.Viewport(w, h, seed=4242, max_ray_depth=depth)
-    part_vp.set_renderer(scene)
+    part_vp.set_renderer(scene, intersection_counters=(walk == "counting"))
     part_vp.set_shard(0, 32)
     ref = np.zeros((h, w, 3), dtype=np.float32)
     cnt = np.zeros(16, dtype=np.uint64)
@@ -512,8 +521,10 @@ def test_full_size_sponza_class_properties(built):
     assert np.array_equal(part.view(np.uint32), ref.view(np.uint32))
     pc = part_vp.counters()
     for i, n in enumerate(ra.COUNTER_NAMES):
-        if n in COMPARED:
+        if n in (COMPARED if walk == "counting" else NOT_INTERSECTION):
             assert pc[n] == int(cnt[i]), (n, pc[n], int(cnt[i]))
+    if walk == "default":
+        assert cw["numRetracedRays"] > 0 and cw["numRayBoxTests"] == 0   # the 4-wide walk ran and handed its undecided rays over
     owned = part != 0
     assert np.array_equal(part[owned].view(np.uint32), whole[owned].view(np.uint32))   # the same pixels in the full frame
 
@@ -522,7 +533,7 @@ def test_full_size_sponza_class_properties(built):
     rays = 0
     for rank in range(2):
         vp = ra.Viewport(w, h, seed=4242, max_ray_depth=depth)
-        vp.set_renderer(scene)
+        vp.set_renderer(scene, intersection_counters=(walk == "counting"))
         vp.set_shard(rank, 2)
         assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), 1) == 0
         for p in params:
@@ -535,7 +546,7 @@ def test_full_size_sponza_class_properties(built):
     assert rays == cw["numRays"]
 
 
-def test_plain_path_tracer_bit_exact(built):
+def test_plain_path_tracer_bit_exact(built, walk):
     """Renderer "Path Tracer" (PathTracer.cpp: BSDF sampling only): all lights x all BSDFs, the mesh scene and the Cornell box
     against the oracle's restatement -- images and counters identical; no shadow rays are cast."""
     for scene, camera, w, h in ((lambda a: scene_zoo.all_lights_scene(a), None, 96, 72), (lambda a: scene_zoo.mesh_scene(a, triangles=20000), None, 96, 54),
@@ -545,7 +556,7 @@ def test_plain_path_tracer_bit_exact(built):
         bn = ra.load_blue_noise()
         desc.contents.blueNoise = bn.ctypes.data
         vp = ra.Viewport(w, h, seed=7, max_ray_depth=6)
-        vp.set_renderer(sc, name="Path Tracer")
+        vp.set_renderer(sc, name="Path Tracer", intersection_counters=(walk == "counting"))
         ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
         cnt = np.zeros(16, dtype=np.uint64)
         for _ in range(3):
@@ -553,7 +564,7 @@ def test_plain_path_tracer_bit_exact(built):
             vp.render_pass_with(p)
             oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=8, plain=True)
         img, img2 = vp.sum_buffer(secondary=True)
-        out = (img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)})
+        out = (img, img2, vp.counters(), ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, walk)
         assert_identical(*out)
         assert out[2]["numShadowRays"] == 0 and out[2]["numRays"] > 3 * w * h
 
@@ -610,9 +621,6 @@ def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
 
 
 # ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_trace_quant.inl) -------
-NOT_INTERSECTION = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits", "numAnalyticHits")
-
-
 def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_args):
     """Like run_both, with the intersection counters OFF (the reference's default) and RTGPU_QUANT=1 set by the caller: single-mesh
     scenes then run k_trace_quant, and what it does not trust is traced again by the binary-tree kernel."""
@@ -850,7 +858,7 @@ def test_lds_staged_top_levels_bit_exact(built, monkeypatch):
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
 
 
-def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch):
+def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch, walk):
     """LightSamplingStrategy::Single runs with dense path state (survivors compacted into a second arena every bounce, finished paths
     parked per pixel, zombies for the last pending shadow ray); RTGPU_NO_DENSE=1 keeps every path in its pixel's slot.  Same images,
     same counters -- on the Cornell box (analytic shapes, area light hits, specular chains), a mesh under two lights (light picking
@@ -864,7 +872,7 @@ def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch):
         outs = []
         for no_dense in ("0", "1"):
             monkeypatch.setenv("RTGPU_NO_DENSE", no_dense)
-            outs.append(run_both(scene, camera, w, h, passes, **args))
+            outs.append(run_both(scene, camera, w, h, passes, walk=walk, **args))
         monkeypatch.delenv("RTGPU_NO_DENSE")
         assert_identical(*outs[0]); assert_identical(*outs[1])
         assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))

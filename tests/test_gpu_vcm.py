@@ -23,12 +23,17 @@ COMPARED = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "n
             "numShadowRayTriangleTests")
 
 
-def run_both(scene, camera, w, h, passes, seed=99, streamed=False, **vcm_args):
+NOT_INTERSECTION = ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits", "numAnalyticHits")
+
+
+def run_both(scene, camera, w, h, passes, seed=99, streamed=False, walk="counting", **vcm_args):
+    """`walk` (tests/conftest.py): "default" = intersection counters off, as the library ships; "counting" = the reference's binary walk
+    with its box / triangle test counters, which are then compared too."""
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
     vp = ra.Viewport(w, h, seed=seed)
-    vp.set_renderer(scene, name="VCM")
+    vp.set_renderer(scene, name="VCM", intersection_counters=(walk == "counting"))
     vp.set_vcm(**vcm_args)
     cam = np.zeros((h, w, 3), dtype=np.float32); cam2 = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
     cnt = np.zeros(16, dtype=np.uint64)
@@ -41,26 +46,26 @@ def run_both(scene, camera, w, h, passes, seed=99, streamed=False, **vcm_args):
         if not streamed or i == passes - 1:     # the query synchronises: without it the passes ride in batches of 8
             photons.append((vp.vcm_num_photons(), vcm.num_photons()))
     img, img2 = vp.sum_buffer(secondary=True)
-    return img, img2, vp.counters(), cam, cam2, light, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, photons
+    return img, img2, vp.counters(), cam, cam2, light, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)}, photons, walk
 
 
 def assert_camera_paths_identical(out):
-    img, img2, counters, cam, cam2, light, ref_counters, photons = out
+    img, img2, counters, cam, cam2, light, ref_counters, photons, walk = out
     assert np.isfinite(cam).all() and not light.any()
     nbad = int(np.count_nonzero(img.view(np.uint32) != cam.view(np.uint32)))
     assert nbad == 0, "%d of %d sum-buffer values differ (max abs %.3e)" % (nbad, cam.size, float(np.abs(img - cam).max()))
     assert np.array_equal(img2.view(np.uint32), cam2.view(np.uint32))
-    for n in COMPARED:
+    for n in (COMPARED if walk == "counting" else NOT_INTERSECTION):
         assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
     for got, want in photons:
         assert got == want
 
 
-def test_vcm_camera_paths_bit_exact_point_and_background(built):
+def test_vcm_camera_paths_bit_exact_point_and_background(built, walk):
     """Three passes (merging is active from the second one on: photon order, hash grid and range query must all match)."""
     w, h = 96, 72
     scene, camera = _two_estimator_scene(w / h)
-    out = run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0)
+    out = run_both(scene, camera, w, h, 3, walk=walk, camera_connecting_weight=0.0)
     assert_camera_paths_identical(out)
     assert out[7][-1][0] > 500     # photons are recorded (most light paths of the background light miss this small scene)
 
@@ -80,45 +85,45 @@ def test_vcm_merging_with_a_large_radius_bit_exact(built):
                                            merging_radius_multiplier=0.8))
 
 
-def test_vcm_streamed_passes_ride_in_batches_bit_exact(built):
+def test_vcm_streamed_passes_ride_in_batches_bit_exact(built, walk):
     """Passes submitted without a synchronising call in between go through the launch sequence 8 at a time (light stages of the
     batch, the 7 hash grids in between, camera stages): 11 passes = one full batch + a partial one whose first merge set comes from
     the previous batch.  Same sums, counters and final photon set as the oracle's pass-at-a-time loop, with a shrinking radius."""
     w, h = 96, 72
     scene, camera = _two_estimator_scene(w / h)
-    out = run_both(scene, camera, w, h, 11, streamed=True, camera_connecting_weight=0.0, initial_merging_radius=0.4, min_merging_radius=0.2,
+    out = run_both(scene, camera, w, h, 11, walk=walk, streamed=True, camera_connecting_weight=0.0, initial_merging_radius=0.4, min_merging_radius=0.2,
                    merging_radius_multiplier=0.9)
     assert_camera_paths_identical(out)
     scene, camera = scenes.cornell_box(w / h)
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 9, streamed=True, camera_connecting_weight=0.0))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 9, walk=walk, streamed=True, camera_connecting_weight=0.0))
 
 
-def test_vcm_camera_paths_bit_exact_all_lights_all_bsdfs(built):
+def test_vcm_camera_paths_bit_exact_all_lights_all_bsdfs(built, walk):
     """Every light type (area lights: the reference's non-solid-angle branch) and every BSDF; 13 lights + 9 light vertices
     = 22 shadow requests per camera vertex."""
     w, h = 80, 60
     scene, camera = scene_zoo.all_lights_scene(w / h)
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, walk=walk, camera_connecting_weight=0.0))
 
 
-def test_vcm_camera_paths_bit_exact_cornell_connection_only_and_merging_only(built):
+def test_vcm_camera_paths_bit_exact_cornell_connection_only_and_merging_only(built, walk):
     w, h = 64, 48
     scene, camera = scenes.cornell_box(w / h)
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0, use_vertex_merging=False))
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, use_vertex_connection=False))
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0, max_path_length=4))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, walk=walk, camera_connecting_weight=0.0, use_vertex_merging=False))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 3, walk=walk, camera_connecting_weight=0.0, use_vertex_connection=False))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, walk=walk, camera_connecting_weight=0.0, max_path_length=4))
 
 
-def test_vcm_mesh_scene_camera_paths_bit_exact(built):
+def test_vcm_mesh_scene_camera_paths_bit_exact(built, walk):
     w, h = 96, 54
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
-    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
+    assert_camera_paths_identical(run_both(scene, camera, w, h, 2, walk=walk, camera_connecting_weight=0.0))
 
 
 def test_vcm_full_image_with_light_path_splats(built):
     w, h = 96, 72
     scene, camera = _two_estimator_scene(w / h)
-    img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 4)
+    img, img2, counters, cam, cam2, light, ref_counters, photons, _ = run_both(scene, camera, w, h, 4)
     assert light.mean() > 0.01 * cam.mean()            # the light image is a real part of the estimate
     total = cam + light
     assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6), float(np.abs(img - total).max())
@@ -139,7 +144,7 @@ def test_reference_furnace_tests_vcm_on_gpu(built, bsdf, passes, expected, tol, 
     w = h = 32
     scene, camera = scenes.furnace(bsdf, **kwargs)
     vp = ra.Viewport(w, h, seed=2024)
-    vp.set_renderer(scene, name="VCM")
+    vp.set_renderer(scene, name="VCM", intersection_counters=True)
     vp.render(camera, passes)
     img = vp.sum_buffer() / np.float32(passes)
     assert np.isfinite(img).all()
@@ -150,7 +155,7 @@ def test_vcm_rejects_sharding(built):
     w, h = 64, 64
     scene, camera = _two_estimator_scene(1.0)
     vp = ra.Viewport(w, h, seed=1)
-    vp.set_renderer(scene, name="VCM")
+    vp.set_renderer(scene, name="VCM", intersection_counters=True)
     vp.set_shard(0, 2)
     with pytest.raises(RuntimeError):
         vp.render_pass_with(vp.next_pass_params(camera))
@@ -169,7 +174,7 @@ def test_vcm_full_size_mesh_textures_and_depth_of_field(built):
     scene, camera = scenes.cornell_box(w / h)
     camera.set_dof(True, 11.0, 0.3)
     assert_camera_paths_identical(run_both(scene, camera, w, h, 2, camera_connecting_weight=0.0))
-    img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 3)
+    img, img2, counters, cam, cam2, light, ref_counters, photons, _ = run_both(scene, camera, w, h, 3)
     total = cam + light
     assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6)
 
@@ -184,7 +189,7 @@ def test_light_tracer_matches_the_oracle(built):
         bn = ra.load_blue_noise()
         desc.contents.blueNoise = bn.ctypes.data
         vp = ra.Viewport(w, h, seed=5, max_ray_depth=5)
-        vp.set_renderer(scene, name="Light Tracer")
+        vp.set_renderer(scene, name="Light Tracer", intersection_counters=True)
         ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
         cnt = np.zeros(16, dtype=np.uint64)
         for i in range(4):
@@ -218,7 +223,7 @@ scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000, with_analytic=False
 desc = scene.desc
 bn = ra.load_blue_noise(); desc.contents.blueNoise = bn.ctypes.data
 vp = ra.Viewport(w, h, seed=99)
-vp.set_renderer(scene, name="VCM")
+vp.set_renderer(scene, name="VCM", intersection_counters=True)
 vp.set_vcm(camera_connecting_weight=0.0)
 ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0)
 cam = np.zeros((h, w, 3), np.float32); light = np.zeros((h, w, 3), np.float32); cnt = np.zeros(16, np.uint64)
@@ -251,7 +256,7 @@ def test_vcm_full_size_frame_sample_against_the_oracle(built):
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
     vp = ra.Viewport(w, h, seed=77)
-    vp.set_renderer(scene, name="VCM")
+    vp.set_renderer(scene, name="VCM", intersection_counters=True)
     vp.set_vcm(use_vertex_merging=False, camera_connecting_weight=0.0)
     ref = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
     vcm = oracle_lib.Vcm(use_vertex_merging=False, camera_connecting_weight=0.0)
@@ -267,7 +272,7 @@ def test_vcm_full_size_frame_sample_against_the_oracle(built):
     assert np.array_equal(img[owned].view(np.uint32), ref[owned].view(np.uint32))
     # the full combination at this size
     vp2 = ra.Viewport(w, h, seed=77)
-    vp2.set_renderer(scene, name="VCM")
+    vp2.set_renderer(scene, name="VCM", intersection_counters=True)
     vp2.render(camera, 3)
     full = vp2.sum_buffer()
     assert np.isfinite(full).all() and vp2.vcm_num_photons() > 100000
@@ -283,7 +288,7 @@ def test_baseline_config5_rough_glass_bdpt_bit_exact(built):
     w, h = 96, 54
     scene, camera = scenes.rough_glass_slab(w / h)
     assert_camera_paths_identical(run_both(scene, camera, w, h, 3, camera_connecting_weight=0.0, **scenes.ROUGH_GLASS_SLAB_VCM))
-    img, img2, counters, cam, cam2, light, ref_counters, photons = run_both(scene, camera, w, h, 6, **scenes.ROUGH_GLASS_SLAB_VCM)
+    img, img2, counters, cam, cam2, light, ref_counters, photons, _ = run_both(scene, camera, w, h, 6, **scenes.ROUGH_GLASS_SLAB_VCM)
     total = cam + light
     assert np.isfinite(total).all() and light.mean() > 0.02 * total.mean()
     assert np.all(np.abs(img - total) <= 1e-5 * np.abs(total) + 1e-6), float(np.abs(img - total).max())
@@ -302,7 +307,7 @@ def test_baseline_config5_full_size_frame_sample(built):
     desc.contents.blueNoise = bn.ctypes.data
     args = dict(scenes.ROUGH_GLASS_SLAB_VCM, camera_connecting_weight=0.0)
     vp = ra.Viewport(w, h, seed=31)
-    vp.set_renderer(scene, name="VCM")
+    vp.set_renderer(scene, name="VCM", intersection_counters=True)
     vp.set_vcm(**args)
     ref = np.zeros((h, w, 3), dtype=np.float32); light = np.zeros((h, w, 3), dtype=np.float32)
     vcm = oracle_lib.Vcm(**args)
@@ -319,7 +324,7 @@ def test_baseline_config5_full_size_frame_sample(built):
     both_nan = np.isnan(img[owned]) & np.isnan(ref[owned])      # the reference's RoughDielectricBSDF::Evaluate NaN, reproduced on both sides
     assert np.all(same | both_nan)
     vp2 = ra.Viewport(w, h, seed=31)
-    vp2.set_renderer(scene, name="VCM")
+    vp2.set_renderer(scene, name="VCM", intersection_counters=True)
     vp2.set_vcm(**scenes.ROUGH_GLASS_SLAB_VCM)
     vp2.render(camera, 3)
     full = vp2.sum_buffer()

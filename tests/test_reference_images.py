@@ -8,7 +8,9 @@ sum buffer, the ray counters, and the first pass's sampler seeds and anti-aliasi
 * The oracle (and, in test_gpu_reference_images.py, the device) then walks the same paths.  Stated tolerance: the reference evaluates
   its MIS weights with _mm_rcp_ss (FastDivide, 12 bits) and normalises sphere frames / mesh tangents with _mm_rsqrt_ps, exact operations
   here; a 2^-12 difference is harmless until it flips a Russian-roulette or hit decision, after which that path is another path.  So:
-  >= 96 % of the pixels within 1e-3 relative (+1e-3 absolute) per channel, mean image within 0.5 %, ray counters within 0.1 %."""
+  per-fixture floors just under what is measured (FLOORS: 99.3 % of the pixels of the Cornell box, whose sphere frames go through
+  _mm_rsqrt_ps, 99.7 % with two lights under `All`, EVERY pixel of the four other scenes) within 1e-3 relative (+1e-3 absolute) per
+  channel, mean image within 0.5 %, ray counters within 0.1 %."""
 import os
 import struct
 
@@ -42,12 +44,17 @@ def mirror_viewport(fx):
     return vp
 
 
-def compare_with_reference(fx, img, counters):
+# fraction of the pixels that must agree with the reference renderer's frame: measured 0.99349 / 0.99740 / 1.0 (oracle and device alike --
+# they are bit-identical to each other), floors a few pixels below
+FLOORS = {"cornell": 0.992, "cornell_two_lights_all": 0.996, "box_mesh": 1.0, "mesh_2k_all": 1.0, "mesh_single": 1.0, "sphere_area": 1.0}
+
+
+def compare_with_reference(fx, img, counters, floor=0.99):
     ref = fx["image"]
     close = np.abs(img - ref) <= 1e-3 * np.abs(ref) + 1e-3
     frac = float(close.all(axis=2).mean())
     mean_ref, mean_img = ref.mean(axis=(0, 1)), img.mean(axis=(0, 1))
-    assert frac >= 0.96, "only %.2f %% of the pixels agree with the reference renderer" % (100 * frac)
+    assert frac >= floor, "only %.2f %% of the pixels agree with the reference renderer (floor %.2f %%)" % (100 * frac, 100 * floor)
     assert np.all(np.abs(mean_img - mean_ref) <= 0.005 * mean_ref + 1e-6), (mean_img, mean_ref)
     for k in ("numRays", "numShadowRays", "numShadowRaysHit"):
         assert abs(int(counters[k]) - fx[k]) <= 0.001 * fx[k] + 2, (k, int(counters[k]), fx[k])
@@ -74,8 +81,7 @@ def test_pass_constants_and_oracle_image_match_the_reference_renderer(built, nam
             assert np.array_equal(np.array([p.sampleOffset[0], p.sampleOffset[1]], np.float32).view(np.uint32), fx["offset"].view(np.uint32)), "anti-aliasing offset differs"
         oracle_lib.render_pass(desc, p, fx["w"], fx["h"], img, None, cnt, threads=8)
     counters = {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:12])}
-    frac = compare_with_reference(fx, img, counters)
-    assert frac >= 0.96
+    compare_with_reference(fx, img, counters, FLOORS[name])
 
 
 def test_cornell_statistics_of_the_survey(built):

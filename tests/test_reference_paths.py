@@ -87,7 +87,8 @@ def test_flat_shaded_mesh_paths_are_identical_to_the_reference(built):
 
 
 @pytest.mark.parametrize("name,first_sites,identical,close,vertices", [("cornell", {"nx", "ny", "nz"}, 0.75, 0.85, 0.75),
-                                                                       ("mesh_2k_all", {"tx", "ty", "tz"}, 0.5, 0.99, 0.55)])
+                                                                       ("mesh_2k_all", {"tx", "ty", "tz"}, 0.5, 0.99, 0.55),
+                                                                       ("mesh_single", {"tx", "ty", "tz"}, 0.48, 0.99, 0.55)])
 def test_paths_agree_up_to_the_first_approximate_instruction(built, name, first_sites, identical, close, vertices):
     """Spheres (Cornell box) and interpolated mesh tangents are where _mm_rsqrt_ps enters: the first differing field of a path that
     differs is a normal / tangent component there (or a throughput that a _mm_rcp_ss MIS weight went into), never a hit id, a distance,
