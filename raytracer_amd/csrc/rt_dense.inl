@@ -63,12 +63,20 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
     __shared__ uint32_t sLivePrefix[RT_DENSE_SHARDS + 1u], sZombiePrefix[RT_DENSE_SHARDS + 1u];
     if (threadIdx.x == 0) { sShadowCount = 0; sLive = 0; sZombies = 0; }
     denseLoadPrefix(dense.in, sLivePrefix);
-    if (threadIdx.x == 64) { uint32_t sum = 0; for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s) { sZombiePrefix[s] = sum; sum += dense.in[RT_DENSE_SHARDS + s]; } sZombiePrefix[RT_DENSE_SHARDS] = sum; }
+    if (threadIdx.x == 64)
+    {
+        uint32_t sum = 0;
+        for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s)
+        {
+            sZombiePrefix[s] = sum; sum += dense.in[RT_DENSE_SHARDS + s];
+            if (blockIdx.x == 0 && dense.in[s] + dense.in[RT_DENSE_SHARDS + s] > dense.shardCapacity) dense.errorFlags[0] = 1u;   // the launch before this one overfilled region s
+        }
+        sZombiePrefix[RT_DENSE_SHARDS] = sum;
+    }
     __syncthreads();
     Counters cnt; zeroCounters(cnt);
     const uint32_t numLive = sLivePrefix[RT_DENSE_SHARDS], count = numLive + sZombiePrefix[RT_DENSE_SHARDS];
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t shard = blockIdx.x & (RT_DENSE_SHARDS - 1u);
     const DevPass pass = passes[0];   // the structural parameters are those of every pass of the batch
     const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
     const float lightPickProbability = 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172 (Single)
@@ -218,7 +226,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
             if (outcome == 0) home[homeIndex] = f4(resultColor.x, resultColor.y, resultColor.z, 0.0f);
         }
 
-        // dense slots of the other arena: ranks from LDS counters, the block's two ranges with one global atomic each
+        // dense slots of the other arena: ranks from LDS counters, the block's two ranges with one global atomic each.  The region follows
+        // the CHUNK of 256 vertices, not the block: consecutive chunks take the regions in turn whatever the grid size, so the regions
+        // fill evenly (a region is a sixteenth of the arena plus a margin of 65536 slots); what still does not fit raises a flag the host
+        // checks instead of overwriting the neighbouring region.
+        const uint32_t shard = (i / RT_BLOCK) & (RT_DENSE_SHARDS - 1u);
         uint32_t rank = 0;
         if (outcome == 1) rank = atomicAdd(&sLive, 1u);
         else if (outcome == 2) rank = atomicAdd(&sZombies, 1u);
@@ -226,6 +238,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
         if (threadIdx.x == 0 && sLive != 0u) sLiveBase = atomicAdd(&dense.out[shard], sLive);
         if (threadIdx.x == 64 && sZombies != 0u) sZombieBase = atomicAdd(&dense.out[RT_DENSE_SHARDS + shard], sZombies);
         __syncthreads();
+        // never outside the region (live paths grow upwards from its start, zombies downwards from its end); whether the two met is
+        // checked on the final counts by the next launch's prologue above
+        if ((outcome == 1 && sLiveBase + rank >= dense.shardCapacity) || (outcome == 2 && sZombieBase + rank >= dense.shardCapacity)) { dense.errorFlags[0] = 1u; outcome = 0; }
         if (outcome != 0)
         {
             const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);

@@ -217,6 +217,7 @@ struct DenseCounts
     const uint32_t* in;     // [0, 16): live paths per region of the arena being read; [16, 32): zombies per region
     uint32_t* out;          // the same for the arena being written (zeroed by the host)
     uint32_t shardCapacity;
+    uint32_t* errorFlags;   // host-visible words of the context (RtgpuContext::deviceFlags): [0] != 0 = a region of the arena overflowed
 };
 
 // prefix sums of the 16 region counts into LDS (prefix[16] = total); all threads of the block call it
@@ -1224,7 +1225,7 @@ struct BatchLane
     // dense path state (rt_dense.inl, LightSamplingStrategy::Single): the second arena of the ping-pong, the parked radiance of
     // finished paths, per bounce the live / zombie counts of the arena's regions (2 * RT_DENSE_SHARDS words per bounce)
     Paths paths2 = { nullptr, 0, 0 };
-    float4* home = nullptr;
+    float4* home = nullptr; size_t homeCapacity = 0;
     uint32_t* denseCounts = nullptr;
     // per-batch work counters, 8 planes of (maxDepth + 2) uint32, zeroed once per batch: path-queue counts,
     // shadow-queue counts, traversal cursors, -, exact-queue counts, exact-shadow-queue counts, exact cursors, - (one of each per
@@ -1283,6 +1284,7 @@ struct RtgpuContext
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
                                        // rtgpu_set_intersection_counters, or RTGPU_INTERSECTION_COUNTERS=1 for the default of new contexts
     unsigned long long* counters = nullptr;   // 16 x u64
+    uint32_t* deviceFlags = nullptr;          // page-locked, device-visible: kernels raise [0] when a region of a dense arena overflows; checked by every synchronising call
 
     // passes queued by rtgpu_render_pass and not yet submitted: up to passBatch of them ride through ONE launch
     // sequence (their paths are simply more slots), which amortises the per-launch tail of the persistent kernels
@@ -1372,7 +1374,7 @@ static void freePaths(BatchLane& l)
     if (l.exactShadowQueue) (void)hipFree(l.exactShadowQueue);
     if (l.paths2.base) (void)hipFree(l.paths2.base);
     if (l.home) (void)hipFree(l.home);
-    l.exactQueue = l.exactShadowQueue = nullptr; l.paths2.base = nullptr; l.paths2.capacity = 0; l.paths2.maxLights = 0; l.home = nullptr;
+    l.exactQueue = l.exactShadowQueue = nullptr; l.paths2.base = nullptr; l.paths2.capacity = 0; l.paths2.maxLights = 0; l.home = nullptr; l.homeCapacity = 0;
     l.paths.base = nullptr; l.paths.capacity = 0; l.paths.maxLights = 0;
     l.queues[0] = l.queues[1] = nullptr; l.shadowQueues[0] = l.shadowQueues[1] = nullptr;
 }
@@ -1535,6 +1537,8 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->deviceFlags, 16 * sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) memset(c->deviceFlags, 0, 16 * sizeof(uint32_t));
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess) e = hipMalloc((void**)&c->seedRingDev, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->seedRingHost, (size_t)RT_SEED_RING * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t), hipHostMallocDefault);
@@ -1618,6 +1622,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
         if (c->lanes[i].accumulated) (void)hipEventDestroy(c->lanes[i].accumulated);
     }
     if (c->counters) (void)hipFree(c->counters);
+    if (c->deviceFlags) (void)hipHostFree(c->deviceFlags);
     if (c->seedRingDev) (void)hipFree(c->seedRingDev);
     if (c->seedRingHost) (void)hipHostFree(c->seedRingHost);
     if (c->passRingDev) (void)hipFree(c->passRingDev);
@@ -1980,14 +1985,29 @@ static size_t arenaCapacityFor(size_t slots) { return (size_t)RT_DENSE_SHARDS * 
 static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
-    if (maxBatch > maxBatchFor(c, maxLights)) maxBatch = maxBatchFor(c, maxLights);
-    const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * maxBatch;
     const bool wantDense = c->denseAllowed && maxLights == 1u;
-    if (!l.paths.base || l.paths.capacity < arenaCapacityFor(wanted) || l.paths.maxLights < maxLights || (wantDense && !l.paths2.base))
+    for (int attempt = 0; attempt < 2; ++attempt)
     {
+        uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
+        if (maxBatch > maxBatchFor(c, maxLights)) maxBatch = maxBatchFor(c, maxLights);
+        const size_t wanted = (size_t)(c->numSlots ? c->numSlots : 1) * maxBatch;
+        if (l.paths.base && l.paths.capacity >= arenaCapacityFor(wanted) && l.paths.maxLights >= maxLights && (!wantDense || (l.paths2.base && l.homeCapacity >= wanted))) break;
         HIP_TRY(hipStreamSynchronize(l.stream));
         freePaths(l);
+        if (attempt == 0)
+        {
+            // The lane budget of rtgpu_create is a guess made before anything was allocated.  Contexts that share a device (several
+            // renderers in one process, rtgpu_create_multi with a repeated index) see less: what is free NOW is shared by the lanes of
+            // this context that still have to allocate, and the batch a lane may hold shrinks with it instead of a late out-of-memory.
+            size_t freeBytes = 0, totalBytes = 0;
+            if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess)
+            {
+                uint32_t lanesLeft = 0;
+                for (uint32_t i = 0; i < c->numLanes; ++i) if (!c->lanes[i].paths.base) lanesLeft++;
+                const size_t share = (size_t)((double)freeBytes * 0.9) / (lanesLeft ? lanesLeft : 1u);
+                if (share < c->laneBudgetBytes) { c->laneBudgetBytes = share; continue; }   // size the arenas again under the smaller budget
+            }
+        }
         const size_t cap = arenaCapacityFor(wanted);
         if (cap >= 0xFFFFFFFFull) return fail(RTGPU_ERR_UNSUPPORTED, "pixels x pass batch exceeds the slot index range");
         const size_t records = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * cap;
@@ -2004,8 +2024,10 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
         {
             HIP_TRY(hipMalloc((void**)&l.paths2.base, records * sizeof(float4)));
             HIP_TRY(hipMalloc((void**)&l.home, wanted * sizeof(float4)));
+            l.homeCapacity = wanted;
             l.paths2.capacity = (uint32_t)cap; l.paths2.maxLights = maxLights;
         }
+        break;
     }
     if (l.queueCountCapacity < maxDepth + 2)
     {
@@ -2174,7 +2196,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 #undef RT_LAUNCH_TRACE_DENSE
             }
             // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
-            const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity };
+            const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags };
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE_DENSE(L, P) hipLaunchKernelGGL((k_shade_dense<L, P>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
                                                      l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters)
@@ -2736,15 +2758,21 @@ RTGPU_API int rtgpu_render_pass(RtgpuContext* c, const RtPassParams* p)
 RTGPU_API int rtgpu_synchronize(RtgpuContext* c)
 {
     if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
-    // every device's queued passes are submitted before the first wait, so that the tails run side by side
+    // every device's queued passes -- the first device's included -- are submitted before the first wait, so that the tails run side by side
     for (RtgpuContext* peer : c->peers) { HIP_TRY(hipSetDevice(peer->device)); int r = flushPending(peer); if (r) return r; }
-    RT_FAN_OUT(c, rtgpu_synchronize(peer));
     HIP_TRY(hipSetDevice(c->device));
     { int r = vcmFlush(c); if (r) return r; }
     { int r = flushPending(c); if (r) return r; }
+    RT_FAN_OUT(c, rtgpu_synchronize(peer));
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(syncLanes(c));
     c->batchesSinceSync = 0; c->batchesAtThisSize = 0;
     if (!c->passBatchFromEnv) c->passBatch = c->passBatchBase;
+    if (c->deviceFlags && c->deviceFlags[0] != 0u)
+    {
+        c->deviceFlags[0] = 0u;
+        return fail(RTGPU_ERR_DEVICE, "dense path state: a region of the arena overflowed (the frame since the last reset is invalid)");
+    }
     return resolveTimed(c);
 }
 
