@@ -22,6 +22,8 @@ static const char* const kOpNames[OP_COUNT] = { "v_fma_f32", "v_perm_b32", "v_cv
 template <int kOp>
 __global__ void __launch_bounds__(256) k_cadence(uint32_t iterations, float seed, float* out, unsigned long long* clocks)
 {
+    extern __shared__ uint32_t sPad[];   // dynamic LDS = 160 KB / (blocks per CU wanted): the dispatcher cannot pile more blocks on a CU
+    if (seed == 123.0f) sPad[threadIdx.x] = 1u;
     float a[8]; uint32_t u[8];
     for (int i = 0; i < 8; ++i) { a[i] = seed + (float)(threadIdx.x + i); u[i] = threadIdx.x * 2654435761u + (uint32_t)i; }
     float b = seed * 0.5f, c = seed * 0.25f; uint32_t sel = 0x07060100u;
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(256) k_cadence(uint32_t iterations, float seed
                 R8(X)
 #undef X
             } else if (kOp == OP_MIX) {
-                // one child of the 4-wide step, twice (2 x 16 = 32 instructions): 3 perm, 6 sdwa cvt, 6 fma, max, max3, min3 -- two independent copies
+                // one child of the 4-wide step, twice (2 x 18 = 36 instructions): 3 perm, 6 sdwa cvt, 6 fma, max, max3, min3 -- two independent copies
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
                 {
@@ -115,6 +117,8 @@ __global__ void __launch_bounds__(256) k_cadence(uint32_t iterations, float seed
 // every lane walks a random cycle of 64-byte nodes: four dwordx4 loads of ITS node per step (the walk's fetch), next = node.w of the first
 __global__ void __launch_bounds__(256) k_l1(const float4* __restrict__ nodes, uint32_t numNodes, uint32_t steps, uint32_t activeLanes, float* out, unsigned long long* clocks)
 {
+    extern __shared__ uint32_t sPad[];
+    if (steps == 0xFFFFFFFFu) sPad[threadIdx.x] = 1u;
     uint32_t cur = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u % numNodes;
     float acc = 0.0f;
     const bool active = (threadIdx.x & 63u) < activeLanes;
@@ -133,18 +137,23 @@ __global__ void __launch_bounds__(256) k_l1(const float4* __restrict__ nodes, ui
     if ((threadIdx.x & 63u) == 0u) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// dynamic LDS that lets exactly `blocksPerCU` 256-thread blocks share a CU's 160 KB
+static size_t ldsFor(uint32_t blocksPerCU) { return blocksPerCU <= 1u ? (size_t)96 << 10 : ((size_t)160 << 10) / blocksPerCU / 1024u * 1024u; }
+
 template <int kOp>
 static void runCadence(uint32_t numCUs, float* out, unsigned long long* clocksDev)
 {
-    const uint32_t iterations = 20000u, perIteration = 32u * 4u;
+    const uint32_t iterations = 20000u, perIteration = kOp == OP_MIX ? 4u * 36u : 4u * 8u;   // 4 rounds of 8 (the mix: of 2 children x 18)
     printf("%-62s", kOpNames[kOp]);
     for (uint32_t wavesPerSimd : { 1u, 2u, 4u, 5u, 8u })
     {
         const dim3 grid(numCUs * wavesPerSimd), block(256);   // a 256-thread block = one wave per SIMD of its CU
+        const size_t lds = ldsFor(wavesPerSimd);
+        CHECK(hipFuncSetAttribute((const void*)k_cadence<kOp>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-        hipLaunchKernelGGL((k_cadence<kOp>), grid, block, 0, 0, 100u, 1.0f, out, clocksDev);   // warm up
+        hipLaunchKernelGGL((k_cadence<kOp>), grid, block, lds, 0, 100u, 1.0f, out, clocksDev);   // warm up
         CHECK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL((k_cadence<kOp>), grid, block, 0, 0, iterations, 1.0f, out, clocksDev);
+        hipLaunchKernelGGL((k_cadence<kOp>), grid, block, lds, 0, iterations, 1.0f, out, clocksDev);
         CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
         float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
         std::vector<unsigned long long> clocks((size_t)grid.x * 4u);
@@ -152,7 +161,8 @@ static void runCadence(uint32_t numCUs, float* out, unsigned long long* clocksDe
         double mean = 0; for (auto c : clocks) mean += (double)c; mean /= (double)clocks.size();
         const double instr = (double)iterations * perIteration;
         // per SIMD: wavesPerSimd waves issued `instr` instructions each within `mean` clocks (if they all ran concurrently)
-        printf("  w%u: %5.2f clk (%4.2f by wall @2.4GHz)", wavesPerSimd, mean / (instr * wavesPerSimd), ms * 1e-3 * 2.4e9 / (instr * wavesPerSimd));
+        // effective clock = ticks a wave ran / the kernel's wall time (every block is resident from start to end: one round of blocks)
+        printf("  w%u: %5.2f clk @%4.2f GHz", wavesPerSimd, mean / (instr * wavesPerSimd), mean / (ms * 1e-3) * 1e-9);
     }
     printf("\n");
 }
@@ -164,7 +174,7 @@ int main()
     printf("device %s, %u CUs, clock %d kHz (clock64 = s_memtime ticks)\n", prop.name, numCUs, prop.clockRate);
     float* out; unsigned long long* clocksDev;
     CHECK(hipMalloc((void**)&out, 64)); CHECK(hipMalloc((void**)&clocksDev, sizeof(unsigned long long) * numCUs * 8u * 4u * 2u));
-    printf("\n(1) cycles per wave64 VALU instruction per SIMD (clock64 ticks of one wave / instructions issued by all waves of its SIMD)\n");
+    printf("\n(1) cycles per wave64 VALU instruction per SIMD (clock64 ticks of one wave / instructions issued by all waves of its SIMD; wN = N resident waves per SIMD, enforced through the LDS allocation) and the effective clock\n");
     runCadence<OP_FMA>(numCUs, out, clocksDev); runCadence<OP_PERM>(numCUs, out, clocksDev); runCadence<OP_CVT_SDWA>(numCUs, out, clocksDev);
     runCadence<OP_CVT>(numCUs, out, clocksDev); runCadence<OP_MAX3>(numCUs, out, clocksDev); runCadence<OP_CNDMASK_SGPR>(numCUs, out, clocksDev);
     runCadence<OP_MINU>(numCUs, out, clocksDev); runCadence<OP_CMP>(numCUs, out, clocksDev); runCadence<OP_PKFMA>(numCUs, out, clocksDev);
@@ -193,8 +203,10 @@ int main()
             {
                 const uint32_t steps = tableBytes >= ((size_t)64 << 20) ? 2000u : 8000u;
                 const dim3 grid(numCUs * wavesPerSimd), block(256);
-                hipLaunchKernelGGL(k_l1, grid, block, 0, 0, dev, numNodes, 200u, activeLanes, out, clocksDev);
-                hipLaunchKernelGGL(k_l1, grid, block, 0, 0, dev, numNodes, steps, activeLanes, out, clocksDev);
+                const size_t lds = ldsFor(wavesPerSimd);
+                CHECK(hipFuncSetAttribute((const void*)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(k_l1, grid, block, lds, 0, dev, numNodes, 200u, activeLanes, out, clocksDev);
+                hipLaunchKernelGGL(k_l1, grid, block, lds, 0, dev, numNodes, steps, activeLanes, out, clocksDev);
                 CHECK(hipDeviceSynchronize());
                 std::vector<unsigned long long> clocks((size_t)grid.x * 4u);
                 CHECK(hipMemcpy(clocks.data(), clocksDev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
