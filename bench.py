@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--triangles", type=int, default=262144)
-    ap.add_argument("--workload", default="sponza", choices=["sponza", "sponza-textured", "cornell", "sphere", "bdpt-glass"])
+    ap.add_argument("--workload", default="sponza", choices=["sponza", "sponza-textured", "sponza-all", "cornell", "sphere", "zoo", "bdpt-glass"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
@@ -59,8 +59,12 @@ def parse_args():
 
 def build_scene(args, aspect):
     from raytracer_amd import scenes
-    if args.workload in ("sponza", "sponza-textured"):
+    if args.workload in ("sponza", "sponza-textured", "sponza-all"):
         return scenes.sponza_class(aspect, args.triangles, textured=args.workload == "sponza-textured")
+    if args.workload == "zoo":   # every light type x every BSDF on analytic shapes: the scene that mixes all hit kinds (tests/scene_zoo.py)
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+        import scene_zoo
+        return scene_zoo.all_lights_scene(aspect)
     if args.workload == "cornell":
         return scenes.cornell_box(aspect)
     if args.workload == "bdpt-glass":
@@ -70,7 +74,10 @@ def build_scene(args, aspect):
 
 def make_viewport(ra, args, scene, device, shard=None):
     from raytracer_amd import scenes
-    vp = ra.Viewport(args.width, args.height, seed=SEED, max_ray_depth=args.depth)
+    if args.workload == "sponza-all":   # SURVEY 8(d)'s path-exact run of config 3: LightSamplingStrategy::All with dimensions = 128 (PathTracerMIS.cpp:141-147)
+        vp = ra.Viewport(args.width, args.height, seed=SEED, max_ray_depth=args.depth, dimensions=128, light_sampling_all=True)
+    else:
+        vp = ra.Viewport(args.width, args.height, seed=SEED, max_ray_depth=args.depth)
     if args.workload == "bdpt-glass":
         vp.set_renderer(scene, name="VCM", device=device, intersection_counters=False)
         vp.set_vcm(**scenes.ROUGH_GLASS_SLAB_VCM)
@@ -367,7 +374,7 @@ def main():
             metric = "Msamples/sec (path segments of camera + light sub-paths) at %dx%d, rough-glass BDPT" % (w, h)
         else:
             what = ("procedural Sponza-class mesh (%d triangles, 8 diffuse materials)" % scene.desc.contents.numTriangles) if args.workload.startswith("sponza") else args.workload
-            label = "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::Single" % (what, args.depth, w, h)
+            label = "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::%s" % (what, args.depth, w, h, "All, dimensions 128" if args.workload == "sponza-all" else "Single")
             if args.workload == "sponza-textured":
                 label += " + albedo / normal maps on all materials, HDR environment map"
             metric = "Msamples/sec (paths x bounces) at %dx%d, Sponza-class PT-MIS" % (w, h)

@@ -52,16 +52,47 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc s
 
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395), as k_shade, reading arena `in`
 // and writing the survivors densely into arena `out`.  kPlain: PathTracer::RenderPixel (Core/Rendering/PathTracer.cpp:73-171).
-template <bool kLean, bool kPlain = false>
+//
+// Hit-kind sort (generic variant, `sortKinds`).  Material::Sample / Evaluate dispatch over nine BSDF classes (Material.cpp:40-83, :182-232), a
+// vertex may instead have left the scene (EvaluateGlobalLights) or hit a light (EvaluateLight), and a zombie only resolves its request: a
+// wave whose 64 vertices mix these kinds executes every branch one after the other.  The 256 vertices a block takes per round are
+// therefore dealt to its threads by KIND -- a counting sort in LDS over twelve keys (zombie, miss, light hit, BSDF 0-8): the first waves of
+// the block get the cheap kinds, the others one or two BSDFs each.  Which thread shades a vertex changes nothing in its arithmetic.
+#define RT_SHADE_KINDS 16u
+RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t slot, bool zombie)
+{
+    if (zombie) return 0u;
+    const float4 rHit = prec(in, R_HIT, slot);
+    const uint32_t objectId = ubits(rHit.x);
+    if (objectId == RT_INVALID_OBJECT) return 1u;
+    const RtObject& obj = scene.objects[objectId];
+    if (obj.objectKind == RT_OBJECT_LIGHT) return 2u;
+    uint32_t material = obj.materialIndex;
+    if (obj.shapeKind == RT_SHAPE_MESH)
+    {
+        const RtMesh& mesh = scene.meshes[obj.meshIndex];
+        const uint32_t ofTriangle = reinterpret_cast<const TriangleShading*>(scene.vertexIndices)[mesh.firstTriangle + ubits(rHit.y)].materialIndex;   // as meshEvaluateIntersection
+        if (ofTriangle != RT_NO_MATERIAL) material = ofTriangle;
+    }
+    return material == RT_NO_MATERIAL ? 3u : 3u + (scene.materials[material].bsdf & 15u) % (RT_SHADE_KINDS - 4u);
+}
+
+template <int kLean, bool kPlain = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
                                                           const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
-                                                          float4* __restrict__ home, unsigned long long* counters)
+                                                          float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds)
 {
+    __shared__ uint32_t sKindCount[RT_SHADE_KINDS], sKindBase[RT_SHADE_KINDS], sDealt[RT_BLOCK];
     __shared__ uint32_t sShadowBuf[RT_APPEND_BUFFER];
+    // The four records of a vertex's next-event request are known long before the vertex knows whether and where it survives (Russian roulette,
+    // BSDF sampling and the block's slot allocation come after): they wait in LDS instead of 16 registers.  142 -> 127 VGPRs for the lean
+    // variant = four waves per SIMD instead of three in a kernel that spends most of its time waiting for dependent gathers (-14 % kernel time).
+    __shared__ float4 sStage[4][RT_BLOCK];   // [request direction | contribution | shading point | throughput at the vertex][thread]
     __shared__ uint32_t sShadowCount, sShadowBase;
     __shared__ uint32_t sLive, sZombies, sLiveBase, sZombieBase;
     __shared__ uint32_t sLivePrefix[RT_DENSE_SHARDS + 1u], sZombiePrefix[RT_DENSE_SHARDS + 1u];
     if (threadIdx.x == 0) { sShadowCount = 0; sLive = 0; sZombies = 0; }
+    if (threadIdx.x < RT_SHADE_KINDS) sKindCount[threadIdx.x] = 0u;
     denseLoadPrefix(dense.in, sLivePrefix);
     if (threadIdx.x == 64)
     {
@@ -82,20 +113,43 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
     const float lightPickProbability = 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172 (Single)
 
     const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
+    // the i-th vertex of the launch: live paths first (region by region), then the zombies (from the top of their regions)
+    auto vertexSlot = [&](uint32_t idx, bool& zombie) -> uint32_t
     {
+        zombie = idx >= numLive;
+        if (!zombie) return denseLiveSlot(sLivePrefix, dense.shardCapacity, idx);
+        const uint32_t z = idx - numLive, s = denseRegionOf(sZombiePrefix, z);
+        return (s + 1u) * dense.shardCapacity - 1u - (z - sZombiePrefix[s]);
+    };
+    for (uint32_t first = blockIdx.x * blockDim.x; first < rounded; first += stride)
+    {
+        uint32_t i = first + threadIdx.x;
+        if (!RT_LEAN(kLean) && sortKinds != 0u)
+        {
+            // deal the round's vertices to the threads by kind
+            bool z = false;
+            const uint32_t kind = i < count ? shadeKindOf(scene, in, vertexSlot(i, z), i >= numLive) : RT_SHADE_KINDS - 1u;
+            const uint32_t rankInKind = atomicAdd(&sKindCount[kind], 1u);
+            __syncthreads();
+            if (threadIdx.x == 0) { uint32_t sum = 0; for (uint32_t k = 0; k < RT_SHADE_KINDS; ++k) { sKindBase[k] = sum; sum += sKindCount[k]; sKindCount[k] = 0u; } }
+            __syncthreads();
+            sDealt[sKindBase[kind] + rankInKind] = i;
+            __syncthreads();
+            i = sDealt[threadIdx.x];
+        }
         // what this vertex leaves behind: 0 nothing (radiance parked), 1 a live path, 2 a zombie (radiance + one pending request)
         uint32_t outcome = 0;
-        float4 oOrigin, oDir, oTp, oResult, oSampler, oRng, oShP, oShTp, oShadow0, oShadow1;
+        float4 oOrigin, oDir, oTp, oResult, oSampler, oRng;
+        bool stagedShTp = false;
         bool rayNeeded = false;
+        uint32_t oHome = 0u;
         if (i < count)
         {
-            uint32_t slot;
-            const bool zombie = i >= numLive;
-            if (!zombie) slot = denseLiveSlot(sLivePrefix, dense.shardCapacity, i);
-            else { const uint32_t z = i - numLive, s = denseRegionOf(sZombiePrefix, z); slot = (s + 1u) * dense.shardCapacity - 1u - (z - sZombiePrefix[s]); }
+            bool zombie;
+            const uint32_t slot = vertexSlot(i, zombie);
             const float4 rResult = prec(in, R_RESULT, slot), rSampler = prec(in, R_SAMPLER, slot), rShTp = prec(in, R_SH_TP, slot);
             const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
+            oHome = homeIndex;
             V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
             resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
             if (!zombie)
@@ -137,7 +191,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
                     ShadingData sd;
                     sd.intersection.material = (flags >> 9) - 1u;   // the previous vertex's material (see k_shade)
                     if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
-                    if (!kLean && hit.subObjectId == RT_LIGHT_OBJECT)
+                    if (!RT_LEAN(kLean) && hit.subObjectId == RT_LIGHT_OBJECT)
                     {
                         // EvaluateLight, PathTracerMIS.cpp:174-212
                         const RtObject& obj = scene.objects[hit.objectId];
@@ -176,10 +230,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
                     {
                         uint32_t lightIndex = 0;
                         if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
+                        float4 oShadow0, oShadow1;
                         rayNeeded = computeLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, oShadow0, oShadow1);
                         numRequests = rayNeeded ? 1u : 0u;   // a request without a ray contributes nothing (resolvePendingLightSamples skips it): not kept
-                        oShP = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
-                        oShTp = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                        sStage[0][threadIdx.x] = oShadow0; sStage[1][threadIdx.x] = oShadow1;
+                        sStage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                        sStage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                        stagedShTp = true;
                     }
                     bool cont = depth < pass.maxRayDepth;
                     if (cont && depth >= pass.minRussianRouletteDepth)   // Russian roulette, :330-347
@@ -212,7 +269,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
                         oSampler = f4(0.0f, fbits(sampler.salt), fbits(sampler.generated), fbits(numRequests));
                         oRng = f4(fbits((uint32_t)sampler.fallback.s[0]), fbits((uint32_t)(sampler.fallback.s[0] >> 32)),
                                   fbits((uint32_t)sampler.fallback.s[1]), fbits((uint32_t)(sampler.fallback.s[1] >> 32)));
-                        if (numRequests == 0u) oShTp = f4(0.0f, 0.0f, 0.0f, fbits(homeIndex));
+                        if (numRequests == 0u) stagedShTp = false;
                     }
                     else if (rayNeeded)
                     {
@@ -230,7 +287,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
         // the CHUNK of 256 vertices, not the block: consecutive chunks take the regions in turn whatever the grid size, so the regions
         // fill evenly (a region is a sixteenth of the arena plus a margin of 65536 slots); what still does not fit raises a flag the host
         // checks instead of overwriting the neighbouring region.
-        const uint32_t shard = (i / RT_BLOCK) & (RT_DENSE_SHARDS - 1u);
+        const uint32_t shard = (first / RT_BLOCK) & (RT_DENSE_SHARDS - 1u);
         uint32_t rank = 0;
         if (outcome == 1) rank = atomicAdd(&sLive, 1u);
         else if (outcome == 2) rank = atomicAdd(&sZombies, 1u);
@@ -246,19 +303,19 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
             const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);
             prec(out, R_RESULT, slot) = oResult;
             prec(out, R_SAMPLER, slot) = oSampler;
-            prec(out, R_SH_TP, slot) = oShTp;
+            prec(out, R_SH_TP, slot) = stagedShTp ? sStage[3][threadIdx.x] : f4(0.0f, 0.0f, 0.0f, fbits(oHome));
             if (outcome == 1) { prec(out, R_ORIGIN, slot) = oOrigin; prec(out, R_DIR, slot) = oDir; prec(out, R_TP, slot) = oTp; prec(out, R_RNG, slot) = oRng; }
             if (ubits(oSampler.w) != 0u)
             {
-                prec(out, R_SH_P, slot) = oShP;
-                pshadow(out, 0, 0, slot) = oShadow0;
-                pshadow(out, 0, 1, slot) = oShadow1;
+                prec(out, R_SH_P, slot) = sStage[2][threadIdx.x];
+                pshadow(out, 0, 0, slot) = sStage[0][threadIdx.x];
+                pshadow(out, 0, 1, slot) = sStage[1][threadIdx.x];
                 if (rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) { sLive = 0; sZombies = 0; }
-        const bool last = (i - threadIdx.x) + stride >= rounded;
+        const bool last = first + stride >= rounded;
         if (last || sShadowCount + RT_BLOCK > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
         else __syncthreads();
     }

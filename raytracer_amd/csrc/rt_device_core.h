@@ -595,9 +595,15 @@ RT_DEV V4 materialGetNormalVector(const RtSceneDesc& d, const RtMaterial& mat, V
 }
 
 // Scene::EvaluateIntersection, Scene.cpp:305-365
-// kLean: the uploaded scene contains only mesh shapes (no analytic shapes, no finite lights among the objects), so
-// the hit can only be a mesh triangle.
-template <bool kLean>
+// kLean: the scene class the shading kernels are specialised for (rtgpu_upload_scene decides), two independent properties:
+//   RT_LEAN(k)     -- only mesh shapes (no analytic shapes, no finite lights among the objects: a hit can only be a mesh triangle), only
+//                     diffuse materials, only background / directional lights;
+//   RT_TEXTURED(k) -- textures may be present (albedo / roughness / ... maps, normal maps, an environment map).
+// 0 = anything, 1 = lean without textures (the Sponza-class benchmark), 2 = lean with textures (a textured Sponza), 3 = anything without
+// textures (Cornell box: analytic shapes, area light, all BSDFs).
+#define RT_LEAN(k) ((k) == 1 || (k) == 2)
+#define RT_TEXTURED(k) ((k) == 0 || (k) == 2)
+template <int kLean>
 __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
 {
     const RtObject& obj = d.objects[hit.objectId];
@@ -606,7 +612,7 @@ __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDe
     const V4 worldPosition = rayAt(ray, hit.distance);
     out.frame.r[3] = transformPoint(invTransform, worldPosition);
 
-    if (kLean)
+    if (RT_LEAN(kLean))
     {
         out.material = obj.materialIndex;
         meshEvaluateIntersection(d, d.meshes[obj.meshIndex], hit, out); cnt.c[C_MESH_HITS]++;
@@ -626,7 +632,7 @@ __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDe
 
     V4 localSpaceTangent = out.frame.r[0];
     V4 localSpaceNormal = out.frame.r[2];
-    if (!kLean && out.material != RT_NO_MATERIAL && d.materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
+    if (RT_TEXTURED(kLean) && out.material != RT_NO_MATERIAL && d.materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
     {
         const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
         const V4 localNormal = materialGetNormalVector(d, d.materials[out.material], out.texCoord);
@@ -649,18 +655,18 @@ struct IlluminateResult { V4 directionToLight; float distance, directPdfW, cosAt
 
 // ILight::Illuminate; returns radiance (4 lanes)
 // kLean: the scene's lights are background and directional lights only
-// BackgroundLight::GetBackgroundColor, BackgroundLight.cpp:45-61 (kLean: no textures in the scene)
-template <bool kLean>
+// BackgroundLight::GetBackgroundColor, BackgroundLight.cpp:45-61 (!RT_TEXTURED: no textures in the scene)
+template <int kLean>
 RT_DEV V4 backgroundColor(const RtSceneDesc& d, const RtLight& L, V4 dir)
 {
     V4 color = load4(L.color);
-    if (!kLean && L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluate(d, L.texture, cartesianToSpherical(dir)));
+    if (RT_TEXTURED(kLean) && L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluate(d, L.texture, cartesianToSpherical(dir)));
     return color;
 }
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static V4 lightIlluminate(const RtSceneDesc& d, const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out)
 {
-    const uint32_t lightType = kLean ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
+    const uint32_t lightType = RT_LEAN(kLean) ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
     out.directionToLight = zero4(); out.distance = -1.0f; out.directPdfW = -1.0f; out.cosAtLight = -1.0f;   // Light.h:64-71
     const V4 color = load4(L.color);
     switch (lightType)
@@ -730,10 +736,10 @@ __device__ __forceinline__ static V4 lightIlluminate(const RtSceneDesc& d, const
 }
 
 // ILight::GetRadiance for a ray that hit / escaped; ray and hitPoint are in light space.
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static V4 lightGetRadiance(const RtSceneDesc& d, const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA)
 {
-    const uint32_t lightType = kLean ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
+    const uint32_t lightType = RT_LEAN(kLean) ? (L.type == RT_LIGHT_BACKGROUND ? (uint32_t)RT_LIGHT_BACKGROUND : (uint32_t)RT_LIGHT_DIRECTIONAL) : L.type;
     switch (lightType)
     {
     case RT_LIGHT_AREA:          // AreaLight.cpp:109-147
@@ -1143,8 +1149,8 @@ struct ShadingData { Intersection intersection; V4 outgoingDirWorldSpace; MatPar
 
 // Material::EvaluateShadingData, Material.cpp:151-158; MaterialParameter<T>::Evaluate, MaterialParameter.h:22-32:
 // value = baseValue * texture->Evaluate(uv) (Vector4 parameters: all four lanes; float parameters: lane x).
-// kLean: the scene has no textures.
-template <bool kLean>
+// !RT_TEXTURED(kLean): the scene has no textures.
+template <int kLean>
 RT_DEV void materialEvaluateShadingData(const RtSceneDesc& d, const RtMaterial& mat, ShadingData& sd)
 {
     sd.mp.baseColor = load4(mat.baseColor);
@@ -1152,7 +1158,7 @@ RT_DEV void materialEvaluateShadingData(const RtSceneDesc& d, const RtMaterial& 
     sd.mp.roughness = mat.roughness;
     sd.mp.metalness = mat.metalness;
     sd.mp.IoR = mat.IoR;
-    if (kLean) return;
+    if (!RT_TEXTURED(kLean)) return;
     const V4 uv = sd.intersection.texCoord;
     if (mat.baseColorTexture != RT_NO_TEXTURE) sd.mp.baseColor = sd.mp.baseColor * textureEvaluate(d, mat.baseColorTexture, uv);
     if (mat.emissionTexture != RT_NO_TEXTURE) sd.mp.emission = sd.mp.emission * textureEvaluate(d, mat.emissionTexture, uv);
@@ -1161,20 +1167,20 @@ RT_DEV void materialEvaluateShadingData(const RtSceneDesc& d, const RtMaterial& 
 }
 // Material::Evaluate, Material.cpp:160-180
 // kLean: every material of the scene uses the diffuse BSDF
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static V4 materialEvaluate(const RtMaterial& mat, const ShadingData& sd, V4 incomingDirWorldSpace, float& outPdfW, float* outRevPdfW = nullptr)
 {
     const V4 incomingLocal = worldToLocal(sd.intersection, incomingDirWorldSpace);
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    return bsdfEvaluate(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW, outRevPdfW);
+    return bsdfEvaluate(RT_LEAN(kLean) ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, outgoingLocal, incomingLocal, outPdfW, outRevPdfW);
 }
 // Material::Sample, Material.cpp:182-232
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static V4 materialSample(const RtMaterial& mat, const ShadingData& sd, const float u[3], V4& outIncomingDirWorldSpace, float& outPdfW, uint32_t& outEvent)
 {
     BsdfSample s;
     const V4 outgoingLocal = worldToLocal(sd.intersection, sd.outgoingDirWorldSpace);
-    if (!bsdfSampleImpl(kLean ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, u, outgoingLocal, s)) { outEvent = EV_NULL; return zero4(); }
+    if (!bsdfSampleImpl(RT_LEAN(kLean) ? (uint32_t)RT_BSDF_DIFFUSE : mat.bsdf, mat, sd.mp, u, outgoingLocal, s)) { outEvent = EV_NULL; return zero4(); }
     outIncomingDirWorldSpace = localToWorld(sd.intersection, s.incomingDir);
     outPdfW = s.pdf;
     outEvent = s.event;

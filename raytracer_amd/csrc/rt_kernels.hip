@@ -661,7 +661,7 @@ RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDi
 
 // PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
 // request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static bool computeLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
                                const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
                                float4& outDirTmax, float4& outContribution)
@@ -693,7 +693,7 @@ __device__ __forceinline__ static bool computeLightSample(const RtSceneDesc& sce
     outContribution = f4(contribution.x, contribution.y, contribution.z, 0.0f);
     return tmax >= 0.0f;   // a shadow ray has to be traced for this request
 }
-template <bool kLean>
+template <int kLean>
 __device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
                                const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
                                const Paths& paths, uint32_t slot, uint32_t requestIndex)
@@ -1280,7 +1280,8 @@ struct RtgpuContext
     bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
-    bool leanScene = false;            // only mesh shapes, diffuse materials, background / directional lights
+    bool sortShadeKinds = false;       // RTGPU_SHADE_SORT=1: the generic k_shade_dense deals a block's vertices to its threads by hit kind (measured 4 % slower: off)
+    int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
                                        // rtgpu_set_intersection_counters, or RTGPU_INTERSECTION_COUNTERS=1 for the default of new contexts
     unsigned long long* counters = nullptr;   // 16 x u64
@@ -1830,14 +1831,28 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     c->sceneDev = d;
     c->numLights = s->numLights;
     c->traversalStackNeed = topDepth + maxMeshDepth;
-    bool lean = getenv("RTGPU_NO_LEAN") == nullptr;
+    bool lean = !(getenv("RTGPU_NO_LEAN") && atoi(getenv("RTGPU_NO_LEAN")) != 0);
     for (uint32_t i = 0; i < s->numObjects && lean; ++i) lean = s->objects[i].objectKind == RT_OBJECT_SHAPE && s->objects[i].shapeKind == RT_SHAPE_MESH;
     for (uint32_t i = 0; i < s->numMaterials && lean; ++i) lean = s->materials[i].bsdf == RT_BSDF_DIFFUSE;
     for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].type == RT_LIGHT_BACKGROUND || s->lights[i].type == RT_LIGHT_DIRECTIONAL;
-    for (uint32_t i = 0; i < s->numMaterials && lean; ++i)
-        lean = (s->materials[i].baseColorTexture & s->materials[i].emissionTexture & s->materials[i].roughnessTexture & s->materials[i].metalnessTexture & s->materials[i].normalMapTexture) == RT_NO_TEXTURE;
-    for (uint32_t i = 0; i < s->numLights && lean; ++i) lean = s->lights[i].texture == RT_NO_TEXTURE;
-    c->leanScene = lean;
+    bool textured = false;
+    for (uint32_t i = 0; i < s->numMaterials; ++i)
+        textured = textured || (s->materials[i].baseColorTexture & s->materials[i].emissionTexture & s->materials[i].roughnessTexture & s->materials[i].metalnessTexture & s->materials[i].normalMapTexture) != RT_NO_TEXTURE;
+    for (uint32_t i = 0; i < s->numLights; ++i) textured = textured || s->lights[i].texture != RT_NO_TEXTURE;
+    c->leanScene = lean ? (textured ? 2 : 1) : (textured ? 0 : 3);
+    {
+        // kinds a vertex of this scene can be: BSDF classes in use, light objects; (misses and zombies exist everywhere)
+        uint32_t bsdfMask = 0u; bool lightObjects = false;
+        for (uint32_t i = 0; i < s->numMaterials; ++i) bsdfMask |= 1u << (s->materials[i].bsdf & 15u);
+        for (uint32_t i = 0; i < s->numObjects; ++i) lightObjects = lightObjects || s->objects[i].objectKind == RT_OBJECT_LIGHT;
+        // Measured (profiles/r03_shade_variants.txt): the sort makes k_shade_dense 4-7 % SLOWER on the Cornell box and on the all-BSDF scene -- the
+        // kernel waits on dependent gathers, it does not issue-stall on divergent branches, and the key costs a second walk hit -> object ->
+        // triangle -> material plus three block barriers.  What did pay on those scenes is occupancy (scene class 3: 196 -> 167 VGPRs, -17 ... -21 %).
+        // So the sort is built, bit-exact (tests) and OFF unless RTGPU_SHADE_SORT=1.
+        const bool mixed = !lean && ((bsdfMask & (bsdfMask - 1u)) != 0u || lightObjects);
+        c->sortShadeKinds = false;
+        if (const char* e = getenv("RTGPU_SHADE_SORT")) c->sortShadeKinds = mixed && atoi(e) != 0;
+    }
     c->sceneReady = true;
     c->vcm.havePhotons = false;   // photons of another scene
     return RTGPU_OK;
@@ -2199,8 +2214,8 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags };
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE_DENSE(L, P) hipLaunchKernelGGL((k_shade_dense<L, P>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
-                                                     l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters)
-            if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(false, true); else if (c->leanScene) RT_LAUNCH_SHADE_DENSE(true, false); else RT_LAUNCH_SHADE_DENSE(false, false);
+                                                     l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters, c->sortShadeKinds ? 1u : 0u)
+            if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true); else if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false); else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false); else RT_LAUNCH_SHADE_DENSE(0, false);
 #undef RT_LAUNCH_SHADE_DENSE
         }
         if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
@@ -2266,7 +2281,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                 hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, l.queues[depth & 1u], pathCounts + depth,
                                    l.queues[(depth + 1u) & 1u], pathCounts + depth + 1, l.shadowQueues[depth & 1u], shadowCounts + depth, c->counters);
             }
-            else if (c->leanScene) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
+            else if (c->leanScene == 1) RT_LAUNCH_SHADE(true); else RT_LAUNCH_SHADE(false);
         }
     }
     // the film is summed in pass order: this batch's accumulate runs after the previous batch's

@@ -26,3 +26,20 @@ def pytest_generate_tests(metafunc):
     reference's binary walk with RT_ENABLE_INTERSECTION_COUNTERS-style box / triangle test counters, which are then compared too."""
     if "walk" in metafunc.fixturenames:
         metafunc.parametrize("walk", ["default", "counting"])
+
+
+@pytest.fixture(autouse=True)
+def _device_memory_log(request):
+    """RT_TEST_MEMLOG=<file>: appends the free device memory before every test (debugging aid for leaks across tests)."""
+    path = os.environ.get("RT_TEST_MEMLOG")
+    if path:
+        import ctypes
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+            with open(path, "a") as f:
+                f.write("%-90s free %.2f GB\n" % (request.node.name, free.value / 2**30))
+        except OSError:
+            pass
+    yield

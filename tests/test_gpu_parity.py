@@ -141,6 +141,17 @@ def test_textured_materials_normal_maps_and_environment_map(built, walk):
     assert not np.array_equal(vp.sum_buffer(), out[0])
 
 
+def test_textured_sponza_class_scene_bit_exact(built, walk):
+    """The shading kernels are specialised per scene class (rt_device_core.h: lean / textured): a mesh-only, diffuse-only scene WITH albedo and
+    normal maps on every material and an HDR environment map on the background light (bench.py --workload sponza-textured in small) runs
+    the "lean + textures" variant; the Cornell box and the all-BSDF scenes above run "anything without textures", the mesh scenes "lean",
+    the textured zoo scene "anything"."""
+    w, h = 96, 54
+    scene, camera = scenes.sponza_class(w / h, 6000, textured=True)
+    assert scene.desc.contents.numTextures == 17
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=5))
+
+
 def test_ingested_json_obj_scene_bit_exact(built, walk):
     """SURVEY 8(f) row 3 end to end: a JSON scene file (helpers::LoadScene) with an OBJ mesh + MTL materials + BMP texture
     (helpers::LoadMesh), textured materials, three light types and a depth-of-field camera, rendered on the GPU and
@@ -166,6 +177,17 @@ def test_single_object_scene_bypasses_top_bvh(built, walk):
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
     assert scene.desc.contents.numObjects == 1
     assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=8))
+
+
+def test_hit_kind_sort_is_invisible(built, monkeypatch):
+    """RTGPU_SHADE_SORT=1: the generic shading kernel deals the 256 vertices a block takes per round to its threads by KIND (zombie / miss /
+    light hit / one of the nine BSDF classes: a counting sort in LDS).  Which thread shades a vertex changes nothing: Cornell box (analytic
+    shapes, glass / metal / diffuse, area light) and the all-lights x all-BSDFs scene are bit-identical to the oracle with it on."""
+    monkeypatch.setenv("RTGPU_SHADE_SORT", "1")
+    w, h = 128, 96
+    for make, args in ((scenes.cornell_box, dict(max_ray_depth=6)), (scene_zoo.all_lights_scene, dict(max_ray_depth=6, dimensions=16))):
+        scene, camera = make(w / h)
+        assert_identical(*run_both(scene, camera, w, h, walk="default", passes=3, **args))
 
 
 def test_lean_and_generic_shade_variants_agree(built, monkeypatch):

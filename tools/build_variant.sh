@@ -1,0 +1,10 @@
+#!/bin/bash
+# builds variants/librtgpu_<name>.so from a copy of the csrc tree after applying sed scripts:  tools/build_variant.sh name [file 'sed-expr']...
+set -e
+name=$1; shift
+W=/tmp/variant_$name; rm -rf $W; mkdir -p $W/raytracer_amd
+cp -r /root/repo/raytracer_amd/csrc $W/raytracer_amd/csrc; cp -r /root/repo/include $W/include
+while [ $# -gt 0 ]; do f=$1; e=$2; shift; shift; sed -i "$e" $W/raytracer_amd/csrc/$f; done
+mkdir -p /root/repo/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $W/raytracer_amd/csrc/rt_kernels.hip $W/raytracer_amd/csrc/rt_vcm_photons.hip -o /root/repo/variants/librtgpu_$name.so
+echo built variants/librtgpu_$name.so
