@@ -164,26 +164,29 @@ def kernel_class(name, reencoded_walk=False):
 
 def pmc_child_sums(args, counter, timeout_s):
     """Runs THIS command's passes (same workload, size, --steps, --warmup; one batch lane, intersection counters off) in a child
-    process under `rocprofv3 --kernel-trace --pmc <counter>` and returns {kernel class: (sum of the counter, launches, ns)}."""
+    process under `rocprofv3 --kernel-trace --pmc <counter ...>` and returns {kernel class: (sum of the counter, launches, ns)} -- or, when
+    `counter` is a list (counters that fit one pass), {kernel class: {counter: sum, ..., "launches": n, "ns": ns}}."""
+    counters = [counter] if isinstance(counter, str) else list(counter)
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="rtbench_pmc_", dir="/tmp")
+    label = " ".join(counters)
     try:
-        cmd = [rocprof, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child",
+        cmd = [rocprof, "--kernel-trace", "--pmc"] + counters + ["-d", tmp, "-o", "r", "--", sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child",
                "--steps", str(args.steps), "--warmup", str(args.warmup), "--width", str(args.width), "--height", str(args.height),
                "--depth", str(args.depth), "--triangles", str(args.triangles), "--workload", args.workload]
         env = dict(os.environ, TMPDIR="/tmp", RTGPU_LANES="1")
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
         if r.returncode != 0 or not dbs:
-            return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (counter, r.returncode, (r.stderr or "")[-300:])
+            return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (label, r.returncode, (r.stderr or "")[-300:])
         cur = sqlite3.connect(dbs[0]).cursor()
         rows = None
-        for query in ("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name",
-                      "select k.name, count(*), sum(p.value) from pmc_events p join kernels k on p.event_id = k.id where p.counter_name = ? group by k.name"):
+        for query in ("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name",
+                      "select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k on p.event_id = k.id group by k.name, p.counter_name"):
             try:
-                rows = cur.execute(query, (counter,)).fetchall()
+                rows = [row for row in cur.execute(query).fetchall() if row[1] in counters]
                 if rows:
                     break
             except sqlite3.Error:
@@ -193,23 +196,74 @@ def pmc_child_sums(args, counter, timeout_s):
             durations = {n: (int(c), int(d)) for n, c, d in cur.execute("select name, count(*), sum(duration) from kernels group by name").fetchall()}
         except sqlite3.Error:
             pass
-        rows = [(n, c, t, durations.get(n, (0, 0))[1]) for n, c, t in (rows or [])]
         if not rows:
-            return None, "no %s rows in the rocprofv3 database" % counter
-        out = {}
+            return None, "no %s rows in the rocprofv3 database" % label
         reencoded = any(n.replace("void ", "").strip().startswith(("k_trace_wide", "k_trace_quant")) for n, _, _, _ in rows)
-        for name, launches, total, ns in rows:
+        multi = {}
+        for name, cname, launches, total in rows:
             cls = kernel_class(name, reencoded)
             if cls:
-                a = out.setdefault(cls, [0.0, 0, 0])
-                a[0] += float(total); a[1] += int(launches); a[2] += int(ns or 0)
-        return out, None
+                a = multi.setdefault(cls, {})
+                a[cname] = a.get(cname, 0.0) + float(total)
+                seen = a.setdefault("_names", {})
+                seen[name] = (int(launches), int(durations.get(name, (0, 0))[1] or 0))
+        for cls, a in multi.items():
+            names = a.pop("_names")
+            a["launches"] = sum(v[0] for v in names.values()); a["ns"] = sum(v[1] for v in names.values())
+        if isinstance(counter, str):
+            return {cls: [a.get(counter, 0.0), a["launches"], a["ns"]] for cls, a in multi.items()}, None
+        return multi, None
     except subprocess.TimeoutExpired:
-        return None, "rocprofv3 --pmc %s timed out" % counter
+        return None, "rocprofv3 --pmc %s timed out" % label
     except Exception as e:   # a profiler problem must not take the benchmark down
-        return None, "rocprofv3 --pmc %s: %r" % (counter, e)
+        return None, "rocprofv3 --pmc %s: %r" % (label, e)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# what tools/microbench/cadence.hip measured on this chip (profiles/r03_microbench_cadence_l1.txt): a wave64 VALU instruction occupies its
+# SIMD for 2.1 clocks with >= 5 resident waves (SIMD-32), and the walk's fetch pattern -- every lane its own 64-byte node, 16 bytes per
+# access -- peaks at 1.8 L1 accesses per clock and CU from an L1 / L2-resident table
+VALU_CLOCKS_PER_WAVE_INSTRUCTION = 2.1
+L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU = 1.8
+PIPE_COUNTERS = ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE",
+                 "TCP_TOTAL_CACHE_ACCESSES_sum"]
+
+
+def measure_pipes(args, num_cus):
+    """Which ceiling is a kernel near?  A third --pmc child run of the same passes (SQ / GRBM / TCP counters that fit one pass), per
+    launch and kernel class:
+      valu_issue  -- wave-level VALU instructions x 2.1 clocks (the microbenchmark's cadence) / SIMD clocks available (4 SIMDs per CU x the
+                     kernel's clocks, GRBM_GUI_ACTIVE summed over the 8 XCDs / 8); lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU);
+      l1_access   -- vector-L1 accesses per clock and CU against the 1.8 the walk's access pattern peaks at;
+      wave_time   -- where the resident waves' time goes: parked on s_waitcnt (memory), stalled at issue, issuing (SQ_WAIT_ANY /
+                     SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES)."""
+    budget = max(120.0, 6.0 * (args.steps + args.warmup))
+    sums, err = pmc_child_sums(args, PIPE_COUNTERS, budget)
+    if sums is None:
+        return None, err
+    out = {}
+    for cls, a in sums.items():
+        n = a.get("launches", 0)
+        clocks = a.get("GRBM_GUI_ACTIVE", 0.0) / 8.0      # per launch population: kernel clocks (one XCD's worth)
+        if not n or clocks <= 0 or not a.get("SQ_INSTS_VALU"):
+            continue
+        simd_clocks = 4.0 * num_cus * clocks
+        wave = a.get("SQ_WAVE_CYCLES", 0.0) or 1.0
+        out[cls] = {
+            "launches": n,
+            "clock_GHz": clocks / (a["ns"] * 1e-9) / 1e9 if a.get("ns") else None,
+            "valu_issue": {"wave_instructions_per_launch": a["SQ_INSTS_VALU"] / n, "clocks_per_instruction": VALU_CLOCKS_PER_WAVE_INSTRUCTION,
+                           "frac": a["SQ_INSTS_VALU"] * VALU_CLOCKS_PER_WAVE_INSTRUCTION / simd_clocks,
+                           "lane_utilisation": a.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * a["SQ_INSTS_VALU"])},
+            "l1_access": {"accesses_per_launch": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n,
+                          "per_clock_per_cu": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks),
+                          "peak_per_clock_per_cu": L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU,
+                          "frac": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks) / L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU},
+            "wave_time": {"waiting_for_memory": a.get("SQ_WAIT_ANY", 0.0) / wave, "issue_stalled": a.get("SQ_WAIT_INST_ANY", 0.0) / wave,
+                          "issuing": a.get("SQ_ACTIVE_INST_ANY", 0.0) / wave},
+        }
+    return out, None
 
 
 def measure_traffic(args):
@@ -403,12 +457,18 @@ def main():
             kernel_name = "k_" + dom
             if dom == "trace" and c1.get("numRetracedRays", 0) > 0:
                 kernel_name = "k_trace_wide"   # the 4-wide walk served the launches (it hands a few rays to k_trace: class "retrace")
+            # achieved / peak / frac / traffic: the HBM roof, as the contract words it (measured fabric traffic / launch time / 8 TB/s).  `bound` says
+            # which ceiling the kernel is actually nearest to -- decided below from the counters -- and `ceilings` holds the evidence.
+            # reference_walk_*: SURVEY 8(d)'s byte model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk, ...): what
+            # the reference's algorithm would move if nothing were cached -- a work measure, not HBM traffic (the caches serve ~4/5 of it and the
+            # 4-wide walk visits fewer nodes), which is why it may exceed the HBM peak.
             roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
-                    "algorithmic_bytes_per_launch": per_launch_bytes, "algorithmic_GBs": algorithmic_gbs,
-                    "algorithmic_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
+                    "reference_walk_bytes_per_launch": per_launch_bytes, "reference_walk_GBs": algorithmic_gbs,
+                    "reference_walk_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
                     "measured": "launch time: HIP events around every launch of a one-lane (serial kernels) replay of the warm-up and timed passes; "
-                                "traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the same passes, 2 x FETCH_SIZE + WRITE_SIZE per launch"}
+                                "traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the same passes, 2 x FETCH_SIZE + WRITE_SIZE per launch; "
+                                "ceilings: a third child run (SQ / GRBM / TCP counters), cadence and L1 peak from tools/microbench/cadence.hip"}
             t = traffic.get(dom) if traffic else None
             if t and t["launches"] != launches and t["profiled_avg_launch_ms"]:
                 # a kernel class whose event pairs span several kernels (the bidirectional integrator's shading stages): bytes and time both
@@ -416,7 +476,7 @@ def main():
                 roof["avg_launch_ms"] = t["profiled_avg_launch_ms"]; roof["launches"] = launches = t["launches"]
                 per_launch_s = t["profiled_avg_launch_ms"] / 1000.0
                 per_launch_bytes = abytes_replay[dom] / max(1, launches)
-                roof["algorithmic_bytes_per_launch"] = per_launch_bytes
+                roof["reference_walk_bytes_per_launch"] = per_launch_bytes
                 roof["measured"] += "; this class's event pairs span several kernels, so launch time and count are the profiled child's"
             if t and t["launches"] == launches:
                 # `achieved` is what crossed the L2 <-> fabric boundary per second while the kernel ran: <= peak by construction.  The
@@ -425,11 +485,25 @@ def main():
                              "traffic_fetch_size_bytes": t["fetch_size_bytes"], "traffic_write_size_bytes": t["write_size_bytes"],
                              "profiled_avg_launch_ms": t["profiled_avg_launch_ms"]})
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-                roof["traffic_over_algorithmic"] = t["hbm_bytes"] / per_launch_bytes if per_launch_bytes else None
+                roof["traffic_over_reference_walk_bytes"] = t["hbm_bytes"] / per_launch_bytes if per_launch_bytes else None
                 out["traffic_per_launch"] = {k: {"launches": v["launches"], "hbm_bytes": v["hbm_bytes"],
                                                  "GBs": (v["hbm_bytes"] / (ktimes[k][0] / 1000.0 / max(1, ktimes[k][1])) / 1e9) if k in ktimes and ktimes[k][0] > 0 else None,
-                                                 "algorithmic_bytes": abytes_replay.get(k, 0) / max(1, v["launches"])}
+                                                 "reference_walk_bytes": abytes_replay.get(k, 0) / max(1, v["launches"])}
                                              for k, v in traffic.items()}
+                pipes, pipes_error = measure_pipes(args, torch.cuda.get_device_properties(local_rank).multi_processor_count)
+                if pipes and dom in pipes:
+                    pd = pipes[dom]
+                    fracs = {"hbm": roof["frac"], "valu_issue": pd["valu_issue"]["frac"], "l1_access": pd["l1_access"]["frac"]}
+                    nearest = max(fracs, key=lambda k: fracs[k])
+                    # no pipe above 2/3 of its ceiling while the resident waves spend most of their time parked on memory waits: the kernel is bound
+                    # by the LATENCY of its dependent fetches at the occupancy its registers allow, not by a throughput roof
+                    roof["bound"] = nearest if fracs[nearest] >= 0.67 else "latency"
+                    roof["ceilings"] = {"fracs": fracs, "nearest": nearest, **pd}
+                    out["pipes_per_kernel_class"] = {k: {"valu_issue_frac": v["valu_issue"]["frac"], "lane_utilisation": v["valu_issue"]["lane_utilisation"],
+                                                         "l1_access_frac": v["l1_access"]["frac"], "waiting_for_memory": v["wave_time"]["waiting_for_memory"]}
+                                                     for k, v in pipes.items()}
+                else:
+                    roof["ceilings_error"] = pipes_error or "no counters for the dominant kernel class"
             else:
                 roof.update({"achieved": None, "traffic": None, "frac": None,
                              "traffic_error": traffic_error or ("launch population mismatch: %s" % (t,))})
@@ -437,7 +511,7 @@ def main():
             out["kernel_time_ms"] = {k: round(v[0], 3) for k, v in ktimes.items()}
             out["kernel_launches"] = {k: v[1] for k, v in ktimes.items()}
             tot_bytes = sum(abytes.values())
-            out["whole_pass_algorithmic_GBs"] = tot_bytes / elapsed / 1e9
+            out["whole_pass_reference_walk_GBs"] = tot_bytes / elapsed / 1e9
 
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, camera, ra)
