@@ -77,7 +77,13 @@ RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t 
     return material == RT_NO_MATERIAL ? 3u : 3u + (scene.materials[material].bsdf & 15u) % (RT_SHADE_KINDS - 4u);
 }
 
-template <int kLean, bool kPlain = false>
+//
+// kAll: LightSamplingStrategy::All (PathTracerMIS.cpp:141-147: every light is sampled at every vertex, up to RT_DENSE_MAX_LIGHTS of them here).
+// The 2 x numLights request records of a vertex cannot wait in registers or LDS for its output slot, so they are written to the vertex's OWN
+// slot of the input arena first -- its previous requests were folded in at the top of the iteration, the space is free -- and copied to the
+// output slot once the block has allocated it (the copy reads what the same lane just wrote: L2 hits).
+#define RT_DENSE_MAX_LIGHTS 7u   // 256 vertices x 7 requests fit the block's append buffer between two flushes
+template <int kLean, bool kPlain = false, bool kAll = false>
 __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
                                                           const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
                                                           float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds)
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
     const uint32_t stride = gridDim.x * blockDim.x;
     const DevPass pass = passes[0];   // the structural parameters are those of every pass of the batch
     const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
-    const float lightPickProbability = 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172 (Single)
+    const float lightPickProbability = kAll ? 1.0f : 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172
 
     const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
     // the i-th vertex of the launch: live paths first (region by region), then the zombies (from the top of their regions)
@@ -142,11 +148,12 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
         float4 oOrigin, oDir, oTp, oResult, oSampler, oRng;
         bool stagedShTp = false;
         bool rayNeeded = false;
-        uint32_t oHome = 0u;
+        uint32_t oHome = 0u, inSlot = 0u, rayMask = 0u;
         if (i < count)
         {
             bool zombie;
             const uint32_t slot = vertexSlot(i, zombie);
+            inSlot = slot;
             const float4 rResult = prec(in, R_RESULT, slot), rSampler = prec(in, R_SAMPLER, slot), rShTp = prec(in, R_SH_TP, slot);
             const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
             oHome = homeIndex;
@@ -225,8 +232,22 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
                     Sampler sampler; loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise);
                     sampler.seed = passes[homeIndex / slotsPerPass].seed;
 
-                    // SampleLights (next event estimation, one light), PathTracerMIS.cpp:125-155
-                    if (!kPlain && scene.numLights != 0)
+                    // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
+                    if (!kPlain && kAll && scene.numLights != 0)
+                    {
+                        for (uint32_t l = 0; l < scene.numLights; ++l)
+                        {
+                            float4 dirTmax, contribution;
+                            if (computeLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, dirTmax, contribution)) rayMask |= 1u << l;
+                            pshadow(in, l, 0, slot) = dirTmax; pshadow(in, l, 1, slot) = contribution;
+                        }
+                        rayNeeded = rayMask != 0u;
+                        numRequests = rayNeeded ? scene.numLights : 0u;
+                        sStage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                        sStage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                        stagedShTp = true;
+                    }
+                    else if (!kPlain && scene.numLights != 0)
                     {
                         uint32_t lightIndex = 0;
                         if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
@@ -308,15 +329,26 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
             if (ubits(oSampler.w) != 0u)
             {
                 prec(out, R_SH_P, slot) = sStage[2][threadIdx.x];
+                if (kAll)
+                {
+                    for (uint32_t l = 0; l < scene.numLights; ++l)
+                    {
+                        pshadow(out, l, 0, slot) = pshadow(in, l, 0, inSlot); pshadow(out, l, 1, slot) = pshadow(in, l, 1, inSlot);
+                        if (rayMask & (1u << l)) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * out.capacity + slot;
+                    }
+                }
+                else
+                {
                 pshadow(out, 0, 0, slot) = sStage[0][threadIdx.x];
                 pshadow(out, 0, 1, slot) = sStage[1][threadIdx.x];
                 if (rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
+                }
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) { sLive = 0; sZombies = 0; }
         const bool last = first + stride >= rounded;
-        if (last || sShadowCount + RT_BLOCK > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
+        if (last || sShadowCount + RT_BLOCK * (kAll ? RT_DENSE_MAX_LIGHTS : 1u) > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
         else __syncthreads();
     }
     flushCounters(cnt, counters);

@@ -1193,6 +1193,39 @@ __global__ void __launch_bounds__(RT_BLOCK) k_evaluate_textures(const RtSceneDes
 // =====================================================================================================
 // Host side of the C-ABI
 // =====================================================================================================
+// Synchronous copies between HOST memory the caller owns and the device.  HIP would page-lock a large pageable range on the fly and keep the
+// registration cached; the caller then frees the range (a std::vector of the host mirror, a numpy array) and a later allocation lands on the
+// same addresses -- on some boxes of the pool the HSA runtime aborts the process a few dozen contexts later (no message; it went away with
+// this).  So anything above 64 KB that is not page-locked already (hipHostMalloc / hipHostRegister: the viewport's sum bitmaps) travels
+// through a page-locked staging buffer of the library, 8 MB at a time.
+#include <mutex>
+static std::mutex gStagingMutex;
+static void* gStaging = nullptr;
+static const size_t kStagingBytes = (size_t)8 << 20;
+static bool hostRangeIsPageLocked(const void* p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // ordinary pageable memory: "invalid value"
+    return attr.type == hipMemoryTypeHost;
+}
+static hipError_t rtMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind)
+{
+    if (bytes == 0) return hipSuccess;
+    const bool h2d = kind == hipMemcpyHostToDevice, d2h = kind == hipMemcpyDeviceToHost;
+    if ((!h2d && !d2h) || bytes <= ((size_t)64 << 10) || hostRangeIsPageLocked(h2d ? src : dst)) return hipMemcpy(dst, src, bytes, kind);
+    std::lock_guard<std::mutex> lock(gStagingMutex);
+    if (!gStaging) { const hipError_t e = hipHostMalloc(&gStaging, kStagingBytes, hipHostMallocDefault); if (e != hipSuccess) { gStaging = nullptr; return e; } }
+    for (size_t done = 0; done < bytes; done += kStagingBytes)
+    {
+        const size_t n = bytes - done < kStagingBytes ? bytes - done : kStagingBytes;
+        if (h2d) memcpy(gStaging, static_cast<const char*>(src) + done, n);
+        const hipError_t e = h2d ? hipMemcpy(static_cast<char*>(dst) + done, gStaging, n, kind) : hipMemcpy(gStaging, static_cast<const char*>(src) + done, n, kind);
+        if (e != hipSuccess) return e;
+        if (d2h) memcpy(static_cast<char*>(dst) + done, gStaging, n);
+    }
+    return hipSuccess;
+}
+
 static thread_local std::string gLastError;
 
 static int fail(int code, const std::string& msg) { gLastError = msg; return code; }
@@ -1435,7 +1468,7 @@ static int uploadArray(RtgpuContext* c, const T* host, size_t count, const T** o
     void* dev = nullptr;
     HIP_TRY(hipMalloc(&dev, count * sizeof(T)));
     c->sceneAllocs.push_back(dev);
-    HIP_TRY(hipMemcpy(dev, host, count * sizeof(T), hipMemcpyHostToDevice));
+    HIP_TRY(rtMemcpy(dev, host, count * sizeof(T), hipMemcpyHostToDevice));
     *outDev = static_cast<const T*>(dev);
     return RTGPU_OK;
 }
@@ -1467,7 +1500,7 @@ static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* o
     void* dIn = nullptr; void* dOut = nullptr;
     hipError_t e = hipMalloc(&dIn, inBytes ? inBytes : 4);
     if (e == hipSuccess) e = hipMalloc(&dOut, outBytes ? outBytes : 4);
-    if (e == hipSuccess) e = hipMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dIn, in, inBytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemsetAsync(dOut, 0, outBytes, c->lanes[0].stream);   // on the kernel's stream: the lanes do not synchronise with the null stream
     if (e == hipSuccess)
     {
@@ -1475,7 +1508,7 @@ static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* o
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(c->lanes[0].stream);
     }
-    if (e == hipSuccess) e = hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = rtMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost);
     if (dIn) (void)hipFree(dIn);
     if (dOut) (void)hipFree(dOut);
     if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_kat: ") + hipGetErrorString(e));
@@ -1483,6 +1516,28 @@ static int katRoundTrip(RtgpuContext* c, const void* in, size_t inBytes, void* o
 }
 
 #include "rt_multi.inl"
+
+// Streams are recycled through a process-wide pool instead of being created and destroyed with every context: a test session (or an
+// application that opens a renderer per frame size) goes through hundreds of contexts, and on some boxes of the pool the HSA runtime's
+// event thread aborts the process after a few hundred stream (hardware queue) create / destroy cycles (no message; ROCm 7.0.2).  A context
+// returns its idle streams at destruction, after it has synchronised them.
+#include <mutex>
+static std::mutex gStreamPoolMutex;
+static std::unordered_map<int, std::vector<hipStream_t>> gStreamPool;   // device -> idle non-blocking streams
+static hipError_t acquireStream(int device, hipStream_t* out)
+{
+    {
+        std::lock_guard<std::mutex> lock(gStreamPoolMutex);
+        auto& pool = gStreamPool[device];
+        if (!pool.empty()) { *out = pool.back(); pool.pop_back(); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+static void releaseStream(int device, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lock(gStreamPoolMutex);
+    gStreamPool[device].push_back(stream);
+}
 
 extern "C" {
 
@@ -1533,7 +1588,7 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     hipError_t e = hipSuccess;
     for (uint32_t i = 0; i < RT_MAX_LANES && e == hipSuccess; ++i)
     {
-        e = hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking);
+        e = acquireStream(c->device, &c->lanes[i].stream);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lanes[i].accumulated, hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
@@ -1631,7 +1686,7 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
     for (int i = 0; i < RT_SEED_RING; ++i) if (c->seedEvents[i]) (void)hipEventDestroy(c->seedEvents[i]);
     for (auto& t : c->pendingTimed) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
-    for (uint32_t i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamDestroy(c->lanes[i].stream);
+    for (uint32_t i = 0; i < RT_MAX_LANES; ++i) if (c->lanes[i].stream) { (void)hipStreamSynchronize(c->lanes[i].stream); releaseStream(c->device, c->lanes[i].stream); }
     delete c;
 }
 
@@ -1904,7 +1959,7 @@ static int rebuildSlots(RtgpuContext* c)
     if (c->numSlots)
     {
         HIP_TRY(hipMalloc((void**)&c->slotPixel, slots.size() * sizeof(uint32_t)));
-        HIP_TRY(hipMemcpy(c->slotPixel, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(rtMemcpy(c->slotPixel, slots.data(), slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     return RTGPU_OK;
 }
@@ -1979,13 +2034,13 @@ static uint32_t maxStreamingBatch(const RtgpuContext* c)
 }
 
 // Device bytes one path slot costs a batch lane when a vertex can have `maxLights` next-event requests: the records of both arenas
-// (the second one only exists for one request per vertex), the parked radiance, the queues.  LightSamplingStrategy::All with many
+// (the second one only exists with dense path state: up to RT_DENSE_MAX_LIGHTS requests per vertex), the parked radiance, the queues.  LightSamplingStrategy::All with many
 // lights makes slots fat (64 lights: 2.2 KB), so the batch a lane can hold shrinks with it -- down to one pass.
 static size_t bytesPerSlot(uint32_t maxLights)
 {
     if (maxLights == 0) maxLights = 1;
     const size_t arena = ((size_t)R_NUM_BASE + (size_t)maxLights * RT_SHADOW_RECORDS) * sizeof(float4);
-    return arena * (maxLights == 1u ? 2u : 1u) + sizeof(float4) + sizeof(uint32_t) * (3u + 3u * (size_t)maxLights);
+    return arena * (maxLights <= RT_DENSE_MAX_LIGHTS ? 2u : 1u) + sizeof(float4) + sizeof(uint32_t) * (3u + 3u * (size_t)maxLights);
 }
 static uint32_t maxBatchFor(const RtgpuContext* c, uint32_t maxLights)
 {
@@ -2000,7 +2055,7 @@ static size_t arenaCapacityFor(size_t slots) { return (size_t)RT_DENSE_SHARDS * 
 static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32_t maxDepth)
 {
     if (maxLights == 0) maxLights = 1;
-    const bool wantDense = c->denseAllowed && maxLights == 1u;
+    const bool wantDense = c->denseAllowed && maxLights <= RT_DENSE_MAX_LIGHTS;
     for (int attempt = 0; attempt < 2; ++attempt)
     {
         uint32_t maxBatch = (c->passBatchFromEnv || c->numSlots < 400000u) ? c->passBatch : maxStreamingBatch(c);   // the largest batch streaming can reach
@@ -2162,8 +2217,10 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
     const uint32_t maxRayDepth = first.maxRayDepth;
 
     HIP_TRY(hipMemsetAsync(l.queueCounts, 0, (size_t)8 * l.queueCountCapacity * sizeof(uint32_t), l.stream));
-    // One next-event request per vertex (LightSamplingStrategy::Single, or none: "Path Tracer"): DENSE path state (rt_dense.inl)
-    const bool dense = c->denseAllowed && c->debugMode < 0 && maxLights <= 1u && l.paths2.base != nullptr;
+    // DENSE path state (rt_dense.inl): one next-event request per vertex (LightSamplingStrategy::Single, or none: "Path Tracer"), or one per light
+    // under LightSamplingStrategy::All with a handful of lights (the benchmark scene has two)
+    const bool dense = c->denseAllowed && c->debugMode < 0 && maxLights <= RT_DENSE_MAX_LIGHTS && l.paths2.base != nullptr;
+    const bool denseAll = dense && first.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL && !c->plainPathTracer;
     if (dense)
     {
         const uint32_t shardCapacity = (totalSlots + RT_DENSE_SHARDS - 1u) / RT_DENSE_SHARDS + 65536u;
@@ -2213,9 +2270,12 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
             const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags };
             LaunchTimer t(c, l.stream, KC_SHADE);
-#define RT_LAUNCH_SHADE_DENSE(L, P) hipLaunchKernelGGL((k_shade_dense<L, P>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
+#define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
                                                      l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters, c->sortShadeKinds ? 1u : 0u)
-            if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true); else if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false); else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false); else RT_LAUNCH_SHADE_DENSE(0, false);
+            if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true, false);
+            else if (denseAll) { if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, true); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, true); else RT_LAUNCH_SHADE_DENSE(0, false, true); }
+            else if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, false); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, false);
+            else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false, false); else RT_LAUNCH_SHADE_DENSE(0, false, false);
 #undef RT_LAUNCH_SHADE_DENSE
         }
         if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
@@ -2716,7 +2776,7 @@ RTGPU_API int rtgpu_vcm_num_photons(RtgpuContext* c, uint32_t* outCount)
     *outCount = 0;
     if (!c->vcm.havePhotons || !c->vcm.arena.photonCount) return RTGPU_OK;
     std::vector<uint32_t> counts(c->numSlots);
-    HIP_TRY(hipMemcpy(counts.data(), c->vcm.arena.photonCount + (size_t)c->vcm.lastPhotonPass * c->numSlots, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(rtMemcpy(counts.data(), c->vcm.arena.photonCount + (size_t)c->vcm.lastPhotonPass * c->numSlots, counts.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     unsigned long long total = 0; for (uint32_t n : counts) total += n;
     *outCount = (uint32_t)total;
     return RTGPU_OK;
@@ -2798,8 +2858,8 @@ RTGPU_API int rtgpu_read_sum(RtgpuContext* c, float* sumRGB, float* secondaryRGB
     int r = rtgpu_synchronize(c); if (r) return r;
     r = gatherPeers(c); if (r) return r;
     const size_t bytes = (size_t)c->width * c->height * 3 * sizeof(float);
-    if (sumRGB) HIP_TRY(hipMemcpy(sumRGB, c->sum, bytes, hipMemcpyDeviceToHost));
-    if (secondaryRGB) HIP_TRY(hipMemcpy(secondaryRGB, c->secondary, bytes, hipMemcpyDeviceToHost));
+    if (sumRGB) HIP_TRY(rtMemcpy(sumRGB, c->sum, bytes, hipMemcpyDeviceToHost));
+    if (secondaryRGB) HIP_TRY(rtMemcpy(secondaryRGB, c->secondary, bytes, hipMemcpyDeviceToHost));
     return RTGPU_OK;
 }
 
@@ -2839,7 +2899,7 @@ RTGPU_API int rtgpu_get_counters(RtgpuContext* c, RtCounters* out)
     if (!c || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
     int r = rtgpu_synchronize(c); if (r) return r;
     unsigned long long host[16];
-    HIP_TRY(hipMemcpy(host, c->counters, sizeof(host), hipMemcpyDeviceToHost));
+    HIP_TRY(rtMemcpy(host, c->counters, sizeof(host), hipMemcpyDeviceToHost));
     memset(out, 0, sizeof(*out));
     out->numRays = host[C_RAYS]; out->numShadowRays = host[C_SHADOW]; out->numShadowRaysHit = host[C_SHADOW_HIT];
     out->numPrimaryRays = host[C_PRIMARY]; out->numRayBoxTests = host[C_BOX]; out->numPassedRayBoxTests = host[C_BOX_PASS];
@@ -2898,9 +2958,9 @@ RTGPU_API int rtgpu_compute_block_errors(RtgpuContext* c, uint32_t numPasses, ui
     if (e == hipSuccess) e = hipMalloc((void**)&dFirst, numBlocks * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&dRowErrors, rows.size() * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&dOut, numBlocks * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(dBlocks, blocks, numBlocks * sizeof(RtBlock), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dRows, rows.data(), rows.size() * sizeof(ErrorRow), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dFirst, firstRow.data(), numBlocks * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dBlocks, blocks, numBlocks * sizeof(RtBlock), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dRows, rows.data(), rows.size() * sizeof(ErrorRow), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dFirst, firstRow.data(), numBlocks * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess)
     {
         hipStream_t st = c->lanes[0].stream;
@@ -2910,7 +2970,7 @@ RTGPU_API int rtgpu_compute_block_errors(RtgpuContext* c, uint32_t numPasses, ui
         hipLaunchKernelGGL(k_block_error_total, dim3((numBlocks + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, dBlocks, dFirst, numBlocks, dRowErrors, c->width * c->height, dOut);
         e = hipStreamSynchronize(st);
     }
-    if (e == hipSuccess) e = hipMemcpy(outErrors, dOut, numBlocks * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = rtMemcpy(outErrors, dOut, numBlocks * sizeof(float), hipMemcpyDeviceToHost);
     for (void* p : { (void*)dBlocks, (void*)dRows, (void*)dFirst, (void*)dRowErrors, (void*)dOut }) if (p) (void)hipFree(p);
     if (e != hipSuccess) return fail(RTGPU_ERR_DEVICE, std::string("rtgpu_compute_block_errors: ") + hipGetErrorString(e));
     return RTGPU_OK;
@@ -2996,7 +3056,7 @@ RTGPU_API int rtgpu_postprocess(RtgpuContext* c, const RtPostprocessParams* p, u
         if (e == hipSuccess) hipLaunchKernelGGL(k_postprocess_bloom, dim3((uint32_t)((pixels + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, stream, c->sum, levels, dFront, c->width, c->height, *p, scale);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e == hipSuccess) e = hipMemcpy(frontBufferBGRA, dFront, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = rtMemcpy(frontBufferBGRA, dFront, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipFree(dFront);
     if (dBlur) (void)hipFree(dBlur);
     if (dLines) (void)hipFree(dLines);
@@ -3015,14 +3075,14 @@ RTGPU_API int rtgpu_evaluate_textures(RtgpuContext* c, uint32_t count, const uin
     hipError_t e = hipMalloc((void**)&dIndex, count * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&dUv, (size_t)count * 2 * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&dOut, (size_t)count * 4 * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(dIndex, textureIndex, count * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dUv, uv, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dIndex, textureIndex, count * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rtMemcpy(dUv, uv, (size_t)count * 2 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess)
     {
         hipLaunchKernelGGL(k_evaluate_textures, dim3((count + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->lanes[0].stream, c->sceneDev, count, dIndex, dUv, dOut);
         e = hipStreamSynchronize(c->lanes[0].stream);
     }
-    if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)count * 4 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = rtMemcpy(out, dOut, (size_t)count * 4 * sizeof(float), hipMemcpyDeviceToHost);
     if (dIndex) (void)hipFree(dIndex);
     if (dUv) (void)hipFree(dUv);
     if (dOut) (void)hipFree(dOut);
@@ -3063,7 +3123,7 @@ RTGPU_API int rtgpu_kat_sampler(RtgpuContext* c, const uint16_t* blueNoise, cons
     if (blueNoise)
     {
         HIP_TRY(hipMalloc((void**)&dBlue, (size_t)128 * 128 * 4 * sizeof(uint16_t)));
-        const hipError_t e = hipMemcpy(dBlue, blueNoise, (size_t)128 * 128 * 4 * sizeof(uint16_t), hipMemcpyHostToDevice);
+        const hipError_t e = rtMemcpy(dBlue, blueNoise, (size_t)128 * 128 * 4 * sizeof(uint16_t), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(dBlue); return fail(RTGPU_ERR_DEVICE, hipGetErrorString(e)); }
     }
     std::vector<float> out((size_t)n * 2 * count);

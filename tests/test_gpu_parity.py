@@ -568,6 +568,43 @@ def test_full_size_sponza_class_properties(built, walk):
     assert rays == cw["numRays"]
 
 
+def test_full_size_sponza_class_under_the_all_strategy(built):
+    """SURVEY 8(d)'s second C3 run -- LightSamplingStrategy::All with dimensions = 128, the configuration whose sample stream is path-exact
+    (PathTracerMIS.cpp:141-147) -- at BASELINE's full size, with the library's defaults (4-wide walk, dense path state with one request per
+    light and vertex): the tiles shard 0 of 32 owns equal the CPU oracle bit for bit, with identical ray counters, and they are the same pixels
+    of the unsharded frame (bench.py --workload sponza-all times this pipeline)."""
+    w, h, depth, passes = 1920, 1080, 8, 2
+    scene, camera = scenes.sponza_class(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    args = dict(seed=777, max_ray_depth=depth, dimensions=128, light_sampling_all=True)
+    full = ra.Viewport(w, h, **args)
+    full.set_renderer(scene)
+    params = [full.next_pass_params(camera) for _ in range(passes)]
+    for p in params:
+        full.render_pass_with(p)
+    whole = full.sum_buffer()
+    cw = full.counters()
+    assert cw["numPrimaryRays"] == w * h * passes and cw["numRetracedRays"] > 0 and cw["numShadowRays"] > cw["numRays"]   # two lights: more shadow rays than path segments
+    part_vp = ra.Viewport(w, h, **args)
+    part_vp.set_renderer(scene)
+    part_vp.set_shard(0, 32)
+    ref = np.zeros((h, w, 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for p in params:
+        part_vp.render_pass_with(p)
+        oracle_lib.render_pass(desc, p, w, h, ref, None, cnt, shard=(0, 32), threads=16)
+    part = part_vp.sum_buffer()
+    assert np.array_equal(part.view(np.uint32), ref.view(np.uint32))
+    pc = part_vp.counters()
+    for i, n in enumerate(ra.COUNTER_NAMES):
+        if n in NOT_INTERSECTION:
+            assert pc[n] == int(cnt[i]), (n, pc[n], int(cnt[i]))
+    owned = part != 0
+    assert np.array_equal(part[owned].view(np.uint32), whole[owned].view(np.uint32))
+
+
 def test_plain_path_tracer_bit_exact(built, walk):
     """Renderer "Path Tracer" (PathTracer.cpp: BSDF sampling only): all lights x all BSDFs, the mesh scene and the Cornell box
     against the oracle's restatement -- images and counters identical; no shadow rays are cast."""
@@ -887,7 +924,10 @@ def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch, walk):
     from the per-pixel generator), with Russian roulette off and a short depth limit (every path ends as a zombie or at the limit), for
     the plain "Path Tracer", and with more passes than one batch."""
     cases = [(scenes.cornell_box, dict(max_ray_depth=6), 5), (lambda a: scene_zoo.mesh_scene(a, triangles=8000), dict(max_ray_depth=8), 3),
-             (lambda a: scenes.sponza_class(a, 20000), dict(max_ray_depth=2, min_russian_roulette_depth=9), 19)]
+             (lambda a: scenes.sponza_class(a, 20000), dict(max_ray_depth=2, min_russian_roulette_depth=9), 19),
+             # LightSamplingStrategy::All with a handful of lights is dense too (every vertex carries one request per light)
+             (lambda a: scenes.sponza_class(a, 20000), dict(max_ray_depth=7, light_sampling_all=True, dimensions=128), 3),
+             (lambda a: scene_zoo.mesh_scene(a, triangles=8000), dict(max_ray_depth=5, light_sampling_all=True, dimensions=128, min_russian_roulette_depth=9), 2)]
     w, h = 96, 54
     for make, args, passes in cases:
         scene, camera = make(w / h)
