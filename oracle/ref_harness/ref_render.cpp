@@ -252,8 +252,73 @@ static void seedRandom(Random& rng, uint64_t seed)
 
 static const char* kBsdfNames[] = { "null", "diffuse", "roughDiffuse", "dielectric", "roughDielectric", "metal", "roughMetal", "plastic", "roughPlastic" };
 
+// ---- adaptive-rendering known-answer file (tests/golden/adaptive_kat.bin) ---------------------------------------------------------------
+// The reference's own Viewport::BuildInitialBlocksList / ComputeBlockError / UpdateBlocksList (Viewport.cpp:552-581, :618-733; Viewport.cpp is
+// one of the translation units that build here) driven on synthetic sum buffers: `rounds` times the two sum bitmaps are filled with a
+// seeded field whose noise shrinks from round to round and differs across the frame (so that blocks split, drop and survive), the pass
+// counter is advanced by two and UpdateBlocksList runs.  Recorded per round: the buffers, the block list before, every block's error as
+// ComputeBlockError returns it, the block list after.  Layout: uint32 magic 'RAK1', width, height, rounds, numInitialPasses, minBlockSize,
+// maxBlockSize, 0; float subdivisionTreshold, convergenceTreshold; uint32 numInitialBlocks; blocks[numInitialBlocks][4] (minX, maxX, minY,
+// maxY); then per round: uint32 passesFinished, numBefore; float sum[h][w][3], secondary[h][w][3]; float errors[numBefore];
+// uint32 numAfter; blocks[numAfter][4]; float converged; uint32 activePixels.
+static int adaptiveKat(const char* outPath)
+{
+    const uint32 width = 72, height = 52, rounds = 8;
+    Viewport viewport;
+    RenderingParams params;
+    params.numThreads = 1;
+    params.adaptiveSettings.enable = true; params.adaptiveSettings.numInitialPasses = 4; params.adaptiveSettings.minBlockSize = 5;
+    params.adaptiveSettings.maxBlockSize = 32; params.adaptiveSettings.subdivisionTreshold = 0.03f; params.adaptiveSettings.convergenceTreshold = 0.0015f;
+    if (!viewport.SetRenderingParams(params) || !viewport.Resize(width, height)) return 2;
+    viewport.Reset();     // -> BuildInitialBlocksList
+    FILE* f = fopen(outPath, "wb");
+    if (!f) return 2;
+    const uint32 header[8] = { 0x314B4152u, width, height, rounds, params.adaptiveSettings.numInitialPasses, params.adaptiveSettings.minBlockSize, params.adaptiveSettings.maxBlockSize, 0u };
+    fwrite(header, 4, 8, f);
+    fwrite(&params.adaptiveSettings.subdivisionTreshold, 4, 1, f); fwrite(&params.adaptiveSettings.convergenceTreshold, 4, 1, f);
+    auto writeBlocks = [&]() {
+        const uint32 n = viewport.mBlocks.Size(); fwrite(&n, 4, 1, f);
+        for (uint32 i = 0; i < n; ++i) { const uint32 b[4] = { viewport.mBlocks[i].minX, viewport.mBlocks[i].maxX, viewport.mBlocks[i].minY, viewport.mBlocks[i].maxY }; fwrite(b, 4, 4, f); }
+    };
+    writeBlocks();
+    uint64_t state = 0x9E3779B97F4A7C15ULL;
+    auto uniform = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return (float)((state >> 40) & 0xFFFFFFu) * (1.0f / 16777216.0f); };
+    for (uint32 round = 1; round <= rounds; ++round)
+    {
+        const uint32 passes = 2u * round;
+        viewport.mProgress.passesFinished = passes;
+        for (uint32 y = 0; y < height; ++y)
+            for (uint32 x = 0; x < width; ++x)
+            {
+                // a smooth image; noise that is strong in the lower right corner, weak in the upper left one and fades with the rounds
+                const float base[3] = { 0.2f + 0.6f * (float)x / (float)width, 0.5f, 0.9f - 0.7f * (float)y / (float)height };
+                const float noisy = (float)(x * y) / (float)(width * height);
+                const float amplitude = (0.004f + 2.5f * noisy * noisy) / (float)round;
+                Float3& s = viewport.mSum.GetPixelRef<Float3>(x, y); Float3& t = viewport.mSecondarySum.GetPixelRef<Float3>(x, y);
+                float sv[3], tv[3];
+                for (int k = 0; k < 3; ++k) { sv[k] = (float)passes * base[k]; tv[k] = 0.5f * sv[k] * (1.0f + amplitude * (uniform() - 0.5f)); }
+                s = Float3(sv[0], sv[1], sv[2]); t = Float3(tv[0], tv[1], tv[2]);
+            }
+        const uint32 numBefore = viewport.mBlocks.Size();
+        fwrite(&passes, 4, 1, f); fwrite(&numBefore, 4, 1, f);
+        for (int which = 0; which < 2; ++which)
+        {
+            const Bitmap& b = which == 0 ? viewport.mSum : viewport.mSecondarySum;
+            for (uint32 y = 0; y < height; ++y) fwrite(reinterpret_cast<const uint8_t*>(b.GetData()) + (size_t)y * b.GetStride(), 4, (size_t)width * 3, f);
+        }
+        for (uint32 i = 0; i < numBefore; ++i) { const float e = viewport.ComputeBlockError(viewport.mBlocks[i]); fwrite(&e, 4, 1, f); }
+        viewport.UpdateBlocksList();
+        writeBlocks();
+        fwrite(&viewport.mProgress.converged, 4, 1, f); fwrite(&viewport.mProgress.activePixels, 4, 1, f);
+        fprintf(stderr, "adaptive kat round %u: %u -> %u blocks, converged %.3f\n", round, numBefore, viewport.mBlocks.Size(), viewport.mProgress.converged);
+    }
+    fclose(f);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && strcmp(argv[1], "--adaptive-kat") == 0) return adaptiveKat(argv[2]);
     if (argc < 3) { fprintf(stderr, "usage: ref_render <scene.bin> <out.bin> [threads] [passes]\n"); return 2; }
     Reader r;
     {

@@ -46,6 +46,8 @@ public:
     // asked for, at an even pass count (otherwise the value of the last evaluation is returned)
     const RenderingProgress& GetProgress();
     const std::vector<RtBlock>& GetBlocks() const { return mBlocks; }
+    // known-answer hook: the list walk of UpdateBlocksList with the pass counter and the block errors supplied by the caller
+    void UpdateBlocksListWithErrors(uint32 passesFinished, std::vector<float> errors);
     uint32 GetPassesFinished() const { return mProgress.passesFinished; }
     // counters of the LAST pass (synchronises), like the reference
     const RayTracingCounters& GetCounters();
@@ -69,6 +71,7 @@ private:
     RenderingProgress mProgress;
     void BuildInitialBlocksList();
     bool UpdateBlocksList();
+    void ApplyBlockErrors(std::vector<float>& errors);
     std::vector<RtBlock> mBlocks;
     uint32 mErrorEvaluatedAtPass = 0;
     Bitmap mSum, mSecondarySum, mFrontBuffer;

@@ -627,8 +627,19 @@ bool Viewport::UpdateBlocksList()   // Viewport.cpp:648-733
     if (mProgress.passesFinished < settings.numInitialPasses) return true;
     std::vector<float> errors;
     if (!mRenderer->ComputeBlockErrors(mProgress.passesFinished, mBlocks, errors)) return false;
-    // Same walk as the reference: swap-and-pop removal, so a block swapped into slot i is not looked at in this update.
-    // Every block that IS visited still sits at its original index, which is why the errors can be computed up front.
+    ApplyBlockErrors(errors);
+    if (mBlocks.empty()) return true;   // everything converged: Render() stops submitting passes (the reference renders zero tiles)
+    return mRenderer->SetActiveBlocks(mBlocks);
+}
+
+// The list walk of Viewport::UpdateBlocksList given every block's ComputeBlockError (tests/golden/adaptive_kat.bin holds the reference's
+// lists before and after, with the errors it computed).  Same walk as the reference: swap-and-pop removal, so a block swapped into slot i
+// is not looked at in this update.  Every block that IS visited still sits at its original index, which is why the errors can be
+// computed up front.
+void Viewport::ApplyBlockErrors(std::vector<float>& errors)
+{
+    const AdaptiveRenderingSettings& settings = mParams.adaptiveSettings;
+    if (mProgress.passesFinished < settings.numInitialPasses) return;
     std::vector<RtBlock> newBlocks;
     for (uint32 i = 0; i < mBlocks.size(); ++i)
     {
@@ -657,8 +668,13 @@ bool Viewport::UpdateBlocksList()   // Viewport.cpp:648-733
     for (const RtBlock& block : mBlocks) mProgress.activePixels += (block.maxX - block.minX) * (block.maxY - block.minY);
     mProgress.converged = 1.0f - (float)mProgress.activePixels / (float)(mWidth * mHeight);
     mProgress.activeBlocks = (uint32)mBlocks.size();
-    if (mBlocks.empty()) return true;   // everything converged: Render() stops submitting passes (the reference renders zero tiles)
-    return mRenderer->SetActiveBlocks(mBlocks);
+}
+
+// test hook (rth_viewport_kat_update_blocks): the pass counter and the errors come from a known-answer file instead of a renderer
+void Viewport::UpdateBlocksListWithErrors(uint32 passesFinished, std::vector<float> errors)
+{
+    mProgress.passesFinished = passesFinished;
+    ApplyBlockErrors(errors);
 }
 
 const Bitmap& Viewport::GetSumBuffer()

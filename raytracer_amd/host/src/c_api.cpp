@@ -473,6 +473,15 @@ RTH_API int rth_viewport_progress(void* v, float* averageError, float* converged
     return (int)b.size();
 }
 
+// Viewport::UpdateBlocksList's list walk on caller-supplied block errors (tests/golden/adaptive_kat.bin: the reference's own lists)
+RTH_API int rth_viewport_kat_update_blocks(void* v, uint32_t passesFinished, const float* errors, uint32_t numErrors)
+{
+    Viewport& vp = static_cast<ViewportHandle*>(v)->viewport;
+    if (numErrors != vp.GetBlocks().size()) return -1;
+    vp.UpdateBlocksListWithErrors(passesFinished, std::vector<float>(errors, errors + numErrors));
+    return (int)vp.GetBlocks().size();
+}
+
 // ---- known-answer-test entry points for the host-side algorithms -----------------------------------
 // boxes: n * 6 floats (min xyz, max xyz).  outNodes: capacity 2n nodes of 8 uint32.  outOrder: n.
 RTH_API int rth_kat_bvh_build(const float* boxes, uint32_t n, uint32_t* outNodes, uint32_t* outNumNodes, uint32_t* outOrder)
