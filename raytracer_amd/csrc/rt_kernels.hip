@@ -655,6 +655,7 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
 #define RT_COUNTER_RETRACED 12   // counters[]: rays k_trace_quant handed to the binary-tree kernel (RtCounters::numRetracedRays)
 #include "rt_trace_quant.inl"
 #include "rt_trace_wide.inl"
+#include "rt_trace_wide2.inl"
 
 RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
 RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
@@ -1307,6 +1308,8 @@ struct RtgpuContext
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
     QuantBvh quant;                    // 32-byte child pairs of a single-mesh scene (rt_trace_quant.inl); pairs == nullptr: none
     WideBvh wide;                      // 4-wide collapse of the same tree (rt_trace_wide.inl); nodes == nullptr: none
+    WideScene wide2;                   // two-level scenes: 4-wide top-level tree over 4-wide mesh trees (rt_trace_wide2.inl); nodes == nullptr: none
+    bool wide2Allowed = true;          // RTGPU_WIDE2=0: two-level scenes keep the binary walk
     bool wideAllowed = true;           // RTGPU_WIDE=0: single-mesh scenes walk the binary tree (k_trace) even with the intersection counters off
     bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
     bool denseAllowed = true;          // RTGPU_NO_DENSE=1: path state stays in the pixel's slot for the whole path (the first layout)
@@ -1576,6 +1579,7 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     memset(&c->wide, 0, sizeof(c->wide));
     if (const char* e = getenv("RTGPU_LDS_TOP")) c->ldsTopAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_NO_DENSE")) c->denseAllowed = atoi(e) == 0;
+    if (const char* e = getenv("RTGPU_WIDE2")) c->wide2Allowed = atoi(e) != 0;
     memset(&c->quant, 0, sizeof(c->quant));
     if (const char* e = getenv("RTGPU_PASS_BATCH")) { c->passBatch = (uint32_t)atoi(e); c->passBatchFromEnv = true; }
     if (c->passBatch < 1) c->passBatch = 1;
@@ -1862,7 +1866,57 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     // single-mesh scenes (Scene::Traverse's one-object bypass): the re-encoded tree of the default traversal kernel
     memset(&c->quant, 0, sizeof(c->quant));
     memset(&c->wide, 0, sizeof(c->wide));
-    if (s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH)
+    memset(&c->wide2, 0, sizeof(c->wide2));
+    const bool singleMesh = s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH;
+    bool anyMesh = false;
+    for (uint32_t o = 0; o < s->numObjects; ++o) anyMesh = anyMesh || (s->objects[o].objectKind == RT_OBJECT_SHAPE && s->objects[o].shapeKind == RT_SHAPE_MESH);
+    // (a handful of analytic objects -- sphere + area light: a top-level tree of one or three nodes -- gain nothing from wider nodes and pay
+    //  for the re-trace launch: measured 3-5 % slower, the binary kernel keeps them)
+    if (!singleMesh && s->numObjects > 1u && (anyMesh || s->numTopNodes >= 7u))
+    {
+        // every other scene: the two-level 4-wide walk (rt_trace_wide2.inl).  One node / gate array for all levels; levels[o] for mesh object o,
+        // levels[numObjects] for the top-level tree.  A level that cannot be built (a malformed tree) leaves the scene to the binary walk.
+        std::vector<float4> allNodes, allGates;
+        std::vector<WideLevel> levels(s->numObjects + 1u);
+        memset(levels.data(), 0, levels.size() * sizeof(WideLevel));
+        bool ok = true;
+        auto append = [&](const WideLevelBuild& b, WideLevel& level, uint32_t triBase)
+        {
+            level.nodeBase = (uint32_t)(allNodes.size() / 4u); level.gateBase = (uint32_t)allGates.size(); level.triBase = triBase; level.valid = 1u;
+            memcpy(level.base, b.base, sizeof(b.base)); memcpy(level.step, b.step, sizeof(b.step)); memcpy(level.bound, b.bound, sizeof(b.bound));
+            allNodes.insert(allNodes.end(), b.nodes.begin(), b.nodes.end()); allGates.insert(allGates.end(), b.gate.begin(), b.gate.end());
+        };
+        if (s->numObjects > 1u)
+        {
+            const WideLevelBuild top = buildWideLevel(s->topNodes, s->numTopNodes, s->numObjects, topDepth);
+            if (top.ok) append(top, levels[s->numObjects], 0u); else ok = false;
+        }
+        std::unordered_map<uint32_t, uint32_t> builtMesh;   // mesh index -> the first object whose level holds its tree (instances share it)
+        for (uint32_t o = 0; o < s->numObjects && ok; ++o)
+        {
+            const RtObject& obj = s->objects[o];
+            if (obj.objectKind != RT_OBJECT_SHAPE || obj.shapeKind != RT_SHAPE_MESH) continue;
+            const RtMesh& mesh = s->meshes[obj.meshIndex];
+            if (mesh.numNodes == 0u) continue;   // nothing to hit (Traverse_Object returns at once)
+            const auto found = builtMesh.find(obj.meshIndex);
+            if (found != builtMesh.end()) { levels[o] = levels[found->second]; continue; }
+            const WideLevelBuild b = buildWideLevel(s->meshNodes + mesh.firstNode, mesh.numNodes, mesh.numTriangles, bvhDepth(s->meshNodes + mesh.firstNode, mesh.numNodes));
+            if (!b.ok) { ok = false; break; }
+            append(b, levels[o], mesh.firstTriangle);
+            builtMesh[obj.meshIndex] = o;
+        }
+        if (ok && (allNodes.size() / 4u) < RT_NODE_CHILD_MASK && allGates.size() < 0xFFFFFFFFull)
+        {
+            if (allNodes.empty()) allNodes.assign(4u, make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, (uint32_t)RT_WIDE_EMPTY)));   // a one-object scene of an analytic shape
+            if (allGates.empty()) allGates.assign(2u, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+            const float4* devNodes = nullptr; const float4* devGates = nullptr; const WideLevel* devLevels = nullptr;
+            if ((r = uploadArray(c, allNodes.data(), allNodes.size(), &devNodes))) return r;
+            if ((r = uploadArray(c, allGates.data(), allGates.size(), &devGates))) return r;
+            if ((r = uploadArray(c, levels.data(), levels.size(), &devLevels))) return r;
+            c->wide2.nodes = devNodes; c->wide2.gate = devGates; c->wide2.levels = devLevels; c->wide2.numObjects = s->numObjects; c->wide2.bypass = s->numObjects == 1u ? 1u : 0u;
+        }
+    }
+    if (singleMesh)
     {
         const RtMesh& mesh = s->meshes[s->objects[0].meshIndex];
         const QuantBuild q = buildQuantBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, mesh.numTriangles, maxMeshDepth);
@@ -2129,7 +2183,7 @@ static void launchTraceQuant(RtgpuContext* c, hipStream_t stream, const Paths& p
 
 // The 4-wide tree: single-mesh scenes, intersection counters off (they belong to the reference's walk).  Stack: 24 entries per lane, a
 // ray that would need more goes to the binary-tree kernel.
-static bool useWide(const RtgpuContext* c) { return c->wide.nodes != nullptr && c->wideAllowed && !c->countIntersections; }
+static bool useWide(const RtgpuContext* c) { return (c->wide.nodes != nullptr || (c->wide2.nodes != nullptr && c->wide2Allowed)) && c->wideAllowed && !c->countIntersections; }
 
 static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset,
@@ -2140,6 +2194,13 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
                         chunkMin < 64u ? 64u : chunkMin };
     const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
+    if (c->wide.nodes == nullptr)
+    {
+        // a two-level scene (rt_trace_wide2.inl): four waves per SIMD (its registers), 30 KB of LDS per block
+        const dim3 grid2(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 4u));
+        hipLaunchKernelGGL((k_trace_wide2<24>), grid2, block, 0, stream, c->sceneDev, c->wide2, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+        return;
+    }
     static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)
     static const bool unsorted = getenv("RTGPU_WIDE_UNSORTED") != nullptr; // experiments: deferred children in slot order / no leaf set aside
     static const bool eager = getenv("RTGPU_WIDE_POSTPONE_LEAVES") == nullptr;

@@ -835,20 +835,43 @@ def test_adaptive_rendering_with_the_default_walk(built):
     assert ca["numRays"] == cb["numRays"] and ca["numRetracedRays"] > 0 and cb["numRetracedRays"] == 0
 
 
-def test_two_level_scenes_with_the_counters_off(built):
-    """The library's default (intersection counters off) on scenes the 4-wide walk does not serve -- a mesh among analytic shapes and an
-    area light, the Cornell box: k_trace without the counting code, where a wave's idle lanes take over subtrees of its longest any-hit
-    rays at the end of a launch (two-level scenes: inside the donor's mesh, with the local ray rebuilt from the request).  Images and ray
-    counters are the oracle's."""
+def test_two_level_scenes_with_the_counters_off(built, monkeypatch):
+    """The library's default (intersection counters off) on two-level scenes -- a mesh among analytic shapes and an area light, the Cornell
+    box, an instanced mesh beside a sphere: k_trace_wide2 (a 4-wide top-level tree over 4-wide mesh trees, rt_trace_wide2.inl), which hands
+    the rays it does not decide to the binary-tree kernel; and with RTGPU_WIDE2=0 the binary walk without the counting code, where a wave's
+    idle lanes take over subtrees of its longest any-hit rays at the end of a launch.  Images and ray counters are the oracle's either way."""
     w, h = 192, 108
-    scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
-    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=6)
-    assert_quant_identical(*out)
-    assert out[2]["numRetracedRays"] == 0 and out[2]["numAnalyticHits"] > 0 and out[2]["numMeshHits"] > 0
-    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=6, light_sampling_all=True)
-    assert_quant_identical(*out)
-    scene, camera = scenes.cornell_box(w / h)
-    assert_quant_identical(*run_quant(scene, camera, w, h, passes=3, max_ray_depth=6))
+    for wide2 in ("1", "0"):
+        monkeypatch.setenv("RTGPU_WIDE2", wide2)
+        scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
+        out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=6)
+        assert_quant_identical(*out)
+        traced = out[2]["numRays"] + out[2]["numShadowRays"]
+        assert (0 < out[2]["numRetracedRays"] < 0.02 * traced) if wide2 == "1" else out[2]["numRetracedRays"] == 0, (out[2]["numRetracedRays"], traced)
+        assert out[2]["numAnalyticHits"] > 0 and out[2]["numMeshHits"] > 0
+        out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=6, light_sampling_all=True)
+        assert_quant_identical(*out)
+        scene, camera = scenes.cornell_box(w / h)
+        assert_quant_identical(*run_quant(scene, camera, w, h, passes=3, max_ray_depth=6))
+        assert_quant_identical(*run_quant(scene, camera, w, h, passes=2, max_ray_depth=4, min_russian_roulette_depth=9))
+        # two instances of one mesh (they share a tree), a sphere and a two-triangle quad mesh whose tree is a single leaf
+        pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(4000, seed=3)
+        s = ra.Scene()
+        mats = [s.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+        metal = s.add_material("roughMetal", (0.9, 0.8, 0.6), roughness=0.2)
+        s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+        s.add_mesh(pos * np.float32(0.2), idx, nrm, tan, uv, mat, mats, transform=ra.transform_from_euler((0.0, 1.0, 0.0), (0.0, 30.0, 0.0)))
+        s.add_sphere(0.8, ra.transform_from_euler((-6.0, 1.5, 0.5), (0.0, 0.0, 0.0)), metal)
+        quad_pos = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+        quad_nrm = np.tile(np.array([[0, 1, 0]], np.float32), (4, 1)); quad_tan = np.tile(np.array([[1, 0, 0]], np.float32), (4, 1))
+        s.add_mesh(quad_pos, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), quad_nrm, quad_tan, np.zeros((4, 2), np.float32), np.zeros(2, np.uint32), [metal],
+                   transform=ra.transform_from_euler((-8.0, 0.6, 0.5), (0.0, 0.0, 0.0)))
+        s.add_background_light((1.0, 1.5, 2.0))
+        s.add_area_light("rect", [1.0, 1.0], (30.0, 28.0, 25.0), ra.transform_from_euler((-7.0, 6.0, 0.5), (90.0, 0.0, 0.0)))
+        s.build()
+        cam = ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), w / h, 65.0)
+        assert_quant_identical(*run_quant(s, cam, w, h, passes=2, max_ray_depth=6))
+        assert_quant_identical(*run_quant(s, cam, w, h, passes=2, max_ray_depth=5, light_sampling_all=True, dimensions=128))
 
 
 def test_wide_and_exact_traversal_agree_at_full_size(built, monkeypatch):
