@@ -35,11 +35,11 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc s
         sampler.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
         V4 origin, direction;
         cameraGenerateRayParts(pass.camera, coords, sampler, origin, direction);
-        prec(paths, R_ORIGIN, slot) = f4(origin.x, origin.y, origin.z, fbits(0x100u));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
-        prec(paths, R_DIR, slot) = f4(direction.x, direction.y, direction.z, 1.0f);        // lastPdfW = 1
-        prec(paths, R_TP, slot) = f4(1.0f, 1.0f, 1.0f, 1.0f);
-        prec(paths, R_RESULT, slot) = f4(0.0f, 0.0f, 0.0f, fbits(pix));
-        prec(paths, R_SH_TP, slot) = f4(0.0f, 0.0f, 0.0f, fbits(slot));                    // .w: the path's home
+        stStream(prec(paths, R_ORIGIN, slot), f4(origin.x, origin.y, origin.z, fbits(0x100u)));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
+        stStream(prec(paths, R_DIR, slot), f4(direction.x, direction.y, direction.z, 1.0f));        // lastPdfW = 1
+        stStream(prec(paths, R_TP, slot), f4(1.0f, 1.0f, 1.0f, 1.0f));
+        stStream(prec(paths, R_RESULT, slot), f4(0.0f, 0.0f, 0.0f, fbits(pix)));
+        stStream(prec(paths, R_SH_TP, slot), f4(0.0f, 0.0f, 0.0f, fbits(slot)));                    // .w: the path's home
         storeSampler(sampler, paths, slot, 0.0f, 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x < RT_DENSE_SHARDS)
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc s
 RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t slot, bool zombie)
 {
     if (zombie) return 0u;
-    const float4 rHit = prec(in, R_HIT, slot);
+    const float4 rHit = ldStream(prec(in, R_HIT, slot));
     const uint32_t objectId = ubits(rHit.x);
     if (objectId == RT_INVALID_OBJECT) return 1u;
     const RtObject& obj = scene.objects[objectId];
@@ -154,14 +154,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
             bool zombie;
             const uint32_t slot = vertexSlot(i, zombie);
             inSlot = slot;
-            const float4 rResult = prec(in, R_RESULT, slot), rSampler = prec(in, R_SAMPLER, slot), rShTp = prec(in, R_SH_TP, slot);
+            const float4 rResult = ldStream(prec(in, R_RESULT, slot)), rSampler = ldStream(prec(in, R_SAMPLER, slot)), rShTp = ldStream(prec(in, R_SH_TP, slot));
             const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
             oHome = homeIndex;
             V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
             resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
             if (!zombie)
             {
-                const float4 rOrigin = prec(in, R_ORIGIN, slot), rDir = prec(in, R_DIR, slot), rTp = prec(in, R_TP, slot), rHit = prec(in, R_HIT, slot);
+                const float4 rOrigin = ldStream(prec(in, R_ORIGIN, slot)), rDir = ldStream(prec(in, R_DIR, slot)), rTp = ldStream(prec(in, R_TP, slot)), rHit = ldStream(prec(in, R_HIT, slot));
                 const uint32_t flags = ubits(rOrigin.w);
                 const uint32_t depth = flags & 0xFFu;
                 const bool lastSpecular = (flags & 0x100u) != 0;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
                 if (outcome != 1) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
             }
             oResult = f4(resultColor.x, resultColor.y, resultColor.z, fbits(pix));
-            if (outcome == 0) home[homeIndex] = f4(resultColor.x, resultColor.y, resultColor.z, 0.0f);
+            if (outcome == 0) stStream(home[homeIndex], f4(resultColor.x, resultColor.y, resultColor.z, 0.0f));
         }
 
         // dense slots of the other arena: ranks from LDS counters, the block's two ranges with one global atomic each.  The region follows
@@ -322,25 +322,25 @@ __global__ void __launch_bounds__(RT_BLOCK) k_shade_dense(const RtSceneDesc scen
         if (outcome != 0)
         {
             const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);
-            prec(out, R_RESULT, slot) = oResult;
-            prec(out, R_SAMPLER, slot) = oSampler;
-            prec(out, R_SH_TP, slot) = stagedShTp ? sStage[3][threadIdx.x] : f4(0.0f, 0.0f, 0.0f, fbits(oHome));
-            if (outcome == 1) { prec(out, R_ORIGIN, slot) = oOrigin; prec(out, R_DIR, slot) = oDir; prec(out, R_TP, slot) = oTp; prec(out, R_RNG, slot) = oRng; }
+            stStream(prec(out, R_RESULT, slot), oResult);
+            stStream(prec(out, R_SAMPLER, slot), oSampler);
+            stStream(prec(out, R_SH_TP, slot), stagedShTp ? sStage[3][threadIdx.x] : f4(0.0f, 0.0f, 0.0f, fbits(oHome)));
+            if (outcome == 1) { stStream(prec(out, R_ORIGIN, slot), oOrigin); stStream(prec(out, R_DIR, slot), oDir); stStream(prec(out, R_TP, slot), oTp); stStream(prec(out, R_RNG, slot), oRng); }
             if (ubits(oSampler.w) != 0u)
             {
-                prec(out, R_SH_P, slot) = sStage[2][threadIdx.x];
+                stStream(prec(out, R_SH_P, slot), sStage[2][threadIdx.x]);
                 if (kAll)
                 {
                     for (uint32_t l = 0; l < scene.numLights; ++l)
                     {
-                        pshadow(out, l, 0, slot) = pshadow(in, l, 0, inSlot); pshadow(out, l, 1, slot) = pshadow(in, l, 1, inSlot);
+                        stStream(pshadow(out, l, 0, slot), pshadow(in, l, 0, inSlot)); stStream(pshadow(out, l, 1, slot), pshadow(in, l, 1, inSlot));
                         if (rayMask & (1u << l)) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * out.capacity + slot;
                     }
                 }
                 else
                 {
-                pshadow(out, 0, 0, slot) = sStage[0][threadIdx.x];
-                pshadow(out, 0, 1, slot) = sStage[1][threadIdx.x];
+                stStream(pshadow(out, 0, 0, slot), sStage[0][threadIdx.x]);
+                stStream(pshadow(out, 0, 1, slot), sStage[1][threadIdx.x]);
                 if (rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
                 }
             }
@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate_home(const float4* __re
         float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
         for (uint32_t b = 0; b < numPasses; ++b)
         {
-            const float4 c = home[(size_t)b * slotsPerPass + pixelSlot];
+            const float4 c = ldStream(home[(size_t)b * slotsPerPass + pixelSlot]);
             sr = sr + c.x; sg = sg + c.y; sb = sb + c.z;
             if ((passes[b].passIndex % 2u) == 0u) { tr = tr + c.x; tg = tg + c.y; tb = tb + c.z; }
         }

@@ -71,6 +71,30 @@ RT_DEV float4& pshadow(const Paths& p, uint32_t light, uint32_t k, uint32_t slot
     return p.base[((size_t)R_NUM_BASE + (size_t)light * RT_SHADOW_RECORDS + k) * p.capacity + slot];
 }
 RT_DEV float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+// Path records are STREAMED: a bounce reads a record once and writes its successor once, gigabytes per launch, through the same 4 MB-per-XCD
+// L2 that holds the scene's nodes, triangles and shading records.  Non-temporal accesses keep the stream from evicting the geometry.
+#ifndef RT_STREAMING_HINTS
+#define RT_STREAMING_HINTS 1
+#endif
+typedef float rt_float4v __attribute__((ext_vector_type(4)));
+RT_DEV float4 ldStream(const float4& r)
+{
+#if RT_STREAMING_HINTS
+    const rt_float4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_float4v*>(&r));
+    return f4(v.x, v.y, v.z, v.w);
+#else
+    return r;
+#endif
+}
+RT_DEV void stStream(float4& r, const float4& v)
+{
+#if RT_STREAMING_HINTS
+    const rt_float4v t = { v.x, v.y, v.z, v.w };
+    __builtin_nontemporal_store(t, reinterpret_cast<rt_float4v*>(&r));
+#else
+    r = v;
+#endif
+}
 RT_DEV float fbits(uint32_t u) { return __uint_as_float(u); }
 RT_DEV uint32_t ubits(float f) { return __float_as_uint(f); }
 

@@ -129,14 +129,14 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                 if (shadow)
                 {
                     light = request / paths.capacity; slot = request - light * paths.capacity;
-                    origin = prec(paths, R_SH_P, slot); dir = pshadow(paths, light, 0, slot);
+                    origin = ldStream(prec(paths, R_SH_P, slot)); dir = ldStream(pshadow(paths, light, 0, slot));
                     maxDistance = dir.w;           // hitPoint.distance = illuminateResult.distance * 0.999f
                     offset = tune.shadowOffset;
                 }
                 else
                 {
                     slot = request; light = 0u;
-                    origin = prec(paths, R_ORIGIN, slot); dir = prec(paths, R_DIR, slot);
+                    origin = ldStream(prec(paths, R_ORIGIN, slot)); dir = ldStream(prec(paths, R_DIR, slot));
                     offset = 0.001f;
                 }
                 Ray world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));

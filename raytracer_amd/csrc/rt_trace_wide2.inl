@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     auto loadWorldRay = [&]() -> Ray
     {
         float4 origin, dir; float offset;
-        if (shadow) { origin = prec(paths, R_SH_P, slot); dir = pshadow(paths, light, 0, slot); offset = tune.shadowOffset; }
-        else { origin = prec(paths, R_ORIGIN, slot); dir = prec(paths, R_DIR, slot); offset = 0.001f; }
+        if (shadow) { origin = ldStream(prec(paths, R_SH_P, slot)); dir = ldStream(pshadow(paths, light, 0, slot)); offset = tune.shadowOffset; }
+        else { origin = ldStream(prec(paths, R_ORIGIN, slot)); dir = ldStream(prec(paths, R_DIR, slot)); offset = 0.001f; }
         Ray world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));
         if (shadow || (ubits(origin.w) & 0xFFu) != 0u) world.origin = world.origin + world.dir * offset;
         return world;
