@@ -2226,25 +2226,8 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
         return;
     }
     static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)
-    static const bool unsorted = getenv("RTGPU_WIDE_UNSORTED") != nullptr; // experiments: deferred children in slot order / no leaf set aside
-    static const bool eager = getenv("RTGPU_WIDE_POSTPONE_LEAVES") == nullptr;
-    static const bool smallBlocks = getenv("RTGPU_WIDE_BLOCK64") != nullptr;   // experiment: one wave per block (a finished wave frees its LDS at once)
-    if (smallBlocks && !diag && !unsorted && eager)
-    {
-        const dim3 grid64(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u) * 4u), block64(64);
-        hipLaunchKernelGGL((k_trace_wide<24, false, true, false, 64>), grid64, block64, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
-        return;
-    }
-    static const bool share = getenv("RTGPU_WIDE_SHARE") != nullptr;   // experiment: idle lanes take subtrees of busy any-hit rays in the drain phase
-    if (share && !diag && !unsorted && eager)
-    {
-        hipLaunchKernelGGL((k_trace_wide<24, false, true, false, RT_BLOCK, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
-        return;
-    }
-#define RT_LAUNCH_WIDE(D, S, P) hipLaunchKernelGGL((k_trace_wide<24, D, S, P>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
-    if (diag) { if (unsorted) { if (eager) RT_LAUNCH_WIDE(true, false, false); else RT_LAUNCH_WIDE(true, false, true); } else { if (eager) RT_LAUNCH_WIDE(true, true, false); else RT_LAUNCH_WIDE(true, true, true); } }
-    else { if (unsorted) { if (eager) RT_LAUNCH_WIDE(false, false, false); else RT_LAUNCH_WIDE(false, false, true); } else { if (eager) RT_LAUNCH_WIDE(false, true, false); else RT_LAUNCH_WIDE(false, true, true); } }
-#undef RT_LAUNCH_WIDE
+    if (diag) hipLaunchKernelGGL((k_trace_wide<24, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+    else hipLaunchKernelGGL((k_trace_wide<24, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
 }
 
 // Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.

@@ -9,8 +9,9 @@
 // the per-step overhead (stack, loop, scheduling ballots) is paid half as often.
 // What came of it (profiles/r02_wide_*): the kernel is no longer latency-bound but ISSUE-bound -- vector ALU busy 90 % at 57 % lane
 // utilisation -- so what counts is instructions per visit (137 after the permute / pair-sort step below, 161 before): 164.5 -> 147 ms
-// per 69 passes of the benchmark against k_trace.  Variants that add live state (a leaf set aside, shared any-hit rays, fat leaves,
-// one gate per ray) spill on the 96-VGPR cliff and lose; they are kept behind template flags with their measurements.
+// per 69 passes of the benchmark against k_trace.  Variants that add live state (a leaf set aside, shared any-hit rays in the drain phase,
+// fat leaves, one gate per ray, deferred children in slot order, one-wave blocks) spilled on the 96-VGPR cliff or lost otherwise; their
+// measurements are in profiles/r02_wide_diag.txt and DESIGN 4, their code is in the history (round 2), not here.
 //
 // Node n = records nodes[4 n .. 4 n + 3], one per child: {min.xyz, max.xyz as 16-bit grid coordinates (rounded outwards, QuantBvh's
 // grid), reference}.  A reference is an interior node's index, a leaf (first triangle | count << 30, the binary tree's own leaves of
@@ -63,15 +64,15 @@ struct WideTuning
     }
 #define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
 
-template <int kStack, bool kDiag = false, bool kSort = true, bool kPostpone = false, int kBlock = RT_BLOCK, bool kShare = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
+template <int kStack, bool kDiag = false>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                          uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
 {
-    __shared__ uint32_t sStack[kStack * kBlock];
+    __shared__ uint32_t sStack[kStack * RT_BLOCK];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * kBlock]: bank = lane, conflict free at any depth
+    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
     const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
     const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
@@ -84,12 +85,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;     // folded slab constants: t(q) = fma(q, a, b)
     float best = 0, second = 0, tol = 0;
     uint32_t selX = RT_WIDE_SEL_X_POS, selY = RT_WIDE_SEL_Y_POS, selZ = RT_WIDE_SEL_Z_POS;   // which plane of an axis the ray meets first
-    uint32_t cur = RT_QUANT_DONE, pend = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;   // pend: a leaf set aside while the lane keeps walking interior nodes
+    uint32_t cur = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;
     bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
-    uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0, drainIterations = 0;
+    uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
 
-    uint32_t chunkSize = count / (gridDim.x * ((uint32_t)kBlock / 64u) * 4u);
+    uint32_t chunkSize = count / (gridDim.x * ((uint32_t)RT_BLOCK / 64u) * 4u);
     chunkSize = chunkSize < tune.chunkMin ? tune.chunkMin : (chunkSize > 1024u ? 1024u : chunkSize);
     WaveChunk chunk = { 0u, 0u };
 
@@ -166,62 +167,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                     selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
                     tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
                     best = maxDistance; second = inf; occluded = false; overflow = false;
-                    sp = 0u; cur = 0u; pend = RT_QUANT_DONE;   // node 0 holds the children of the binary tree's root
+                    sp = 0u; cur = 0u;   // node 0 holds the children of the binary tree's root
                     have = true;
                     if (shadow) numShadowRays++;   // (a request handed to the binary-tree kernel is counted there)
                 }
             }
             continue;
-        }
-        // kShare (an experiment that did not pay: 147 -> 159 ms, the extra live state spills seven registers and the drain phase stays at
-        // 17 % of the wave time -- its length is the lifetime of the rays started last, not a few long ones).  Drain phase: the queue is
-        // empty and the wave lasts as long as its longest ray; occlusion is an OR over subtrees, so a lane with nothing to do takes the
-        // OLDEST deferred node of a busy any-hit ray of its wave and searches it as a ray of its own for the same request.
-        if (kShare && exhausted && nIdle != 0u && nIdle != 64u && ++drainIterations > RT_SPLIT_AFTER)
-        {
-            const bool canDonate = have && shadow && sp != 0u && cur != RT_QUANT_DONE;
-            const unsigned long long mDonors = __ballot(canDonate);
-            if (mDonors != 0ull)
-            {
-                const unsigned long long mIdle = __ballot(!have);
-                const uint32_t lane = threadIdx.x & 63u;
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const uint32_t nDonors = (uint32_t)__popcll(mDonors), nTakers = (uint32_t)__popcll(mIdle);
-                const uint32_t pairs = nDonors < nTakers ? nDonors : nTakers;
-                const bool donate = canDonate && (uint32_t)__popcll(mDonors & below) < pairs;
-                const uint32_t takerRank = (uint32_t)__popcll(mIdle & below);
-                const bool take = !have && takerRank < pairs;
-                uint32_t src = lane;
-                if (take)
-                {
-                    unsigned long long m = mDonors;
-                    for (uint32_t k = 0; k < takerRank; ++k) m &= m - 1ull;
-                    src = (uint32_t)__ffsll((long long)m) - 1u;
-                }
-                uint32_t entry = 0u;
-                if (donate)
-                {
-                    entry = stack[0];                    // the oldest deferred node leaves the donor's stack, the newest takes its place
-                    --sp;
-                    stack[0] = stack[sp * kBlock];
-                }
-                // the donor's ray travels with the node (shuffles are evaluated by every lane; one value at a time: the kernel sits on a
-                // register cliff).  A taker is never a donor, so the sources do not change underneath.
-#define RT_WIDE_TAKE_F(x) { const float t_ = __shfl(x, (int)src); if (take) x = t_; }
-#define RT_WIDE_TAKE_U(x) { const uint32_t t_ = (uint32_t)__shfl((int)x, (int)src); if (take) x = t_; }
-                RT_WIDE_TAKE_F(ox) RT_WIDE_TAKE_F(oy) RT_WIDE_TAKE_F(oz) RT_WIDE_TAKE_F(dx) RT_WIDE_TAKE_F(dy) RT_WIDE_TAKE_F(dz)
-                RT_WIDE_TAKE_F(ax) RT_WIDE_TAKE_F(ay) RT_WIDE_TAKE_F(az) RT_WIDE_TAKE_F(bx) RT_WIDE_TAKE_F(by) RT_WIDE_TAKE_F(bz)
-                RT_WIDE_TAKE_F(best) RT_WIDE_TAKE_U(selX) RT_WIDE_TAKE_U(selY) RT_WIDE_TAKE_U(selZ) RT_WIDE_TAKE_U(slot) RT_WIDE_TAKE_U(light)
-#undef RT_WIDE_TAKE_F
-#undef RT_WIDE_TAKE_U
-                const uint32_t tentry = (uint32_t)__shfl((int)entry, (int)src);
-                if (take)
-                {
-                    second = inf; tol = 0.0f; occluded = false; overflow = false; shadow = true;
-                    sp = 0u; cur = tentry; pend = RT_QUANT_DONE; have = true;
-                }
-                continue;
-            }
         }
         if ((mI | mO) == 0ull) break;
         if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
@@ -239,8 +190,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     float n0, f0, n1, f1, n2, f2, n3, f3;
                     RT_WIDE_SLAB(q0, n0, f0); RT_WIDE_SLAB(q1, n1, f1); RT_WIDE_SLAB(q2, n2, f2); RT_WIDE_SLAB(q3, n3, f3);
-                    if (kSort)
-                    {
                         // (key, reference) pairs sorted so that the children the ray enters come first, farthest first, and the ones it misses
                         // last: key = 0x7FFFFFFF - bits(entry distance) (the distance is >= 0, so its bits order like the float), miss = all ones
                         const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
@@ -253,35 +202,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                         const uint32_t numHit = (h0 ? 1u : 0u) + (h1 ? 1u : 0u) + (h2 ? 1u : 0u) + (h3 ? 1u : 0u);
                         // the first numHit - 1 references are deferred, the last one (the nearest child) is walked next.  The three stores are
                         // unconditional (what lands above the new top is free space; the overflow check keeps three entries in reserve)
-                        uint32_t* const top = stack + sp * kBlock;
-                        top[0] = r0; top[kBlock] = r1; top[2 * kBlock] = r2;
+                        uint32_t* const top = stack + sp * RT_BLOCK;
+                        top[0] = r0; top[RT_BLOCK] = r1; top[2 * RT_BLOCK] = r2;
                         if (numHit != 0u) { cur = numHit == 1u ? r0 : (numHit == 2u ? r1 : (numHit == 3u ? r2 : r3)); sp += numHit - 1u; }
                         else if (sp == 0u) cur = RT_QUANT_DONE;
-                        else { --sp; cur = stack[sp * kBlock]; }
-                    }
-                    else
-                    {
-                    // the nearest child is walked next; the other children the ray enters are deferred (in slot order: any order gives the
-                    // same candidates, and a full sort costs more instructions than the occasional later cull saves)
-                    const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
-                    const uint32_t miss = 0xFFFFFFFFu;
-                    const uint32_t k0 = h0 ? ((ubits(n0) & ~3u) | 0u) : miss, k1 = h1 ? ((ubits(n1) & ~3u) | 1u) : miss;   // entry distance >= 0: its bits order like the float
-                    const uint32_t k2 = h2 ? ((ubits(n2) & ~3u) | 2u) : miss, k3 = h3 ? ((ubits(n3) & ~3u) | 3u) : miss;
-                    const uint32_t kMin = min(min(k0, k1), min(k2, k3));
-                    const uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
-                    if (h0 && k0 != kMin) { stack[sp * kBlock] = r0; ++sp; }
-                    if (h1 && k1 != kMin) { stack[sp * kBlock] = r1; ++sp; }
-                    if (h2 && k2 != kMin) { stack[sp * kBlock] = r2; ++sp; }
-                    if (h3 && k3 != kMin) { stack[sp * kBlock] = r3; ++sp; }
-                    if (kMin != miss) cur = (kMin & 2u) ? ((kMin & 1u) ? r3 : r2) : ((kMin & 1u) ? r1 : r0);
-                    else if (sp == 0u) cur = RT_QUANT_DONE;
-                    else { --sp; cur = stack[sp * kBlock]; }
-                    }
+                        else { --sp; cur = stack[sp * RT_BLOCK]; }
                     if (sp + 3u > (uint32_t)kStack) { overflow = true; cur = RT_QUANT_DONE; }   // the next step could not push: the binary-tree kernel takes the ray
-                    // kPostpone (an experiment that did not pay: interior-loop lane utilisation 0.52 -> 0.55, 4 % more visits from the later culling,
-                    // and a leaf phase twice as long: k_trace_wide 156 -> 171 ms): the first leaf a lane reaches is set aside and the lane goes on
-                    // with its next deferred node, so that it stays in this loop.  Any order gives the same candidates.
-                    if (kPostpone && RT_WIDE_IS_LEAF(cur) && pend == RT_QUANT_DONE && sp != 0u) { pend = cur; --sp; cur = stack[sp * kBlock]; }
                 }
                 in = in && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
                 const unsigned long long m = __ballot(in);
@@ -292,10 +218,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
         else if (other)
         {
             // ---- leaves (the current one and the one set aside): MeshShape::Traverse_Leaf(_Shadow), MeshShape.cpp:134-207 ----
-#pragma unroll 1
-            for (int which = 0; which < (kPostpone ? 2 : 1); ++which)
+            for (int once = 0; once < 1; ++once)
             {
-                const uint32_t leaf = which == 0 ? cur : pend;
+                const uint32_t leaf = cur;
                 if (!RT_WIDE_IS_LEAF(leaf) || occluded) continue;
                 if (kDiag) diagLeaves++;
                 const uint32_t numLeaves = leaf >> RT_NODE_LEAVES_SHIFT, first = leaf & RT_NODE_CHILD_MASK;
@@ -333,12 +258,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kSt
                     }
                 }
             }
-            pend = RT_QUANT_DONE;
             if (occluded) cur = RT_QUANT_DONE;
             if (cur != RT_QUANT_DONE)
             {
                 if (sp == 0u) cur = RT_QUANT_DONE;
-                else { --sp; cur = stack[sp * kBlock]; }
+                else { --sp; cur = stack[sp * RT_BLOCK]; }
             }
             if (cur == RT_QUANT_DONE)
             {

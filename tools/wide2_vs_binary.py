@@ -1,3 +1,5 @@
+"""Exactness check of the two-level 4-wide walk (k_trace_wide2) ON the device: the same passes with RTGPU_WIDE2=1 and =0 (the binary walk),
+640x480 x 16 passes per scene and depth; prints the number of differing pixels and the ray counters of both.  usage: python tools/wide2_vs_binary.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
