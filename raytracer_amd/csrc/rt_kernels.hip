@@ -1239,7 +1239,7 @@ static hipError_t rtMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKi
     const bool h2d = kind == hipMemcpyHostToDevice, d2h = kind == hipMemcpyDeviceToHost;
     if ((!h2d && !d2h) || bytes <= ((size_t)64 << 10) || hostRangeIsPageLocked(h2d ? src : dst)) return hipMemcpy(dst, src, bytes, kind);
     std::lock_guard<std::mutex> lock(gStagingMutex);
-    if (!gStaging) { const hipError_t e = hipHostMalloc(&gStaging, kStagingBytes, hipHostMallocDefault); if (e != hipSuccess) { gStaging = nullptr; return e; } }
+    if (!gStaging) { const hipError_t e = hipHostMalloc(&gStaging, kStagingBytes, hipHostMallocPortable); if (e != hipSuccess) { gStaging = nullptr; return e; } }
     for (size_t done = 0; done < bytes; done += kStagingBytes)
     {
         const size_t n = bytes - done < kStagingBytes ? bytes - done : kStagingBytes;
