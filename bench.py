@@ -259,6 +259,10 @@ def measure_pipes(args, num_cus):
             "l1_access": {"accesses_per_launch": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / n,
                           "per_clock_per_cu": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks),
                           "peak_per_clock_per_cu": L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU,
+                          # the same microbenchmark at 5 waves per SIMD when the table does not fit the caches (profiles/r03_microbench_cadence_l1.txt): what the
+                          # memory system sustains for this access pattern depends on where the nodes live -- the walk's 27 MB of nodes, triangles and leaf
+                          # boxes sit between the 8 MB and the 64 MB row
+                          "peak_by_table_size_at_5_waves": {"1 MB (L2)": 1.86, "8 MB": 1.24, "64 MB (Infinity Cache)": 0.70, "1 GB (HBM)": 0.62},
                           "frac": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks) / L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU},
             "wave_time": {"waiting_for_memory": a.get("SQ_WAIT_ANY", 0.0) / wave, "issue_stalled": a.get("SQ_WAIT_INST_ANY", 0.0) / wave,
                           "issuing": a.get("SQ_ACTIVE_INST_ANY", 0.0) / wave},
