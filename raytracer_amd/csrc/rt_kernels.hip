@@ -1931,13 +1931,11 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         }
         if (ok && (allNodes.size() / 4u) < RT_NODE_CHILD_MASK && allGates.size() < 0xFFFFFFFFull)
         {
-            if (allNodes.empty()) allNodes.assign(4u, make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, (uint32_t)RT_WIDE_EMPTY)));   // a one-object scene of an analytic shape
-            if (allGates.empty()) allGates.assign(2u, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
             const float4* devNodes = nullptr; const float4* devGates = nullptr; const WideLevel* devLevels = nullptr;
             if ((r = uploadArray(c, allNodes.data(), allNodes.size(), &devNodes))) return r;
             if ((r = uploadArray(c, allGates.data(), allGates.size(), &devGates))) return r;
             if ((r = uploadArray(c, levels.data(), levels.size(), &devLevels))) return r;
-            c->wide2.nodes = devNodes; c->wide2.gate = devGates; c->wide2.levels = devLevels; c->wide2.numObjects = s->numObjects; c->wide2.bypass = s->numObjects == 1u ? 1u : 0u;
+            c->wide2.nodes = devNodes; c->wide2.gate = devGates; c->wide2.levels = devLevels; c->wide2.numObjects = s->numObjects;
         }
     }
     if (singleMesh)

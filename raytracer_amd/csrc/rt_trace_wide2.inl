@@ -35,8 +35,7 @@ struct WideScene
     const float4* nodes;
     const float4* gate;
     const WideLevel* levels;   // [numObjects] mesh objects (valid only for those), [numObjects] = the top level
-    uint32_t numObjects;
-    uint32_t bypass;           // one object: Scene::Traverse's bypass, no top-level tree and no box test in front of the object
+    uint32_t numObjects;       // >= 2 (one-object scenes are Scene::Traverse's bypass: no top-level tree; k_trace_wide or k_trace serve them)
 };
 
 #define RT_WIDE2_WORLD_WORDS 6u   // per lane in LDS: the world ray's invDir and (stale) originDivDir
@@ -139,14 +138,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 sp = 0u; levelBase = 0u; leafRest = 0u; have = true;
                 worldTerms[0 * RT_BLOCK] = world.invDir.x; worldTerms[1 * RT_BLOCK] = world.invDir.y; worldTerms[2 * RT_BLOCK] = world.invDir.z;
                 worldTerms[3 * RT_BLOCK] = world.originDivDir.x; worldTerms[4 * RT_BLOCK] = world.originDivDir.y; worldTerms[5 * RT_BLOCK] = world.originDivDir.z;
-                if (wide.bypass)
-                {
-                    // one object: no tree, no box in front of it (Scene.cpp:231-235); the lane starts at the object loop
-                    ox = world.origin.x; oy = world.origin.y; oz = world.origin.z; dx = world.dir.x; dy = world.dir.y; dz = world.dir.z;
-                    if (!rayIsNaNFree(world)) { handOver = true; cur = RT_QUANT_DONE; }
-                    else { cur = RT_QUANT_DONE; leafRest = 0u | (1u << RT_NODE_LEAVES_SHIFT); }
-                }
-                else if (!enterLevel(world, *topLevel)) { handOver = true; cur = RT_QUANT_DONE; }
+                if (!enterLevel(world, *topLevel)) { handOver = true; cur = RT_QUANT_DONE; }
                 else
                 {
                     cur = 0u;   // node 0 of the top level holds the children of the binary tree's root
@@ -251,7 +243,6 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     {
                         const Ray world = loadWorldRay();
                         ox = world.origin.x; oy = world.origin.y; oz = world.origin.z; dx = world.dir.x; dy = world.dir.y; dz = world.dir.z;
-                        if (!wide.bypass)
                         {
                             ax = topLevel->step[0] * world.invDir.x; ay = topLevel->step[1] * world.invDir.y; az = topLevel->step[2] * world.invDir.z;
                             bx = __fmaf_rn(topLevel->base[0], world.invDir.x, -world.originDivDir.x);
@@ -260,7 +251,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                             selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
                             nodeBase = topLevel->nodeBase;
                         }
-                        if (leafRest == 0u) { if (wide.bypass) finish = true; else { popOrDone(); if (cur == RT_QUANT_DONE) finish = true; } }
+                        if (leafRest == 0u) { popOrDone(); if (cur == RT_QUANT_DONE) finish = true; }
                     }
                 }
             }
@@ -326,8 +317,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     if (occluded) finish = true;
                     else if (!finish && !enteredMesh && leafRest == 0u)
                     {
-                        if (wide.bypass) finish = true;
-                        else { popOrDone(); if (cur == RT_QUANT_DONE) finish = true; }
+                        popOrDone(); if (cur == RT_QUANT_DONE) finish = true;
                     }
                 }
             }
