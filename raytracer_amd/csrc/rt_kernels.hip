@@ -1384,6 +1384,8 @@ struct RtgpuContext
         VcmArena arena = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0 };
         uint32_t* mergeQueue = nullptr; uint32_t* connectQueue = nullptr;
         uint32_t* overflowQueue = nullptr;   // closest-hit rays k_trace hands to k_trace_monster
+        uint32_t* exactQueue = nullptr; uint32_t* exactShadowQueue = nullptr;   // what the 4-wide walks hand to the binary-tree kernel (as BatchLane's)
+        uint32_t traceSerial = 0;            // trace launches since the counters were zeroed: every launch has its own hand-over counters
         uint32_t* queues[4] = { nullptr, nullptr, nullptr, nullptr };          // light ping-pong, camera ping-pong
         uint32_t* shadowQueues[4] = { nullptr, nullptr, nullptr, nullptr };
         uint32_t* counts = nullptr;                                               // 6 planes of RT_VCM_COUNT_PLANE
@@ -2462,11 +2464,12 @@ static int flushPending(RtgpuContext* c)
 // Bidirectional integrator: host side (kernels in rt_vcm.inl)
 // =====================================================================================================
 #define RT_VCM_COUNT_PLANE (RT_VCM_MAX_PATH_LENGTH + 4u)
+#define RT_VCM_NUM_COUNT_PLANES 16u   // 0-9 as before; 10-11 / 12-13 / 14-15: per trace launch the hand-over counts (closest, any-hit) and cursor of the 4-wide walks
 
 static void freeVcm(RtgpuContext* c)
 {
     RtgpuContext::Vcm& v = c->vcm;
-    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue, v.connectQueue, v.overflowQueue,
+    void* ptrs[] = { v.lightPaths.base, v.cameraPaths.base, v.arena.recs, v.arena.lightVertices, v.arena.photonRaw, v.arena.lvCount, v.arena.photonCount, v.arena.cameraVertex, v.mergeQueue, v.connectQueue, v.overflowQueue, v.exactQueue, v.exactShadowQueue,
                      v.queues[0], v.queues[1], v.queues[2], v.queues[3], v.shadowQueues[0], v.shadowQueues[1], v.shadowQueues[2], v.shadowQueues[3], v.counts,
                      v.passDev, v.seedDev, v.devsDev, v.gridsDev };
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2498,6 +2501,8 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV, uint32_t batch)
     HIP_TRY(hipMalloc((void**)&v.mergeQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.connectQueue, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.overflowQueue, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.exactQueue, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.exactShadowQueue, cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.lvCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.arena.photonCount, cap * sizeof(uint32_t)));
     HIP_TRY(hipMemset(v.arena.photonCount, 0, cap * sizeof(uint32_t)));
@@ -2506,7 +2511,7 @@ static int ensureVcm(RtgpuContext* c, uint32_t maxLV, uint32_t batch)
     for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.queues[k], cap * sizeof(uint32_t)));
     for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * sizeof(uint32_t)));
     for (int k = 2; k < 4; ++k) HIP_TRY(hipMalloc((void**)&v.shadowQueues[k], cap * (size_t)(requests ? requests : 1u) * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&v.counts, (size_t)RT_VCM_NUM_COUNT_PLANES * RT_VCM_COUNT_PLANE * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.passDev, (size_t)RT_VCM_MAX_BATCH * sizeof(DevPass)));
     HIP_TRY(hipMalloc((void**)&v.seedDev, (size_t)RT_VCM_MAX_BATCH * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&v.devsDev, (size_t)RT_VCM_MAX_BATCH * sizeof(VcmDev)));
@@ -2526,7 +2531,22 @@ static void launchTrace(RtgpuContext* c, hipStream_t stream, const Paths& paths,
     static const int abortEnv = getenv("RTGPU_ABORT_CLOSEST_AFTER") ? atoi(getenv("RTGPU_ABORT_CLOSEST_AFTER")) : -1;   // test hook: 0 sends every ray in flight at exhaustion
     if (abortEnv >= 0) tune.abortClosestAfter = (uint32_t)abortEnv;
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
-    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
+    dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
+    RtgpuContext::Vcm& v = c->vcm;
+    // RTGPU_VCM_WIDE=1: the 4-wide walks in front of the bidirectional integrator's launches too.  Bit-exact (tests/test_gpu_vcm.py), and measured
+    // 2 % SLOWER on the Sponza-class scene (16.2 -> 16.6 ms per pass): this pipeline runs on ONE stream, so nothing hides the forty extra re-trace
+    // launches per pass batch, and BASELINE config 5 is three analytic objects, which the wide walk does not serve anyway.  Off by default.
+    static const bool vcmWide = getenv("RTGPU_VCM_WIDE") && atoi(getenv("RTGPU_VCM_WIDE")) != 0;
+    if (vcmWide && useWide(c) && v.exactQueue && v.traceSerial < 2u * RT_VCM_COUNT_PLANE)
+    {
+        // what the wide walk does not decide goes through the binary-tree kernel below, which keeps its hand-over of degenerate closest-hit rays to
+        // k_trace_monster
+        const uint32_t k = v.traceSerial++;
+        uint32_t* exactCount = v.counts + 10u * RT_VCM_COUNT_PLANE + k; uint32_t* exactShadowCount = v.counts + 12u * RT_VCM_COUNT_PLANE + k;
+        launchTraceWide(c, stream, paths, tq, tqc, tsq, tsc, cursor, v.exactQueue, exactCount, v.exactShadowQueue, exactShadowCount, shadowOffset, nullptr, 0u);
+        tq = v.exactQueue; tqc = exactCount; tsq = v.exactShadowQueue; tsc = exactShadowCount; cursor = v.counts + 14u * RT_VCM_COUNT_PLANE + k;
+        travGrid = dim3(c->numCUs);
+    }
     LaunchTimer t(c, stream, KC_TRACE);
 #define RT_VCM_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, stream, c->sceneDev, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
     if (stackClass == 24u) { if (c->countIntersections) RT_VCM_TRACE(24, true); else RT_VCM_TRACE(24, false); }
@@ -2639,7 +2659,8 @@ static int vcmFlush(RtgpuContext* c)
     HIP_TRY(hipStreamSynchronize(stream));   // the host vectors and the pending seeds are temporaries
     const VcmBatch batch = { v.passDev, v.devsDev, v.gridsDev, c->numSlots };
 
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)RT_VCM_NUM_COUNT_PLANES * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    v.traceSerial = 0u;
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE; uint32_t* csc = v.counts + 4 * RT_VCM_COUNT_PLANE; uint32_t* ccur = v.counts + 5 * RT_VCM_COUNT_PLANE;
     uint32_t* cmc = v.counts + 6 * RT_VCM_COUNT_PLANE; uint32_t* ccc = v.counts + 9 * RT_VCM_COUNT_PLANE;
@@ -2759,7 +2780,8 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
     HIP_TRY(hipMemcpyAsync(v.gridsDev, &noGrid, sizeof(noGrid), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const VcmBatch batch = { v.passDev, v.devsDev, v.gridsDev, c->numSlots };
-    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)10 * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(v.counts, 0, (size_t)RT_VCM_NUM_COUNT_PLANES * RT_VCM_COUNT_PLANE * sizeof(uint32_t), stream));
+    v.traceSerial = 0u;
     uint32_t* lpc = v.counts; uint32_t* lsc = v.counts + RT_VCM_COUNT_PLANE; uint32_t* lcur = v.counts + 2 * RT_VCM_COUNT_PLANE;
     uint32_t* cpc = v.counts + 3 * RT_VCM_COUNT_PLANE;
     uint32_t** lq = v.queues; uint32_t** lsq = v.shadowQueues;

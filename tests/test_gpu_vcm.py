@@ -120,6 +120,46 @@ def test_vcm_mesh_scene_camera_paths_bit_exact(built, walk):
     assert_camera_paths_identical(run_both(scene, camera, w, h, 2, walk=walk, camera_connecting_weight=0.0))
 
 
+def test_vcm_behind_the_wide_walks_bit_exact():
+    """RTGPU_VCM_WIDE=1 (read once per process: a child process): the 4-wide walks -- two levels on the mesh + analytic scene, one on a single
+    mesh -- serve the bidirectional integrator's trace launches and hand what they do not decide to k_trace.  Camera-path radiance and ray
+    counters are the oracle's.  (Measured 2 % slower than the binary walk on this single-stream pipeline, hence opt-in.)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+import oracle_lib, scene_zoo, raytracer_amd as ra
+from raytracer_amd import scenes
+w, h = 96, 54
+for make in (lambda a: scene_zoo.mesh_scene(a, triangles=20000), lambda a: scenes.sponza_class(a, 20000), scenes.cornell_box):
+    scene, camera = make(w / h)
+    desc = scene.desc
+    bn = ra.load_blue_noise(); desc.contents.blueNoise = bn.ctypes.data
+    vp = ra.Viewport(w, h, seed=99)
+    vp.set_renderer(scene, name="VCM")
+    vp.set_vcm(camera_connecting_weight=0.0)
+    cam = np.zeros((h, w, 3), np.float32); light = np.zeros((h, w, 3), np.float32); cnt = np.zeros(16, np.uint64)
+    vcm = oracle_lib.Vcm(camera_connecting_weight=0.0)
+    for i in range(3):
+        p = vp.next_pass_params(camera)
+        vp.render_pass_with(p)
+        vcm.render_pass(desc, p, w, h, cam, None, light, cnt)
+    img = vp.sum_buffer()
+    c = vp.counters()
+    assert np.array_equal(img.view(np.uint32), cam.view(np.uint32)), int(np.count_nonzero(img.view(np.uint32) != cam.view(np.uint32)))
+    for k, n in enumerate(ra.COUNTER_NAMES):
+        if n in ("numRays", "numShadowRays", "numShadowRaysHit", "numPrimaryRays", "numMeshHits"):
+            assert c[n] == int(cnt[k]), (n, c[n], int(cnt[k]))
+    assert c["numRetracedRays"] > 0
+print("OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RTGPU_VCM_WIDE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_vcm_full_image_with_light_path_splats(built):
     w, h = 96, 72
     scene, camera = _two_estimator_scene(w / h)
@@ -210,7 +250,8 @@ def test_degenerate_closest_hit_rays_take_the_cooperative_path(built):
     """k_trace hands closest-hit rays that outlive the queue by far (exactly axis-parallel directions walk most of the tree) to
     k_trace_monster, which searches the smallest distance with a whole block and falls back to the sequential order on ties.
     RTGPU_ABORT_CLOSEST_AFTER=0 sends EVERY closest-hit ray still in flight when the queue runs dry down that path: images,
-    ray / shadow-ray / hit counters must not change (box / triangle test counters are off on this path)."""
+    ray / shadow-ray / hit counters must not change (box / triangle test counters are off on this path).  RTGPU_WIDE=0: the binary walk serves
+    every ray here (with the 4-wide walk in front only the re-traced rays would reach k_trace)."""
     import os
     import subprocess
     import sys
@@ -242,7 +283,7 @@ print("OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for env_value in ("0", "3"):
-        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RTGPU_ABORT_CLOSEST_AFTER=env_value), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, RTGPU_ABORT_CLOSEST_AFTER=env_value, RTGPU_WIDE="0"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
 
 
