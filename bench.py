@@ -230,7 +230,25 @@ PIPE_COUNTERS = ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ
                  "TCP_TOTAL_CACHE_ACCESSES_sum"]
 
 
-def measure_pipes(args, num_cus):
+# the divergent-fetch microbenchmark at 5 waves per SIMD and 36 of 64 lanes active (the walk's interior loop runs at 0.52-0.57 lane utilisation): L1
+# accesses per clock and CU against the size of the table the nodes are drawn from (profiles/r03_microbench_cadence_l1.txt).  8 waves per SIMD give
+# the same or less at every size: past the L2 these are THROUGHPUT figures of the cache hierarchy for this access pattern, not latency figures.
+FETCH_PEAK_BY_TABLE_BYTES = [(8 << 10, 1.58), (1 << 20, 1.70), (8 << 20, 1.22), (64 << 20, 0.66), (1 << 30, 0.60)]
+
+
+def fetch_peak_at(footprint_bytes):
+    """Log-linear interpolation of FETCH_PEAK_BY_TABLE_BYTES."""
+    import math
+    t = FETCH_PEAK_BY_TABLE_BYTES
+    if not footprint_bytes or footprint_bytes <= t[0][0]:
+        return t[0][1]
+    for (b0, p0), (b1, p1) in zip(t, t[1:]):
+        if footprint_bytes <= b1:
+            return p0 + (p1 - p0) * (math.log(footprint_bytes / b0) / math.log(b1 / b0))
+    return t[-1][1]
+
+
+def measure_pipes(args, num_cus, footprint_bytes=None):
     """Which ceiling is a kernel near?  A third --pmc child run of the same passes (SQ / GRBM / TCP counters that fit one pass), per
     launch and kernel class:
       valu_issue  -- wave-level VALU instructions x 2.1 clocks (the microbenchmark's cadence) / SIMD clocks available (4 SIMDs per CU x the
@@ -263,7 +281,11 @@ def measure_pipes(args, num_cus):
                           # memory system sustains for this access pattern depends on where the nodes live -- the walk's 27 MB of nodes, triangles and leaf
                           # boxes sit between the 8 MB and the 64 MB row
                           "peak_by_table_size_at_5_waves": {"1 MB (L2)": 1.86, "8 MB": 1.24, "64 MB (Infinity Cache)": 0.70, "1 GB (HBM)": 0.62},
-                          "frac": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks) / L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU},
+                          "frac": a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks) / L1_DIVERGENT_ACCESSES_PER_CLOCK_PER_CU,
+                          # ... and interpolated at the bytes THIS scene's walk fetches from (rtgpu_get_walk_info): the ceiling that applies
+                          "walk_footprint_bytes": footprint_bytes,
+                          "peak_at_footprint": fetch_peak_at(footprint_bytes) if footprint_bytes else None,
+                          "frac_at_footprint": (a.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (num_cus * clocks) / fetch_peak_at(footprint_bytes)) if footprint_bytes else None},
             "wave_time": {"waiting_for_memory": a.get("SQ_WAIT_ANY", 0.0) / wave, "issue_stalled": a.get("SQ_WAIT_INST_ANY", 0.0) / wave,
                           "issuing": a.get("SQ_ACTIVE_INST_ANY", 0.0) / wave},
         }
@@ -494,14 +516,25 @@ def main():
                                                  "GBs": (v["hbm_bytes"] / (ktimes[k][0] / 1000.0 / max(1, ktimes[k][1])) / 1e9) if k in ktimes and ktimes[k][0] > 0 else None,
                                                  "reference_walk_bytes": abytes_replay.get(k, 0) / max(1, v["launches"])}
                                              for k, v in traffic.items()}
-                pipes, pipes_error = measure_pipes(args, torch.cuda.get_device_properties(local_rank).multi_processor_count)
+                class WalkInfo(C.Structure):
+                    _fields_ = [("kernel", C.c_uint32), ("reserved", C.c_uint32), ("nodeBytes", C.c_uint64), ("leafBoxBytes", C.c_uint64), ("triangleBytes", C.c_uint64)]
+                wi = WalkInfo()
+                lib.rtgpu_get_walk_info(ctx, C.byref(wi))
+                footprint = int(wi.nodeBytes + wi.leafBoxBytes + wi.triangleBytes) if dom in ("trace",) else None
+                out["walk"] = {"kernel": ["k_trace (binary tree)", "k_trace_wide", "k_trace_wide2"][wi.kernel], "node_bytes": int(wi.nodeBytes),
+                               "leaf_box_bytes": int(wi.leafBoxBytes), "triangle_bytes": int(wi.triangleBytes)}
+                pipes, pipes_error = measure_pipes(args, torch.cuda.get_device_properties(local_rank).multi_processor_count, footprint)
                 if pipes and dom in pipes:
                     pd = pipes[dom]
-                    fracs = {"hbm": roof["frac"], "valu_issue": pd["valu_issue"]["frac"], "l1_access": pd["l1_access"]["frac"]}
+                    fracs = {"hbm": roof["frac"], "valu_issue": pd["valu_issue"]["frac"],
+                             "cache_fetch": pd["l1_access"]["frac_at_footprint"] if pd["l1_access"]["frac_at_footprint"] is not None else pd["l1_access"]["frac"]}
                     nearest = max(fracs, key=lambda k: fracs[k])
-                    # no pipe above 2/3 of its ceiling while the resident waves spend most of their time parked on memory waits: the kernel is bound
-                    # by the LATENCY of its dependent fetches at the occupancy its registers allow, not by a throughput roof
-                    roof["bound"] = nearest if fracs[nearest] >= 0.67 else "latency"
+                    # cache_fetch: the kernel's vector-L1 accesses per clock and CU over what the divergent-fetch microbenchmark sustains from a table of
+                    # the walk's footprint -- a throughput ceiling of L1 / L2 / Infinity Cache for one-node-per-lane fetches (more waves per SIMD do not
+                    # raise it; 3, 4 or 5 traversal blocks per CU give the same end-to-end rate, profiles/r03_streaming_hints_and_sweeps.txt).  The launch
+                    # average includes the refill, leaf and drain phases; the interior loop alone (52 % of the wave time, ~80 % of the accesses) runs at it.
+                    # Below 0.6 of every ceiling the kernel is called latency-bound.
+                    roof["bound"] = nearest if fracs[nearest] >= 0.6 else "latency"
                     roof["ceilings"] = {"fracs": fracs, "nearest": nearest, **pd}
                     out["pipes_per_kernel_class"] = {k: {"valu_issue_frac": v["valu_issue"]["frac"], "lane_utilisation": v["valu_issue"]["lane_utilisation"],
                                                          "l1_access_frac": v["l1_access"]["frac"], "waiting_for_memory": v["wave_time"]["waiting_for_memory"]}

@@ -560,6 +560,19 @@ int rtgpu_get_kernel_times(RtgpuContext* ctx, double ms[RTGPU_NUM_KERNEL_CLASSES
                            uint64_t launches[RTGPU_NUM_KERNEL_CLASSES],
                            const char* names[RTGPU_NUM_KERNEL_CLASSES]);
 
+/* Which traversal kernel serves the uploaded scene with the intersection counters off, and the bytes its walk fetches from: the node
+ * records, the leaves' exact boxes and the triangles (what decides where the memory system serves the walk's divergent fetches from;
+ * bench.py prices the kernel's access rate against the microbenchmark's figure for this footprint).  Diagnostic, like the timing calls. */
+#define RTGPU_WALK_BINARY 0u   /* k_trace: the reference's binary tree (also every scene with the counters on) */
+#define RTGPU_WALK_WIDE   1u   /* k_trace_wide: 4-wide collapse of a single mesh's tree */
+#define RTGPU_WALK_WIDE2  2u   /* k_trace_wide2: 4-wide top level over 4-wide mesh trees */
+typedef struct RtWalkInfo
+{
+    uint32_t kernel, reserved;
+    uint64_t nodeBytes, leafBoxBytes, triangleBytes;
+} RtWalkInfo;
+int rtgpu_get_walk_info(RtgpuContext* ctx, RtWalkInfo* out);
+
 #ifdef __cplusplus
 }
 #endif

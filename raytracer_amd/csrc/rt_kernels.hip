@@ -1334,6 +1334,7 @@ struct RtgpuContext
     WideBvh wide;                      // 4-wide collapse of the same tree (rt_trace_wide.inl); nodes == nullptr: none
     WideScene wide2;                   // two-level scenes: 4-wide top-level tree over 4-wide mesh trees (rt_trace_wide2.inl); nodes == nullptr: none
     bool wide2Allowed = true;          // RTGPU_WIDE2=0: two-level scenes keep the binary walk
+    uint64_t walkNodeBytes[3] = { 0, 0, 0 }, walkLeafBoxBytes[3] = { 0, 0, 0 }, walkTriangleBytes = 0;   // rtgpu_get_walk_info, per RTGPU_WALK_* kernel
     bool wideAllowed = true;           // RTGPU_WIDE=0: single-mesh scenes walk the binary tree (k_trace) even with the intersection counters off
     bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
     bool denseAllowed = true;          // RTGPU_NO_DENSE=1: path state stays in the pixel's slot for the whole path (the first layout)
@@ -1938,6 +1939,7 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
             if ((r = uploadArray(c, allGates.data(), allGates.size(), &devGates))) return r;
             if ((r = uploadArray(c, levels.data(), levels.size(), &devLevels))) return r;
             c->wide2.nodes = devNodes; c->wide2.gate = devGates; c->wide2.levels = devLevels; c->wide2.numObjects = s->numObjects;
+            c->walkNodeBytes[RTGPU_WALK_WIDE2] = allNodes.size() * sizeof(float4); c->walkLeafBoxBytes[RTGPU_WALK_WIDE2] = allGates.size() * sizeof(float4);
         }
     }
     if (singleMesh)
@@ -1957,11 +1959,13 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
                 const float4* devWide = nullptr;
                 if ((r = uploadArray(c, w.nodes.data(), w.nodes.size(), &devWide))) return r;
                 c->wide.nodes = devWide; c->wide.gate = devGate; c->wide.numNodes = (uint32_t)(w.nodes.size() / 4u);
+                c->walkNodeBytes[RTGPU_WALK_WIDE] = w.nodes.size() * sizeof(float4); c->walkLeafBoxBytes[RTGPU_WALK_WIDE] = q.gate.size() * sizeof(float4);
                 memcpy(c->wide.base, q.base, sizeof(q.base)); memcpy(c->wide.step, q.step, sizeof(q.step)); memcpy(c->wide.bound, q.bound, sizeof(q.bound));
             }
         }
     }
     c->sceneDev = d;
+    c->walkNodeBytes[RTGPU_WALK_BINARY] = ((uint64_t)s->numTopNodes + s->numMeshNodes) * sizeof(RtNode); c->walkTriangleBytes = (uint64_t)s->numTriangles * sizeof(RtTriangle);
     c->numLights = s->numLights;
     c->traversalStackNeed = topDepth + maxMeshDepth;
     bool lean = !(getenv("RTGPU_NO_LEAN") && atoi(getenv("RTGPU_NO_LEAN")) != 0);
@@ -3257,6 +3261,15 @@ RTGPU_API int rtgpu_enable_timing(RtgpuContext* c, int enable)
     RT_FAN_OUT(c, rtgpu_enable_timing(peer, enable));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->timing = enable != 0;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_get_walk_info(RtgpuContext* c, RtWalkInfo* out)
+{
+    if (!c || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    const uint32_t kernel = !useWide(c) ? RTGPU_WALK_BINARY : (c->wide.nodes ? RTGPU_WALK_WIDE : RTGPU_WALK_WIDE2);
+    out->kernel = kernel; out->reserved = 0u;
+    out->nodeBytes = c->walkNodeBytes[kernel]; out->leafBoxBytes = c->walkLeafBoxBytes[kernel]; out->triangleBytes = c->walkTriangleBytes;
     return RTGPU_OK;
 }
 

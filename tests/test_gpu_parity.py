@@ -502,6 +502,31 @@ def test_c_abi_error_paths(built):
     assert lib.rtgpu_create(99, C.byref(ctx)) == -1               # device index out of range
 
 
+def test_walk_info_names_the_kernel_that_serves_the_scene(built):
+    """rtgpu_get_walk_info: single-mesh scenes walk the 4-wide collapse, mesh + analytic scenes the two-level one, either falls back to the
+    reference's binary tree with the intersection counters on; the byte counts are those of the uploaded arrays."""
+    class WalkInfo(C.Structure):
+        _fields_ = [("kernel", C.c_uint32), ("reserved", C.c_uint32), ("nodeBytes", C.c_uint64), ("leafBoxBytes", C.c_uint64), ("triangleBytes", C.c_uint64)]
+    lib = ra.rtgpu_lib()
+    for make, expected in ((lambda a: scenes.sponza_class(a, 6000), 1), (lambda a: scene_zoo.mesh_scene(a, triangles=2000), 2), (scenes.sphere_area_light, 0)):
+        scene, camera = make(1.0)
+        vp = ra.Viewport(32, 32, seed=1)
+        vp.set_renderer(scene)
+        vp.render(camera, 1)   # (the mirror uploads the scene with the first pass)
+        wi = WalkInfo()
+        assert lib.rtgpu_get_walk_info(vp.device_context(), C.byref(wi)) == 0
+        assert wi.kernel == expected, (wi.kernel, expected)
+        d = scene.desc.contents
+        assert wi.triangleBytes == d.numTriangles * 36
+        if expected == 0:
+            assert wi.nodeBytes == (d.numTopNodes + d.numMeshNodes) * 32
+        else:
+            assert wi.nodeBytes % 64 == 0 and wi.nodeBytes > 0 and wi.leafBoxBytes > 0
+            assert lib.rtgpu_set_intersection_counters(vp.device_context(), 1) == 0
+            assert lib.rtgpu_get_walk_info(vp.device_context(), C.byref(wi)) == 0 and wi.kernel == 0
+    assert lib.rtgpu_get_walk_info(None, None) == -1
+
+
 def test_full_size_sponza_class_properties(built, walk):
     """BASELINE config 3 at its full size (1920x1080, Sponza-class mesh of ~262 k triangles, depth 8), through
     size-independent properties and an oracle-checked sample -- with walk = "default" this is exactly the pipeline bench.py times

@@ -137,6 +137,33 @@ __global__ void __launch_bounds__(256) k_l1(const float4* __restrict__ nodes, ui
     if ((threadIdx.x & 63u) == 0u) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// the same walk over nodes of `kLoads` x 16 bytes stored `stride16` x 16 bytes apart (48-byte nodes: dense = 3, one per 64-byte half line = 4)
+template <int kLoads>
+__global__ void __launch_bounds__(256) k_node(const float4* __restrict__ nodes, uint32_t numNodes, uint32_t stride16, uint32_t steps, uint32_t activeLanes, float* out, unsigned long long* clocks)
+{
+    extern __shared__ uint32_t sPad[];
+    if (steps == 0xFFFFFFFFu) sPad[threadIdx.x] = 1u;
+    uint32_t cur = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u % numNodes;
+    float acc = 0.0f;
+    const bool active = (threadIdx.x & 63u) < activeLanes;
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    if (active)
+        for (uint32_t s = 0; s < steps; ++s)
+        {
+            const float4* p = nodes + (size_t)stride16 * cur;
+            float4 q[kLoads];
+#pragma unroll
+            for (int k = 0; k < kLoads; ++k) q[k] = p[k];
+#pragma unroll
+            for (int k = 0; k < kLoads; ++k) acc += q[k].x;
+            cur = __float_as_uint(q[0].w);
+        }
+    const unsigned long long t1 = clock64();
+    if (acc == 123.456f) out[0] = acc;
+    if ((threadIdx.x & 63u) == 0u) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
 // dynamic LDS that lets exactly `blocksPerCU` 256-thread blocks share a CU's 160 KB
 static size_t ldsFor(uint32_t blocksPerCU) { return blocksPerCU <= 1u ? (size_t)96 << 10 : ((size_t)160 << 10) / blocksPerCU / 1024u * 1024u; }
 
@@ -167,13 +194,15 @@ static void runCadence(uint32_t numCUs, float* out, unsigned long long* clocksDe
     printf("\n");
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    const bool onlyFormats = argc > 1 && argv[1][0] == '3';   // `cadence 3`: section (3) only
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const uint32_t numCUs = (uint32_t)prop.multiProcessorCount;
     printf("device %s, %u CUs, clock %d kHz (clock64 = s_memtime ticks)\n", prop.name, numCUs, prop.clockRate);
     float* out; unsigned long long* clocksDev;
     CHECK(hipMalloc((void**)&out, 64)); CHECK(hipMalloc((void**)&clocksDev, sizeof(unsigned long long) * numCUs * 8u * 4u * 2u));
+    if (!onlyFormats) {
     printf("\n(1) cycles per wave64 VALU instruction per SIMD (clock64 ticks of one wave / instructions issued by all waves of its SIMD; wN = N resident waves per SIMD, enforced through the LDS allocation) and the effective clock\n");
     runCadence<OP_FMA>(numCUs, out, clocksDev); runCadence<OP_PERM>(numCUs, out, clocksDev); runCadence<OP_CVT_SDWA>(numCUs, out, clocksDev);
     runCadence<OP_CVT>(numCUs, out, clocksDev); runCadence<OP_MAX3>(numCUs, out, clocksDev); runCadence<OP_CNDMASK_SGPR>(numCUs, out, clocksDev);
@@ -217,6 +246,41 @@ int main()
             printf("\n");
         }
         CHECK(hipFree(dev));
+    }
+    }
+    printf("\n(3) node formats: the same random walk over N nodes of L x 16 bytes at a stride of S x 16 bytes, 5 waves per SIMD, 36 active lanes; clocks per wave step\n");
+    for (uint32_t numNodes : { 65536u, 262144u, 1048576u })
+    {
+        std::vector<uint32_t> perm(numNodes);
+        for (uint32_t i = 0; i < numNodes; ++i) perm[i] = i;
+        uint64_t s = 88172645463325252ull;
+        for (uint32_t i = numNodes - 1; i > 0; --i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; const uint32_t j = (uint32_t)(s % (i + 1)); std::swap(perm[i], perm[j]); }
+        printf("%8u nodes:", numNodes);
+        struct Format { int loads; uint32_t stride16; const char* name; };
+        for (const Format f : { Format{ 4, 4u, "64 B / 4 loads" }, Format{ 3, 4u, "48 of 64 B / 3 loads" }, Format{ 3, 3u, "48 B dense / 3 loads" }, Format{ 2, 2u, "32 B / 2 loads" }, Format{ 2, 4u, "32 of 64 B / 2 loads" } })
+        {
+            std::vector<float4> host((size_t)numNodes * f.stride16, make_float4(1.0f, 2.0f, 3.0f, 0.0f));
+            for (uint32_t i = 0; i < numNodes; ++i) host[(size_t)perm[i] * f.stride16].w = __builtin_bit_cast(float, perm[(i + 1) % numNodes]);
+            float4* dev; CHECK(hipMalloc((void**)&dev, host.size() * sizeof(float4)));
+            CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice));
+            const uint32_t wavesPerSimd = 5u, steps = 4000u, activeLanes = 36u;
+            const dim3 grid(numCUs * wavesPerSimd), block(256);
+            const size_t lds = ldsFor(wavesPerSimd);
+            auto launch = [&](uint32_t n)
+            {
+                if (f.loads == 4) { CHECK(hipFuncSetAttribute((const void*)k_node<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_node<4>, grid, block, lds, 0, dev, numNodes, f.stride16, n, activeLanes, out, clocksDev); }
+                else if (f.loads == 3) { CHECK(hipFuncSetAttribute((const void*)k_node<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_node<3>, grid, block, lds, 0, dev, numNodes, f.stride16, n, activeLanes, out, clocksDev); }
+                else { CHECK(hipFuncSetAttribute((const void*)k_node<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); hipLaunchKernelGGL(k_node<2>, grid, block, lds, 0, dev, numNodes, f.stride16, n, activeLanes, out, clocksDev); }
+            };
+            launch(200u); launch(steps);
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> clocks((size_t)grid.x * 4u);
+            CHECK(hipMemcpy(clocks.data(), clocksDev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            double mean = 0; for (auto c : clocks) mean += (double)c; mean /= (double)clocks.size();
+            printf("  %s: %5.0f", f.name, mean / steps);
+            CHECK(hipFree(dev));
+        }
+        printf("\n");
     }
     return 0;
 }
