@@ -400,11 +400,29 @@ RT_DEV float bcGrayscale(const uint8_t* blockData, uint32_t x, uint32_t y)
 }
 // One texel as Bitmap::GetPixel / GetPixelBlock decode it (Bitmap.cpp:335-517, 520-832; loads: Math/Vector4Load.h):
 // every UNorm load is float(integer) * RN(1 / max) -- the SSE paths scale by powers of two around that, exactly.
+// kSimple: the scene holds only RT_FORMAT_IS_SIMPLE bitmaps (scene class 4, below) -- the same decode, three-and-a-half cases instead of 23, small
+// enough to be inlined at every call site of the shading kernel.
+#define RT_FORMAT_IS_SIMPLE(f) ((f) == RT_FORMAT_B8G8R8_UNORM || (f) == RT_FORMAT_B8G8R8A8_UNORM || (f) == RT_FORMAT_R8G8B8A8_UNORM || (f) == RT_FORMAT_R16G16B16A16_HALF)
+template <bool kSimple = false>
 RT_DEV V4 bitmapTexel(const RtTexture& t, const uint8_t* texels, uint32_t x, uint32_t y)
 {
     const uint8_t* row = texels + t.dataOffset + (size_t)t.stride * y;
     const float s8 = 1.0f / 255.0f, s16 = 1.0f / 65535.0f;
     V4 c = zero4();
+    if (kSimple)
+    {
+        if (t.format == RT_FORMAT_R16G16B16A16_HALF) c = V4(halfToFloat(rd16(row + 8 * x)), halfToFloat(rd16(row + 8 * x + 2)), halfToFloat(rd16(row + 8 * x + 4)), halfToFloat(rd16(row + 8 * x + 6)));
+        else
+        {
+            const uint32_t bytes = t.format == RT_FORMAT_B8G8R8_UNORM ? 3u : 4u;
+            const uint8_t* e = row + bytes * x;
+            const float e0 = (float)(int32_t)e[0] * s8, e1 = (float)(int32_t)e[1] * s8, e2 = (float)(int32_t)e[2] * s8;
+            const float e3 = bytes == 4u ? (float)(int32_t)e[3] * s8 : 0.0f;
+            c = t.format == RT_FORMAT_R8G8B8A8_UNORM ? V4(e0, e1, e2, e3) : V4(e2, e1, e0, e3);
+        }
+        if (!t.linearSpace) c = srgbToLinear(c);
+        return c;
+    }
     switch (t.format)
     {
     case RT_FORMAT_R8_UNORM:       c = splat((float)(int32_t)row[x] * s8); break;
@@ -481,6 +499,7 @@ RT_DEV float smoothStep(float x) { return x * x * (3.0f - x * 2.0f); }   // Math
 // Vector4::Lerp(v1, v2, w) = MulAndAdd(v2 - v1, w, v1), Vector4Impl.h:58-61
 RT_DEV V4 lerp4(V4 v1, V4 v2, V4 w) { return mulAdd(v2 - v1, w, v1); }
 // BitmapTexture::Evaluate, BitmapTexture.cpp:32-93
+template <bool kSimple = false>
 RT_DEV V4 bitmapTextureEvaluate(const RtTexture& t, const uint8_t* texels, V4 coords)
 {
     const int32_t sw = (int32_t)t.width, sh = (int32_t)t.height;
@@ -493,13 +512,13 @@ RT_DEV V4 bitmapTextureEvaluate(const RtTexture& t, const uint8_t* texels, V4 co
     if (!(iy < sh)) ty -= sh;
     if (ix < 0) tx += sw;                                                               // texelCoords += size & (intCoords < 0)
     if (iy < 0) ty += sh;
-    if (t.filter == RT_FILTER_NEAREST) return bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)ty);
+    if (t.filter == RT_FILTER_NEAREST) return bitmapTexel<kSimple>(t, texels, (uint32_t)tx, (uint32_t)ty);
     int32_t tz = tx + 1, tw = ty + 1;
     if (!(tz < sw)) tz -= sw;                                                           // wrap secondary coordinates
     if (!(tw < sh)) tw -= sh;
     // GetPixelBlock: colors[0] = (x, y), [1] = (z, y), [2] = (x, w), [3] = (z, w)
-    const V4 c0 = bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)ty), c1 = bitmapTexel(t, texels, (uint32_t)tz, (uint32_t)ty);
-    const V4 c2 = bitmapTexel(t, texels, (uint32_t)tx, (uint32_t)tw), c3 = bitmapTexel(t, texels, (uint32_t)tz, (uint32_t)tw);
+    const V4 c0 = bitmapTexel<kSimple>(t, texels, (uint32_t)tx, (uint32_t)ty), c1 = bitmapTexel<kSimple>(t, texels, (uint32_t)tz, (uint32_t)ty);
+    const V4 c2 = bitmapTexel<kSimple>(t, texels, (uint32_t)tx, (uint32_t)tw), c3 = bitmapTexel<kSimple>(t, texels, (uint32_t)tz, (uint32_t)tw);
     float weightX = scx - (float)ix, weightY = scy - (float)iy;                         // scaledCoords - intCoords.ConvertToFloat()
     if (t.filter == RT_FILTER_BILINEAR_SMOOTHSTEP) { weightX = smoothStep(weightX); weightY = smoothStep(weightY); }
     const V4 value0 = lerp4(c0, c2, splat(weightY));
@@ -585,10 +604,20 @@ RT_DEV V4 textureEvaluate(const RtSceneDesc& d, uint32_t index, V4 coords)
     if (t.kind != RT_TEXTURE_MIX) return textureEvaluateLeaf(d, t, coords);
     return lerp4(textureEvaluateInner(d, t.mixA, coords), textureEvaluateInner(d, t.mixB, coords), textureEvaluateInner(d, t.mixWeight, coords));
 }
+// the shading kernels' texture lookups: scene class 4 holds nothing but simple bitmaps, whose evaluation is inlined (no call: the callee's register
+// budget is what keeps the other textured classes at two waves per SIMD)
+#define RT_SIMPLE_TEXTURES(k) ((k) == 4)
+template <int kLean>
+RT_DEV V4 textureEvaluateK(const RtSceneDesc& d, uint32_t index, V4 coords)
+{
+    if (RT_SIMPLE_TEXTURES(kLean)) return bitmapTextureEvaluate<true>(d.textures[index], d.texelData, coords);
+    return textureEvaluate(d, index, coords);
+}
 // Material::GetNormalVector, Material.cpp:120-138 (normalMap != NULL)
+template <int kLean>
 RT_DEV V4 materialGetNormalVector(const RtSceneDesc& d, const RtMaterial& mat, V4 uv)
 {
-    V4 normal = textureEvaluate(d, mat.normalMapTexture, uv);
+    V4 normal = textureEvaluateK<kLean>(d, mat.normalMapTexture, uv);
     normal = mulSub(normal, 2.0f, splat(1.0f));                    // UnipolarToBipolar
     normal.z = sqrtf(Max(0.0f, 1.0f - dot2(normal, normal)));      // reconstruct Z
     return lerp4(V4(0.0f, 0.0f, 1.0f, 0.0f), normal, splat(mat.normalMapStrength));
@@ -601,8 +630,8 @@ RT_DEV V4 materialGetNormalVector(const RtSceneDesc& d, const RtMaterial& mat, V
 //   RT_TEXTURED(k) -- textures may be present (albedo / roughness / ... maps, normal maps, an environment map).
 // 0 = anything, 1 = lean without textures (the Sponza-class benchmark), 2 = lean with textures (a textured Sponza), 3 = anything without
 // textures (Cornell box: analytic shapes, area light, all BSDFs).
-#define RT_LEAN(k) ((k) == 1 || (k) == 2)
-#define RT_TEXTURED(k) ((k) == 0 || (k) == 2)
+#define RT_LEAN(k) ((k) == 1 || (k) == 2 || (k) == 4)
+#define RT_TEXTURED(k) ((k) == 0 || (k) == 2 || (k) == 4)
 template <int kLean>
 __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDesc& d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
 {
@@ -635,7 +664,7 @@ __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDe
     if (RT_TEXTURED(kLean) && out.material != RT_NO_MATERIAL && d.materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
     {
         const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
-        const V4 localNormal = materialGetNormalVector(d, d.materials[out.material], out.texCoord);
+        const V4 localNormal = materialGetNormalVector<kLean>(d, d.materials[out.material], out.texCoord);
         V4 newNormal = localSpaceTangent * localNormal.x;
         newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
         newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
@@ -660,7 +689,7 @@ template <int kLean>
 RT_DEV V4 backgroundColor(const RtSceneDesc& d, const RtLight& L, V4 dir)
 {
     V4 color = load4(L.color);
-    if (RT_TEXTURED(kLean) && L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluate(d, L.texture, cartesianToSpherical(dir)));
+    if (RT_TEXTURED(kLean) && L.texture != RT_NO_TEXTURE) color = color * max4(zero4(), textureEvaluateK<kLean>(d, L.texture, cartesianToSpherical(dir)));
     return color;
 }
 template <int kLean>
@@ -1160,10 +1189,10 @@ RT_DEV void materialEvaluateShadingData(const RtSceneDesc& d, const RtMaterial& 
     sd.mp.IoR = mat.IoR;
     if (!RT_TEXTURED(kLean)) return;
     const V4 uv = sd.intersection.texCoord;
-    if (mat.baseColorTexture != RT_NO_TEXTURE) sd.mp.baseColor = sd.mp.baseColor * textureEvaluate(d, mat.baseColorTexture, uv);
-    if (mat.emissionTexture != RT_NO_TEXTURE) sd.mp.emission = sd.mp.emission * textureEvaluate(d, mat.emissionTexture, uv);
-    if (mat.roughnessTexture != RT_NO_TEXTURE) sd.mp.roughness = (splat(mat.roughness) * textureEvaluate(d, mat.roughnessTexture, uv)).x;
-    if (mat.metalnessTexture != RT_NO_TEXTURE) sd.mp.metalness = (splat(mat.metalness) * textureEvaluate(d, mat.metalnessTexture, uv)).x;
+    if (mat.baseColorTexture != RT_NO_TEXTURE) sd.mp.baseColor = sd.mp.baseColor * textureEvaluateK<kLean>(d, mat.baseColorTexture, uv);
+    if (mat.emissionTexture != RT_NO_TEXTURE) sd.mp.emission = sd.mp.emission * textureEvaluateK<kLean>(d, mat.emissionTexture, uv);
+    if (mat.roughnessTexture != RT_NO_TEXTURE) sd.mp.roughness = (splat(mat.roughness) * textureEvaluateK<kLean>(d, mat.roughnessTexture, uv)).x;
+    if (mat.metalnessTexture != RT_NO_TEXTURE) sd.mp.metalness = (splat(mat.metalness) * textureEvaluateK<kLean>(d, mat.metalnessTexture, uv)).x;
 }
 // Material::Evaluate, Material.cpp:160-180
 // kLean: every material of the scene uses the diffuse BSDF

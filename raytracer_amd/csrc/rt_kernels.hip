@@ -1342,7 +1342,7 @@ struct RtgpuContext
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     bool sortShadeKinds = false;       // RTGPU_SHADE_SORT=1: the generic k_shade_dense deals a block's vertices to its threads by hit kind (measured 4 % slower: off)
-    int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures
+    int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures, 4 lean + simple bitmaps only
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
                                        // rtgpu_set_intersection_counters, or RTGPU_INTERSECTION_COUNTERS=1 for the default of new contexts
     unsigned long long* counters = nullptr;   // 16 x u64
@@ -1978,6 +1978,13 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     for (uint32_t i = 0; i < s->numLights; ++i) textured = textured || s->lights[i].texture != RT_NO_TEXTURE;
     c->leanScene = lean ? (textured ? 2 : 1) : (textured ? 0 : 3);
     {
+        // class 4: a lean scene whose textures are all plain 8-bit BGR(A) / RGBA or half-float RGBA bitmaps (what Demo/MeshLoader.cpp makes of an OBJ's
+        // diffuse and normal maps: 24-bit .bmp files) -- the shading kernel inlines their evaluation.  RTGPU_NO_SIMPLE_TEXTURES=1: class 2 instead.
+        bool simple = c->leanScene == 2 && s->numTextures != 0u && !(getenv("RTGPU_NO_SIMPLE_TEXTURES") && atoi(getenv("RTGPU_NO_SIMPLE_TEXTURES")) != 0);
+        for (uint32_t i = 0; i < s->numTextures && simple; ++i) simple = s->textures[i].kind == RT_TEXTURE_BITMAP && RT_FORMAT_IS_SIMPLE(s->textures[i].format);
+        if (simple) c->leanScene = 4;
+    }
+    {
         // kinds a vertex of this scene can be: BSDF classes in use, light objects; (misses and zombies exist everywhere)
         uint32_t bsdfMask = 0u; bool lightObjects = false;
         for (uint32_t i = 0; i < s->numMaterials; ++i) bsdfMask |= 1u << (s->materials[i].bsdf & 15u);
@@ -2345,9 +2352,9 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 #define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
                                                      l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters, c->sortShadeKinds ? 1u : 0u)
             if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true, false);
-            else if (denseAll) { if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, true); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, true); else RT_LAUNCH_SHADE_DENSE(0, false, true); }
+            else if (denseAll) { if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, true); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, true); else if (c->leanScene == 4) RT_LAUNCH_SHADE_DENSE(4, false, true); else RT_LAUNCH_SHADE_DENSE(0, false, true); }
             else if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, false); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, false);
-            else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false, false); else RT_LAUNCH_SHADE_DENSE(0, false, false);
+            else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false, false); else if (c->leanScene == 4) RT_LAUNCH_SHADE_DENSE(4, false, false); else RT_LAUNCH_SHADE_DENSE(0, false, false);
 #undef RT_LAUNCH_SHADE_DENSE
         }
         if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));

@@ -359,7 +359,7 @@ def sponza_class_mesh(target_triangles=262144, seed=7, refine=False):
     return build(k, kf).arrays()
 
 
-def sponza_class(aspect, target_triangles=262144, seed=7, textured=False):
+def sponza_class(aspect, target_triangles=262144, seed=7, textured=False, extra_texture=False):
     """BASELINE config 3: Sponza-class mesh, background light (1, 1.5, 2) + delta directional light
     (20000, 19000, 18000) pitched 80 degrees -- the lights of the reference's Data/TestScenes/sponza.json."""
     pos, idx, nrm, tan, uv, mat = sponza_class_mesh(target_triangles, seed, refine=True)
@@ -378,6 +378,10 @@ def sponza_class(aspect, target_triangles=262144, seed=7, textured=False):
             scene.set_material_texture(m, "normal", scene.add_bitmap_texture(bump, "B8G8R8A8_UNorm"), 1.0)
         sky = rng.uniform(0.2, 1.5, size=(256, 512, 4)).astype(np.float16)
         env = scene.add_bitmap_texture(sky, "R16G16B16A16_Half")
+        if extra_texture:
+            # one texture that is not a plain bitmap (the roughness map of a diffuse material): the scene leaves the "simple bitmaps" class of the
+            # shading kernels
+            scene.set_material_texture(mats[0], "roughness", scene.add_checkerboard_texture((1.0, 1.0, 1.0), (0.0, 0.0, 0.0)))
     scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
     scene.add_background_light((1.0, 1.5, 2.0), texture=env)
     scene.add_directional_light((20000.0, 19000.0, 18000.0), np.float32(1.0) / np.float32(180.0) * np.float32(3.14159265359),

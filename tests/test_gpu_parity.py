@@ -141,15 +141,42 @@ def test_textured_materials_normal_maps_and_environment_map(built, walk):
     assert not np.array_equal(vp.sum_buffer(), out[0])
 
 
-def test_textured_sponza_class_scene_bit_exact(built, walk):
+@pytest.mark.parametrize("simple_bitmaps", [True, False])
+def test_textured_sponza_class_scene_bit_exact(built, walk, simple_bitmaps):
     """The shading kernels are specialised per scene class (rt_device_core.h: lean / textured): a mesh-only, diffuse-only scene WITH albedo and
     normal maps on every material and an HDR environment map on the background light (bench.py --workload sponza-textured in small) runs
-    the "lean + textures" variant; the Cornell box and the all-BSDF scenes above run "anything without textures", the mesh scenes "lean",
-    the textured zoo scene "anything"."""
+    the "lean + simple bitmaps" variant (8-bit BGRA and half-float RGBA bitmaps only: their evaluation is inlined) or, with one more texture
+    of another kind in the scene, the "lean + textures" variant; the Cornell box and the all-BSDF scenes above run "anything without
+    textures", the mesh scenes "lean", the textured zoo scene "anything"."""
     w, h = 96, 54
-    scene, camera = scenes.sponza_class(w / h, 6000, textured=True)
-    assert scene.desc.contents.numTextures == 17
+    scene, camera = scenes.sponza_class(w / h, 6000, textured=True, extra_texture=not simple_bitmaps)
+    assert scene.desc.contents.numTextures == (17 if simple_bitmaps else 18)
     assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=5))
+
+
+def test_simple_bitmap_formats_and_filters_bit_exact(built):
+    """Scene class "lean + simple bitmaps": every format the inlined evaluation decodes (24-bit BGR as Demo/MeshLoader.cpp's .bmp files, BGRA8,
+    RGBA8, half-float RGBA) under the three filters, sRGB and linear, as albedo / normal / environment maps."""
+    w, h = 64, 48
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(3000, 11, refine=True)
+    rng = np.random.RandomState(5)
+    scene = ra.Scene()
+    mats = [scene.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    formats = [("B8G8R8_UNorm", 3, np.uint8), ("B8G8R8A8_UNorm", 4, np.uint8), ("R8G8B8A8_UNorm", 4, np.uint8), ("R16G16B16A16_Half", 4, np.float16)]
+    filters = ["nearest", "bilinear", "smoothstep"]
+    for i, m in enumerate(mats):
+        name, channels, dtype = formats[i % len(formats)]
+        size = (37 + 5 * i, 64 + 3 * i)   # odd sizes: the wrap of the secondary texel
+        texels = (rng.uniform(0.05, 1.0, size=size + (channels,)) * (255 if dtype == np.uint8 else 1)).astype(dtype)
+        scene.set_material_texture(m, "baseColor", scene.add_bitmap_texture(texels, name, linear_space=(i % 2 == 0), filter=filters[i % 3]))
+        bump = (127.5 + 25.0 * rng.standard_normal(size + (4,))).clip(0, 255).astype(np.uint8)
+        scene.set_material_texture(m, "normal", scene.add_bitmap_texture(bump, "R8G8B8A8_UNorm", filter=filters[(i + 1) % 3]), 0.8)
+    env = scene.add_bitmap_texture(rng.uniform(0.2, 1.5, size=(32, 64, 4)).astype(np.float16), "R16G16B16A16_Half", filter="bilinear")
+    scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    scene.add_background_light((1.0, 1.5, 2.0), texture=env)
+    scene.build()
+    camera = ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), w / h, 65.0)
+    assert_identical(*run_both(scene, camera, w, h, walk="default", passes=2, max_ray_depth=4))
 
 
 def test_ingested_json_obj_scene_bit_exact(built, walk):
