@@ -18,13 +18,15 @@ def run(budget=300.0, seed=1, min_cases=0, log=print):
     bn = ra.load_blue_noise()
     threads = min(64, os.cpu_count() or 1)
     while time.time() < t_end or cases < min_cases:
-        kind = rng.randint(4)
+        kind = rng.randint(5)
         w, h = [(64, 48), (128, 72), (160, 96), (96, 160)][rng.randint(4)]
         if kind == 0: scene, camera = scenes.sponza_class(w / h, int(rng.choice([300, 3000, 20000])), seed=int(rng.randint(1, 1000)))
+        elif kind == 4:   # textured: the "lean + simple bitmaps" / "lean + textures" shading kernels
+            scene, camera = scenes.sponza_class(w / h, int(rng.choice([300, 3000])), seed=int(rng.randint(1, 1000)), textured=True, extra_texture=bool(rng.randint(2)))
         elif kind == 1: scene, camera = scene_zoo.mesh_scene(w / h, triangles=int(rng.choice([2000, 8000])))
         elif kind == 2: scene, camera = scenes.cornell_box(w / h)
         else: scene, camera = scenes.sphere_area_light(w / h)
-        if kind == 0:
+        if kind in (0, 4):
             camera = ra.Camera((float(rng.uniform(-13, 13)), float(rng.uniform(0.3, 10)), float(rng.uniform(-5, 5))), (float(rng.uniform(-60, 60)), float(rng.uniform(0, 360)), 0.0),
                                w / h, float(rng.uniform(30, 100)))
         args = dict(max_ray_depth=int(rng.choice([0, 2, 6, 10])), min_russian_roulette_depth=int(rng.choice([1, 4, 20])), light_sampling_all=bool(rng.randint(2)),
