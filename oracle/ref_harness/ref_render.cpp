@@ -74,6 +74,8 @@
 #include "Shapes/RectShape.h"
 #include "Shapes/MeshShape.h"
 #include "Material/Material.h"
+#include "Textures/BitmapTexture.h"
+#include "Utils/Bitmap.h"
 #include "Rendering/Viewport.h"
 #include "Rendering/Renderer.h"
 #include "Rendering/PathTracerMIS.h"
@@ -330,12 +332,13 @@ int main(int argc, char** argv)
         fclose(f);
     }
     const uint64_t magic = r.get<uint64_t>();
-    if (magic != 0x3130304645525452ULL) { fprintf(stderr, "ref_render: bad magic\n"); return 2; }   // "RTREF001"
+    if (magic != 0x3230304645525452ULL) { fprintf(stderr, "ref_render: bad magic\n"); return 2; }   // "RTREF002"
     const uint32 width = r.get<uint32>(), height = r.get<uint32>(); uint32 passes = r.get<uint32>(), threads = r.get<uint32>();
     const uint32 maxRayDepth = r.get<uint32>(), minRouletteDepth = r.get<uint32>(), dimensions = r.get<uint32>(), blueNoise = r.get<uint32>(), samplingAll = r.get<uint32>();
     const uint32 numMaterials = r.get<uint32>(), numMeshes = r.get<uint32>(), numObjects = r.get<uint32>(), numLights = r.get<uint32>(), dumpImage = r.get<uint32>();
     const float aaSpread = r.get<float>(); (void)r.get<float>();
     const uint64_t seed = r.get<uint64_t>();
+    const uint32 numTextures = r.get<uint32>(); (void)r.get<uint32>();
     if (argc > 3) threads = (uint32)atoi(argv[3]);
     if (argc > 4) passes = (uint32)atoi(argv[4]);
 
@@ -359,15 +362,33 @@ int main(int argc, char** argv)
         camera.mDOF.enable = dof != 0; camera.mDOF.focalPlaneDistance = focal; camera.mDOF.aperture = aperture;
     }
 
+    // bitmap textures: Bitmap::Init copies the texels; BitmapTexture(bitmap) is the constructor Demo/MeshLoader.cpp uses (default filter)
+    std::vector<TexturePtr> textures;
+    for (uint32 i = 0; i < numTextures; ++i)
+    {
+        const uint32 tw = r.get<uint32>(), th = r.get<uint32>(), format = r.get<uint32>(), linear = r.get<uint32>(), stride = r.get<uint32>(), bytes = r.get<uint32>();
+        (void)r.get<uint32>(); (void)r.get<uint32>();
+        const uint8_t* texels = r.array<uint8_t>(((size_t)bytes + 3u) & ~(size_t)3u);
+        if (!r.ok || format == 0u || format > (uint32)Bitmap::Format::BC5) return 2;
+        Bitmap::InitData init;
+        init.width = tw; init.height = th; init.format = (Bitmap::Format)format; init.data = texels; init.stride = stride; init.linearSpace = linear != 0;
+        BitmapPtr bitmap = std::make_shared<Bitmap>("fixture");
+        if (!bitmap->Init(init)) { fprintf(stderr, "ref_render: Bitmap::Init failed\n"); return 2; }
+        textures.push_back(std::make_shared<BitmapTexture>(bitmap));
+    }
+
     std::vector<MaterialPtr> materials;
     for (uint32 i = 0; i < numMaterials; ++i)
     {
-        const uint32 bsdf = r.get<uint32>(); const float* c = r.array<float>(10);
+        const uint32 bsdf = r.get<uint32>(); const float* c = r.array<float>(10); const int32* t = r.array<int32>(5); const float normalMapStrength = r.get<float>();
         if (!r.ok || bsdf > 8) return 2;
         MaterialPtr m = Material::Create();
         m->SetBsdf(kBsdfNames[bsdf]);
         m->baseColor.baseValue = Vector4(c[0], c[1], c[2], 0.0f); m->emission.baseValue = Vector4(c[3], c[4], c[5], 0.0f);
         m->roughness.baseValue = c[6]; m->metalness.baseValue = c[7]; m->IoR = c[8]; m->K = c[9];
+        auto textureOf = [&](int32 index) -> TexturePtr { return index >= 0 && (uint32)index < numTextures ? textures[(uint32)index] : TexturePtr(); };
+        m->baseColor.texture = textureOf(t[0]); m->emission.texture = textureOf(t[1]); m->roughness.texture = textureOf(t[2]); m->metalness.texture = textureOf(t[3]);
+        m->normalMap = textureOf(t[4]); m->normalMapStrength = normalMapStrength;
         m->Compile();
         materials.push_back(m);
     }

@@ -289,6 +289,8 @@ class Scene:
                                             C.c_uint32(stride), 1 if linear_space else 0, self.FILTERS[filter])
         if tid < 0:
             raise ValueError("bad bitmap texture")
+        self.calls.append(("bitmap_texture", dict(id=int(tid), width=int(w), height=int(h), format=fmt, stride=int(stride), linear_space=bool(linear_space),
+                                                  filter=filter, pixels=a, has_palette=palette is not None)))
         if palette is not None:
             pal = np.ascontiguousarray(palette, dtype=np.uint8).reshape(-1, 4)
             if host_lib().rth_texture_set_palette(self._h, tid, pal.ctypes.data_as(C.c_void_p), C.c_uint32(pal.shape[0])) != 0:
@@ -315,6 +317,7 @@ class Scene:
         slots = dict(baseColor=0, emission=1, roughness=2, metalness=3, normal=4)
         if host_lib().rth_material_set_texture(self._h, int(material), slots[slot], int(texture), C.c_float(strength)) != 0:
             raise ValueError("bad material / texture id")
+        self.calls.append(("material_texture", dict(material=int(material), slot=slot, texture=int(texture), strength=float(strength))))
 
     def add_directional_light(self, color, angle_rad=0.2, transform=None):
         host_lib().rth_add_light_directional(self._h, _color(color), C.c_float(angle_rad), transform or _IDENTITY)

@@ -28,10 +28,31 @@ def available():
 
 def export_scene(path, scene, camera, width, height, passes, threads, max_ray_depth, min_rr_depth=1, dimensions=64, use_blue_noise=True,
                  light_sampling_all=False, aa_spread=0.5, seed=1234, dump_image=True):
-    materials, meshes, objects, lights = [], [], [], []
+    materials, meshes, objects, lights, textures = [], [], [], [], []
+    texture_index = {}     # the library's texture id -> index in the exported list
+    slots = dict(baseColor=0, emission=1, roughness=2, metalness=3, normal=4)
+    material_textures = {}  # material -> [five texture indices or -1, normalMapStrength]
     for kind, a in scene.calls:
+        if kind == "bitmap_texture":
+            # the reference's public API constructs a BitmapTexture with its default filter and no palette: only those are exported
+            if a["filter"] != "smoothstep" or a["has_palette"] or a["stride"] == 0:
+                raise ValueError("only plain bitmaps with the default filter are exported")
+            raw = a["pixels"].tobytes()
+            texture_index[a["id"]] = len(textures)
+            textures.append(struct.pack("<8I", a["width"], a["height"], scene.FORMATS[a["format"]], int(a["linear_space"]), a["stride"], len(raw), 0, 0) + raw + b"\0" * (-len(raw) % 4))
+        elif kind == "material_texture":
+            entry = material_textures.setdefault(a["material"], [-1, -1, -1, -1, -1, 1.0])
+            entry[slots[a["slot"]]] = texture_index[a["texture"]]
+            if a["slot"] == "normal":
+                entry[5] = a["strength"]
+    material_count = 0
+    for kind, a in scene.calls:
+        if kind in ("bitmap_texture", "material_texture"):
+            continue
         if kind == "material":
-            materials.append(struct.pack("<I10f", BSDF_IDS[a["bsdf"]], *a["base_color"], *a["emission"], a["roughness"], a["metalness"], a["ior"], a["k"]))
+            t = material_textures.get(material_count, [-1, -1, -1, -1, -1, 1.0])
+            material_count += 1
+            materials.append(struct.pack("<I10f5if", BSDF_IDS[a["bsdf"]], *a["base_color"], *a["emission"], a["roughness"], a["metalness"], a["ior"], a["k"], *t[:5], t[5]))
         elif kind in ("sphere", "box", "rect"):
             p = {"sphere": [a.get("radius", 0.0), 0, 0, 0], "box": list(a.get("size", (0, 0, 0))) + [0], "rect": list(a.get("size", (0, 0))) + list(a.get("tex_scale", (1, 1)))}[kind]
             objects.append(struct.pack("<IiII4f16f", {"sphere": 0, "box": 1, "rect": 2}[kind], a["material"], 0, 0, *p, *a["transform"]))
@@ -65,12 +86,12 @@ def export_scene(path, scene, camera, width, height, passes, threads, max_ray_de
             raise ValueError("scene element %r is not exported" % kind)
     c = camera.settings
     with open(path, "wb") as f:
-        f.write(b"RTREF001")
+        f.write(b"RTREF002")
         f.write(struct.pack("<14I", width, height, passes, threads, max_ray_depth, min_rr_depth, dimensions, int(use_blue_noise), int(light_sampling_all),
                             len(materials), len(meshes), len(objects), len(lights), int(dump_image)))
-        f.write(struct.pack("<2fQ", aa_spread, 0.0, seed))
+        f.write(struct.pack("<2fQ2I", aa_spread, 0.0, seed, len(textures), 0))
         f.write(struct.pack("<3f3f2fI2fI", *c["translation"], *c["orientation_deg"], c["fov_rad"], c["aspect"], int(c["dof"]), c["focal_plane_distance"], c["aperture"], 0))
-        for group in (materials, meshes, objects, lights):
+        for group in (textures, materials, meshes, objects, lights):
             for blob in group:
                 f.write(blob)
 

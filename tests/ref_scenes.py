@@ -57,6 +57,45 @@ def mesh_single(aspect):
     return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
 
 
+def mesh_albedo(aspect):
+    """mesh_single with an albedo map on every material -- 24-bit BGR sRGB, BGRA8 linear and RGBA8 sRGB in turn -- and no normal maps: nothing
+    on this path goes through an approximate instruction in the reference, so every pixel of its frame is expected."""
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(3000, seed=7, refine=True)
+    s = ra.Scene()
+    mats = [s.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    for i, m in enumerate(mats):
+        size = 40 + 12 * i
+        y, x = np.mgrid[0:size, 0:size]
+        fmt, channels, linear = [("B8G8R8_UNorm", 3, False), ("B8G8R8A8_UNorm", 4, True), ("R8G8B8A8_UNorm", 4, False)][i % 3]
+        texels = np.stack([140 + 110 * np.sin(x * (0.19 + 0.02 * i) + y * 0.23 + 1.3 * c) for c in range(channels)], axis=2).clip(0, 255).astype(np.uint8)
+        s.set_material_texture(m, "baseColor", s.add_bitmap_texture(texels, fmt, linear_space=linear))
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    s.add_background_light((1.0, 1.5, 2.0))
+    s.build()
+    return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+
+
+def mesh_textured(aspect):
+    """mesh_single WITH what Demo/MeshLoader.cpp gives a textured OBJ: an sRGB albedo map (24-bit BGR, as its .bmp files load) and a normal map
+    (BGRA8, linear) on every material, the BitmapTexture constructor's default filter -- the scene class the shading kernels serve with the
+    inlined bitmap evaluation ("lean + simple bitmaps")."""
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(3000, seed=7, refine=True)
+    rng = np.random.RandomState(17)
+    s = ra.Scene()
+    mats = [s.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    for i, m in enumerate(mats):
+        size = 48 + 8 * i
+        y, x = np.mgrid[0:size, 0:size]
+        albedo = np.stack([128 + 100 * np.sin(x * (0.21 + 0.03 * i) + y * 0.17 + c) for c in range(3)], axis=2).clip(0, 255).astype(np.uint8)
+        s.set_material_texture(m, "baseColor", s.add_bitmap_texture(albedo, "B8G8R8_UNorm", linear_space=False))
+        bump = (127.5 + 22.0 * rng.standard_normal((size, size, 4))).clip(0, 255).astype(np.uint8)
+        s.set_material_texture(m, "normal", s.add_bitmap_texture(bump, "B8G8R8A8_UNorm"), 0.75)
+    s.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    s.add_background_light((1.0, 1.5, 2.0))
+    s.build()
+    return s, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+
+
 # name -> (scene function, width, height, passes, maxRayDepth, lightSamplingAll, dimensions)
 FIXTURES = {
     "cornell": (cornell, 64, 48, 16, 4, False, 64),
@@ -65,5 +104,7 @@ FIXTURES = {
     "box_mesh": (box_mesh, 64, 48, 8, 5, False, 64),
     "mesh_2k_all": (mesh_2k, 64, 36, 8, 6, True, 128),
     "mesh_single": (mesh_single, 64, 36, 8, 6, False, 64),
+    "mesh_albedo": (mesh_albedo, 64, 36, 8, 6, False, 64),
+    "mesh_textured": (mesh_textured, 64, 36, 8, 2, False, 64),
 }
 SEED = 1234

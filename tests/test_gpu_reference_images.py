@@ -6,7 +6,7 @@ import pytest
 
 import ref_scenes
 import raytracer_amd as ra
-from test_reference_images import FLOORS, compare_with_reference, load_fixture
+from test_reference_images import COUNTER_TOL, FLOORS, compare_with_reference, load_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -22,4 +22,4 @@ def test_device_image_matches_the_reference_renderer(built, name, walk):
     vp.set_renderer(scene, intersection_counters=(walk == "counting"))     # CreateRenderer + SetRenderer + Reset, like the reference's callers
     vp.render(camera, fx["passes"])
     img = vp.sum_buffer()
-    compare_with_reference(fx, img, vp.counters(), FLOORS[name])
+    compare_with_reference(fx, img, vp.counters(), FLOORS[name], COUNTER_TOL.get(name, 0.001))

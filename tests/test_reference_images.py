@@ -1,5 +1,5 @@
 """Image-level parity against the REFERENCE'S OWN renderer.  tests/golden/ref_render/*.bin hold what rt::Viewport::Render ->
-rt::PathTracerMIS::RenderPixel -> the reference's traversal / shading object code rendered for five small scenes
+rt::PathTracerMIS::RenderPixel -> the reference's traversal / shading object code rendered for eight small scenes
 (tests/golden/make_ref_render_fixtures.py; oracle/ref_harness/ref_render.cpp says which few functions around them are glue): the float3
 sum buffer, the ray counters, and the first pass's sampler seeds and anti-aliasing offset.
 
@@ -46,10 +46,15 @@ def mirror_viewport(fx):
 
 # fraction of the pixels that must agree with the reference renderer's frame: measured 0.99349 / 0.99740 / 1.0 (oracle and device alike --
 # they are bit-identical to each other), floors a few pixels below
-FLOORS = {"cornell": 0.992, "cornell_two_lights_all": 0.996, "box_mesh": 1.0, "mesh_2k_all": 1.0, "mesh_single": 1.0, "sphere_area": 1.0}
+# mesh_textured (albedo + normal maps on every material): the albedo maps alone leave every pixel identical (sRGB and linear: measured 1.0); with
+# a normal map the reference normalises EVERY hit's mapped normal with _mm_rsqrt_ps (Scene.cpp:337, FastNormalized3: 12 bits), an exact operation
+# here, so every bounce direction differs in the fourth digit and one path in ~200 lands on another triangle: 90.6 % of the pixels agree to 1e-3
+# at 8 spp (median relative difference 2e-4), means within 0.4 %, ray counts within 0.04 %.  A wrong tangent-space convention would leave ~0 %.
+FLOORS = {"cornell": 0.992, "cornell_two_lights_all": 0.996, "box_mesh": 1.0, "mesh_2k_all": 1.0, "mesh_single": 1.0, "mesh_albedo": 1.0, "mesh_textured": 0.89, "sphere_area": 1.0}
+COUNTER_TOL = {"mesh_textured": 0.01}   # (2953 occluded shadow rays in that frame: the flipped paths move the count by 0.5 %); 0.001 elsewhere
 
 
-def compare_with_reference(fx, img, counters, floor=0.99):
+def compare_with_reference(fx, img, counters, floor=0.99, counter_tol=0.001):
     ref = fx["image"]
     close = np.abs(img - ref) <= 1e-3 * np.abs(ref) + 1e-3
     frac = float(close.all(axis=2).mean())
@@ -57,7 +62,7 @@ def compare_with_reference(fx, img, counters, floor=0.99):
     assert frac >= floor, "only %.2f %% of the pixels agree with the reference renderer (floor %.2f %%)" % (100 * frac, 100 * floor)
     assert np.all(np.abs(mean_img - mean_ref) <= 0.005 * mean_ref + 1e-6), (mean_img, mean_ref)
     for k in ("numRays", "numShadowRays", "numShadowRaysHit"):
-        assert abs(int(counters[k]) - fx[k]) <= 0.001 * fx[k] + 2, (k, int(counters[k]), fx[k])
+        assert abs(int(counters[k]) - fx[k]) <= counter_tol * fx[k] + 2, (k, int(counters[k]), fx[k])
     assert int(counters["numPrimaryRays"]) == fx["numPrimaryRays"]
     return frac
 
@@ -81,7 +86,7 @@ def test_pass_constants_and_oracle_image_match_the_reference_renderer(built, nam
             assert np.array_equal(np.array([p.sampleOffset[0], p.sampleOffset[1]], np.float32).view(np.uint32), fx["offset"].view(np.uint32)), "anti-aliasing offset differs"
         oracle_lib.render_pass(desc, p, fx["w"], fx["h"], img, None, cnt, threads=8)
     counters = {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:12])}
-    compare_with_reference(fx, img, counters, FLOORS[name])
+    compare_with_reference(fx, img, counters, FLOORS[name], COUNTER_TOL.get(name, 0.001))
 
 
 def test_cornell_statistics_of_the_survey(built):
