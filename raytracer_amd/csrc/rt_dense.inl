@@ -82,12 +82,6 @@ RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t 
 // The 2 x numLights request records of a vertex cannot wait in registers or LDS for its output slot, so they are written to the vertex's OWN
 // slot of the input arena first -- its previous requests were folded in at the top of the iteration, the space is free -- and copied to the
 // output slot once the block has allocated it (the copy reads what the same lane just wrote: L2 hits).
-// Occupancy the register allocator is held to per scene class: "lean + simple bitmaps" needs 135 VGPRs on its own and fits four waves per SIMD with
-// 8-16 bytes of scratch (measured +4 % end to end on the textured Sponza-class scene); "lean + textures" 173 -> 168 = three waves (+8 %), "anything"
-// 192 -> 168 = three waves (+1.5 %); the lean and the untextured classes keep what they get (forcing THEM further was slower,
-// profiles/r03_shade_variants.txt).
-#define RT_SHADE_MIN_WAVES(k, all) ((k) == 4 ? 4 : (((k) == 2 || ((k) == 0 && !(all))) ? 3 : 1))   // ("anything" under `All`: 216 VGPRs, left alone)
-#define RT_DENSE_MAX_LIGHTS 7u   // 256 vertices x 7 requests fit the block's append buffer between two flushes
 template <int kLean, bool kPlain = false, bool kAll = false>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_MIN_WAVES(kLean, kAll), RT_SHADE_MIN_WAVES(kLean, kAll) > 1 ? RT_SHADE_MIN_WAVES(kLean, kAll) : 10))) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
                                                           const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,

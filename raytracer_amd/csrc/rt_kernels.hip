@@ -36,129 +36,7 @@
 
 using namespace rtd;
 
-// =====================================================================================================
-// Device-side data
-// =====================================================================================================
-// Path state lives in HBM as 16-byte RECORDS, one array per record kind (record-major, slot-minor): a lane moves a
-// whole record with one dwordx4 access, a wave's accesses to consecutive slots coalesce into 1 KB, and a path
-// vertex touches 7-9 arrays (and as many DRAM pages / TLB entries) instead of 34 scalar planes.
-enum PathRecord : uint32_t
-{
-    R_ORIGIN,    // ray origin xyz BEFORE the 1e-3 offset | flags: depth (bits 0-7), lastSpecular << 8, (previous vertex's material + 1) << 9
-    R_DIR,       // ray direction xyz as passed to Ray()   | lastPdfW
-    R_TP,        // throughput (4 lanes: RayColor::AlmostZero tests all four)
-    R_RESULT,    // accumulated radiance rgb of this path  | pixel: x | y << 16
-    R_HIT,       // objectId, subObjectId, distance, u
-    R_SAMPLER,   // hit v | GenericSampler salt, generated | number of NEE requests pending for this vertex
-    R_RNG,       // per-pixel xoroshiro128+ state (2 x 64 bit)
-    R_SH_P,      // shading point xyz (shadow ray origin before the 1e-4 offset)
-    R_SH_TP,     // throughput at the vertex (the NEE fma uses it)
-    R_NUM_BASE
-};
-// per NEE request two records, light-major: {direction xyz, tmax (< 0: no ray / occluded)}, {contribution rgb, -}
-#define RT_SHADOW_RECORDS 2
-
-struct Paths
-{
-    float4* base;       // (R_NUM_BASE + maxLights * RT_SHADOW_RECORDS) * capacity records
-    uint32_t capacity;
-    uint32_t maxLights; // NEE requests per vertex (1 for LightSamplingStrategy::Single)
-};
-
-RT_DEV float4& prec(const Paths& p, uint32_t record, uint32_t slot) { return p.base[(size_t)record * p.capacity + slot]; }
-RT_DEV float4& pshadow(const Paths& p, uint32_t light, uint32_t k, uint32_t slot)
-{
-    return p.base[((size_t)R_NUM_BASE + (size_t)light * RT_SHADOW_RECORDS + k) * p.capacity + slot];
-}
-RT_DEV float4 f4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
-// Path records are STREAMED: a bounce reads a record once and writes its successor once, gigabytes per launch, through the same 4 MB-per-XCD
-// L2 that holds the scene's nodes, triangles and shading records.  Non-temporal accesses keep the stream from evicting the geometry.
-#ifndef RT_STREAMING_HINTS
-#define RT_STREAMING_HINTS 1
-#endif
-typedef float rt_float4v __attribute__((ext_vector_type(4)));
-RT_DEV float4 ldStream(const float4& r)
-{
-#if RT_STREAMING_HINTS
-    const rt_float4v v = __builtin_nontemporal_load(reinterpret_cast<const rt_float4v*>(&r));
-    return f4(v.x, v.y, v.z, v.w);
-#else
-    return r;
-#endif
-}
-RT_DEV void stStream(float4& r, const float4& v)
-{
-#if RT_STREAMING_HINTS
-    const rt_float4v t = { v.x, v.y, v.z, v.w };
-    __builtin_nontemporal_store(t, reinterpret_cast<rt_float4v*>(&r));
-#else
-    r = v;
-#endif
-}
-RT_DEV float fbits(uint32_t u) { return __uint_as_float(u); }
-RT_DEV uint32_t ubits(float f) { return __float_as_uint(f); }
-
-struct DevPass
-{
-    RtCamera camera;
-    const uint32_t* seed;
-    uint32_t numDimensions;
-    uint32_t blueNoiseLayers;
-    float sampleOffset[2];
-    uint32_t passIndex;
-    uint32_t maxRayDepth;
-    uint32_t minRussianRouletteDepth;
-    uint32_t lightSamplingStrategy;
-    float lightSamplingWeight[4];
-    float bsdfSamplingWeight[4];
-    uint64_t rngKey[2];
-    uint32_t width, height;
-};
-
-#define RT_BLOCK 256
-
-// per-block counter flush: LDS tally, then one 64-bit atomic per counter per block
-RT_DEV void flushCounters(const Counters& c, unsigned long long* global)
-{
-    __shared__ uint32_t sC[RT_NUM_COUNTERS];
-    if (threadIdx.x < RT_NUM_COUNTERS) sC[threadIdx.x] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < RT_NUM_COUNTERS; ++k) if (c.c[k]) atomicAdd(&sC[k], c.c[k]);
-    __syncthreads();
-    if (threadIdx.x < RT_NUM_COUNTERS && sC[threadIdx.x]) atomicAdd(&global[threadIdx.x], (unsigned long long)sC[threadIdx.x]);
-}
-RT_DEV void zeroCounters(Counters& c) {
-#pragma unroll
-    for (int k = 0; k < RT_NUM_COUNTERS; ++k) c.c[k] = 0;
-}
-
-// GenericSampler + per-pixel RNG state of a path (R_SAMPLER.yz, R_RNG); `sampler` is the record already loaded
-RT_DEV void loadSampler(Sampler& s, const Paths& p, uint32_t slot, uint32_t pix, const float4& sampler, const DevPass& pass, const uint16_t* blueNoise)
-{
-    s.seed = pass.seed; s.numDims = pass.numDimensions; s.blueNoiseLayers = pass.blueNoiseLayers; s.blueNoise = blueNoise;
-    s.bx = (pix & 0xFFFFu) & 127u; s.by = (pix >> 16) & 127u;
-    s.salt = ubits(sampler.y); s.generated = ubits(sampler.z);
-    const float4 rng = prec(p, R_RNG, slot);
-    s.fallback.s[0] = (uint64_t)ubits(rng.x) | ((uint64_t)ubits(rng.y) << 32);
-    s.fallback.s[1] = (uint64_t)ubits(rng.z) | ((uint64_t)ubits(rng.w) << 32);
-}
-RT_DEV void storeSampler(const Sampler& s, const Paths& p, uint32_t slot, float hitV, uint32_t pendingRequests)
-{
-    prec(p, R_SAMPLER, slot) = f4(hitV, fbits(s.salt), fbits(s.generated), fbits(pendingRequests));
-    prec(p, R_RNG, slot) = f4(fbits((uint32_t)s.fallback.s[0]), fbits((uint32_t)(s.fallback.s[0] >> 32)),
-                              fbits((uint32_t)s.fallback.s[1]), fbits((uint32_t)(s.fallback.s[1] >> 32)));
-}
-
-// The path's current ray exactly as the reference holds it: Ray(origin, direction) -- which normalises and
-// computes invDir / originDivDir from the UN-offset origin -- and then origin += dir * 0.001f for
-// secondary rays, leaving originDivDir stale (PathTracerMIS.cpp:392-393).
-RT_DEV Ray makePathRay(const float4& origin, const float4& dir, uint32_t depth)
-{
-    Ray ray = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));
-    if (depth > 0) ray.origin = ray.origin + ray.dir * 0.001f;
-    return ray;
-}
+#include "rt_device_state.h"
 
 // =====================================================================================================
 // Kernels
@@ -233,41 +111,6 @@ RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSiz
     if (chunk.end < chunk.next) chunk.end = chunk.next;
 }
 
-// ---- dense path state (rt_dense.inl): an arena is RT_DENSE_SHARDS regions, region s holds its live paths upwards from s * shardCapacity ----
-#define RT_DENSE_SHARDS 16u
-
-struct DenseCounts
-{
-    const uint32_t* in;     // [0, 16): live paths per region of the arena being read; [16, 32): zombies per region
-    uint32_t* out;          // the same for the arena being written (zeroed by the host)
-    uint32_t shardCapacity;
-    uint32_t* errorFlags;   // host-visible words of the context (RtgpuContext::deviceFlags): [0] != 0 = a region of the arena overflowed
-};
-
-// prefix sums of the 16 region counts into LDS (prefix[16] = total); all threads of the block call it
-RT_DEV void denseLoadPrefix(const uint32_t* __restrict__ counts, uint32_t* sPrefix)
-{
-    if (threadIdx.x == 0)
-    {
-        uint32_t sum = 0;
-        for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s) { sPrefix[s] = sum; sum += counts[s]; }
-        sPrefix[RT_DENSE_SHARDS] = sum;
-    }
-}
-RT_DEV uint32_t denseRegionOf(const uint32_t* sPrefix, uint32_t idx)
-{
-    uint32_t s = idx >= sPrefix[8] ? 8u : 0u;
-    s += idx >= sPrefix[s + 4u] ? 4u : 0u;
-    s += idx >= sPrefix[s + 2u] ? 2u : 0u;
-    s += idx >= sPrefix[s + 1u] ? 1u : 0u;
-    return s;
-}
-// slot of the idx-th live path
-RT_DEV uint32_t denseLiveSlot(const uint32_t* sPrefix, uint32_t shardCapacity, uint32_t idx)
-{
-    const uint32_t s = denseRegionOf(sPrefix, idx);
-    return s * shardCapacity + (idx - sPrefix[s]);
-}
 
 #define RT_SPLIT_AFTER 32u   // drain iterations of a wave before its shadow rays start sharing subtrees
 
@@ -681,419 +524,7 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
 #include "rt_trace_wide.inl"
 #include "rt_trace_wide2.inl"
 
-RT_DEV float CombineMis(float samplePdf, float otherPdf) { return FastDivide(samplePdf, samplePdf + otherPdf); }        // PathTracerMIS.cpp:16-24
-RT_DEV float PdfAtoW(float pdfA, float distance, float cosThere) { return FastDivide(pdfA * Sqr(distance), Abs(cosThere)); }   // :26-29
-
-// PathTracerMIS::SampleLight up to the shadow ray (PathTracerMIS.cpp:43-79, 97-119): produces the NEE
-// request {direction, tmax, contribution}; the occlusion test and the accumulation happen in k_trace_shadow.
-template <int kLean>
-__device__ __forceinline__ static bool computeLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
-                               const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
-                               float4& outDirTmax, float4& outContribution)
-{
-    float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
-    float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
-    IlluminateResult ir;
-    const V4 radiance = lightIlluminate<kLean>(scene, light, sd.intersection, u, ir);
-    if (!almostZero4(radiance))
-    {
-        float bsdfPdfW = 0.0f;
-        const V4 factor = materialEvaluate<kLean>(mat, sd, neg(ir.directionToLight), bsdfPdfW);
-        if (!almostZero4(factor))
-        {
-            float weight = 1.0f;
-            const bool isLastPathSegment = depth >= pass.maxRayDepth;
-            if (!(light.flags & RT_LIGHT_FLAG_DELTA) && !isLastPathSegment)
-            {
-                const float continuationProbability = 1.0f;
-                bsdfPdfW *= continuationProbability;
-                weight = CombineMis(ir.directPdfW * lightPickProbability, bsdfPdfW);
-            }
-            contribution = (radiance * factor) * FastDivide(weight, lightPickProbability * ir.directPdfW);
-            dir = ir.directionToLight;
-            tmax = ir.distance * 0.999f;
-        }
-    }
-    outDirTmax = f4(dir.x, dir.y, dir.z, tmax);
-    outContribution = f4(contribution.x, contribution.y, contribution.z, 0.0f);
-    return tmax >= 0.0f;   // a shadow ray has to be traced for this request
-}
-template <int kLean>
-__device__ __forceinline__ static bool prepareLightSample(const RtSceneDesc& scene, const DevPass& pass, Sampler& sampler, const RtLight& light,
-                               const ShadingData& sd, const RtMaterial& mat, uint32_t depth, float lightPickProbability,
-                               const Paths& paths, uint32_t slot, uint32_t requestIndex)
-{
-    float4 dirTmax, contribution;
-    const bool ray = computeLightSample<kLean>(scene, pass, sampler, light, sd, mat, depth, lightPickProbability, dirTmax, contribution);
-    pshadow(paths, requestIndex, 0, slot) = dirTmax;
-    pshadow(paths, requestIndex, 1, slot) = contribution;
-    return ray;
-}
-
-// Folds the finished NEE requests of the path's previous vertex into its radiance:
-// accumulatedColor = sum of the unoccluded SampleLight() results in light order, times mLightSamplingWeight,
-// then resultColor.MulAndAccumulate(throughput, ...) (PathTracerMIS.cpp:141-151, 320).  k_trace_shadow marks
-// occluded requests with tmax < 0.
-RT_DEV void resolvePendingLightSamples(const Paths& paths, uint32_t slot, uint32_t numRequests, V4 lightSamplingWeight, V4& resultColor, Counters& cnt)
-{
-    if (numRequests == 0) return;
-    V4 accumulated = zero4();
-    bool any = false;
-    for (uint32_t l = 0; l < numRequests; ++l)
-    {
-        if (pshadow(paths, l, 0, slot).w < 0.0f) continue;   // no shadow ray was needed, or k_trace found an occluder
-        const float4 c = pshadow(paths, l, 1, slot);
-        accumulated = accumulated + V4(c.x, c.y, c.z, 0.0f);
-        any = true;
-        cnt.c[C_SHADOW_HIT]++;   // counters.numShadowRaysHit: the shadow ray reached the light (PathTracerMIS.cpp:96-99)
-    }
-    if (!any) return;
-    accumulated = accumulated * lightSamplingWeight;
-    const float4 tp = prec(paths, R_SH_TP, slot);
-    resultColor = mulAdd(V4(tp.x, tp.y, tp.z, 0.0f), accumulated, resultColor);
-}
-
-#define RT_APPEND_BUFFER 2048u
-
-// Publishes a block's LDS append buffer with ONE global atomic and coalesced stores.  Called by all threads of
-// the block at a block-uniform point (after a __syncthreads()).
-RT_DEV void flushAppendBuffer(const uint32_t* buf, uint32_t& count, uint32_t& base, uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount)
-{
-    const uint32_t n = count;
-    if (n != 0)
-    {
-        if (threadIdx.x == 0) base = atomicAdd(queueCount, n);
-        __syncthreads();
-        const uint32_t b = base;
-        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) queue[b + k] = buf[k];
-        __syncthreads();
-        if (threadIdx.x == 0) count = 0;
-    }
-    __syncthreads();
-}
-
-// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395).
-// kPlain: the renderer "Path Tracer" instead (PathTracer::RenderPixel, Core/Rendering/PathTracer.cpp:73-171): the same walk without
-// next event estimation, MIS weights and sampling weights.
-template <bool kLean, bool kPlain = false>
-__global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
-                                                    const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
-                                                    uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
-                                                    uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
-                                                    unsigned long long* counters)
-{
-    __shared__ uint32_t sPathBuf[RT_APPEND_BUFFER], sShadowBuf[RT_APPEND_BUFFER];
-    __shared__ uint32_t sPathCount, sShadowCount, sPathBase, sShadowBase;
-    if (threadIdx.x == 0) { sPathCount = 0; sShadowCount = 0; }
-    __syncthreads();
-    Counters cnt; zeroCounters(cnt);
-    const uint32_t count = *countIn;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // the structural parameters are identical for all passes of a batch (the host flushes when they change);
-    // seeds, camera, anti-aliasing offset and rng keys are per pass
-    const DevPass pass = passes[0];
-    const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
-    // GetLightPickingProbability, PathTracerMIS.cpp:157-172
-    const float lightPickProbability = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1.0f / (float)scene.numLights : 1.0f;
-    const uint32_t maxRequestsPerVertex = pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE ? 1u : (scene.numLights < 8u ? scene.numLights : 8u);
-
-    // every lane of a wave runs the same number of iterations so that the ballot below sees whole waves
-    const uint32_t rounded = (count + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += stride)
-    {
-        bool alive = false;
-        uint32_t slot = 0;
-        unsigned long long rayMask = 0ull;   // NEE requests of this vertex that need a shadow ray (bit = request index)
-        if (i < count)
-        {
-            slot = queueIn[i];
-            const float4 rOrigin = prec(paths, R_ORIGIN, slot), rDir = prec(paths, R_DIR, slot), rTp = prec(paths, R_TP, slot);
-            const float4 rResult = prec(paths, R_RESULT, slot), rHit = prec(paths, R_HIT, slot), rSampler = prec(paths, R_SAMPLER, slot);
-            const uint32_t flags = ubits(rOrigin.w);
-            uint32_t depth = flags & 0xFFu;
-            const bool lastSpecular = (flags & 0x100u) != 0;
-            const float lastPdfW = rDir.w;
-            const uint32_t pix = ubits(rResult.w);
-            const Ray ray = makePathRay(rOrigin, rDir, depth);
-            V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
-            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-            resolvePendingLightSamples(paths, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
-            Hit hit;
-            hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
-            bool samplerStored = false;
-
-            do
-            {
-                if (hit.objectId == RT_INVALID_OBJECT)
-                {
-                    // EvaluateGlobalLights, PathTracerMIS.cpp:214-252
-                    V4 result = zero4();
-                    for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
-                    {
-                        const RtLight& light = scene.lights[scene.globalLights[g]];
-                        const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
-                        float directPdfW = 0.0f;
-                        const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
-                        if (kPlain) result = result + lightContribution;   // PathTracer::EvaluateGlobalLights, PathTracer.cpp:47-71
-                        else if (!almostZero4(lightContribution))
-                        {
-                            float misWeight = 1.0f;
-                            if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
-                            result = mulAdd(lightContribution, misWeight, result);
-                        }
-                    }
-                    if (!kPlain) result = result * bsdfSamplingWeight;
-                    resultColor = mulAdd(throughput, result, resultColor);
-                    break;
-                }
-
-                ShadingData sd;
-                // The reference keeps ONE ShadingData for the whole path (PathTracerMIS.cpp:258) and LightSceneObject::
-                // EvaluateIntersection does not touch `material` (SceneObject_Light.cpp:62-73): when a path hits an area light,
-                // IntersectionData::material is still the PREVIOUS vertex's, and its normal map (if any) is applied to the
-                // light's frame (Scene.cpp:327).  The previous material rides in the flags word: (index + 1) << 9.
-                sd.intersection.material = (flags >> 9) - 1u;   // 0 -> RT_NO_MATERIAL
-                if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
-
-                if (!kLean && hit.subObjectId == RT_LIGHT_OBJECT)
-                {
-                    // EvaluateLight, PathTracerMIS.cpp:174-212
-                    const RtObject& obj = scene.objects[hit.objectId];
-                    const RtLight& light = scene.lights[obj.lightIndex];
-                    const M4 worldToLight = loadM4(obj.invTransform);
-                    const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
-                    const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
-                    const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
-                    float directPdfA = 0.0f;
-                    V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
-                    if (kPlain) resultColor = mulAdd(throughput, lightContribution, resultColor);   // PathTracer::EvaluateLight, PathTracer.cpp:26-45
-                    else if (!almostZero4(lightContribution))
-                    {
-                        float misWeight = 1.0f;
-                        if (depth > 0 && !lastSpecular)
-                        {
-                            const float directPdfW = PdfAtoW(directPdfA, hit.distance, cosAtLight);
-                            misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
-                        }
-                        lightContribution = lightContribution * bsdfSamplingWeight;
-                        resultColor = mulAdd(throughput, lightContribution * misWeight, resultColor);
-                    }
-                    else
-                    {
-                        resultColor = mulAdd(throughput, zero4(), resultColor);
-                    }
-                    break;
-                }
-
-                sd.outgoingDirWorldSpace = neg(ray.dir);
-                const RtMaterial& mat = scene.materials[sd.intersection.material];
-                materialEvaluateShadingData<kLean>(scene, mat, sd);
-
-                // emission, PathTracerMIS.cpp:309-317
-                resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);
-
-                Sampler sampler; loadSampler(sampler, paths, slot, pix, rSampler, pass, scene.blueNoise);
-                sampler.seed = passes[slot / slotsPerPass].seed;
-
-                // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
-                uint32_t numRequests = 0;
-                if (!kPlain && scene.numLights != 0)
-                {
-                    if (pass.lightSamplingStrategy == RT_LIGHT_SAMPLING_SINGLE)
-                    {
-                        uint32_t lightIndex = 0;
-                        if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
-                        if (prepareLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, paths, slot, 0)) rayMask = 1ull;
-                        numRequests = 1;
-                    }
-                    else
-                    {
-                        for (uint32_t l = 0; l < scene.numLights; ++l)
-                        {
-                            const bool ray = prepareLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, paths, slot, l);
-                            if (ray)
-                            {
-                                if (l < 8u) rayMask |= 1ull << l;
-                                else shadowQueue[atomicAdd(shadowCount, 1u)] = l * paths.capacity + slot;   // more than 64 lights: per-lane append
-                            }
-                        }
-                        numRequests = scene.numLights;
-                    }
-                    prec(paths, R_SH_P, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
-                    prec(paths, R_SH_TP, slot) = f4(throughput.x, throughput.y, throughput.z, 0.0f);
-                }
-
-                bool cont = true;
-                if (depth >= pass.maxRayDepth) cont = false;
-
-                // Russian roulette, PathTracerMIS.cpp:330-347
-                if (cont && depth >= pass.minRussianRouletteDepth)
-                {
-                    const float minColorValue = 0.125f;
-                    const float threshold = minColorValue + (1.0f - minColorValue) * colorMax(sd.mp.baseColor);
-                    if (sampler.getFloat() > threshold) cont = false;
-                    else throughput = throughput * (1.0f / threshold);
-                }
-
-                // BSDF sampling, PathTracerMIS.cpp:349-395
-                if (cont)
-                {
-                    float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
-                    float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
-                    const V4 bsdfValue = materialSample<kLean>(mat, sd, u, incomingDirWorldSpace, pdf, event);
-                    if (event == EV_NULL) cont = false;
-                    else
-                    {
-                        throughput = throughput * bsdfValue;
-                        if (almostZero4(throughput)) cont = false;
-                        else
-                        {
-                            prec(paths, R_ORIGIN, slot) = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
-                                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
-                            prec(paths, R_DIR, slot) = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
-                            prec(paths, R_TP, slot) = f4(throughput.x, throughput.y, throughput.z, throughput.w);
-                            alive = true;
-                        }
-                    }
-                }
-                storeSampler(sampler, paths, slot, hit.v, numRequests);
-                samplerStored = true;
-            } while (false);
-
-            if (!samplerStored && ubits(rSampler.w) != 0u) prec(paths, R_SAMPLER, slot).w = fbits(0u);   // the resolved requests are spent
-            prec(paths, R_RESULT, slot) = f4(resultColor.x, resultColor.y, resultColor.z, rResult.w);
-            if (!alive) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
-        }
-
-        // Queue appends go through per-block LDS buffers: a returning atomic on ONE global word sustains only ~88
-        // operations per microsecond on this chip, so per-wave appends (hundreds of thousands per launch) would
-        // dominate the kernel; a block publishes ~RT_APPEND_BUFFER entries per global atomic instead.
-        for (unsigned long long pending = rayMask; pending != 0ull; pending &= pending - 1ull)
-        {
-            const uint32_t l = (uint32_t)(__ffsll((long long)pending) - 1);
-            sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * paths.capacity + slot;
-        }
-        if (alive) sPathBuf[atomicAdd(&sPathCount, 1u)] = slot;
-        __syncthreads();
-        // flush when the next iteration could overflow a buffer (wave-uniform decision on block-shared counters)
-        const bool last = (i - threadIdx.x) + stride >= rounded;
-        if (last || sPathCount + RT_BLOCK > RT_APPEND_BUFFER) flushAppendBuffer(sPathBuf, sPathCount, sPathBase, queueOut, countOut);
-        if (last || sShadowCount + RT_BLOCK * maxRequestsPerVertex > RT_APPEND_BUFFER) flushAppendBuffer(sShadowBuf, sShadowCount, sShadowBase, shadowQueue, shadowCount);
-    }
-    flushCounters(cnt, counters);
-}
-
-// DebugRenderer::RenderPixel after the primary ray's traversal (Core/Rendering/DebugRenderer.cpp:26-195, renderer "Debug"): one colour
-// per pixel from the first hit.  mode = DebugRenderingMode (DebugRenderer.h:7-33; the four counter modes exist only under
-// RT_ENABLE_INTERSECTION_COUNTERS, off in the reference).
-enum { DBG_CAMERA_LIGHT = 0, DBG_TRIANGLE_ID, DBG_DEPTH, DBG_POSITION, DBG_NORMALS, DBG_TANGENTS, DBG_BITANGENTS, DBG_TEXCOORDS,
-       DBG_BASE_COLOR, DBG_EMISSION, DBG_ROUGHNESS, DBG_METALNESS, DBG_IOR, DBG_NUM_MODES };
-RT_DEV V4 hsvToRgb(float hue, float saturation, float value)   // Core/Color/ColorHelpers.h:133-156
-{
-    const int h_i = (int)(hue * 6.0f);
-    const float f = hue * 6 - h_i;
-    const float p = value * (1 - saturation);
-    const float q = value * (1 - f * saturation);
-    const float t = value * (1 - (1 - f) * saturation);
-    if (h_i == 0) return V4(value, t, p, 0.0f);
-    else if (h_i == 1) return V4(q, value, p, 0.0f);
-    else if (h_i == 2) return V4(p, value, t, 0.0f);
-    else if (h_i == 3) return V4(p, q, value, 0.0f);
-    else if (h_i == 4) return V4(t, p, value, 0.0f);
-    else if (h_i == 5) return V4(value, p, q, 0.0f);
-    return zero4();
-}
-RT_DEV V4 debugTriangleIdColor(uint32_t objectId, uint32_t subObjectId)   // DebugRenderer.cpp:98-106
-{
-    const uint64_t hash = murmurFmix64((uint64_t)objectId | ((uint64_t)subObjectId << 32));
-    const float hue = (float)(uint32_t)hash / (float)UINT32_MAX;
-    const float saturation = 0.5f + 0.5f * (float)(uint32_t)(hash >> 32) / (float)UINT32_MAX;
-    return hsvToRgb(hue, saturation, 1.0f);
-}
-__global__ void __launch_bounds__(RT_BLOCK) k_debug_shade(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
-                                                          uint32_t mode, unsigned long long* counters)
-{
-    Counters cnt; zeroCounters(cnt);
-    const uint32_t count = *countIn;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
-    {
-        const uint32_t slot = queueIn[i];
-        const float4 rOrigin = prec(paths, R_ORIGIN, slot), rDir = prec(paths, R_DIR, slot), rHit = prec(paths, R_HIT, slot);
-        const Ray ray = makePathRay(rOrigin, rDir, 0u);
-        Hit hit; hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = prec(paths, R_SAMPLER, slot).x;
-        V4 color = zero4();
-        if (hit.objectId != RT_INVALID_OBJECT)
-        {
-            if (hit.subObjectId == RT_LIGHT_OBJECT) color = V4(1.0f, 1.0f, 0.0f, 0.0f);
-            else
-            {
-                ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
-                if (mode != DBG_TRIANGLE_ID && mode != DBG_DEPTH)
-                {
-                    if (hit.distance < FLT_MAX) sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
-                    materialEvaluateShadingData<false>(scene, scene.materials[sd.intersection.material], sd);
-                }
-                switch (mode)
-                {
-                case DBG_CAMERA_LIGHT: { const float NdotL = dot3(ray.dir, sd.intersection.frame.r[2]); color = sd.mp.baseColor * Abs(NdotL); break; }
-                case DBG_DEPTH: { const float invDepth = 1.0f - 1.0f / (1.0f + hit.distance / 10.0f); color = splat(invDepth); break; }
-                case DBG_TRIANGLE_ID:
-                {
-                    color = debugTriangleIdColor(hit.objectId, hit.subObjectId);
-                    break;
-                }
-                case DBG_TANGENTS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[0], splat(0.5f), splat(0.5f)))); break;
-                case DBG_BITANGENTS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[1], splat(0.5f), splat(0.5f)))); break;
-                case DBG_NORMALS: color = min4(splat(1.0f), max4(zero4(), mulAdd(sd.intersection.frame.r[2], splat(0.5f), splat(0.5f)))); break;
-                case DBG_POSITION: color = max4(zero4(), sd.intersection.frame.r[3]); break;
-                case DBG_TEXCOORDS: color = V4(sd.intersection.texCoord.x - floorf(sd.intersection.texCoord.x), sd.intersection.texCoord.y - floorf(sd.intersection.texCoord.y), 0.0f, 0.0f); break;
-                case DBG_BASE_COLOR: color = sd.mp.baseColor; break;
-                case DBG_EMISSION: color = sd.mp.emission; break;
-                case DBG_ROUGHNESS: color = splat(sd.mp.roughness); break;
-                case DBG_METALNESS: color = splat(sd.mp.metalness); break;
-                default: color = splat(sd.mp.IoR); break;
-                }
-            }
-        }
-        prec(paths, R_RESULT, slot) = f4(color.x, color.y, color.z, prec(paths, R_RESULT, slot).w);
-    }
-    flushCounters(cnt, counters);
-}
-
-// Film::AccumulateColor (Film.cpp:25-39): float3 sum buffers, tight stride, row y = tile row y.  The passes of a
-// batch are added per pixel IN PASS ORDER, so the float sum is the one the reference builds pass after pass; the
-// secondary sum receives the even passes (Viewport.cpp:303).
-__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t slotsPerPass, uint32_t numPasses, float* __restrict__ sum,
-                                                         float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes,
-                                                         unsigned long long* counters)
-{
-    Counters cnt; zeroCounters(cnt);
-    const V4 lightSamplingWeight = load4(passes[0].lightSamplingWeight);
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t pixelSlot = blockIdx.x * blockDim.x + threadIdx.x; pixelSlot < slotsPerPass; pixelSlot += stride)
-    {
-        const uint32_t pix = ubits(prec(paths, R_RESULT, pixelSlot).w);
-        const size_t idx = 3 * ((size_t)(pix >> 16) * width + (pix & 0xFFFFu));
-        float sr = sum[idx + 0], sg = sum[idx + 1], sb = sum[idx + 2];
-        float tr = secondary[idx + 0], tg = secondary[idx + 1], tb = secondary[idx + 2];
-        for (uint32_t b = 0; b < numPasses; ++b)
-        {
-            const uint32_t slot = b * slotsPerPass + pixelSlot;
-            const float4 rResult = prec(paths, R_RESULT, slot);
-            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-            resolvePendingLightSamples(paths, slot, ubits(prec(paths, R_SAMPLER, slot).w), lightSamplingWeight, resultColor, cnt);   // NEE of the path's last vertex
-            sr = sr + resultColor.x; sg = sg + resultColor.y; sb = sb + resultColor.z;
-            if ((passes[b].passIndex % 2u) == 0u) { tr = tr + resultColor.x; tg = tg + resultColor.y; tb = tb + resultColor.z; }
-        }
-        sum[idx + 0] = sr; sum[idx + 1] = sg; sum[idx + 2] = sb;
-        secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
-    }
-    flushCounters(cnt, counters);
-}
-
-#include "rt_dense.inl"
-#include "rt_vcm.inl"
+#include "rt_shade_kernels.h"
 #include "rt_kat.inl"
 
 // Viewport::PostProcessTile (Viewport.cpp:495-550): sum buffer -> 0x00RRGGBB front buffer, one thread per pixel

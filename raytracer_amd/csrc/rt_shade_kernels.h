@@ -1,0 +1,52 @@
+// rt_shade_kernels.h -- declarations of the kernels rt_shade.hip defines, for the host side in rt_kernels.hip
+#pragma once
+#include "rt_vcm_state.h"
+
+template <bool kLean, bool kPlain = false>
+__global__ void __launch_bounds__(RT_BLOCK) k_shade(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
+                                                    const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                    uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                    uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                    unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_debug_shade(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                          uint32_t mode, unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint32_t slotsPerPass, uint32_t numPasses, float* __restrict__ sum,
+                                                         float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes,
+                                                         unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
+                                                             const uint32_t* __restrict__ slotPixel, uint32_t numSlots, uint32_t shardCapacity, uint32_t* __restrict__ counts,
+                                                             unsigned long long* counters);
+template <int kLean, bool kPlain = false, bool kAll = false>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_MIN_WAVES(kLean, kAll), RT_SHADE_MIN_WAVES(kLean, kAll) > 1 ? RT_SHADE_MIN_WAVES(kLean, kAll) : 10))) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
+                                                          const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                          float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds);
+__global__ void __launch_bounds__(RT_BLOCK) k_accumulate_home(const float4* __restrict__ home, const uint32_t* __restrict__ slotPixel, uint32_t slotsPerPass, uint32_t numPasses,
+                                                              float* __restrict__ sum, float* __restrict__ secondary, uint32_t width, const DevPass* __restrict__ passes);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const Paths cp,
+                                                       const VcmArena a, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
+                                                       uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
+                                                              const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                              uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                              uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                              float* __restrict__ sum, float* __restrict__ secondary, unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
+                                                       const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                       uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                       uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                       float* __restrict__ sum, float* __restrict__ secondary, unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_finish(const VcmBatch b, const Paths lp, uint32_t numSlots, float* __restrict__ sum,
+                                                               float* __restrict__ secondary, unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
+                                                               const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
+                                                               uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
+                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
+                                                               uint32_t* __restrict__ mergeQueue, uint32_t* __restrict__ mergeCount,
+                                                               uint32_t* __restrict__ connectQueue, uint32_t* __restrict__ connectCount, unsigned long long* counters);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_connect(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
+                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                          uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_merge(const RtSceneDesc scene, const VcmBatch b, const VcmArena a,
+                                                        const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, uint32_t cooperativeMin);
+__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_finish(const VcmBatch b, uint32_t numPasses, const Paths cp, const VcmArena a,
+                                                                float* __restrict__ sum, float* __restrict__ secondary, uint32_t width, unsigned long long* counters);

@@ -6,5 +6,9 @@ W=/tmp/variant_$name; rm -rf $W; mkdir -p $W/raytracer_amd
 cp -r /root/repo/raytracer_amd/csrc $W/raytracer_amd/csrc; cp -r /root/repo/include $W/include
 while [ $# -gt 0 ]; do f=$1; e=$2; shift; shift; sed -i "$e" $W/raytracer_amd/csrc/$f; done
 mkdir -p /root/repo/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -fvisibility=hidden $W/raytracer_amd/csrc/rt_kernels.hip $W/raytracer_amd/csrc/rt_vcm_photons.hip -o /root/repo/variants/librtgpu_$name.so
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden"
+/opt/rocm/bin/hipcc $F -mllvm -simplifycfg-sink-common=false -c $W/raytracer_amd/csrc/rt_shade.hip -o $W/rt_shade.o &
+/opt/rocm/bin/hipcc $F -c $W/raytracer_amd/csrc/rt_kernels.hip -o $W/rt_kernels.o
+wait
+/opt/rocm/bin/hipcc $F -shared $W/rt_kernels.o $W/rt_shade.o $W/raytracer_amd/csrc/rt_vcm_photons.hip -o /root/repo/variants/librtgpu_$name.so
 echo built variants/librtgpu_$name.so

@@ -4,10 +4,16 @@
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/rt_kernels_resources.s"
+s = ""
 if len(sys.argv) <= 1:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
-                           os.path.join(ROOT, "raytracer_amd/csrc/rt_kernels.hip"), "-o", path], stderr=subprocess.DEVNULL)
-s = open(path).read()
+    # the library's two device translation units, with the flags __graft_entry__.build() gives them
+    for unit, extra in (("rt_kernels.hip", []), ("rt_shade.hip", ["-mllvm", "-simplifycfg-sink-common=false"])):
+        out = "/tmp/%s_resources.s" % unit.split(".")[0]
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + extra + ["-S", "--cuda-device-only",
+                               os.path.join(ROOT, "raytracer_amd/csrc", unit), "-o", out], stderr=subprocess.DEVNULL)
+        s += open(out).read()
+else:
+    s = open(path).read()
 for m in re.finditer(r'\.name:\s+(\S+)\n(.*?)\.vgpr_count:\s+(\d+)', s, re.S):
     name, body = m.group(1), m.group(2)
     dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.split('(')[0].replace("void ", "")
