@@ -317,7 +317,13 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
         __syncthreads();
         // never outside the region (live paths grow upwards from its start, zombies downwards from its end); whether the two met is
         // checked on the final counts by the next launch's prologue above
-        if ((outcome == 1 && sLiveBase + rank >= dense.shardCapacity) || (outcome == 2 && sZombieBase + rank >= dense.shardCapacity)) { dense.errorFlags[0] = 1u; outcome = 0; }
+        if ((outcome == 1 && sLiveBase + rank >= dense.shardCapacity) || (outcome == 2 && sZombieBase + rank >= dense.shardCapacity)) 
+        {
+            // the vertex is dropped and the frame is invalid until the next reset (every synchronising call reports the flag); its home still gets what
+            // the path had gathered, so that k_accumulate_home never adds a previous batch's value
+            dense.errorFlags[0] = 1u; outcome = 0;
+            stStream(home[oHome], f4(oResult.x, oResult.y, oResult.z, 0.0f));
+        }
         if (outcome != 0)
         {
             const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);

@@ -1595,7 +1595,13 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
                 uint32_t lanesLeft = 0;
                 for (uint32_t i = 0; i < c->numLanes; ++i) if (!c->lanes[i].paths.base) lanesLeft++;
                 const size_t share = (size_t)((double)freeBytes * 0.9) / (lanesLeft ? lanesLeft : 1u);
-                if (share < c->laneBudgetBytes) { c->laneBudgetBytes = share; continue; }   // size the arenas again under the smaller budget
+                if (share < c->laneBudgetBytes)
+                {
+                    c->laneBudgetBytes = share;   // size the arenas again under the smaller budget
+                    if (c->passBatch > maxBatchFor(c, maxLights)) c->passBatch = maxBatchFor(c, maxLights);
+                    if (c->passBatchBase > c->passBatch) c->passBatchBase = c->passBatch;
+                    continue;
+                }
             }
         }
         const size_t cap = arenaCapacityFor(wanted);
@@ -1678,7 +1684,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 {
     if (c->pending.empty()) return RTGPU_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t numPasses = maxPasses && maxPasses < c->pending.size() ? maxPasses : (uint32_t)c->pending.size();
+    uint32_t numPasses = maxPasses && maxPasses < c->pending.size() ? maxPasses : (uint32_t)c->pending.size();
     const DevPass& first = c->pending[0].pass;
     const uint32_t maxLights = first.lightSamplingStrategy == RT_LIGHT_SAMPLING_ALL ? c->numLights : 1u;
     BatchLane& l = c->lanes[c->nextLane];
@@ -1688,6 +1694,17 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
     int r = RTGPU_OK;
     for (uint32_t i = 0; i < c->numLanes && r == RTGPU_OK; ++i) r = ensurePaths(c, c->lanes[i], maxLights, first.maxRayDepth);
     if (r) { c->pending.clear(); return r; }
+    // The arenas may have been sized under a budget that shrank at allocation (several contexts on one device, little free memory): the batch
+    // is what the lane's allocation holds, the rest stays queued for the next flush.
+    {
+        const size_t perPass = c->numSlots ? c->numSlots : 1u;
+        while (numPasses > 1u && (arenaCapacityFor(perPass * numPasses) > l.paths.capacity || (l.paths2.base && perPass * numPasses > l.homeCapacity))) --numPasses;
+        if (arenaCapacityFor(perPass * numPasses) > l.paths.capacity || (l.paths2.base && perPass * numPasses > l.homeCapacity))
+        {
+            c->pending.clear();
+            return fail(RTGPU_ERR_OUT_OF_MEMORY, "a batch lane's path-state arena does not hold one pass of this frame");
+        }
+    }
 
     // contiguous ring slots for the batch (seeds + pass constants); wait until their previous users have finished
     if (c->seedCursor + numPasses > RT_SEED_RING) c->seedCursor = 0;

@@ -17,7 +17,32 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_render   # noqa: E402
 import ref_scenes   # noqa: E402
 
+def write_fixture(name, w, h, passes, depth, sampling_all, dims, out):
+    with open(os.path.join(HERE, "ref_render", name + ".bin"), "wb") as f:
+        f.write(struct.pack("<8I", 0x31465252, w, h, passes, depth, int(sampling_all), dims, len(out["first_pass_seeds"])))
+        f.write(struct.pack("<4Q", out["numRays"], out["numPrimaryRays"], out["numShadowRays"], out["numShadowRaysHit"]))
+        f.write(out["first_pass_sample_offset"].astype("<f4").tobytes())
+        f.write(out["first_pass_seeds"].astype("<u4").tobytes())
+        f.write(out["image"].astype("<f4").tobytes())
+
+
+def make_statistical(names=None):
+    for name, (make, w, h, passes, depth, sampling_all, dims) in ref_scenes.STATISTICAL_FIXTURES.items():
+        if names and name not in names:
+            continue
+        scene, camera = make(w / h)
+        path = "/tmp/ref_fixture_%s.bin" % name
+        ref_render.export_scene(path, scene, camera, w, h, passes, 1, depth, dimensions=dims, light_sampling_all=sampling_all, seed=ref_scenes.SEED)
+        stats, out = ref_render.run(path, threads=1)       # one thread: the per-thread generator's light picks are then a function of the seed
+        os.remove(path)
+        write_fixture(name, w, h, passes, depth, sampling_all, dims, out)
+        print(name, stats["mean"], out["numRays"], out["numShadowRays"])
+
+
 if __name__ == "__main__":
+    make_statistical()
+    if len(sys.argv) > 1 and sys.argv[1] == "statistical":
+        sys.exit(0)
     for name, (make, w, h, passes, depth, sampling_all, dims) in ref_scenes.FIXTURES.items():
         scene, camera = make(w / h)
         path = "/tmp/ref_fixture_%s.bin" % name
@@ -26,10 +51,5 @@ if __name__ == "__main__":
         again, out2 = ref_render.run(path, threads=1)      # the result must not depend on the thread count
         assert np.array_equal(out["image"], out2["image"]), name
         os.remove(path)
-        with open(os.path.join(HERE, "ref_render", name + ".bin"), "wb") as f:
-            f.write(struct.pack("<8I", 0x31465252, w, h, passes, depth, int(sampling_all), dims, len(out["first_pass_seeds"])))
-            f.write(struct.pack("<4Q", out["numRays"], out["numPrimaryRays"], out["numShadowRays"], out["numShadowRaysHit"]))
-            f.write(out["first_pass_sample_offset"].astype("<f4").tobytes())
-            f.write(out["first_pass_seeds"].astype("<u4").tobytes())
-            f.write(out["image"].astype("<f4").tobytes())
+        write_fixture(name, w, h, passes, depth, sampling_all, dims, out)
         print(name, stats["mean"], out["numRays"], out["numShadowRays"])

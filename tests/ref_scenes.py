@@ -107,4 +107,12 @@ FIXTURES = {
     "mesh_albedo": (mesh_albedo, 64, 36, 8, 6, False, 64),
     "mesh_textured": (mesh_textured, 64, 36, 8, 2, False, 64),
 }
+# The headline's own light-picking mode: two lights under LightSamplingStrategy::Single.  The reference picks the light with its per-THREAD
+# generator (PathTracerMIS.cpp:136), so its frame is a function of the scene only at numThreads = 1, and this library (per-pixel generator)
+# cannot reproduce the picks: the comparison is statistical -- same estimator, independent picks, many passes.  The path GEOMETRY does not
+# depend on the pick (the sampler dimensions are consumed alike), so numRays is expected to agree like in the exact fixtures.
+# name -> (scene function, width, height, passes, maxRayDepth, lightSamplingAll, dimensions); rendered by the reference on ONE thread
+STATISTICAL_FIXTURES = {
+    "mesh_2k_single": (mesh_2k, 64, 36, 4096, 6, False, 64),
+}
 SEED = 1234

@@ -89,6 +89,45 @@ def test_pass_constants_and_oracle_image_match_the_reference_renderer(built, nam
     compare_with_reference(fx, img, counters, FLOORS[name], COUNTER_TOL.get(name, 0.001))
 
 
+def compare_statistically(fx, img, counters):
+    """Two lights under LightSamplingStrategy::Single: the reference's frame (one thread, per-thread generator) and ours (per-pixel generator)
+    pick different lights at every vertex -- independent estimates of the same image.  Stated tolerance at 4096 passes: image mean within
+    0.5 % per channel, means of 16 x 12-pixel blocks within 2 % (two of the REFERENCE'S OWN runs with different picks differ by 0.02 % / 0.6 %
+    there), numRays within 0.1 % (the path geometry does not depend on the pick), shadow-ray counters within 1 %."""
+    ref = fx["image"]
+    mean_ref, mean_img = ref.mean(axis=(0, 1)), img.mean(axis=(0, 1))
+    assert np.all(np.abs(mean_img - mean_ref) <= 0.005 * mean_ref), (mean_img, mean_ref)
+    h, w = ref.shape[:2]
+    blocks = lambda x: x.reshape(h // 12, 12, w // 16, 16, 3).mean(axis=(1, 3))
+    rel = np.abs(blocks(img) - blocks(ref)) / blocks(ref)
+    assert rel.max() <= 0.02, "block means differ from the reference renderer's by up to %.2f %%" % (100 * rel.max())
+    assert abs(int(counters["numRays"]) - fx["numRays"]) <= 0.001 * fx["numRays"], (int(counters["numRays"]), fx["numRays"])
+    for k in ("numShadowRays", "numShadowRaysHit"):
+        assert abs(int(counters[k]) - fx[k]) <= 0.01 * fx[k], (k, int(counters[k]), fx[k])
+    assert int(counters["numPrimaryRays"]) == fx["numPrimaryRays"]
+    return float(rel.max())
+
+
+@pytest.mark.parametrize("name", sorted(ref_scenes.STATISTICAL_FIXTURES))
+def test_oracle_matches_the_reference_renderer_statistically_under_single_with_two_lights(built, name):
+    """The headline workload's light-picking mode (PathTracerMIS.cpp:125-155 with `Single` and two lights), reference side: see compare_statistically."""
+    fx = load_fixture(name)
+    scene, camera = ref_scenes.STATISTICAL_FIXTURES[name][0](fx["w"] / fx["h"])
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    vp = mirror_viewport(fx)
+    img = np.zeros((fx["h"], fx["w"], 3), dtype=np.float32)
+    cnt = np.zeros(16, dtype=np.uint64)
+    for i in range(fx["passes"]):
+        p = vp.next_pass_params(camera)
+        if i == 0:
+            assert np.array_equal(np.ctypeslib.as_array(p.seed, shape=(p.numDimensions,)), fx["seeds"])
+        oracle_lib.render_pass(desc, p, fx["w"], fx["h"], img, None, cnt, threads=8)
+        ra.host_lib().rth_viewport_finish_pass(vp._h)   # the tail of Viewport::Render: the next pass gets its own per-pixel generator key
+    compare_statistically(fx, img, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:12])})
+
+
 def test_cornell_statistics_of_the_survey(built):
     """SURVEY section 6 measured the real reference on the Cornell box (640x480, 16 passes, depth 4): mean RGB 0.268601 / 0.220071 /
     0.262727, 3.1358 rays per path, 1.5628 shadow rays per path.  Different seed, same estimator: the oracle at 320x240 must land within
