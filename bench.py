@@ -390,10 +390,13 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     vp.render(camera, args.steps)
+    gather_s = 0.0
     if world > 1:
         lib.rtgpu_synchronize(ctx)
+        render_s = time.perf_counter() - t0     # this rank's own passes (the ranks finish at different times: load balance)
         gather.run()
         torch.cuda.synchronize()
+        gather_s = time.perf_counter() - t0 - render_s   # on rank 0 this includes waiting for the slowest peer
     if rank == 0:
         host.rth_viewport_fetch_sum(vp._h)   # Viewport::GetSumBuffer: synchronises, the frame is in the viewport's (page-locked) host bitmap afterwards
     sync_all()
@@ -438,7 +441,31 @@ def main():
         delta[k] = counted[k]
     own_counts = dict(delta)
 
+    scaling_report = None
     if world > 1:
+        # what a first measured curve needs to explain itself: every rank's share of the work and of the time, the exchange, and the proof that the
+        # assembled frame is the one-GPU frame
+        mine = torch.tensor([float(own_counts["numRays"]), float(own_counts["numShadowRays"]), render_s, gather_s, elapsed], dtype=torch.float64, device="cuda")
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        per_rank = [t.tolist() for t in per_rank]
+        scaling_report = {
+            "per_rank_numRays": [int(r[0]) for r in per_rank], "per_rank_numShadowRays": [int(r[1]) for r in per_rank],
+            "per_rank_render_ms": [round(1000.0 * r[2], 3) for r in per_rank], "per_rank_gather_ms": [round(1000.0 * r[3], 3) for r in per_rank],
+            "per_rank_timed_region_ms": [round(1000.0 * r[4], 3) for r in per_rank],
+            "load_imbalance_numRays": max(r[0] for r in per_rank) / (sum(r[0] for r in per_rank) / world),
+            "gather_bytes_per_peer": int(gather.pad * 12),
+        }
+        if rank == 0:
+            # the same warm-up + timed passes on ONE device, whole frame: the gathered frame must be that frame, bit for bit
+            whole = make_viewport(ra, args, scene, local_rank, None)
+            whole.render(camera, args.warmup + args.steps)
+            one_gpu = whole.sum_buffer()
+            del whole
+            scaling_report["frame_check"] = {"equal_to_one_gpu_replay": bool(np.array_equal(one_gpu.view(np.uint32), host_sum.view(np.uint32))),
+                                             "mean_gathered": float(host_sum.mean()), "mean_one_gpu": float(one_gpu.mean()),
+                                             "max_abs_diff": float(np.abs(one_gpu - host_sum).max())}
+            assert scaling_report["frame_check"]["mean_gathered"] == scaling_report["frame_check"]["mean_one_gpu"], scaling_report["frame_check"]
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -470,6 +497,8 @@ def main():
             "intersection_counters": "off in the timed region (reference default); counts from an identical instrumented replay",
             "image": {"finite": image_ok, "mean_per_pass": image_mean},
         }
+        if scaling_report:
+            out["multi_gpu"] = scaling_report
         # roofline of the dominant kernel class (rank 0's own launches and rank 0's own counters)
         abytes = algorithmic_bytes(own_counts)
         abytes_replay = algorithmic_bytes(counted_totals)   # warm-up + timed passes: what the replay's launches processed
@@ -623,12 +652,15 @@ def reference_baseline(args, scene, camera, ra):
     """oracle/_ref/ref_render (built by oracle/ref_harness from the reference's own sources where /root/reference exists; the binary
     travels, the sources do not).  Returns None when it is not there or does not support the workload."""
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_render")
-    if not os.path.exists(exe) or args.workload not in ("sponza", "cornell", "sphere"):
+    # every PathTracerMIS workload: the reference's objects render textured materials, an environment map and LightSamplingStrategy::All too
+    # (bdpt-glass: VertexConnectionAndMerging.cpp does not build here, DESIGN 3)
+    if not os.path.exists(exe) or args.workload not in ("sponza", "sponza-textured", "sponza-all", "cornell", "sphere", "zoo"):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     try:
         import ref_render
-        return ref_render.timed_baseline(exe, args, scene, camera, ra)
+        sampling_all = args.workload == "sponza-all"
+        return ref_render.timed_baseline(exe, args, scene, camera, ra, dimensions=128 if sampling_all else 64, light_sampling_all=sampling_all)
     except Exception as e:
         sys.stderr.write("reference baseline unavailable: %r\n" % (e,))
         return None

@@ -434,7 +434,7 @@ int main(int argc, char** argv)
     }
     for (uint32 i = 0; i < numLights; ++i)
     {
-        const uint32 kind = r.get<uint32>(), shapeKind = r.get<uint32>(); (void)r.get<uint32>(); (void)r.get<uint32>();
+        const uint32 kind = r.get<uint32>(), shapeKind = r.get<uint32>(), texturePlusOne = r.get<uint32>(); (void)r.get<uint32>();
         const float* c = r.array<float>(4); const float* p = r.array<float>(4); const Matrix4 transform = readMatrix(r);
         if (!r.ok) return 2;
         const Vector4 color(c[0], c[1], c[2], 0.0f);
@@ -443,7 +443,12 @@ int main(int argc, char** argv)
         else if (kind == 1) light = std::make_unique<PointLight>(color);
         else if (kind == 2) light = std::make_unique<SpotLight>(color, p[0]);
         else if (kind == 3) light = std::make_unique<DirectionalLight>(color, p[0]);
-        else if (kind == 4) light = std::make_unique<BackgroundLight>(color);
+        else if (kind == 4)
+        {
+            auto background = std::make_unique<BackgroundLight>(color);
+            if (texturePlusOne != 0u) { if (texturePlusOne > numTextures) return 2; background->mTexture = textures[texturePlusOne - 1u]; }   // environment map (BackgroundLight.h:16)
+            light = std::move(background);
+        }
         else return 2;
         auto object = std::make_unique<LightSceneObject>(std::move(light));
         object->SetTransform(transform);

@@ -1,4 +1,4 @@
-// rt_dense.inl -- PathTracerMIS / PathTracer passes with DENSE path state (LightSamplingStrategy::Single).  Included by rt_kernels.hip.
+// rt_dense.inl -- PathTracerMIS / PathTracer passes with DENSE path state (LightSamplingStrategy::Single).  Included by rt_shade.hip (and rt_tail.hip for the vertex body).
 //
 // The first layout kept a path in the slot of its pixel for its whole life: after a few bounces the live slots are sparse, every
 // 16-byte record access of k_shade pulls its own 64/128-byte line from HBM (measured: 3.1x the bytes the kernel needs, L2 hit rate
@@ -15,6 +15,7 @@
 //     film per pixel in pass order -- the float sums are those of the reference's pass-after-pass accumulation, whatever order the
 //     paths were compacted in.
 // Arithmetic and consumption order of the samples are those of k_shade (same functions, same sequence): the images are bit-identical.
+#ifndef RT_SHADE_FUNCTIONS_ONLY
 // k_generate for dense state: slot i = home i; the regions of the first arena are simply filled one after the other
 __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
                                                              const uint32_t* __restrict__ slotPixel, uint32_t numSlots, uint32_t shardCapacity, uint32_t* __restrict__ counts,
@@ -50,6 +51,179 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc s
     }
 }
 
+#endif   // RT_SHADE_FUNCTIONS_ONLY
+
+// What a vertex leaves behind (denseShadeVertex): outcome 0 nothing (its radiance is parked at home[]), 1 a live path, 2 a zombie (radiance + one
+// pending next-event request); the records of the survivor, for the caller to store -- k_shade_dense at a fresh dense slot of the other arena,
+// k_tail (rt_tail.hip) in place.
+struct DenseVertex
+{
+    uint32_t outcome;
+    float4 oOrigin, oDir, oTp, oResult, oSampler, oRng;
+    bool stagedShTp;     // stage[3][thread] holds R_SH_TP (throughput at the vertex | home); otherwise it is {0, 0, 0, home}
+    bool rayNeeded;      // the vertex's next-event request needs its shadow ray
+    uint32_t oHome, rayMask;
+};
+
+// The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395) over the records of arena `in` at `slot`;
+// kPlain: PathTracer::RenderPixel (Core/Rendering/PathTracer.cpp:73-171).  `stage` = four LDS rows of RT_BLOCK float4 (the next-event request
+// waits there, see k_shade_dense).
+template <int kLean, bool kPlain, bool kAll>
+__device__ __forceinline__ static void denseShadeVertex(const RtSceneDesc& scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const DevPass& pass, const Paths& in,
+                                                        uint32_t slot, bool zombie, V4 lightSamplingWeight, V4 bsdfSamplingWeight, float lightPickProbability,
+                                                        float4 (*stage)[RT_BLOCK], float4* __restrict__ home, Counters& cnt, DenseVertex& v)
+{
+    const float4 rResult = ldStream(prec(in, R_RESULT, slot)), rSampler = ldStream(prec(in, R_SAMPLER, slot)), rShTp = ldStream(prec(in, R_SH_TP, slot));
+    const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
+    v.oHome = homeIndex;
+    V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
+    resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
+    if (!zombie)
+    {
+        const float4 rOrigin = ldStream(prec(in, R_ORIGIN, slot)), rDir = ldStream(prec(in, R_DIR, slot)), rTp = ldStream(prec(in, R_TP, slot)), rHit = ldStream(prec(in, R_HIT, slot));
+        const uint32_t flags = ubits(rOrigin.w);
+        const uint32_t depth = flags & 0xFFu;
+        const bool lastSpecular = (flags & 0x100u) != 0;
+        const float lastPdfW = rDir.w;
+        const Ray ray = makePathRay(rOrigin, rDir, depth);
+        V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
+        Hit hit;
+        hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
+        uint32_t numRequests = 0;
+        do
+        {
+            if (hit.objectId == RT_INVALID_OBJECT)
+            {
+                // EvaluateGlobalLights, PathTracerMIS.cpp:214-252
+                V4 result = zero4();
+                for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
+                {
+                    const RtLight& light = scene.lights[scene.globalLights[g]];
+                    const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
+                    float directPdfW = 0.0f;
+                    const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
+                    if (kPlain) result = result + lightContribution;   // PathTracer::EvaluateGlobalLights, PathTracer.cpp:47-71
+                    else if (!almostZero4(lightContribution))
+                    {
+                        float misWeight = 1.0f;
+                        if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                        result = mulAdd(lightContribution, misWeight, result);
+                    }
+                }
+                if (!kPlain) result = result * bsdfSamplingWeight;
+                resultColor = mulAdd(throughput, result, resultColor);
+                break;
+            }
+            ShadingData sd;
+            sd.intersection.material = (flags >> 9) - 1u;   // the previous vertex's material (see k_shade)
+            if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
+            if (!RT_LEAN(kLean) && hit.subObjectId == RT_LIGHT_OBJECT)
+            {
+                // EvaluateLight, PathTracerMIS.cpp:174-212
+                const RtObject& obj = scene.objects[hit.objectId];
+                const RtLight& light = scene.lights[obj.lightIndex];
+                const M4 worldToLight = loadM4(obj.invTransform);
+                const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
+                const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
+                const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
+                float directPdfA = 0.0f;
+                V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
+                if (kPlain) resultColor = mulAdd(throughput, lightContribution, resultColor);   // PathTracer::EvaluateLight, PathTracer.cpp:26-45
+                else if (!almostZero4(lightContribution))
+                {
+                    float misWeight = 1.0f;
+                    if (depth > 0 && !lastSpecular)
+                    {
+                        const float directPdfW = PdfAtoW(directPdfA, hit.distance, cosAtLight);
+                        misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
+                    }
+                    lightContribution = lightContribution * bsdfSamplingWeight;
+                    resultColor = mulAdd(throughput, lightContribution * misWeight, resultColor);
+                }
+                else resultColor = mulAdd(throughput, zero4(), resultColor);
+                break;
+            }
+            sd.outgoingDirWorldSpace = neg(ray.dir);
+            const RtMaterial& mat = scene.materials[sd.intersection.material];
+            materialEvaluateShadingData<kLean>(scene, mat, sd);
+            resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);   // emission, :309-317
+
+            Sampler sampler; loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise);
+            sampler.seed = passes[homeIndex / slotsPerPass].seed;
+
+            // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
+            if (!kPlain && kAll && scene.numLights != 0)
+            {
+                for (uint32_t l = 0; l < scene.numLights; ++l)
+                {
+                    float4 dirTmax, contribution;
+                    if (computeLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, dirTmax, contribution)) v.rayMask |= 1u << l;
+                    pshadow(in, l, 0, slot) = dirTmax; pshadow(in, l, 1, slot) = contribution;
+                }
+                v.rayNeeded = v.rayMask != 0u;
+                numRequests = v.rayNeeded ? scene.numLights : 0u;
+                stage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                stage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                v.stagedShTp = true;
+            }
+            else if (!kPlain && scene.numLights != 0)
+            {
+                uint32_t lightIndex = 0;
+                if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
+                float4 oShadow0, oShadow1;
+                v.rayNeeded = computeLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, oShadow0, oShadow1);
+                numRequests = v.rayNeeded ? 1u : 0u;   // a request without a ray contributes nothing (resolvePendingLightSamples skips it): not kept
+                stage[0][threadIdx.x] = oShadow0; stage[1][threadIdx.x] = oShadow1;
+                stage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
+                stage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
+                v.stagedShTp = true;
+            }
+            bool cont = depth < pass.maxRayDepth;
+            if (cont && depth >= pass.minRussianRouletteDepth)   // Russian roulette, :330-347
+            {
+                const float minColorValue = 0.125f;
+                const float threshold = minColorValue + (1.0f - minColorValue) * colorMax(sd.mp.baseColor);
+                if (sampler.getFloat() > threshold) cont = false;
+                else throughput = throughput * (1.0f / threshold);
+            }
+            if (cont)   // BSDF sampling, :349-395
+            {
+                float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
+                float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
+                const V4 bsdfValue = materialSample<kLean>(mat, sd, u, incomingDirWorldSpace, pdf, event);
+                if (event != EV_NULL)
+                {
+                    throughput = throughput * bsdfValue;
+                    if (!almostZero4(throughput))
+                    {
+                        v.oOrigin = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
+                                     fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
+                        v.oDir = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
+                        v.oTp = f4(throughput.x, throughput.y, throughput.z, throughput.w);
+                        v.outcome = 1;
+                    }
+                }
+            }
+            if (v.outcome == 1)
+            {
+                v.oSampler = f4(0.0f, fbits(sampler.salt), fbits(sampler.generated), fbits(numRequests));
+                v.oRng = f4(fbits((uint32_t)sampler.fallback.s[0]), fbits((uint32_t)(sampler.fallback.s[0] >> 32)),
+                          fbits((uint32_t)sampler.fallback.s[1]), fbits((uint32_t)(sampler.fallback.s[1] >> 32)));
+                if (numRequests == 0u) v.stagedShTp = false;
+            }
+            else if (v.rayNeeded)
+            {
+                v.outcome = 2;   // the path ends here, its last next-event sample still needs its shadow ray
+                v.oSampler = f4(0.0f, 0.0f, 0.0f, fbits(numRequests));
+            }
+        } while (false);
+        if (v.outcome != 1) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
+    }
+    v.oResult = f4(resultColor.x, resultColor.y, resultColor.z, fbits(pix));
+    if (v.outcome == 0) stStream(home[homeIndex], f4(resultColor.x, resultColor.y, resultColor.z, 0.0f));
+}
+
+#ifndef RT_SHADE_FUNCTIONS_ONLY
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395), as k_shade, reading arena `in`
 // and writing the survivors densely into arena `out`.  kPlain: PathTracer::RenderPixel (Core/Rendering/PathTracer.cpp:73-171).
 //
@@ -143,165 +317,17 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             i = sDealt[threadIdx.x];
         }
         // what this vertex leaves behind: 0 nothing (radiance parked), 1 a live path, 2 a zombie (radiance + one pending request)
-        uint32_t outcome = 0;
-        float4 oOrigin, oDir, oTp, oResult, oSampler, oRng;
-        bool stagedShTp = false;
-        bool rayNeeded = false;
-        uint32_t oHome = 0u, inSlot = 0u, rayMask = 0u;
+        DenseVertex v;
+        v.outcome = 0; v.stagedShTp = false; v.rayNeeded = false; v.oHome = 0u; v.rayMask = 0u;
+        uint32_t inSlot = 0u;
         if (i < count)
         {
             bool zombie;
             const uint32_t slot = vertexSlot(i, zombie);
             inSlot = slot;
-            const float4 rResult = ldStream(prec(in, R_RESULT, slot)), rSampler = ldStream(prec(in, R_SAMPLER, slot)), rShTp = ldStream(prec(in, R_SH_TP, slot));
-            const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
-            oHome = homeIndex;
-            V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
-            resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
-            if (!zombie)
-            {
-                const float4 rOrigin = ldStream(prec(in, R_ORIGIN, slot)), rDir = ldStream(prec(in, R_DIR, slot)), rTp = ldStream(prec(in, R_TP, slot)), rHit = ldStream(prec(in, R_HIT, slot));
-                const uint32_t flags = ubits(rOrigin.w);
-                const uint32_t depth = flags & 0xFFu;
-                const bool lastSpecular = (flags & 0x100u) != 0;
-                const float lastPdfW = rDir.w;
-                const Ray ray = makePathRay(rOrigin, rDir, depth);
-                V4 throughput(rTp.x, rTp.y, rTp.z, rTp.w);
-                Hit hit;
-                hit.objectId = ubits(rHit.x); hit.subObjectId = ubits(rHit.y); hit.distance = rHit.z; hit.u = rHit.w; hit.v = rSampler.x;
-                uint32_t numRequests = 0;
-                do
-                {
-                    if (hit.objectId == RT_INVALID_OBJECT)
-                    {
-                        // EvaluateGlobalLights, PathTracerMIS.cpp:214-252
-                        V4 result = zero4();
-                        for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
-                        {
-                            const RtLight& light = scene.lights[scene.globalLights[g]];
-                            const Ray lightSpaceRay = transformRayUnsafe(loadM4(light.invTransform), ray);
-                            float directPdfW = 0.0f;
-                            const V4 lightContribution = lightGetRadiance<kLean>(scene, light, lightSpaceRay, zero4(), 1.0f, directPdfW);
-                            if (kPlain) result = result + lightContribution;   // PathTracer::EvaluateGlobalLights, PathTracer.cpp:47-71
-                            else if (!almostZero4(lightContribution))
-                            {
-                                float misWeight = 1.0f;
-                                if (depth > 0 && !lastSpecular) misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
-                                result = mulAdd(lightContribution, misWeight, result);
-                            }
-                        }
-                        if (!kPlain) result = result * bsdfSamplingWeight;
-                        resultColor = mulAdd(throughput, result, resultColor);
-                        break;
-                    }
-                    ShadingData sd;
-                    sd.intersection.material = (flags >> 9) - 1u;   // the previous vertex's material (see k_shade)
-                    if (hit.distance < FLT_MAX) sceneEvaluateIntersection<kLean>(scene, ray, hit, sd.intersection, cnt);
-                    if (!RT_LEAN(kLean) && hit.subObjectId == RT_LIGHT_OBJECT)
-                    {
-                        // EvaluateLight, PathTracerMIS.cpp:174-212
-                        const RtObject& obj = scene.objects[hit.objectId];
-                        const RtLight& light = scene.lights[obj.lightIndex];
-                        const M4 worldToLight = loadM4(obj.invTransform);
-                        const Ray lightSpaceRay = transformRayUnsafe(worldToLight, ray);
-                        const V4 lightSpaceHitPoint = transformPoint(worldToLight, sd.intersection.frame.r[3]);
-                        const float cosAtLight = -dot3(sd.intersection.frame.r[2], ray.dir);
-                        float directPdfA = 0.0f;
-                        V4 lightContribution = lightGetRadiance<false>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA);
-                        if (kPlain) resultColor = mulAdd(throughput, lightContribution, resultColor);   // PathTracer::EvaluateLight, PathTracer.cpp:26-45
-                        else if (!almostZero4(lightContribution))
-                        {
-                            float misWeight = 1.0f;
-                            if (depth > 0 && !lastSpecular)
-                            {
-                                const float directPdfW = PdfAtoW(directPdfA, hit.distance, cosAtLight);
-                                misWeight = CombineMis(lastPdfW, directPdfW * lightPickProbability);
-                            }
-                            lightContribution = lightContribution * bsdfSamplingWeight;
-                            resultColor = mulAdd(throughput, lightContribution * misWeight, resultColor);
-                        }
-                        else resultColor = mulAdd(throughput, zero4(), resultColor);
-                        break;
-                    }
-                    sd.outgoingDirWorldSpace = neg(ray.dir);
-                    const RtMaterial& mat = scene.materials[sd.intersection.material];
-                    materialEvaluateShadingData<kLean>(scene, mat, sd);
-                    resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);   // emission, :309-317
-
-                    Sampler sampler; loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise);
-                    sampler.seed = passes[homeIndex / slotsPerPass].seed;
-
-                    // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
-                    if (!kPlain && kAll && scene.numLights != 0)
-                    {
-                        for (uint32_t l = 0; l < scene.numLights; ++l)
-                        {
-                            float4 dirTmax, contribution;
-                            if (computeLightSample<kLean>(scene, pass, sampler, scene.lights[l], sd, mat, depth, lightPickProbability, dirTmax, contribution)) rayMask |= 1u << l;
-                            pshadow(in, l, 0, slot) = dirTmax; pshadow(in, l, 1, slot) = contribution;
-                        }
-                        rayNeeded = rayMask != 0u;
-                        numRequests = rayNeeded ? scene.numLights : 0u;
-                        sStage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
-                        sStage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
-                        stagedShTp = true;
-                    }
-                    else if (!kPlain && scene.numLights != 0)
-                    {
-                        uint32_t lightIndex = 0;
-                        if (scene.numLights > 1) lightIndex = sampler.fallbackInt() % scene.numLights;
-                        float4 oShadow0, oShadow1;
-                        rayNeeded = computeLightSample<kLean>(scene, pass, sampler, scene.lights[lightIndex], sd, mat, depth, lightPickProbability, oShadow0, oShadow1);
-                        numRequests = rayNeeded ? 1u : 0u;   // a request without a ray contributes nothing (resolvePendingLightSamples skips it): not kept
-                        sStage[0][threadIdx.x] = oShadow0; sStage[1][threadIdx.x] = oShadow1;
-                        sStage[2][threadIdx.x] = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z, 0.0f);
-                        sStage[3][threadIdx.x] = f4(throughput.x, throughput.y, throughput.z, fbits(homeIndex));
-                        stagedShTp = true;
-                    }
-                    bool cont = depth < pass.maxRayDepth;
-                    if (cont && depth >= pass.minRussianRouletteDepth)   // Russian roulette, :330-347
-                    {
-                        const float minColorValue = 0.125f;
-                        const float threshold = minColorValue + (1.0f - minColorValue) * colorMax(sd.mp.baseColor);
-                        if (sampler.getFloat() > threshold) cont = false;
-                        else throughput = throughput * (1.0f / threshold);
-                    }
-                    if (cont)   // BSDF sampling, :349-395
-                    {
-                        float pdf = 0.0f; V4 incomingDirWorldSpace = zero4(); uint32_t event = EV_NULL;
-                        float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
-                        const V4 bsdfValue = materialSample<kLean>(mat, sd, u, incomingDirWorldSpace, pdf, event);
-                        if (event != EV_NULL)
-                        {
-                            throughput = throughput * bsdfValue;
-                            if (!almostZero4(throughput))
-                            {
-                                oOrigin = f4(sd.intersection.frame.r[3].x, sd.intersection.frame.r[3].y, sd.intersection.frame.r[3].z,
-                                             fbits((depth + 1u) | (((event & EV_SPECULAR) != 0) ? 0x100u : 0u) | ((sd.intersection.material + 1u) << 9)));
-                                oDir = f4(incomingDirWorldSpace.x, incomingDirWorldSpace.y, incomingDirWorldSpace.z, pdf);
-                                oTp = f4(throughput.x, throughput.y, throughput.z, throughput.w);
-                                outcome = 1;
-                            }
-                        }
-                    }
-                    if (outcome == 1)
-                    {
-                        oSampler = f4(0.0f, fbits(sampler.salt), fbits(sampler.generated), fbits(numRequests));
-                        oRng = f4(fbits((uint32_t)sampler.fallback.s[0]), fbits((uint32_t)(sampler.fallback.s[0] >> 32)),
-                                  fbits((uint32_t)sampler.fallback.s[1]), fbits((uint32_t)(sampler.fallback.s[1] >> 32)));
-                        if (numRequests == 0u) stagedShTp = false;
-                    }
-                    else if (rayNeeded)
-                    {
-                        outcome = 2;   // the path ends here, its last next-event sample still needs its shadow ray
-                        oSampler = f4(0.0f, 0.0f, 0.0f, fbits(numRequests));
-                    }
-                } while (false);
-                if (outcome != 1) cnt.c[C_RAYS] += depth + 1u;   // counters.numRays += depth + 1, PathTracerMIS.cpp:412
-            }
-            oResult = f4(resultColor.x, resultColor.y, resultColor.z, fbits(pix));
-            if (outcome == 0) stStream(home[homeIndex], f4(resultColor.x, resultColor.y, resultColor.z, 0.0f));
+            denseShadeVertex<kLean, kPlain, kAll>(scene, passes, slotsPerPass, pass, in, slot, zombie, lightSamplingWeight, bsdfSamplingWeight, lightPickProbability, sStage, home, cnt, v);
         }
+        uint32_t outcome = v.outcome;
 
         // dense slots of the other arena: ranks from LDS counters, the block's two ranges with one global atomic each.  The region follows
         // the CHUNK of 256 vertices, not the block: consecutive chunks take the regions in turn whatever the grid size, so the regions
@@ -322,16 +348,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
             // the vertex is dropped and the frame is invalid until the next reset (every synchronising call reports the flag); its home still gets what
             // the path had gathered, so that k_accumulate_home never adds a previous batch's value
             dense.errorFlags[0] = 1u; outcome = 0;
-            stStream(home[oHome], f4(oResult.x, oResult.y, oResult.z, 0.0f));
+            stStream(home[v.oHome], f4(v.oResult.x, v.oResult.y, v.oResult.z, 0.0f));
         }
         if (outcome != 0)
         {
             const uint32_t slot = outcome == 1 ? shard * dense.shardCapacity + sLiveBase + rank : (shard + 1u) * dense.shardCapacity - 1u - (sZombieBase + rank);
-            stStream(prec(out, R_RESULT, slot), oResult);
-            stStream(prec(out, R_SAMPLER, slot), oSampler);
-            stStream(prec(out, R_SH_TP, slot), stagedShTp ? sStage[3][threadIdx.x] : f4(0.0f, 0.0f, 0.0f, fbits(oHome)));
-            if (outcome == 1) { stStream(prec(out, R_ORIGIN, slot), oOrigin); stStream(prec(out, R_DIR, slot), oDir); stStream(prec(out, R_TP, slot), oTp); stStream(prec(out, R_RNG, slot), oRng); }
-            if (ubits(oSampler.w) != 0u)
+            stStream(prec(out, R_RESULT, slot), v.oResult);
+            stStream(prec(out, R_SAMPLER, slot), v.oSampler);
+            stStream(prec(out, R_SH_TP, slot), v.stagedShTp ? sStage[3][threadIdx.x] : f4(0.0f, 0.0f, 0.0f, fbits(v.oHome)));
+            if (outcome == 1) { stStream(prec(out, R_ORIGIN, slot), v.oOrigin); stStream(prec(out, R_DIR, slot), v.oDir); stStream(prec(out, R_TP, slot), v.oTp); stStream(prec(out, R_RNG, slot), v.oRng); }
+            if (ubits(v.oSampler.w) != 0u)
             {
                 stStream(prec(out, R_SH_P, slot), sStage[2][threadIdx.x]);
                 if (kAll)
@@ -339,14 +365,14 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(R
                     for (uint32_t l = 0; l < scene.numLights; ++l)
                     {
                         stStream(pshadow(out, l, 0, slot), pshadow(in, l, 0, inSlot)); stStream(pshadow(out, l, 1, slot), pshadow(in, l, 1, inSlot));
-                        if (rayMask & (1u << l)) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * out.capacity + slot;
+                        if (v.rayMask & (1u << l)) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = l * out.capacity + slot;
                     }
                 }
                 else
                 {
                 stStream(pshadow(out, 0, 0, slot), sStage[0][threadIdx.x]);
                 stStream(pshadow(out, 0, 1, slot), sStage[1][threadIdx.x]);
-                if (rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
+                if (v.rayNeeded) sShadowBuf[atomicAdd(&sShadowCount, 1u)] = slot;   // request index = light 0 * capacity + slot
                 }
             }
         }
@@ -381,3 +407,4 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate_home(const float4* __re
         secondary[idx + 0] = tr; secondary[idx + 1] = tg; secondary[idx + 2] = tb;
     }
 }
+#endif   // RT_SHADE_FUNCTIONS_ONLY

@@ -1,6 +1,6 @@
 // rt_device_core.h -- device-side building blocks of the MI355X path tracer: per-pixel sampler, analytic
 // shapes, lights, BSDFs, hit-frame evaluation and the two-level BVH traversal.  All functions are
-// __device__ __forceinline__; the wavefront kernels that call them are in rt_kernels.hip.
+// __device__ __forceinline__; the wavefront kernels that call them are in rt_trace.hip / rt_shade.hip / rt_tail.hip.
 // File:line citations are relative to the reference repository (Witek902/Raytracer).
 #pragma once
 

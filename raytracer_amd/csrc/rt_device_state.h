@@ -1,4 +1,4 @@
-// rt_device_state.h -- device-side path state shared by the translation units of the library (rt_kernels.hip: traversal, host side;
+// rt_device_state.h -- device-side path state shared by the translation units of the library (rt_runtime.hip: host side; rt_trace.hip: traversal;
 // rt_shade.hip: the shading kernels): the record arenas, per-pass constants, counter / sampler plumbing and the dense-arena helpers.
 #pragma once
 #include "rt_device_core.h"

@@ -1,21 +1,9 @@
 // rt_kat.inl -- known-answer-test hook of the C-ABI (rtgpu_kat, rtgpu_kat_sampler, rtgpu_kat_mesh): the DEVICE functions of
 // rt_device_math.h / rt_device_core.h / rt_device_vcm.h / rt_device_traverse.h evaluated on the record layouts of tests/golden/*.kat
 // (written by the reference's own translation units, see tests/golden/README.md), so that every SURVEY 8(a) row has a
-// device-vs-reference-vector check that does not go through the CPU restatement.  One thread per record; included by rt_kernels.hip.
+// device-vs-reference-vector check that does not go through the CPU restatement.  One thread per record; included by rt_trace.hip; the function ids are in rt_trace_kernels.h.
 //
 // Function ids and record layouts: tests/golden/README.md (the ids the fixtures carry in their headers).
-enum
-{
-    KAT_SIN_LANE = 1, KAT_SINCOS = 2, KAT_FASTLOG = 3, KAT_FASTACOS = 4, KAT_FASTATAN2 = 5,
-    KAT_FLOAT_NORMAL2 = 6, KAT_HEMISPHERE_COS = 7, KAT_SPHERE = 8, KAT_CIRCLE = 9, KAT_ORTHO_BASIS = 10,
-    KAT_FRESNEL_DIELECTRIC = 11, KAT_FRESNEL_METAL = 12, KAT_REFRACT3 = 13, KAT_REFLECT3 = 14,
-    KAT_BOX_RAY = 20, KAT_BOX_RAY_TWOSIDED = 21, KAT_TRIANGLE_RAY = 22, KAT_MAKE_RAY = 23, KAT_TRANSFORM_RAY = 24,
-    KAT_FAST_INVERSE = 25,
-    KAT_SHAPE_INTERSECT = 30, KAT_SHAPE_SAMPLE = 31, KAT_SHAPE_PDF = 32, KAT_SHAPE_EVAL = 33,
-    KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41, KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44,
-    KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51, KAT_BSDF_PDFS = 52,
-    KAT_CAMERA_RAY = 60, KAT_CAMERA_FILM = 61, KAT_FILM_SPLAT = 62, KAT_PACKED_PHOTON = 63, KAT_HSV_TO_RGB = 64,
-};
 
 RT_DEV void katPut(float* o, V4 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
 RT_DEV void katLoad(void* dst, const float* src, uint32_t bytes)
@@ -255,7 +243,6 @@ __global__ void __launch_bounds__(64) k_kat_sampler(const uint16_t* __restrict__
 // and meshEvaluateIntersection, on the single mesh object of the uploaded scene, objectID reported as 7 like the generator does
 // (layout of tests/golden/mesh_kat.bin).  rays: n * 7 floats (origin, direction, tmax) in the mesh's space; out: n * 19 words
 //   [objectId, subObjectId, distance, u, v, shadowHit, frame0.xyzw, frame2.xyzw, texCoord.xyzw, material]
-#define RT_KAT_MESH_STACK 64
 __global__ void __launch_bounds__(64) k_kat_mesh(const RtSceneDesc scene, const float* __restrict__ rays, uint32_t n, uint32_t* __restrict__ out)
 {
     __shared__ uint32_t sStack[RT_KAT_MESH_STACK * 64];

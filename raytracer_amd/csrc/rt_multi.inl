@@ -1,4 +1,4 @@
-// rt_multi.inl -- one context over several devices of a node (rtgpu_create_multi).  Included by rt_kernels.hip.
+// rt_multi.inl -- one context over several devices of a node (rtgpu_create_multi).  Included by rt_runtime.hip.
 //
 // The reference scales a frame by handing 2-D tiles to the threads of its pool (Viewport.cpp:244-262, ThreadPool.cpp:176-260); here the
 // 64x64 tiles are dealt round-robin to the devices (RtgpuShard: tile % worldSize == rank), each device runs the whole launch sequence over

@@ -1,4 +1,6 @@
-// rt_kernels.hip -- wavefront PathTracerMIS for MI355X (gfx950) and the C-ABI of include/rtgpu.h.
+// rt_runtime.hip -- the host side of the C-ABI of include/rtgpu.h: contexts, batch lanes, path-state arenas, scene upload, the launch
+// sequences of the integrators.  The kernels live in rt_trace.hip (traversal, camera rays, post-process, known-answer hooks), rt_shade.hip
+// (shading) and rt_tail.hip (the fused tail of a batch); this unit launches them through rt_trace_kernels.h / rt_shade_kernels.h.
 //
 // One pass (= one sample per owned pixel) is a fixed sequence of launches on the context's stream:
 //
@@ -22,8 +24,7 @@
 // result independent of the wavefront schedule and reproducible against the CPU oracle.
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
-#include "rt_device_core.h"
-#include "rt_device_traverse.h"
+#include "rt_trace_common.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -36,615 +37,13 @@
 
 using namespace rtd;
 
-#include "rt_device_state.h"
-
-// =====================================================================================================
-// Kernels
-// =====================================================================================================
-
-// Viewport::RenderTile per-pixel prologue + Camera::GenerateRay (Viewport.cpp:305-331, Camera.cpp:81-118)
-__global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass,
-                                                       const Paths paths, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
-                                                       uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount,
-                                                       unsigned long long* counters)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
-    {
-        // several passes ride in one batch: slot = passInBatch * slotsPerPass + pixelSlot
-        const uint32_t passInBatch = slot / slotsPerPass;
-        const DevPass& pass = passes[passInBatch];
-        const uint32_t pix = slotPixel[slot - passInBatch * slotsPerPass];
-        const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
-        const uint32_t realY = pass.height - 1u - y;
-        // invSize = VECTOR_ONE2 / FromIntegers(w, h, 1, 1); coords = (FromIntegers(x, realY) + sampleOffset) * invSize
-        const float invW = 1.0f / (float)(int32_t)pass.width, invH = 1.0f / (float)(int32_t)pass.height;
-        const V4 coords(((float)(int32_t)x + pass.sampleOffset[0]) * invW, ((float)(int32_t)realY + pass.sampleOffset[1]) * invH, 0.0f, 0.0f);
-
-        Sampler sampler;
-        sampler.seed = pass.seed; sampler.numDims = pass.numDimensions; sampler.blueNoiseLayers = pass.blueNoiseLayers; sampler.blueNoise = scene.blueNoise;
-        sampler.resetPixel(x, y, pass.rngKey[0], pass.rngKey[1]);
-
-        // Camera::GenerateRay up to (not including) the Ray constructor, which trace/shade re-run from origin+direction
-        V4 origin, direction;
-        cameraGenerateRayParts(pass.camera, coords, sampler, origin, direction);
-
-        prec(paths, R_ORIGIN, slot) = f4(origin.x, origin.y, origin.z, fbits(0x100u));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
-        prec(paths, R_DIR, slot) = f4(direction.x, direction.y, direction.z, 1.0f);        // lastPdfW = 1
-        prec(paths, R_TP, slot) = f4(1.0f, 1.0f, 1.0f, 1.0f);
-        prec(paths, R_RESULT, slot) = f4(0.0f, 0.0f, 0.0f, fbits(pix));
-        storeSampler(sampler, paths, slot, 0.0f, 0u);
-        queue[slot] = slot;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        *queueCount = numSlots;
-        atomicAdd(&counters[C_PRIMARY], (unsigned long long)numSlots);
-    }
-}
-
-// Work distribution of the persistent traversal kernel.  A wave owns a CHUNK of consecutive queue indices obtained
-// with one global atomic and hands them to its idle lanes locally; only when the chunk is used up does it touch
-// the global cursor again (a single word sustains only ~88 returning atomics per microsecond).
-struct WaveChunk { uint32_t next, end; };
-
-// Gives idle lanes (want == true) indices from the wave's chunk; returns 0xFFFFFFFF for lanes that got none.
-RT_DEV uint32_t waveTake(bool want, WaveChunk& chunk)
-{
-    const unsigned long long mask = __ballot(want);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    const uint32_t available = chunk.end - chunk.next;
-    const uint32_t idx = (want && rank < available) ? chunk.next + rank : 0xFFFFFFFFu;
-    const uint32_t taken = (uint32_t)__popcll(mask) < available ? (uint32_t)__popcll(mask) : available;
-    chunk.next += taken;
-    return idx;
-}
-
-RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSize, uint32_t count)
-{
-    uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(cursor, chunkSize);
-    base = __shfl(base, 0);
-    chunk.next = base < count ? base : count;
-    chunk.end = base + chunkSize < count ? base + chunkSize : count;
-    if (chunk.end < chunk.next) chunk.end = chunk.next;
-}
-
-
-#define RT_SPLIT_AFTER 32u   // drain iterations of a wave before its shadow rays start sharing subtrees
-
-// Wave scheduling knobs of the persistent traversal kernel (wave-uniform, passed as kernel arguments)
-struct TravTuning
-{
-    uint32_t refillMinIdle;   // refill once this many lanes of the wave have no ray (or all of them)
-    uint32_t otherMinLanes;   // run the "other" phase (leaves, objects, finishing) once this many lanes wait for it
-    float shadowOffset;       // any-hit rays start at origin + direction * shadowOffset: 1e-4 (PathTracerMIS.cpp:86, VCM.cpp:673 ...);
-                              // 0 for the Light Tracer, whose offset is along the surface normal and already in the stored origin
-    uint32_t* overflowQueue;  // closest-hit rays still running this long after the queue ran dry are handed to k_trace_monster
-    uint32_t* overflowCount;  // (null: never)
-    uint32_t abortClosestAfter;   // ... measured in scheduling rounds of the wave after its queue is exhausted
-    const uint32_t* denseCounts;  // dense path state: the closest-hit rays are the live paths of the arena's regions (no queue); else null
-    uint32_t denseShardCapacity;
-};
-#define RT_ABORT_CLOSEST_AFTER 768u
-
-// ONE persistent traversal kernel per bounce: it serves the closest-hit rays of the paths alive at bounce k
-// (Scene::Traverse, Scene.cpp:219-243) AND the NEE shadow rays queued by the shade of bounce k-1
-// (Scene::Traverse_Shadow, Scene.cpp:245-261; PathTracerMIS.cpp:81-96).  The two sets are independent, and
-// serving them from one work cursor halves the number of launches whose tail (a few long rays keeping the
-// grid alive) would otherwise be paid twice.  An occluded NEE request is marked by tmax = -1; the contribution
-// is folded in later by resolvePendingLightSamples.
-// Occupancy: 5 waves per SIMD (<= 96 VGPRs; the register allocator gets there without spilling once the world ray and
-// the hit record are not carried) x 24.6 KB of LDS stack per block = 5 blocks per CU.  The interior loop waits ~800 ns
-// per dependent node fetch, so every extra wave is throughput.
-#define RT_LDS_TOP_NODES 224u   // 7 KB: the stack class of 24 entries leaves 7.4 KB per block at five blocks per CU
-template <int kStack, bool kCount, bool kLdsTop = false>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace(const RtSceneDesc scene, const Paths paths,
-                                                    const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                    const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
-                                                    uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
-{
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
-    __shared__ float4 sTop[kLdsTop ? RT_LDS_TOP_NODES * 2u : 1u];
-    __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
-    Counters cnt; zeroCounters(cnt);
-    if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
-    const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
-    const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
-    TravState s; s.mode = TRAV_DONE; s.shadow = false;
-    uint32_t slot = 0, light = 0;
-    bool have = false, exhausted = false;
-    // chunk size: large enough to make global atomics rare, small enough to keep the tail of the launch balanced
-    uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
-    chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
-    WaveChunk chunk = { 0u, 0u };
-    // the world ray of the lane's current request, rebuilt from the path state exactly as at refill time
-    auto loadWorldRay = [&]() -> Ray
-    {
-        if (s.shadow)
-        {
-            const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
-            Ray shadowRay = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
-            shadowRay.origin = shadowRay.origin + shadowRay.dir * tune.shadowOffset;   // PathTracerMIS.cpp:86
-            return shadowRay;
-        }
-        const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
-        return makePathRay(origin, dir, ubits(origin.w) & 0xFFu);
-    };
-    // HitPoint of a closest-hit ray, written through at every accepted hit (T6: objectId, subObjectId, distance, u, v)
-    auto onHit = [&](uint32_t objectId, uint32_t subObjectId, float distance, float u, float v)
-    {
-        prec(paths, R_HIT, slot) = f4(fbits(objectId), fbits(subObjectId), distance, u);
-        prec(paths, R_SAMPLER, slot).x = v;
-    };
-    // Drain-phase work sharing for any-hit rays.  When the queue is used up, a launch lasts as long as its longest
-    // ray, and some NEE rays are very long: a direction that is exactly a coordinate axis makes two of the three slab
-    // tests meaningless in the reference's box * invDir - origin * invDir formulation (inf - inf), and such a ray
-    // walks every node whose remaining slab it overlaps -- tens of thousands of steps, alone in its wave.  Occlusion
-    // is an OR over subtrees, so the deferred subtrees on a shadow ray's stack can be searched by other lanes: a
-    // lane with nothing to do takes the OLDEST deferred node (the largest subtree) of a busy shadow ray in its wave
-    // and searches it as a ray of its own with the same request id; whoever finds an occluder marks the request.
-    // Closest-hit rays are never split (their box culling and tie-breaking depend on the visiting order), and the
-    // counting variant does not split at all, so the intersection counters stay those of the serial traversal.
-    const bool splitShadowRays = !kCount;
-    const bool singleMeshLevel = scene.numObjects == 1u;   // bypass scenes: a mesh level is all a ray has (degenerate closest-hit rays can be handed over)
-    // Single-mesh scenes (Scene::Traverse's one-object bypass, Scene.cpp:231-235, into MeshShape::Traverse): everything a ray
-    // needs to enter the mesh is the same for all rays, so it is fetched ONCE per wave (uniform -> scalar registers) instead
-    // of through three dependent loads (object -> mesh -> root node) behind every refill.
-    bool bypassMesh = false;
-    M4 bypassInvTransform; const RtNode* bypassNodes = nullptr; uint32_t bypassTriBase = 0, bypassRoot = 0;
-    if (scene.numObjects == 1u && scene.objects[0].objectKind == RT_OBJECT_SHAPE && scene.objects[0].shapeKind == RT_SHAPE_MESH)
-    {
-        const RtMesh& mesh = scene.meshes[scene.objects[0].meshIndex];
-        if (mesh.numNodes != 0u)
-        {
-            bypassMesh = true;
-            bypassInvTransform = loadM4(scene.objects[0].invTransform);
-            bypassNodes = scene.meshNodes + mesh.firstNode;
-            bypassTriBase = mesh.firstTriangle;
-            bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
-        }
-    }
-    // LDS-staged node packets: the device copy of a mesh tree is in breadth-first order, so its top levels are its first nodes
-    LdsTop top = { sTop, 0u };
-    if (kLdsTop && bypassMesh)
-    {
-        const uint32_t numNodes = scene.meshes[scene.objects[0].meshIndex].numNodes;
-        top.count = numNodes > 2u ? (numNodes - 2u < RT_LDS_TOP_NODES ? numNodes - 2u : RT_LDS_TOP_NODES) : 0u;
-        const float4* src = reinterpret_cast<const float4*>(bypassNodes + 2);
-        for (uint32_t i = threadIdx.x; i < top.count * 2u; i += RT_BLOCK) sTop[i] = src[i];
-        __syncthreads();
-    }
-    uint32_t drainIterations = 0, closestDrain = 0;
-    for (;;)
-    {
-        const bool interior = have && travIsInterior(s);
-        const bool other = have && !interior;
-        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
-        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
-        // A closest-hit ray that is still running long after the queue ran dry is a degenerate one (an exactly axis-parallel
-        // direction turns two of three slab tests into inf - inf, and the ray walks most of the tree alone -- tens of
-        // milliseconds).  Such rays cannot be split like any-hit rays (the visiting order decides ties), so they are handed
-        // to k_trace_monster, which finds the same hit cooperatively.  Single-mesh scenes, counters off.
-        if (splitShadowRays && singleMeshLevel && tune.overflowQueue && exhausted && ++closestDrain > tune.abortClosestAfter)
-        {
-            const bool abortLane = have && !s.shadow;
-            const unsigned long long mAbort = __ballot(abortLane);
-            if (mAbort != 0ull)
-            {
-                const uint32_t lane = threadIdx.x & 63u;
-                uint32_t base = 0;
-                if (lane == (uint32_t)(__ffsll((long long)mAbort) - 1)) base = atomicAdd(tune.overflowCount, (uint32_t)__popcll(mAbort));
-                base = (uint32_t)__shfl((int)base, __ffsll((long long)mAbort) - 1);
-                if (abortLane) { tune.overflowQueue[base + (uint32_t)__popcll(mAbort & ((1ull << lane) - 1ull))] = slot; have = false; }
-                continue;
-            }
-        }
-        // Idle lanes get work from the queue (refill) or, once the queue is used up, from a busy shadow ray of the wave
-        const bool refill = !exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle);
-        unsigned long long mDonors = 0ull;
-        const bool canDonate = have && s.shadow && s.mode == TRAV_MESH && s.stackSize > s.levelBase;
-        if (splitShadowRays && exhausted && nIdle != 0u && ++drainIterations > RT_SPLIT_AFTER) mDonors = __ballot(canDonate);
-        if (refill || mDonors != 0ull)
-        {
-            uint32_t request = 0xFFFFFFFFu, donated = 0u, meshContextObject = 0u;
-            bool shadowRequest = true;
-            if (refill)
-            {
-                if (chunk.next >= chunk.end)
-                {
-                    waveClaimChunk(chunk, cursor, chunkSize, count);
-                    if (chunk.next >= chunk.end) { exhausted = true; continue; }
-                }
-                const uint32_t idx = waveTake(!have, chunk);
-                if (idx != 0xFFFFFFFFu)
-                {
-                    shadowRequest = idx >= numClosest;
-                    request = shadowRequest ? shadowQueue[idx - numClosest] : (tune.denseCounts ? denseLiveSlot(sDensePrefix, tune.denseShardCapacity, idx) : queue[idx]);
-                    if (shadowRequest) cnt.c[C_SHADOW]++;
-                }
-            }
-            else
-            {
-                // the k-th idle lane takes the OLDEST deferred node (stack bottom of the level) of the k-th donor
-                const unsigned long long mIdle = __ballot(!have);
-                const uint32_t lane = threadIdx.x & 63u;
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const uint32_t nDonors = (uint32_t)__popcll(mDonors), nTakers = (uint32_t)__popcll(mIdle);
-                const uint32_t pairs = nDonors < nTakers ? nDonors : nTakers;
-                const bool donate = canDonate && (uint32_t)__popcll(mDonors & below) < pairs;
-                const uint32_t takerRank = (uint32_t)__popcll(mIdle & below);
-                const bool take = !have && takerRank < pairs;
-                uint32_t src = lane;
-                if (take)
-                {
-                    unsigned long long m = mDonors;
-                    for (uint32_t k = 0; k < takerRank; ++k) m &= m - 1ull;
-                    src = (uint32_t)__ffsll((long long)m) - 1u;
-                }
-                uint32_t entry = 0u;
-                if (donate)
-                {
-                    // the oldest entry of the mesh level leaves the donor's stack; the newest one takes its place (any-hit rays: the order
-                    // of the remaining subtrees is free), so that nothing stale is left for the level below in a two-level scene
-                    entry = stack.base[s.levelBase * stack.stride];
-                    --s.stackSize;
-                    stack.base[s.levelBase * stack.stride] = stack.base[s.stackSize * stack.stride];
-                }
-                const uint32_t donorRequest = (uint32_t)__shfl((int)(light * paths.capacity + slot), (int)src);
-                donated = (uint32_t)__shfl((int)entry, (int)src);
-                if (take) request = donorRequest;
-                // two-level scenes: the taker continues inside the DONOR'S mesh (it rebuilds the local ray from the request like a mesh entry does)
-                if (!bypassMesh) meshContextObject = (uint32_t)__shfl((int)s.objectId, (int)src);
-            }
-            if (request != 0xFFFFFFFFu)
-            {
-                float maxDistance = __uint_as_float(0x7f800000u);
-                s.shadow = shadowRequest;
-                if (!shadowRequest) slot = request;
-                else
-                {
-                    light = request / paths.capacity; slot = request - light * paths.capacity;
-                    maxDistance = pshadow(paths, light, 0, slot).w;   // hitPoint.distance = illuminateResult.distance * 0.999f
-                }
-                have = true;
-                if (bypassMesh)
-                {
-                    // = travBegin + the object step of travStepOther for the one mesh object
-                    s.ray = transformRayUnsafe(bypassInvTransform, loadWorldRay());
-                    s.nanFree = rayIsNaNFree(s.ray);
-                    s.hitDistance = maxDistance;
-                    s.stackSize = 0; s.levelBase = 0; s.leafNext = 1; s.leafEnd = 1; s.objectId = 0; s.triBase = bypassTriBase;
-                    s.occluded = false; s.nodes = bypassNodes; s.cur = bypassRoot; s.mode = TRAV_MESH;
-                }
-                else if (refill)
-                {
-                    travBegin(s, scene, loadWorldRay(), maxDistance, s.shadow);
-                    // other single-object scenes start at the object loop (BVH bypass): enter the object right away instead
-                    // of queueing for the "other" phase
-                    if (!travIsInterior(s) && s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
-                }
-                // a taken subtree: same ray, same mesh, but only the donated node instead of the root
-                if (!refill && bypassMesh) { if (s.mode == TRAV_MESH) s.cur = donated; }
-                else if (!refill)
-                {
-                    const RtObject& obj = scene.objects[meshContextObject];
-                    const RtMesh& mesh = scene.meshes[obj.meshIndex];
-                    s.ray = transformRayUnsafe(loadM4(obj.invTransform), loadWorldRay());   // = the donor's local ray (Scene::Traverse_Object_Shadow's)
-                    s.nanFree = rayIsNaNFree(s.ray); s.hitDistance = maxDistance;
-                    s.stackSize = 0; s.levelBase = 0; s.leafNext = 0; s.leafEnd = 0;   // nothing above the mesh: when its level is exhausted the ray is done
-                    s.objectId = meshContextObject; s.triBase = mesh.firstTriangle; s.nodes = scene.meshNodes + mesh.firstNode;
-                    s.occluded = false; s.cur = donated; s.mode = TRAV_MESH;
-                }
-            }
-            continue;
-        }
-        if ((mI | mO) == 0ull) break;
-        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
-        {
-            // INTERIOR PHASE as a tight inner loop: only (cur, stackSize) change per step, everything else of the lane
-            // state is loop invariant, so the wave keeps stepping without re-evaluating the refill logic until enough
-            // lanes wait at leaves / level exits.  Hardware min/max unless some lane's ray could produce a NaN in a
-            // slab test (axis-parallel rays).
-            bool in = interior;
-            if (__all(!have || s.nanFree))
-            {
-                for (;;)
-                {
-                    if (in) travStepInterior<kCount, false>(s, stack, cnt, top);
-                    in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
-                    const unsigned long long m = __ballot(in);
-                    if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
-                }
-            }
-            else
-            {
-                for (;;)
-                {
-                    if (in) travStepInterior<kCount, true>(s, stack, cnt, top);
-                    in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
-                    const unsigned long long m = __ballot(in);
-                    if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
-                }
-            }
-        }
-        else if (other)
-        {
-            if (s.mode != TRAV_DONE) travStepOther<kCount>(s, scene, stack, cnt, loadWorldRay, onHit);
-            if (s.mode == TRAV_DONE)
-            {
-                if (s.shadow)
-                {
-                    if (s.occluded) pshadow(paths, light, 0, slot).w = -1.0f;   // unoccluded requests are tallied when they are resolved
-                }
-                else
-                {
-                    // nothing was hit: HitPoint stays {RT_INVALID_OBJECT, distance = FLT_MAX-ish infinity} (HitPoint.h:14-51)
-                    if (s.hitDistance == __uint_as_float(0x7f800000u)) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), s.hitDistance, 0.0f);
-                }
-                have = false;
-            }
-        }
-    }
-    flushCounters(cnt, counters);
-}
-
-// Closest hit of a degenerate ray, found by a whole block.  The sequential result is "smallest distance; among equal distances
-// the triangle visited first".  The smallest distance does not depend on the order, so it is searched in parallel: a shared LDS
-// stack of nodes, every thread pops one, tests the two children with the reference's slab test (same NaN behaviour, culling with
-// <= the best distance so far so that every triangle AT the final distance is still visited) or the leaf's triangles, and
-// publishes hits through a 64-bit atomic min of (distance bits, triangle).  If two different triangles ever report the same
-// distance, or the stack overflows, one thread repeats the search sequentially with the ordinary state machine (exactly the
-// reference's order); otherwise the winner is unique and its record (distance, u, v from the same Moller-Trumbore evaluation)
-// is what the sequential traversal would have written.  Single-mesh scenes (the bypass path of k_trace).
-#define RT_MONSTER_BLOCK 512
-#define RT_MONSTER_STACK 8192
-__global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount)
-{
-    __shared__ uint32_t sStack[RT_MONSTER_STACK];
-    __shared__ uint32_t sTop, sTaken, sFlags;            // sFlags: 1 = tie, 2 = stack overflow
-    __shared__ unsigned long long sBest;
-    __shared__ uint32_t sSerialStack[64];
-    const uint32_t count = *queueCount;
-    if (count == 0u) return;
-    const RtMesh& mesh = scene.meshes[scene.objects[0].meshIndex];
-    const RtNode* nodes = scene.meshNodes + mesh.firstNode;
-    const RtTriangle* tris = scene.triangles + mesh.firstTriangle;
-    const M4 invTransform = loadM4(scene.objects[0].invTransform);
-    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x)
-    {
-        const uint32_t slot = queue[q];
-        const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
-        const Ray ray = transformRayUnsafe(invTransform, makePathRay(origin, dir, ubits(origin.w) & 0xFFu));
-        if (threadIdx.x == 0)
-        {
-            sStack[0] = packNode(nodes[0].childIndex, nodes[0].leaves); sTop = 1u; sFlags = 0u;
-            sBest = ((unsigned long long)0x7f800000u << 32) | 0xFFFFFFFFull;   // +inf, no triangle
-        }
-        __syncthreads();
-        for (;;)
-        {
-            const uint32_t n = sTop;
-            __syncthreads();
-            if (n == 0u || sFlags != 0u) break;
-            const uint32_t take = n < RT_MONSTER_BLOCK ? n : RT_MONSTER_BLOCK;
-            uint32_t entry = 0u;
-            const bool active = threadIdx.x < take;
-            if (active) entry = sStack[n - 1u - threadIdx.x];
-            if (threadIdx.x == 0) sTop = n - take;
-            __syncthreads();
-            if (active)
-            {
-                const float best = __uint_as_float((uint32_t)(sBest >> 32));
-                const uint32_t numLeaves = entry >> RT_NODE_LEAVES_SHIFT, first = entry & RT_NODE_CHILD_MASK;
-                if (numLeaves == 0u)
-                {
-                    const NodePair np = loadNodePair(nodes, first);
-                    float distanceA, distanceB;
-                    const bool hitA = intersectBoxRay(ray, V4(np.a0.x, np.a0.y, np.a0.z, 0.0f), V4(np.a1.x, np.a1.y, np.a1.z, 0.0f), distanceA) && distanceA <= best;
-                    const bool hitB = intersectBoxRay(ray, V4(np.b0.x, np.b0.y, np.b0.z, 0.0f), V4(np.b1.x, np.b1.y, np.b1.z, 0.0f), distanceB) && distanceB <= best;
-                    const uint32_t pushes = (hitA ? 1u : 0u) + (hitB ? 1u : 0u);
-                    if (pushes != 0u)
-                    {
-                        const uint32_t at = atomicAdd(&sTop, pushes);
-                        if (at + pushes > RT_MONSTER_STACK) atomicOr(&sFlags, 2u);
-                        else
-                        {
-                            uint32_t k = at;
-                            if (hitA) sStack[k++] = packNode(__float_as_uint(np.a0.w), __float_as_uint(np.a1.w));
-                            if (hitB) sStack[k] = packNode(__float_as_uint(np.b0.w), __float_as_uint(np.b1.w));
-                        }
-                    }
-                }
-                else
-                {
-                    for (uint32_t i = 0; i < numLeaves; ++i)
-                    {
-                        const uint32_t triangleIndex = first + i;
-                        V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
-                        float u, v, dist;
-                        if (intersectTriangleRay(ray, v0, e1, e2, u, v, dist) && dist <= best)
-                        {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | triangleIndex;
-                            const unsigned long long old = atomicMin(&sBest, key);
-                            if ((uint32_t)(old >> 32) == __float_as_uint(dist) && (uint32_t)old != triangleIndex) atomicOr(&sFlags, 1u);
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0)
-        {
-            if (sFlags == 0u)
-            {
-                const uint32_t triangleIndex = (uint32_t)sBest;
-                if (triangleIndex == 0xFFFFFFFFu) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), __uint_as_float(0x7f800000u), 0.0f);
-                else
-                {
-                    V4 v0, e1, e2; loadTriangle(tris + triangleIndex, v0, e1, e2);
-                    float u = 0.0f, v = 0.0f, dist = 0.0f;
-                    (void)intersectTriangleRay(ray, v0, e1, e2, u, v, dist);
-                    prec(paths, R_HIT, slot) = f4(fbits(0u), fbits(triangleIndex), dist, u);
-                    prec(paths, R_SAMPLER, slot).x = v;
-                }
-            }
-            else
-            {
-                // the sequential traversal, exactly as k_trace's bypass path runs it
-                Counters cnt; zeroCounters(cnt);
-                const LdsStack stack = { sSerialStack, 1u };
-                TravState s;
-                s.ray = ray; s.nanFree = false; s.shadow = false; s.occluded = false;
-                s.hitDistance = __uint_as_float(0x7f800000u);
-                s.stackSize = 0; s.levelBase = 0; s.leafNext = 1; s.leafEnd = 1; s.objectId = 0; s.triBase = mesh.firstTriangle;
-                s.nodes = nodes; s.cur = packNode(nodes[0].childIndex, nodes[0].leaves); s.mode = TRAV_MESH;
-                auto reloadWorldRay = [&]() -> Ray { return ray; };
-                auto onHit = [&](uint32_t objectId, uint32_t subObjectId, float distance, float u, float v)
-                {
-                    prec(paths, R_HIT, slot) = f4(fbits(objectId), fbits(subObjectId), distance, u);
-                    prec(paths, R_SAMPLER, slot).x = v;
-                };
-                while (s.mode != TRAV_DONE)
-                {
-                    if (travIsInterior(s)) travStepInterior<false, true>(s, stack, cnt);
-                    else travStepOther<false>(s, scene, stack, cnt, reloadWorldRay, onHit);
-                }
-                if (s.hitDistance == __uint_as_float(0x7f800000u)) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), s.hitDistance, 0.0f);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-#define RT_COUNTER_RETRACED 12   // counters[]: rays k_trace_quant handed to the binary-tree kernel (RtCounters::numRetracedRays)
+#define RT_HOST_BUILDERS 1
 #include "rt_trace_quant.inl"
 #include "rt_trace_wide.inl"
 #include "rt_trace_wide2.inl"
-
+#include "rt_trace_kernels.h"
 #include "rt_shade_kernels.h"
-#include "rt_kat.inl"
-
-// Viewport::PostProcessTile (Viewport.cpp:495-550): sum buffer -> 0x00RRGGBB front buffer, one thread per pixel
-struct PostScale { float c[3]; };
-__global__ void __launch_bounds__(RT_BLOCK) k_postprocess(const float* __restrict__ sum, uint32_t* __restrict__ front, uint32_t width, uint32_t height,
-                                                          const RtPostprocessParams params, const PostScale colorScale)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width * height) return;
-    const uint32_t y = i / width, x = i - y * width;
-    front[i] = postProcessPixel(sum[3 * (size_t)i + 0], sum[3 * (size_t)i + 1], sum[3 * (size_t)i + 2], x, y, params, colorScale.c);
-}
-
-// ---- bloom: Bitmap::GaussianBlur (Core/Utils/Bitmap.cpp:880-1020) ---------------------------------------------------------
-// n box blurs per line, each a running sum in the reference's order (BoxBlur_Internal, :880-914), so a line is sequential;
-// one thread per (line, colour channel).  The two line buffers live in global scratch, element-major (element e of
-// thread t at [e * numThreads + t]) so that the threads of a wave touch consecutive words.
-struct BlurPlan { uint32_t n, wl, wu; float m; };
-RT_DEV void boxBlurLine(float* __restrict__ dst, const float* __restrict__ src, uint32_t radius, uint32_t width, uint32_t stride)
-{
-    const float factor = 1.0f / (float)(2u * radius + 1u);
-    uint32_t b = 0, e = 0, t = 0;
-    const float firstValue = src[0], lastValue = src[(size_t)(width - 1u) * stride];
-    float val = firstValue * (float)(radius + 1u);
-    for (uint32_t j = 0; j < radius; j++) val = val + src[(size_t)(b++) * stride];
-    for (uint32_t j = 0; j <= radius; j++) { val = val + (src[(size_t)(b++) * stride] - firstValue); dst[(size_t)(t++) * stride] = val * factor; }
-    for (uint32_t j = radius + 1u; j < width - radius; j++) { val = val + (src[(size_t)(b++) * stride] - src[(size_t)(e++) * stride]); dst[(size_t)(t++) * stride] = val * factor; }
-    for (uint32_t j = width - radius; j < width; j++) { val = val + (lastValue - src[(size_t)(e++) * stride]); dst[(size_t)(t++) * stride] = val * factor; }
-}
-__global__ void __launch_bounds__(RT_BLOCK) k_blur_lines(float* __restrict__ image, uint32_t width, uint32_t height, uint32_t vertical, const BlurPlan plan,
-                                                         float* __restrict__ lineA, float* __restrict__ lineB)
-{
-    const uint32_t numLines = vertical ? width : height, length = vertical ? height : width;
-    const uint32_t numThreads = numLines * 3u;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= numThreads) return;
-    const uint32_t line = t / 3u, channel = t - line * 3u;
-    const size_t pixelStride = vertical ? (size_t)width * 3u : 3u;
-    float* px = image + (vertical ? (size_t)line * 3u : (size_t)line * width * 3u) + channel;
-    // horizontal: source = B, target = A (:952-953); vertical: source = A, target = B (:983-984)
-    float* source = (vertical ? lineA : lineB) + t;
-    float* target = (vertical ? lineB : lineA) + t;
-    for (uint32_t e = 0; e < length; ++e) source[(size_t)e * numThreads] = px[(size_t)e * pixelStride];
-    for (uint32_t i = 0; i < plan.n; ++i)
-    {
-        const uint32_t radius = (float)i < plan.m ? plan.wl : plan.wu;
-        boxBlurLine(target, source, radius, length, numThreads);
-        float* tmp = source; source = target; target = tmp;
-    }
-    // horizontal reads targetLinePtr AFTER the last swap (:961-964: the buffer the last blur read from, i.e. n-1 blurs);
-    // vertical reads tempLineA (:1003-1009: the last blur's output for even n)
-    const float* result = vertical ? lineA + t : target;
-    for (uint32_t e = 0; e < length; ++e) px[(size_t)e * pixelStride] = result[(size_t)e * numThreads];
-}
-
-// Viewport::PostProcessTile with bloom (:512-524): rgb * (1 - bloomFactor) + bloomFactor * sum of weighted blur levels
-struct BloomLevels { const float* level[5]; };
-__global__ void __launch_bounds__(RT_BLOCK) k_postprocess_bloom(const float* __restrict__ sum, const BloomLevels blurred, uint32_t* __restrict__ front, uint32_t width, uint32_t height,
-                                                                const RtPostprocessParams params, const PostScale colorScale)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width * height) return;
-    const uint32_t y = i / width, x = i - y * width;
-    const float bloomWeights[5] = { 0.35f, 0.25f, 0.15f, 0.15f, 0.1f };
-    float rgb[3];
-    for (int k = 0; k < 3; ++k)
-    {
-        float v = sum[3 * (size_t)i + k] * (1.0f - params.bloomFactor);
-        float bloomColor = 0.0f;
-        for (int l = 0; l < 5; ++l) bloomColor = __fmaf_rn(blurred.level[l][3 * (size_t)i + k], bloomWeights[l], bloomColor);
-        rgb[k] = __fmaf_rn(bloomColor, params.bloomFactor, v);
-    }
-    front[i] = postProcessPixel(rgb[0], rgb[1], rgb[2], x, y, params, colorScale.c);
-}
-
-// Viewport::ComputeBlockError (Viewport.cpp:552-581) in two steps that keep the reference's summation order: one thread
-// per (block, row) adds the pixel errors of its row left to right, then one thread per block adds the rows top to bottom.
-struct ErrorRow { uint32_t block, y; };
-__global__ void __launch_bounds__(RT_BLOCK) k_block_error_rows(const float* __restrict__ sum, const float* __restrict__ secondary, uint32_t width,
-                                                               const RtBlock* __restrict__ blocks, const ErrorRow* __restrict__ rows, uint32_t numRows,
-                                                               float imageScalingFactor, float* __restrict__ rowErrors)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numRows) return;
-    const RtBlock b = blocks[rows[i].block];
-    const uint32_t y = rows[i].y;
-    const float scaleB = 2.0f * imageScalingFactor;
-    float rowError = 0.0f;
-    for (uint32_t x = b.minX; x < b.maxX; ++x)
-    {
-        const size_t p = 3 * ((size_t)y * width + x);
-        const float ax = imageScalingFactor * sum[p], ay = imageScalingFactor * sum[p + 1], az = imageScalingFactor * sum[p + 2];
-        const float bx = scaleB * secondary[p], by = scaleB * secondary[p + 1], bz = scaleB * secondary[p + 2];
-        const float dx = fabsf(ax - bx), dy = fabsf(ay - by), dz = fabsf(az - bz);
-        const float error = (dx + 2.0f * dy + dz) / sqrtf(RTD_EPSILON + ax + 2.0f * ay + az);
-        rowError += error;
-    }
-    rowErrors[i] = rowError;
-}
-__global__ void __launch_bounds__(RT_BLOCK) k_block_error_total(const RtBlock* __restrict__ blocks, const uint32_t* __restrict__ firstRow, uint32_t numBlocks,
-                                                                const float* __restrict__ rowErrors, uint32_t totalArea, float* __restrict__ outErrors)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numBlocks) return;
-    const RtBlock b = blocks[i];
-    float totalError = 0.0f;
-    for (uint32_t r = 0; r < b.maxY - b.minY; ++r) totalError += rowErrors[firstRow[i] + r];
-    const uint32_t blockArea = (b.maxX - b.minX) * (b.maxY - b.minY);
-    outErrors[i] = totalError * sqrtf((float)blockArea / (float)totalArea) / (float)blockArea;
-}
-
-// ITexture::Evaluate for a list of (texture, uv) pairs -- rtgpu_evaluate_textures
-__global__ void __launch_bounds__(RT_BLOCK) k_evaluate_textures(const RtSceneDesc scene, uint32_t count, const uint32_t* __restrict__ textureIndex,
-                                                                const float* __restrict__ uv, float* __restrict__ out)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const V4 c = textureEvaluate(scene, textureIndex[i], V4(uv[2 * i], uv[2 * i + 1], 0.0f, 0.0f));
-    out[4 * i + 0] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
-}
+#include "rt_tail_kernels.h"
 
 // =====================================================================================================
 // Host side of the C-ABI
@@ -694,8 +93,8 @@ static int fail(int code, const std::string& msg) { gLastError = msg; return cod
                         std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
-enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_RETRACE, KC_COUNT };
-static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "retrace", "", "", "" };
+enum KernelClass { KC_GENERATE = 0, KC_TRACE, KC_SHADE, KC_ACCUMULATE, KC_RETRACE, KC_TAIL, KC_COUNT };
+static const char* const kKernelClassNames[RTGPU_NUM_KERNEL_CLASSES] = { "generate", "trace", "shade", "accumulate", "retrace", "tail", "", "" };
 
 #define RT_SEED_RING 128
 
@@ -772,6 +171,7 @@ struct RtgpuContext
     bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
+    uint32_t tailDepth = 0;            // the bounce at which a dense batch hands over to k_tail (rt_tail.hip); 0 = never
     bool sortShadeKinds = false;       // RTGPU_SHADE_SORT=1: the generic k_shade_dense deals a block's vertices to its threads by hit kind (measured 4 % slower: off)
     int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures, 4 lean + simple bitmaps only
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
@@ -1661,9 +1061,14 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset,
                             const uint32_t* denseCounts, uint32_t denseShardCapacity)
 {
+    // A block traces the rays its walk does not decide itself (rt_trace_wide.inl) where launches are short: a 1/8 shard of a full-HD frame gains 10 %
+    // (ten launches per batch less to wait for), a full frame loses 1.4 % (a block holds its slot of the CU while one wave walks; the separate launch
+    // ran beside the other lanes' kernels) -- profiles/r04_local_exact_ab.txt.  RTGPU_LOCAL_EXACT=0 / 1 forces it.
+    static const int localExactEnv = getenv("RTGPU_LOCAL_EXACT") ? atoi(getenv("RTGPU_LOCAL_EXACT")) : -1;
+    const bool localExact = localExactEnv >= 0 ? localExactEnv != 0 : c->numSlots < 400000u;
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
-                        chunkMin < 64u ? 64u : chunkMin };
+                        chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u };
     const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
     if (c->wide.nodes == nullptr)
@@ -1677,6 +1082,17 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)
     if (diag) hipLaunchKernelGGL((k_trace_wide<24, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
     else hipLaunchKernelGGL((k_trace_wide<24, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+}
+
+// The bounce at which a dense batch hands its remaining paths to k_tail (0: never).  RTGPU_TAIL_DEPTH=n forces bounce n (0: off).
+static uint32_t tailDepthFor(const RtgpuContext* c, uint32_t totalSlots, uint32_t maxRayDepth, bool denseAll, uint32_t stackClass)
+{
+    static const int env = getenv("RTGPU_TAIL_DEPTH") ? atoi(getenv("RTGPU_TAIL_DEPTH")) : -1;
+    if (env == 0 || denseAll || c->wide.nodes == nullptr || !useWide(c) || stackClass != 24u || c->debugMode >= 0) return 0u;
+    uint32_t depth = env > 0 ? (uint32_t)env : c->tailDepth;
+    (void)totalSlots;
+    if (depth > maxRayDepth + 1u) return 0u;
+    return depth;
 }
 
 // Submits the queued passes as one batch: generate -> {trace -> shade} per bounce -> trace -> accumulate.
@@ -1759,10 +1175,28 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             hipLaunchKernelGGL(k_generate_dense, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters);
         }
         const bool haveNee = c->numLights != 0 && !c->plainPathTracer;
+        // The fused tail (rt_tail.hip): from bounce `tailDepth` on, one persistent launch takes the batch's remaining paths to their end.  Single-mesh
+        // scenes behind the 4-wide walk, one next-event request per vertex.
+        const uint32_t tailDepth = tailDepthFor(c, totalSlots, maxRayDepth, denseAll, stackClass);
         for (uint32_t depth = 0; depth <= maxRayDepth + 1u; ++depth)
         {
             const Paths& in = (depth & 1u) ? l.paths2 : l.paths;
             const Paths& out = (depth & 1u) ? l.paths : l.paths2;
+            if (tailDepth != 0u && depth == tailDepth)
+            {
+                const TailArgs args = { l.denseCounts + (size_t)plane * depth, shardCapacity, cursors + depth, c->tune.refillMinIdle, c->tune.otherMinLanes };
+                static const uint32_t tailBlocksPerCU = getenv("RTGPU_TAIL_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_TAIL_BLOCKS_PER_CU")) : 4u;   // tuning knob
+                uint32_t tailBlocks = (totalSlots + RT_TAIL_PATHS - 1u) / RT_TAIL_PATHS;   // never more blocks than chunks of the whole batch
+                if (tailBlocks > c->numCUs * tailBlocksPerCU) tailBlocks = c->numCUs * tailBlocksPerCU;
+                const dim3 tailGrid(tailBlocks ? tailBlocks : 1u);
+                LaunchTimer t(c, l.stream, KC_TAIL);
+#define RT_LAUNCH_TAIL(L, P) hipLaunchKernelGGL((k_tail<L, P>), tailGrid, block, 0, l.stream, c->sceneDev, c->wide, passesDev, c->numSlots, in, args, l.home, c->counters)
+                if (c->plainPathTracer) RT_LAUNCH_TAIL(0, true);
+                else if (c->leanScene == 1) RT_LAUNCH_TAIL(1, false); else if (c->leanScene == 2) RT_LAUNCH_TAIL(2, false);
+                else if (c->leanScene == 3) RT_LAUNCH_TAIL(3, false); else if (c->leanScene == 4) RT_LAUNCH_TAIL(4, false); else RT_LAUNCH_TAIL(0, false);
+#undef RT_LAUNCH_TAIL
+                break;
+            }
             const bool haveClosest = depth <= maxRayDepth, haveShadow = depth > 0 && haveNee;
             if (haveClosest || haveShadow)
             {

@@ -1,6 +1,6 @@
 // rt_shade.hip -- the shading kernels of the library, a translation unit of their own: PathTracerMIS / PathTracer / Debug shading over
 // slot-per-pixel and dense path state (rt_shade.inl, rt_dense.inl) and the bidirectional integrator's kernels (rt_vcm.inl).  The host side
-// (rt_kernels.hip) launches them through the declarations of rt_shade_kernels.h.
+// (rt_runtime.hip) launches them through the declarations of rt_shade_kernels.h.
 //
 // Why its own unit: it is compiled with -mllvm -simplifycfg-sink-common=false.  SimplifyCFG's common-code sinking merges the stores that
 // different branches of the BSDF / shape / counter code make into ONE store through a pointer phi, which SROA cannot promote: the BSDF

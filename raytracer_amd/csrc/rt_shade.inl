@@ -91,6 +91,7 @@ RT_DEV void flushAppendBuffer(const uint32_t* buf, uint32_t& count, uint32_t& ba
     __syncthreads();
 }
 
+#ifndef RT_SHADE_FUNCTIONS_ONLY   // (rt_tail.hip takes the functions above and none of the kernels below)
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395).
 // kPlain: the renderer "Path Tracer" instead (PathTracer::RenderPixel, Core/Rendering/PathTracer.cpp:73-171): the same walk without
 // next event estimation, MIS weights and sampling weights.
@@ -383,4 +384,4 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
     }
     flushCounters(cnt, counters);
 }
-
+#endif   // RT_SHADE_FUNCTIONS_ONLY

@@ -1,4 +1,4 @@
-// rt_shade_kernels.h -- declarations of the kernels rt_shade.hip defines, for the host side in rt_kernels.hip
+// rt_shade_kernels.h -- declarations of the kernels rt_shade.hip defines, for the host side in rt_runtime.hip
 #pragma once
 #include "rt_vcm_state.h"
 

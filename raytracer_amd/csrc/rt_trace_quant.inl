@@ -1,7 +1,7 @@
 // rt_trace_quant.inl -- an EXPERIMENT (RTGPU_QUANT=1; measured no faster than k_trace: 182 vs 183 ms) and the home of what the default
 // walk of single-mesh scenes, k_trace_wide (rt_trace_wide.inl), shares with it: the 16-bit grid, the per-leaf exact boxes and the
 // exactness argument below.  The kernel here walks the binary tree of the reference with its child pairs re-encoded in 32 bytes.
-// Included by rt_kernels.hip.
+// Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS).
 //
 // Why.  k_trace (rt_device_traverse.h) is bound by the vector L1: a lane fetches its 64-byte node pair with four 16-byte loads, and a
 // divergent 16-byte access occupies the texture-cache pipeline for a cycle whatever it uses of the line -- 0.71 accesses per clock and
@@ -54,6 +54,7 @@ struct QuantTuning
     uint32_t* exactShadowQueue; uint32_t* exactShadowCount;   // any-hit requests handed to it
 };
 
+#ifdef RT_DEVICE_KERNELS
 template <int kStack>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_quant(const RtSceneDesc scene, const QuantBvh bvh, const Paths paths,
                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
@@ -255,6 +256,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
 }
 
+#endif   // RT_DEVICE_KERNELS
+
+#ifdef RT_HOST_BUILDERS
 // ---- host: the reference's binary BVH (BVH::Node, 32 bytes, children adjacent) re-encoded ----
 struct QuantBuild
 {
@@ -327,3 +331,4 @@ static QuantBuild buildQuantBvh(const RtNode* nodes, uint32_t numNodes, uint32_t
     q.ok = true;
     return q;
 }
+#endif   // RT_HOST_BUILDERS

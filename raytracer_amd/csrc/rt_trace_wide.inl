@@ -1,5 +1,5 @@
 // rt_trace_wide.inl -- traversal of single-mesh scenes over a 4-WIDE tree collapsed from the reference's binary tree (same SAH splits,
-// same leaves), one ray per lane.  Included by rt_kernels.hip after rt_trace_quant.inl, whose grid, leaf gates and exactness argument it
+// same leaves), one ray per lane.  Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS) after rt_trace_quant.inl, whose grid, leaf gates and exactness argument it
 // shares.
 //
 // Why.  k_trace waits ~0.8 us per dependent node fetch with 20 waves per CU to hide it: the walk is a chain of ~29 round
@@ -39,8 +39,10 @@ struct WideTuning
     uint32_t* exactShadowQueue; uint32_t* exactShadowCount;   // any-hit requests handed to it
     const uint32_t* denseCounts; uint32_t denseShardCapacity; // dense path state (TravTuning)
     uint32_t chunkMin;                                        // smallest piece of the work queue a wave claims at once
+    uint32_t localExact;                                      // != 0: a block traces the rays its walk does not decide itself (k_trace_wide; RTGPU_LOCAL_EXACT=0: off)
 };
 
+#ifdef RT_DEVICE_KERNELS
 // slab test of one child record against the ray's folded constants; near is clamped to >= 0 (its bits then order like the float).
 // Which of an axis's two planes the ray meets first is a property of the RAY (the sign of its direction), so three byte permutes with
 // per-ray selectors (v_perm_b32) put {near plane, far plane} of every axis into one word and the six min / max of the textbook slab
@@ -64,14 +66,34 @@ struct WideTuning
     }
 #define RT_WIDE_IS_LEAF(ref) ((((ref) >> RT_NODE_LEAVES_SHIFT) - 1u) < 2u)   // one or two triangles; not an interior node (0), not RT_WIDE_EMPTY / RT_QUANT_DONE (3)
 
-template <int kStack, bool kDiag = false>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
-                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                         const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
-                                                         uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
+// The block's own list of the rays its walk does not decide (LDS): they are traced by the reference's walk (traceBinaryLoop) in the same launch
+// when the block's 4-wide walk is done, instead of by a launch of their own behind this one (ten launches of 70 ... 1600 us per batch for 0.1 %
+// of the rays, profiles/r03_timeline_serial_start_of_round.txt).  What does not fit the list goes to the launch's queues as before.
+struct WideLocal
 {
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
-    __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
+    uint32_t* exact; uint32_t* exactCount;       // closest-hit rays (path slots)
+    uint32_t* shadow; uint32_t* shadowCount;     // any-hit requests (light * capacity + slot)
+    uint32_t capacity;                           // entries per list; 0: no local lists
+};
+RT_DEV void widePushExact(const WideTuning& tune, const WideLocal& local, bool shadowRequest, uint32_t request)
+{
+    if (local.capacity != 0u)
+    {
+        const uint32_t i = atomicAdd(shadowRequest ? local.shadowCount : local.exactCount, 1u);   // (the consumer clamps the count to the capacity)
+        if (i < local.capacity) { (shadowRequest ? local.shadow : local.exact)[i] = request; return; }
+    }
+    if (shadowRequest) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
+    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = request;
+}
+#define RT_WIDE_LOCAL_EXACT 256u   // per block and kind: ~40 x what a block of the benchmark hands over per launch
+
+// The walk as a device function (k_trace_wide below; k_tail, rt_tail.hip, runs it over a block's own queues in LDS: `queue`, `shadowQueue`,
+// the counts and `cursor` are generic pointers, `sharingWaves` = the waves that claim from `cursor`).
+template <int kStack, bool kDiag = false>
+RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Paths& paths, const uint32_t* queue, const uint32_t* queueCount,
+                          const uint32_t* shadowQueue, const uint32_t* shadowCount, uint32_t* cursor, unsigned long long* counters, const WideTuning& tune,
+                          const WideLocal& handOver, uint32_t* sStack, uint32_t* sDensePrefix, uint32_t sharingWaves)
+{
     uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
     const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
@@ -90,7 +112,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
 
-    uint32_t chunkSize = count / (gridDim.x * ((uint32_t)RT_BLOCK / 64u) * 4u);
+    uint32_t chunkSize = count / (sharingWaves * 4u);
     chunkSize = chunkSize < tune.chunkMin ? tune.chunkMin : (chunkSize > 1024u ? 1024u : chunkSize);
     WaveChunk chunk = { 0u, 0u };
 
@@ -153,8 +175,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 if (!trusted)
                 {
                     // a zero direction component (NaNs in the reference's slab test) or an origin far outside the mesh: the reference's walk only
-                    if (shadow) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
-                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
+                    widePushExact(tune, handOver, shadow, shadow ? request : slot);
                     numRetraced++; numUntrusted++;
                 }
                 else
@@ -269,8 +290,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 // ---- finished ----
                 if (overflow)
                 {
-                    if (shadow) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = light * paths.capacity + slot;
-                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
+                    widePushExact(tune, handOver, shadow, shadow ? light * paths.capacity + slot : slot);
                     numRetraced++; numOverflow++;
                     if (shadow) numShadowRays--;   // counted by the kernel that resolves it
                 }
@@ -281,7 +301,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 else if (best == inf) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), inf, 0.0f);   // HitPoint.h:14-51
                 else if (second <= best + tol)
                 {
-                    tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;   // a runner-up too close to call: the reference's own walk decides
+                    widePushExact(tune, handOver, false, slot);   // a runner-up too close to call: the reference's own walk decides
                     numRetraced++;
                 }
                 have = false;
@@ -323,6 +343,35 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     }
 }
 
+
+template <int kStack, bool kDiag = false>
+__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
+                                                         const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
+                                                         const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
+                                                         uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
+{
+    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
+    __shared__ uint32_t sLocalExact[RT_WIDE_LOCAL_EXACT], sLocalShadow[RT_WIDE_LOCAL_EXACT], sLocalCounts[4];   // counts: closest, any-hit, work cursor of the second walk
+    const bool localLists = tune.localExact != 0u && !kDiag;
+    if (threadIdx.x < 4u) sLocalCounts[threadIdx.x] = 0u;
+    __syncthreads();
+    const WideLocal local = { sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], localLists ? RT_WIDE_LOCAL_EXACT : 0u };
+    traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, local, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
+    // the rays this block's walk did not decide, by the reference's own walk (block-uniform branch: the counts are final behind the walk's barrier)
+    __syncthreads();
+    if (threadIdx.x < 2u && sLocalCounts[threadIdx.x] > RT_WIDE_LOCAL_EXACT) sLocalCounts[threadIdx.x] = RT_WIDE_LOCAL_EXACT;
+    __syncthreads();
+    if (sLocalCounts[0] + sLocalCounts[1] != 0u)
+    {
+        const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };
+        traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
+                                              (uint32_t)RT_BLOCK / 64u);
+    }
+}
+#endif   // RT_DEVICE_KERNELS
+
+#ifdef RT_HOST_BUILDERS
 // ---- host: collapse of the reference's binary tree.  A wide node starts as the two children of a binary node; while it has a free
 // slot, its interior child with the largest surface area is replaced by that child's own two children.  Node indices are breadth first.
 struct WideBuild
@@ -385,3 +434,4 @@ static WideBuild buildWideBvh(const RtNode* nodes, uint32_t numNodes, const Quan
     w.ok = true;
     return w;
 }
+#endif   // RT_HOST_BUILDERS

@@ -1,6 +1,6 @@
 // rt_trace_wide2.inl -- the 4-wide walk for TWO-LEVEL scenes (Scene::Traverse over the top-level BVH of the objects, Scene.cpp:219-261, into
 // MeshShape::Traverse for mesh objects, Traverse_Object / Traverse_Object_Shadow for analytic shapes and light objects): a 4-wide collapse
-// of the reference's top-level tree over 4-wide collapses of its mesh trees.  Included by rt_kernels.hip after rt_trace_wide.inl, whose node
+// of the reference's top-level tree over 4-wide collapses of its mesh trees.  Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS) after rt_trace_wide.inl, whose node
 // format, slab test, sorting network and exactness argument it shares; what is new here is only the second level.
 //
 // Why.  Round 2's k_trace_wide serves scenes with ONE mesh object; the Cornell box (ten analytic instances), a Sponza with props, every
@@ -38,6 +38,7 @@ struct WideScene
     uint32_t numObjects;       // >= 2 (one-object scenes are Scene::Traverse's bypass: no top-level tree; k_trace_wide or k_trace serve them)
 };
 
+#ifdef RT_DEVICE_KERNELS
 #define RT_WIDE2_WORLD_WORDS 6u   // per lane in LDS: the world ray's invDir and (stale) originDivDir
 
 template <int kStack>
@@ -353,6 +354,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
 }
 
+#endif   // RT_DEVICE_KERNELS
+
+#ifdef RT_HOST_BUILDERS
 // ---- host: the 4-wide trees of a two-level scene --------------------------------------------------------------------------------------
 struct WideLevelBuild
 {
@@ -403,3 +407,4 @@ static WideLevelBuild buildWideLevel(const RtNode* nodes, uint32_t numNodes, uin
     out.ok = true;
     return out;
 }
+#endif   // RT_HOST_BUILDERS

@@ -1,5 +1,5 @@
 // rt_vcm.inl -- wavefront form of the reference's bidirectional integrator (Core/Rendering/VertexConnectionAndMerging.cpp),
-// included by rt_kernels.hip (it reuses the path-record arena, the persistent traversal kernel and the context).
+// included by rt_shade.hip (it reuses the path-record arena, the persistent traversal kernel and the context).
 //
 // One pass over the whole frame (RenderPixel, :172-318, for every pixel):
 //

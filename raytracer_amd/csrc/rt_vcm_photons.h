@@ -1,4 +1,4 @@
-// rt_vcm_photons.h -- interface between the integrator kernels (rt_kernels.hip / rt_vcm.inl) and the photon hash-grid
+// rt_vcm_photons.h -- interface between the integrator kernels (rt_runtime.hip / rt_vcm.inl) and the photon hash-grid
 // builder (rt_vcm_photons.hip, the one translation unit that uses hipCUB's device scan / radix sort).
 #pragma once
 #include <hip/hip_runtime.h>

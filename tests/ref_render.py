@@ -78,10 +78,9 @@ def export_scene(path, scene, camera, width, height, passes, threads, max_ray_de
             k = {"point_light": 1, "spot_light": 2, "directional_light": 3}[kind]
             lights.append(struct.pack("<4I4f4f16f", k, 0, 0, 0, *a["color"], 0.0, a.get("angle", 0.0), 0, 0, 0, *a["transform"]))
         elif kind == "background_light":
-            if a.get("texture") is not None:
-                raise ValueError("environment maps are not exported")
             ident = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
-            lights.append(struct.pack("<4I4f4f16f", 4, 0, 0, 0, *a["color"], 0.0, 0, 0, 0, 0, *ident))
+            env = texture_index[a["texture"]] + 1 if a.get("texture") is not None else 0   # environment map: BackgroundLight::mTexture
+            lights.append(struct.pack("<4I4f4f16f", 4, 0, env, 0, *a["color"], 0.0, 0, 0, 0, 0, *ident))
         else:
             raise ValueError("scene element %r is not exported" % kind)
     c = camera.settings
@@ -130,12 +129,12 @@ def run(scene_path, threads=None, passes=None, timeout=900):
                        first_pass_seeds=seeds, first_pass_sample_offset=first_offset, image=image)
 
 
-def timed_baseline(exe, args, scene, camera, ra):
+def timed_baseline(exe, args, scene, camera, ra, dimensions=64, light_sampling_all=False):
     """bench.py's cpu_baseline: the same workload on every hardware thread and on one, a bounded number of passes each."""
     threads = os.cpu_count() or 1
     with tempfile.TemporaryDirectory(prefix="rtref_", dir="/tmp") as tmp:
         path = os.path.join(tmp, "scene.bin")
-        export_scene(path, scene, camera, args.width, args.height, 1, threads, args.depth, seed=77, dump_image=False)
+        export_scene(path, scene, camera, args.width, args.height, 1, threads, args.depth, dimensions=dimensions, light_sampling_all=light_sampling_all, seed=77, dump_image=False)
         # calibrate with one pass on all threads, then as many passes as fit the budget (at most 8)
         s1, _ = run(path, threads, 1)
         passes = int(max(1, min(8, (args.cpu_seconds * 0.6) // max(s1["seconds"], 1e-3))))
@@ -144,7 +143,8 @@ def timed_baseline(exe, args, scene, camera, ra):
         single = None
         try:
             small = os.path.join(tmp, "scene_small.bin")
-            export_scene(small, scene, camera, max(64, args.width // 4), max(36, args.height // 4), 1, 1, args.depth, seed=77, dump_image=False)
+            export_scene(small, scene, camera, max(64, args.width // 4), max(36, args.height // 4), 1, 1, args.depth, dimensions=dimensions, light_sampling_all=light_sampling_all,
+                         seed=77, dump_image=False)
             single, _ = run(small, 1, 1)
         except Exception:
             single = None

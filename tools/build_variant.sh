@@ -7,8 +7,12 @@ cp -r /root/repo/raytracer_amd/csrc $W/raytracer_amd/csrc; cp -r /root/repo/incl
 while [ $# -gt 0 ]; do f=$1; e=$2; shift; shift; sed -i "$e" $W/raytracer_amd/csrc/$f; done
 mkdir -p /root/repo/variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=hidden"
-/opt/rocm/bin/hipcc $F -mllvm -simplifycfg-sink-common=false -c $W/raytracer_amd/csrc/rt_shade.hip -o $W/rt_shade.o &
-/opt/rocm/bin/hipcc $F -c $W/raytracer_amd/csrc/rt_kernels.hip -o $W/rt_kernels.o
+OBJS=""
+for u in rt_shade rt_tail; do
+  if [ -f $W/raytracer_amd/csrc/$u.hip ]; then /opt/rocm/bin/hipcc $F -mllvm -simplifycfg-sink-common=false -c $W/raytracer_amd/csrc/$u.hip -o $W/$u.o & OBJS="$OBJS $W/$u.o"; fi
+done
+/opt/rocm/bin/hipcc $F -c $W/raytracer_amd/csrc/rt_trace.hip -o $W/rt_trace.o &
+/opt/rocm/bin/hipcc $F -c $W/raytracer_amd/csrc/rt_runtime.hip -o $W/rt_runtime.o
 wait
-/opt/rocm/bin/hipcc $F -shared $W/rt_kernels.o $W/rt_shade.o $W/raytracer_amd/csrc/rt_vcm_photons.hip -o /root/repo/variants/librtgpu_$name.so
+/opt/rocm/bin/hipcc $F -shared $W/rt_runtime.o $W/rt_trace.o $OBJS $W/raytracer_amd/csrc/rt_vcm_photons.hip -o /root/repo/variants/librtgpu_$name.so
 echo built variants/librtgpu_$name.so

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Per-kernel VGPR / SGPR / scratch / LDS table from hipcc's assembly listing:  python tools/kernel_resources.py [file.s]
-(without an argument: compiles raytracer_amd/csrc/rt_kernels.hip for gfx950 to /tmp first)"""
+(without an argument: compiles the device translation units of raytracer_amd/csrc for gfx950 to /tmp first; UNITS=rt_trace,rt_tail restricts them)"""
 import re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/rt_kernels_resources.s"
+path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/rt_trace_resources.s"
 s = ""
 if len(sys.argv) <= 1:
-    # the library's two device translation units, with the flags __graft_entry__.build() gives them
-    for unit, extra in (("rt_kernels.hip", []), ("rt_shade.hip", ["-mllvm", "-simplifycfg-sink-common=false"])):
+    # the library's device translation units, with the flags __graft_entry__.build() gives them
+    no_sink = ["-mllvm", "-simplifycfg-sink-common=false"]
+    units = [("rt_trace.hip", []), ("rt_shade.hip", no_sink), ("rt_tail.hip", no_sink)]
+    if os.environ.get("UNITS"):
+        units = [(u, e) for u, e in units if u.split(".")[0] in os.environ["UNITS"].split(",")]
+    for unit, extra in units:
+        if not os.path.exists(os.path.join(ROOT, "raytracer_amd/csrc", unit)):
+            continue
         out = "/tmp/%s_resources.s" % unit.split(".")[0]
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"] + extra + ["-S", "--cuda-device-only",
                                os.path.join(ROOT, "raytracer_amd/csrc", unit), "-o", out], stderr=subprocess.DEVNULL)
