@@ -141,11 +141,13 @@ def algorithmic_bytes(c):
     trace_shadow = 32 * c["numShadowRayBoxTests"] + 36 * c["numShadowRayTriangleTests"]
     shade = 176 * c["numMeshHits"] + 192 * c["numAnalyticHits"]
     film = 36 * c["numPrimaryRays"]
-    return {"trace": trace_closest + trace_shadow, "shade": shade, "accumulate": film, "generate": 0}
+    # ("tail": the fused tail of a batch, rt_tail.hip, does trace and shade work of the late bounces -- the per-class counters do not separate it:
+    #  its share is inside "trace" and "shade", which therefore overstate those two classes when a tail runs)
+    return {"trace": trace_closest + trace_shadow, "shade": shade, "accumulate": film, "generate": 0, "retrace": 0, "tail": 0}
 
 
 # kernel-name prefix (as rocprofv3 reports it) -> kernel class of rtgpu_get_kernel_times
-KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_trace_wide", "trace"), ("k_trace_quant", "trace"), ("k_trace", "trace"), ("k_shade", "shade"),
+KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_tail", "tail"), ("k_trace_wide", "trace"), ("k_trace_quant", "trace"), ("k_trace", "trace"), ("k_shade", "shade"),
                          ("k_vcm_light_finish", "accumulate"), ("k_vcm_camera_finish", "accumulate"), ("k_vcm_emit", "generate"), ("k_vcm_", "shade"),
                          ("k_lt_shade", "shade"), ("k_generate", "generate"), ("k_accumulate", "accumulate"))
 

@@ -257,7 +257,7 @@ RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t 
 // slot of the input arena first -- its previous requests were folded in at the top of the iteration, the space is free -- and copied to the
 // output slot once the block has allocated it (the copy reads what the same lane just wrote: L2 hits).
 template <int kLean, bool kPlain = false, bool kAll = false>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_MIN_WAVES(kLean, kAll), RT_SHADE_MIN_WAVES(kLean, kAll) > 1 ? RT_SHADE_MIN_WAVES(kLean, kAll) : 10))) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
+__global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
                                                           const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
                                                           float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds)
 {

@@ -54,9 +54,21 @@ using namespace rtd;
 // this).  So anything above 64 KB that is not page-locked already (hipHostMalloc / hipHostRegister: the viewport's sum bitmaps) travels
 // through a page-locked staging buffer of the library, 8 MB at a time.
 #include <mutex>
-static std::mutex gStagingMutex;
-static void* gStaging = nullptr;
+// one staging buffer (and its lock) per device: contexts on different devices copy side by side (rtgpu_create_multi).  8 MB of page-locked memory
+// per device used, kept for the life of the process (freeing it from an exit handler would race the HIP runtime's own teardown)
+struct Staging { std::mutex mutex; void* buffer = nullptr; };
+static std::mutex gStagingTableMutex;
+static std::unordered_map<int, Staging*> gStaging;
 static const size_t kStagingBytes = (size_t)8 << 20;
+static Staging* stagingOfCurrentDevice()
+{
+    int device = 0;
+    (void)hipGetDevice(&device);
+    std::lock_guard<std::mutex> lock(gStagingTableMutex);
+    Staging*& s = gStaging[device];
+    if (!s) s = new Staging();
+    return s;
+}
 static bool hostRangeIsPageLocked(const void* p)
 {
     hipPointerAttribute_t attr;
@@ -68,15 +80,20 @@ static hipError_t rtMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKi
     if (bytes == 0) return hipSuccess;
     const bool h2d = kind == hipMemcpyHostToDevice, d2h = kind == hipMemcpyDeviceToHost;
     if ((!h2d && !d2h) || bytes <= ((size_t)64 << 10) || hostRangeIsPageLocked(h2d ? src : dst)) return hipMemcpy(dst, src, bytes, kind);
-    std::lock_guard<std::mutex> lock(gStagingMutex);
-    if (!gStaging) { const hipError_t e = hipHostMalloc(&gStaging, kStagingBytes, hipHostMallocPortable); if (e != hipSuccess) { gStaging = nullptr; return e; } }
+    Staging* const st = stagingOfCurrentDevice();
+    std::lock_guard<std::mutex> lock(st->mutex);
+    if (!st->buffer)
+    {
+        const hipError_t e = hipHostMalloc(&st->buffer, kStagingBytes, hipHostMallocPortable);
+        if (e != hipSuccess) { st->buffer = nullptr; return e; }
+    }
     for (size_t done = 0; done < bytes; done += kStagingBytes)
     {
         const size_t n = bytes - done < kStagingBytes ? bytes - done : kStagingBytes;
-        if (h2d) memcpy(gStaging, static_cast<const char*>(src) + done, n);
-        const hipError_t e = h2d ? hipMemcpy(static_cast<char*>(dst) + done, gStaging, n, kind) : hipMemcpy(gStaging, static_cast<const char*>(src) + done, n, kind);
+        if (h2d) memcpy(st->buffer, static_cast<const char*>(src) + done, n);
+        const hipError_t e = h2d ? hipMemcpy(static_cast<char*>(dst) + done, st->buffer, n, kind) : hipMemcpy(st->buffer, static_cast<const char*>(src) + done, n, kind);
         if (e != hipSuccess) return e;
-        if (d2h) memcpy(static_cast<char*>(dst) + done, gStaging, n);
+        if (d2h) memcpy(static_cast<char*>(dst) + done, st->buffer, n);
     }
     return hipSuccess;
 }
@@ -171,7 +188,8 @@ struct RtgpuContext
     bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
-    uint32_t tailDepth = 0;            // the bounce at which a dense batch hands over to k_tail (rt_tail.hip); 0 = never
+    int32_t tailBounce = -1;           // rtgpu_set_schedule: the bounce at which a dense batch hands over to k_tail (rt_tail.hip); 0 = never, -1 = policy
+    int32_t localRetrace = -1;         // rtgpu_set_schedule: the 4-wide walks trace their undecided rays themselves; 0 / 1, -1 = policy
     bool sortShadeKinds = false;       // RTGPU_SHADE_SORT=1: the generic k_shade_dense deals a block's vertices to its threads by hit kind (measured 4 % slower: off)
     int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures, 4 lean + simple bitmaps only
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
@@ -868,7 +886,9 @@ static int rebuildSlots(RtgpuContext* c)
     if (!c->passBatchFromEnv)
     {
         static const uint32_t streamBase = getenv("RTGPU_PASS_BATCH_BASE") ? (uint32_t)atoi(getenv("RTGPU_PASS_BATCH_BASE")) : 5u;
-        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? 16u : (streamBase ? streamBase : 1u);   // full frames: 5 -> 10 -> 20 -> 24 while streaming, one size per round of the lanes (flushBatch)
+        // (small frames / 1/8 shards of a full-HD frame: 20 passes per batch -- 16 -> 20: +3 % at the driver's 20 steps, profiles/r04_tail_sweep.txt)
+        static const uint32_t smallBatch = getenv("RTGPU_SMALL_FRAME_BATCH") ? (uint32_t)atoi(getenv("RTGPU_SMALL_FRAME_BATCH")) : 20u;
+        c->passBatch = c->numSlots != 0 && c->numSlots < 400000u ? (smallBatch ? smallBatch : 1u) : (streamBase ? streamBase : 1u);   // full frames: 5 -> 10 -> 20 -> 24 while streaming, one size per round of the lanes (flushBatch)
         // (very large frames: fewer passes per launch, an arena of 8 passes of an 8K frame would be 47 GB)
         while (c->passBatch > 1u && (size_t)c->numSlots * c->passBatch * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4) > ((size_t)24 << 30)) c->passBatch /= 2u;
     }
@@ -1065,7 +1085,8 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     // (ten launches per batch less to wait for), a full frame loses 1.4 % (a block holds its slot of the CU while one wave walks; the separate launch
     // ran beside the other lanes' kernels) -- profiles/r04_local_exact_ab.txt.  RTGPU_LOCAL_EXACT=0 / 1 forces it.
     static const int localExactEnv = getenv("RTGPU_LOCAL_EXACT") ? atoi(getenv("RTGPU_LOCAL_EXACT")) : -1;
-    const bool localExact = localExactEnv >= 0 ? localExactEnv != 0 : c->numSlots < 400000u;
+    // (the second walk runs on the kernel's 24-entry stacks: scenes whose binary trees need deeper ones keep the separate launch)
+    const bool localExact = c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : c->numSlots < 700000u));   // (a 1/4 shard, 518 k pixels: +0 ... 2 %, with the tail +4 %; halves: 0)
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
                         chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u };
@@ -1088,8 +1109,11 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
 static uint32_t tailDepthFor(const RtgpuContext* c, uint32_t totalSlots, uint32_t maxRayDepth, bool denseAll, uint32_t stackClass)
 {
     static const int env = getenv("RTGPU_TAIL_DEPTH") ? atoi(getenv("RTGPU_TAIL_DEPTH")) : -1;
-    if (env == 0 || denseAll || c->wide.nodes == nullptr || !useWide(c) || stackClass != 24u || c->debugMode >= 0) return 0u;
-    uint32_t depth = env > 0 ? (uint32_t)env : c->tailDepth;
+    if (env == 0 || c->tailBounce == 0 || denseAll || c->wide.nodes == nullptr || !useWide(c) || stackClass != 24u || c->debugMode >= 0) return 0u;
+    // Measured (profiles/r04_tail_sweep.txt, 20 passes): a 1/8 shard of the full-HD benchmark frame gains 6-8 % with the hand-over at bounce 4 or 5 (0.580 ->
+    // 0.544 ms per pass, with 20-pass batches 0.575-0.606 -> 0.526-0.558; bounce 2: -20 %, 3: 0), a 1/4 shard +2 % at bounce 5 and +4 % at bounce 6 together with the block-local re-trace, halves and full frames lose 1-5 % at any bounce: the block-local
+    // rounds pay a drain each and only beat the launch sequence where that is all floors.  So: small frames only.
+    uint32_t depth = env > 0 ? (uint32_t)env : (c->tailBounce > 0 ? (uint32_t)c->tailBounce : (c->numSlots < 400000u ? 5u : (c->numSlots < 700000u ? 6u : 0u)));
     (void)totalSlots;
     if (depth > maxRayDepth + 1u) return 0u;
     return depth;
@@ -2142,6 +2166,16 @@ RTGPU_API int rtgpu_set_concurrency(RtgpuContext* c, uint32_t lanes)
     RT_FAN_OUT(c, rtgpu_set_concurrency(peer, lanes));
     int r = rtgpu_synchronize(c); if (r) return r;
     c->numLanes = lanes; c->nextLane = 0; c->lanesChosen = true;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_set_schedule(RtgpuContext* c, uint32_t knob, int32_t value)
+{
+    if (!c) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL context");
+    if (knob > RTGPU_SCHEDULE_LOCAL_RETRACE || value < -1 || (knob == RTGPU_SCHEDULE_LOCAL_RETRACE && value > 1) || value > 254) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown knob or value out of range");
+    RT_FAN_OUT(c, rtgpu_set_schedule(peer, knob, value));
+    int r = rtgpu_synchronize(c); if (r) return r;
+    if (knob == RTGPU_SCHEDULE_TAIL_BOUNCE) c->tailBounce = value; else c->localRetrace = value;
     return RTGPU_OK;
 }
 

@@ -23,6 +23,8 @@
 #define RT_TRACE_FUNCTIONS_ONLY 1
 #include "rt_trace_kernels.h"
 #include "rt_tail_kernels.h"
+#define RT_SHADE_DEFINITIONS 1
+#include "rt_shade_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>

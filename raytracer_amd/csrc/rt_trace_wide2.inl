@@ -40,6 +40,7 @@ struct WideScene
 
 #ifdef RT_DEVICE_KERNELS
 #define RT_WIDE2_WORLD_WORDS 6u   // per lane in LDS: the world ray's invDir and (stale) originDivDir
+#define RT_WIDE2_LOCAL_EXACT 64u
 
 template <int kStack>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide2(const RtSceneDesc scene, const WideScene wide, const Paths paths,
@@ -50,6 +51,11 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
     __shared__ float sWorld[RT_WIDE2_WORLD_WORDS * RT_BLOCK];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
+    // the block's own hand-over lists (rt_trace_wide.inl, WideLocal): 64 entries per kind keep five blocks of 30.7 KB on a CU
+    __shared__ uint32_t sLocalExact[RT_WIDE2_LOCAL_EXACT], sLocalShadow[RT_WIDE2_LOCAL_EXACT], sLocalCounts[4];
+    if (threadIdx.x < 4u) sLocalCounts[threadIdx.x] = 0u;
+    __syncthreads();
+    const WideLocal localLists = { sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], tune.localExact != 0u ? RT_WIDE2_LOCAL_EXACT : 0u };
     uint32_t* const stack = sStack + threadIdx.x;
     float* const worldTerms = sWorld + threadIdx.x;   // word w at worldTerms[w * RT_BLOCK]
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
@@ -326,8 +332,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             {
                 if (handOver)
                 {
-                    if (shadow) { tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = light * paths.capacity + slot; numShadowRays--; }   // counted by the kernel that resolves it
-                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
+                    if (shadow) { widePushExact(tune, localLists, true, light * paths.capacity + slot); numShadowRays--; }   // counted by the kernel that resolves it
+                    else widePushExact(tune, localLists, false, slot);
                     numRetraced++;
                 }
                 else if (shadow)
@@ -337,7 +343,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 else if (best == inf) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), inf, 0.0f);
                 else if (second <= best + tol)
                 {
-                    tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;   // a runner-up too close to call: the reference's own walk decides
+                    widePushExact(tune, localLists, false, slot);   // a runner-up too close to call: the reference's own walk decides
                     numRetraced++;
                 }
                 have = false; cur = RT_QUANT_DONE; leafRest = 0u; inMesh = false;
@@ -352,6 +358,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     __syncthreads();
     if (threadIdx.x == 0u && sTally[0]) atomicAdd(&counters[C_SHADOW], (unsigned long long)sTally[0]);
     if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
+    // the rays this block's walk did not decide, by the reference's own walk (as k_trace_wide)
+    __syncthreads();
+    if (threadIdx.x < 2u && sLocalCounts[threadIdx.x] > RT_WIDE2_LOCAL_EXACT) sLocalCounts[threadIdx.x] = RT_WIDE2_LOCAL_EXACT;
+    __syncthreads();
+    if (sLocalCounts[0] + sLocalCounts[1] != 0u)
+    {
+        const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };
+        traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
+                                              (uint32_t)RT_BLOCK / 64u);
+    }
 }
 
 #endif   // RT_DEVICE_KERNELS

@@ -810,6 +810,49 @@ def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dens
     assert_quant_identical(*run_quant(box, ra.Camera((0.0, 2.5, 6.0), (20.0, 180.0, 0.0), w / h, 45.0), w, h, passes=2, max_ray_depth=4))
 
 
+def test_fused_tail_and_block_local_retrace_are_invisible(built):
+    """Round 4's launch-sequence variants (rtgpu_set_schedule): the fused tail kernel k_tail taking over at bounce 1, 2, 3, 5 or never, and the 4-wide
+    walks tracing their undecided rays themselves or handing them to a launch of their own.  Every combination renders the oracle's image bit for
+    bit with the oracle's ray counters -- BASELINE config 3's scene class (one mesh, background + directional light under `Single`: k_trace_wide,
+    dense path state), several passes per batch, and the plain path tracer (no next event estimation) once."""
+    w, h = 160, 90
+    scene, camera = scenes.sponza_class(w / h, 20000)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    lib = ra.rtgpu_lib()
+    reference = None
+    for tail_bounce, local_retrace in ((0, 0), (0, 1), (1, 1), (2, 0), (3, 1), (5, 0), (-1, -1)):
+        vp = ra.Viewport(w, h, seed=4242, max_ray_depth=8)
+        vp.set_renderer(scene)
+        ctx = vp.device_context()
+        assert lib.rtgpu_set_schedule(ctx, C.c_uint32(0), C.c_int32(tail_bounce)) == 0 and lib.rtgpu_set_schedule(ctx, C.c_uint32(1), C.c_int32(local_retrace)) == 0
+        if reference is None:
+            ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
+            cnt = np.zeros(16, dtype=np.uint64)
+            for _ in range(5):
+                p = vp.next_pass_params(camera)
+                vp.render_pass_with(p)
+                oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=8)
+            reference = (ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)})
+        else:
+            vp.render(camera, 5)    # the same seed => the same per-pass constants
+        img, img2 = vp.sum_buffer(secondary=True)
+        counters = vp.counters()
+        assert_quant_identical(img, img2, counters, *reference)
+        assert counters["numRetracedRays"] > 0
+    assert lib.rtgpu_set_schedule(ctx, C.c_uint32(2), C.c_int32(0)) == -1 and lib.rtgpu_set_schedule(ctx, C.c_uint32(1), C.c_int32(2)) == -1   # RTGPU_ERR_INVALID_ARGUMENT
+    # the plain path tracer through the tail (k_tail<0, true>)
+    plain = []
+    for tail_bounce in (0, 2):
+        vp = ra.Viewport(w, h, seed=4242, max_ray_depth=6)
+        vp.set_renderer(scene, name="Path Tracer")
+        assert lib.rtgpu_set_schedule(vp.device_context(), C.c_uint32(0), C.c_int32(tail_bounce)) == 0
+        vp.render(camera, 3)
+        plain.append((vp.sum_buffer(), vp.counters()))
+    assert np.array_equal(plain[0][0].view(np.uint32), plain[1][0].view(np.uint32)) and plain[0][1] == plain[1][1]
+
+
 def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
     """A pathological mesh -- 64 nested sheets around the camera axis, sizes and distances growing by 1.6 from one to the next: the SAH
     builder peels them off a few at a time (a tree 22 levels deep for 128 triangles), and a ray through the stack of sheets enters every

@@ -164,6 +164,71 @@ __global__ void __launch_bounds__(256) k_node(const float4* __restrict__ nodes, 
     if ((threadIdx.x & 63u) == 0u) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
+// (4) step models for the next traversal kernel: every lane runs kRays independent random walks over nodes of kLoads x 16
+// bytes; per step and ray it fetches its node and then issues kValu VALU instructions that DEPEND on the fetched words (fma chains seeded by the node),
+// like the slab tests / sort network of k_trace_wide (137 per 4-wide visit).  Compared: today's step (4 loads, 137), an 8-wide node (8 loads = one
+// 128-byte line, ~280: eight slab tests + a 19-exchange sort), two rays per lane (2 x (4 loads, 137) at the occupancy 120 VGPRs allow: 4 waves).
+template <int kLoads, int kValu, int kRays>
+__global__ void __launch_bounds__(256) k_step(const float4* __restrict__ nodes, uint32_t numNodes, uint32_t steps, uint32_t activeLanes, float* out, unsigned long long* clocks)
+{
+    extern __shared__ uint32_t sPad[];
+    if (steps == 0xFFFFFFFFu) sPad[threadIdx.x] = 1u;
+    uint32_t cur[kRays];
+    for (int r = 0; r < kRays; ++r) cur[r] = ((blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + (uint32_t)r * 40503u) % numNodes;
+    float acc[kRays][4];
+    for (int r = 0; r < kRays; ++r) for (int k = 0; k < 4; ++k) acc[r][k] = 1.0f + (float)k;
+    const bool active = (threadIdx.x & 63u) < activeLanes;
+    __syncthreads();
+    const unsigned long long t0 = clock64();
+    if (active)
+        for (uint32_t s = 0; s < steps; ++s)
+        {
+            float4 q[kRays][kLoads];
+#pragma unroll
+            for (int r = 0; r < kRays; ++r)
+            {
+                const float4* p = nodes + (size_t)kLoads * cur[r];
+#pragma unroll
+                for (int k = 0; k < kLoads; ++k) q[r][k] = p[k];
+            }
+#pragma unroll
+            for (int r = 0; r < kRays; ++r)
+            {
+                // kValu dependent-on-the-node instructions in four independent chains (the compiler may not fold asm volatile)
+                float b = q[r][kLoads - 1].x, c = q[r][kLoads / 2].y;
+#pragma unroll
+                for (int i = 0; i < kValu / 4; ++i)
+                {
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[r][0]) : "v"(b), "v"(c));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[r][1]) : "v"(b), "v"(c));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[r][2]) : "v"(b), "v"(c));
+                    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(acc[r][3]) : "v"(b), "v"(c));
+                }
+                cur[r] = __float_as_uint(q[r][0].w);
+            }
+        }
+    const unsigned long long t1 = clock64();
+    float sum = 0; for (int r = 0; r < kRays; ++r) for (int k = 0; k < 4; ++k) sum += acc[r][k];
+    if (sum == 123.456f) out[0] = sum;
+    if ((threadIdx.x & 63u) == 0u) clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
+
+template <int kLoads, int kValu, int kRays>
+static double runStep(uint32_t numCUs, const float4* dev, uint32_t numNodes, uint32_t wavesPerSimd, float* out, unsigned long long* clocksDev)
+{
+    const uint32_t steps = 3000u, activeLanes = 36u;
+    const dim3 grid(numCUs * wavesPerSimd), block(256);
+    const size_t lds = wavesPerSimd <= 1u ? (size_t)96 << 10 : ((size_t)160 << 10) / wavesPerSimd / 1024u * 1024u;
+    CHECK(hipFuncSetAttribute((const void*)k_step<kLoads, kValu, kRays>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_step<kLoads, kValu, kRays>), grid, block, lds, 0, dev, numNodes, 200u, activeLanes, out, clocksDev);
+    hipLaunchKernelGGL((k_step<kLoads, kValu, kRays>), grid, block, lds, 0, dev, numNodes, steps, activeLanes, out, clocksDev);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> clocks((size_t)grid.x * 4u);
+    CHECK(hipMemcpy(clocks.data(), clocksDev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double mean = 0; for (auto c : clocks) mean += (double)c; mean /= (double)clocks.size();
+    return mean / steps;
+}
+
 // dynamic LDS that lets exactly `blocksPerCU` 256-thread blocks share a CU's 160 KB
 static size_t ldsFor(uint32_t blocksPerCU) { return blocksPerCU <= 1u ? (size_t)96 << 10 : ((size_t)160 << 10) / blocksPerCU / 1024u * 1024u; }
 
@@ -197,11 +262,46 @@ static void runCadence(uint32_t numCUs, float* out, unsigned long long* clocksDe
 int main(int argc, char** argv)
 {
     const bool onlyFormats = argc > 1 && argv[1][0] == '3';   // `cadence 3`: section (3) only
+    const bool onlySteps = argc > 1 && argv[1][0] == '4';     // `cadence 4`: section (4) only
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const uint32_t numCUs = (uint32_t)prop.multiProcessorCount;
     printf("device %s, %u CUs, clock %d kHz (clock64 = s_memtime ticks)\n", prop.name, numCUs, prop.clockRate);
     float* out; unsigned long long* clocksDev;
     CHECK(hipMalloc((void**)&out, 64)); CHECK(hipMalloc((void**)&clocksDev, sizeof(unsigned long long) * numCUs * 8u * 4u * 2u));
+    if (onlySteps)
+    {
+        printf("\n(4) step models: clocks per wave step; ray-steps per 1000 clocks and SIMD = waves x rays per lane / clocks; 4-wide-equivalent = x 17/11 for the 8-wide node\n");
+        for (size_t tableBytes : { (size_t)4 << 20, (size_t)8 << 20, (size_t)22 << 20 })
+        {
+            // one table per node size: N random-cycle nodes of 64 bytes, or N / 2 of 128 bytes (the same bytes: an 8-wide collapse has half the nodes)
+            auto makeTable = [&](uint32_t loads) -> std::pair<float4*, uint32_t>
+            {
+                const uint32_t numNodes = (uint32_t)(tableBytes / (16u * loads));
+                std::vector<uint32_t> perm(numNodes);
+                for (uint32_t i = 0; i < numNodes; ++i) perm[i] = i;
+                uint64_t s = 88172645463325252ull;
+                for (uint32_t i = numNodes - 1; i > 0; --i) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; const uint32_t j = (uint32_t)(s % (i + 1)); std::swap(perm[i], perm[j]); }
+                std::vector<float4> host((size_t)numNodes * loads, make_float4(1.0f, 0.5f, 3.0f, 0.0f));
+                for (uint32_t i = 0; i < numNodes; ++i) host[(size_t)perm[i] * loads].w = __builtin_bit_cast(float, perm[(i + 1) % numNodes]);
+                float4* dev; CHECK(hipMalloc((void**)&dev, host.size() * sizeof(float4)));
+                CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(float4), hipMemcpyHostToDevice));
+                return { dev, numNodes };
+            };
+            const auto t4 = makeTable(4u), t8 = makeTable(8u);
+            const double a5 = runStep<4, 136, 1>(numCUs, t4.first, t4.second, 5u, out, clocksDev);
+            const double a4 = runStep<4, 136, 1>(numCUs, t4.first, t4.second, 4u, out, clocksDev);
+            const double b5 = runStep<8, 280, 1>(numCUs, t8.first, t8.second, 5u, out, clocksDev);
+            const double b4 = runStep<8, 280, 1>(numCUs, t8.first, t8.second, 4u, out, clocksDev);
+            const double c4 = runStep<4, 136, 2>(numCUs, t4.first, t4.second, 4u, out, clocksDev);
+            const double c3 = runStep<4, 136, 2>(numCUs, t4.first, t4.second, 3u, out, clocksDev);
+            const double f5 = runStep<4, 0, 1>(numCUs, t4.first, t4.second, 5u, out, clocksDev);
+            printf("table %3zu MB:  today (4 loads, 136 VALU, 5 waves): %5.0f clk = %5.2f   at 4 waves: %5.0f clk = %5.2f   fetch only, 5 waves: %5.0f clk\n", tableBytes >> 20, a5, 5000.0 / a5, a4, 4000.0 / a4, f5);
+            printf("               8-wide (8 loads, 280 VALU): 5 waves %5.0f clk = %5.2f (x17/11 = %5.2f)   4 waves %5.0f clk = %5.2f (x17/11 = %5.2f)\n", b5, 5000.0 / b5, 5000.0 / b5 * 17.0 / 11.0, b4, 4000.0 / b4, 4000.0 / b4 * 17.0 / 11.0);
+            printf("               two rays per lane (2 x (4 loads, 136 VALU)): 4 waves %5.0f clk = %5.2f   3 waves %5.0f clk = %5.2f\n", c4, 8000.0 / c4, c3, 6000.0 / c3);
+            CHECK(hipFree(t4.first)); CHECK(hipFree(t8.first));
+        }
+        return 0;
+    }
     if (!onlyFormats) {
     printf("\n(1) cycles per wave64 VALU instruction per SIMD (clock64 ticks of one wave / instructions issued by all waves of its SIMD; wN = N resident waves per SIMD, enforced through the LDS allocation) and the effective clock\n");
     runCadence<OP_FMA>(numCUs, out, clocksDev); runCadence<OP_PERM>(numCUs, out, clocksDev); runCadence<OP_CVT_SDWA>(numCUs, out, clocksDev);
