@@ -744,4 +744,24 @@ uint32_t rto_sizeof(int what)
     }
 }
 
+// x86 approximation mode of rto_math.h (FastDivide, fastNormalized3).  Returns 1 if the host has the instructions, 0 otherwise (the mode stays off).
+// signature[0..1] (may be null): the bits of this CPU's rcp_ss(3.0) and rsqrt_ps(0.7) -- approximation tables differ between CPU families, the fixtures
+// of tests/golden/ref_render were rendered on one of them (tests/test_reference_images.py skips the every-pixel comparison elsewhere).
+int rto_set_x86_approximations(int enable, uint32_t* signature)
+{
+#ifdef RTO_HAVE_X86_APPROX
+    g_rtoX86Approximations = enable ? 1 : 0;
+    if (signature)
+    {
+        float three = 3.0f;
+        const float a = _mm_cvtss_f32(_mm_rcp_ss(_mm_load_ss(&three))), b = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(0.7f)));
+        memcpy(&signature[0], &a, 4); memcpy(&signature[1], &b, 4);
+    }
+    return 1;
+#else
+    (void)enable; if (signature) { signature[0] = 0u; signature[1] = 0u; }
+    return 0;
+#endif
+}
+
 } // extern "C"

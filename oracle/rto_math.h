@@ -10,7 +10,10 @@
 //   * dpps summation order (x*x' + y*y') + (z*z' + 0)   (Vector4ImplSSE.h:446-459);
 //   * the approximate instructions _mm_rcp_ss (FastDivide, Core/Math/Math.h:120-127) and _mm_rsqrt_ps
 //     (FastNormalize3, Vector4ImplSSE.h:519-524) are replaced by correctly rounded a/b and
-//     v * (1/sqrt(d)): their x86 results are vendor specific, <= 2^-11 relative.
+//     v * (1/sqrt(d)): their x86 results are vendor specific, <= 2^-11 relative.  The only
+//     intrinsics in this file are those two, behind rto_set_x86_approximations (off by default): with them the
+//     oracle reproduces the reference's frames and path vertices BIT FOR BIT (tests/test_reference_images.py,
+//     tests/test_reference_paths.py), which pins every other line of the restatement.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
 #pragma once
@@ -19,6 +22,10 @@
 #include <math.h>
 #include <float.h>
 #include <string.h>
+#if defined(__x86_64__) || defined(_M_X64)
+#include <immintrin.h>   // the x86 approximation mode below (FastDivide, fastNormalized3)
+#define RTO_HAVE_X86_APPROX 1
+#endif
 
 namespace rto {
 
@@ -78,7 +85,18 @@ static inline float Clamp(float x, float lo, float hi) { if (x > hi) return hi; 
 static inline float Lerp(float a, float b, float w) { return a + w * (b - a); }      // Math.h:196-200
 static inline float Signum(float x) { if (x > 0.0f) return 1.0f; else if (x < 0.0f) return -1.0f; else return 0.0f; } // Math.h:147-161
 // FastDivide: a * _mm_rcp_ss(b) in the reference (Math.h:120-127) -> correctly rounded divide here.
-static inline float FastDivide(float a, float b) { return a / b; }
+// x86 approximation mode (rto_set_x86_approximations, x86-64 hosts only): the oracle evaluates the reference's two approximate instructions
+// -- _mm_rcp_ss here, _mm_rsqrt_ps in FastNormalize3 -- with the HOST'S instructions, as the reference does.  It exists to show that they are the ONLY
+// difference between the oracle and the reference's frames (tests/test_reference_images.py: every pixel of every fixture then agrees on a CPU of the
+// family the fixtures were rendered on); the parity oracle of the device is the exact mode (the device has no such instructions).
+inline int g_rtoX86Approximations = 0;
+static inline float FastDivide(float a, float b)
+{
+#ifdef RTO_HAVE_X86_APPROX
+    if (g_rtoX86Approximations) return a * _mm_cvtss_f32(_mm_rcp_ss(_mm_load_ss(&b)));
+#endif
+    return a / b;
+}
 static inline float CopySign(float x, float y)                                        // Math.h:137-144
 {
     uint32_t xi, yi; memcpy(&xi, &x, 4); memcpy(&yi, &y, 4);
@@ -102,7 +120,13 @@ static inline float length3(V4 a) { return sqrtf(dot3(a, a)); }                 
 // Normalize3: v / sqrt(dot3)  (all four lanes divided), Vector4ImplSSE.h:511-517
 static inline V4 normalized3(V4 a) { const float l = sqrtf(dot3(a, a)); return V4(a.x / l, a.y / l, a.z / l, a.w / l); }
 // FastNormalize3: v * _mm_rsqrt_ps(dot) in the reference (:519-524) -> v * (1/sqrt(dot)) here.
-static inline V4 fastNormalized3(V4 a) { const float r = 1.0f / sqrtf(dot3(a, a)); return a * r; }
+static inline V4 fastNormalized3(V4 a)
+{
+#ifdef RTO_HAVE_X86_APPROX
+    if (g_rtoX86Approximations) { const float r = _mm_cvtss_f32(_mm_rsqrt_ps(_mm_set1_ps(dot3(a, a)))); return a * r; }
+#endif
+    const float r = 1.0f / sqrtf(dot3(a, a)); return a * r;
+}
 // Reflect3, Vector4Impl.h:119-124
 static inline V4 reflect3(V4 i, V4 n) { const float d = dot3(i, n); return negMulAdd(splat(d + d), n, i); }
 // Orthogonalize (Gram-Schmidt), Vector4ImplSSE.h:587-591

@@ -158,3 +158,11 @@ def hash_grid_query(points, radius, queries, capacity=1 << 22):
     total = L.rto_hash_grid_query(points.ctypes.data, len(points), radius, queries.ctypes.data, len(queries), offsets.ctypes.data, indices.ctypes.data, capacity)
     assert total <= capacity
     return [indices[int(offsets[q]):int(offsets[q + 1])] for q in range(len(queries))]
+
+
+def set_x86_approximations(enable):
+    """rto_math.h's x86 approximation mode (FastDivide through _mm_rcp_ss, FastNormalize3 through _mm_rsqrt_ps, as the reference evaluates them).
+    Returns (supported, (rcp_ss(3.0) bits, rsqrt_ps(0.7) bits)) -- the signature of this CPU's approximation tables."""
+    sig = (C.c_uint32 * 2)()
+    ok = lib().rto_set_x86_approximations(int(bool(enable)), sig)
+    return bool(ok), (int(sig[0]), int(sig[1]))

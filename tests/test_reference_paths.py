@@ -100,3 +100,19 @@ def test_paths_agree_up_to_the_first_approximate_instruction(built, name, first_
     assert s["identical_vertices"] >= vertices * s["vertices"], s
     assert set(s["first_difference"]) <= first_sites | {"tpx", "tpy", "tpz", "tpw"}, s
     print(name, s)
+
+
+@pytest.mark.parametrize("name", ["box_mesh", "cornell", "mesh_2k_all", "mesh_single"])
+def test_with_the_two_approximate_instructions_every_recorded_vertex_is_the_reference_s(built, name):
+    """The same comparison with the oracle in x86 approximation mode (FastDivide through _mm_rcp_ss, FastNormalize3 through _mm_rsqrt_ps, like the
+    reference; oracle/rto_math.h): no "up to the first approximate instruction" any more -- EVERY path has the reference's vertex count and EVERY
+    recorded field of EVERY vertex its bits (sphere normals and mesh tangents included).  Skipped on a CPU with other approximation tables."""
+    from test_reference_images import FIXTURE_CPU_SIGNATURE
+    ok, signature = oracle_lib.set_x86_approximations(True)
+    try:
+        if not ok or signature != FIXTURE_CPU_SIGNATURE:
+            pytest.skip("this CPU's _mm_rcp_ss / _mm_rsqrt_ps tables are not those of the CPU the fixtures were rendered on")
+        s = compare(name)
+    finally:
+        oracle_lib.set_x86_approximations(False)
+    assert s["same_length"] == s["paths"] == s["identical"] and s["identical_vertices"] == s["vertices"], s
