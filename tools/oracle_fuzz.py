@@ -37,6 +37,11 @@ def run(budget=300.0, seed=1, min_cases=0, log=print):
         desc.contents.blueNoise = bn.ctypes.data
         vp = ra.Viewport(w, h, seed=int(rng.randint(1, 1 << 30)), **args)
         vp.set_renderer(scene, intersection_counters=counters_on)
+        # round 4's launch-sequence variants: the fused tail taking over at a random bounce (or by policy, or never), the block-local re-trace on / off / by policy
+        import ctypes as C
+        schedule = (int(rng.choice([-1, -1, 0, 1, 2, 3, 4])), int(rng.choice([-1, 0, 1])))
+        ra.rtgpu_lib().rtgpu_set_schedule(vp.device_context(), C.c_uint32(0), C.c_int32(schedule[0]))
+        ra.rtgpu_lib().rtgpu_set_schedule(vp.device_context(), C.c_uint32(1), C.c_int32(schedule[1]))
         ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
         cnt = np.zeros(16, dtype=np.uint64)
         for _ in range(passes):
@@ -52,7 +57,7 @@ def run(budget=300.0, seed=1, min_cases=0, log=print):
         default_walk += 0 if counters_on else 1
         if not same:
             bad += 1
-            log("MISMATCH", kind, w, h, args, passes, counters_on, int(np.count_nonzero(img.view(np.uint32) != ref.view(np.uint32))))
+            log("MISMATCH", kind, w, h, args, passes, counters_on, schedule, int(np.count_nonzero(img.view(np.uint32) != ref.view(np.uint32))))
     return cases, bad, default_walk
 
 
