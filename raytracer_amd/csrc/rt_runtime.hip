@@ -1156,14 +1156,14 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
         uint32_t* seedHost = c->seedRingHost + (size_t)slot * RTGPU_MAX_DIMENSIONS;
         uint32_t* seedDev = c->seedRingDev + (size_t)slot * RTGPU_MAX_DIMENSIONS;
         CtxPending& pd = c->pending[i];
-        if (!pd.seeds.empty())
-        {
-            memcpy(seedHost, pd.seeds.data(), pd.seeds.size() * sizeof(uint32_t));
-            HIP_TRY(hipMemcpyAsync(seedDev, seedHost, pd.seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, l.stream));
-        }
+        if (!pd.seeds.empty()) memcpy(seedHost, pd.seeds.data(), pd.seeds.size() * sizeof(uint32_t));
         pd.pass.seed = seedDev;
         c->passRingHost[slot] = pd.pass;
     }
+    // the batch's ring slots are contiguous: ONE copy for the seeds of all its passes and one for their constants (a copy per pass in front of a 20-pass
+    // batch of a small frame was 0.25 ms of stream time before the first kernel, profiles/r04_timeline_serial_shard8.txt)
+    HIP_TRY(hipMemcpyAsync(c->seedRingDev + (size_t)firstSlot * RTGPU_MAX_DIMENSIONS, c->seedRingHost + (size_t)firstSlot * RTGPU_MAX_DIMENSIONS,
+                           (size_t)numPasses * RTGPU_MAX_DIMENSIONS * sizeof(uint32_t), hipMemcpyHostToDevice, l.stream));
     HIP_TRY(hipMemcpyAsync(c->passRingDev + firstSlot, c->passRingHost + firstSlot, numPasses * sizeof(DevPass), hipMemcpyHostToDevice, l.stream));
     const DevPass* passesDev = c->passRingDev + firstSlot;
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/_gpurun_retry.sh <timeout> <command>: gpurun with retries while the pod's GPU slots are busy (exit code 3: nothing charged)
+# tools/gpurun_retry.sh <timeout> <command>: gpurun with retries while the pod's GPU slots are busy (exit code 3: nothing charged)
 t=$1; shift
 for i in $(seq 1 40); do
   /usr/local/graft/bin/gpurun --timeout $t -- "$@" > /tmp/gpurun_last.log 2>&1; rc=$?
