@@ -19,7 +19,7 @@
 // k_generate for dense state: slot i = home i; the regions of the first arena are simply filled one after the other
 __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
                                                              const uint32_t* __restrict__ slotPixel, uint32_t numSlots, uint32_t shardCapacity, uint32_t* __restrict__ counts,
-                                                             unsigned long long* counters)
+                                                             unsigned long long* counters, uint32_t fullRecords)
 {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; slot < numSlots; slot += stride)
@@ -38,10 +38,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc s
         cameraGenerateRayParts(pass.camera, coords, sampler, origin, direction);
         stStream(prec(paths, R_ORIGIN, slot), f4(origin.x, origin.y, origin.z, fbits(0x100u)));   // depth 0, lastSpecular = true (PathTracerMIS.h:29-34)
         stStream(prec(paths, R_DIR, slot), f4(direction.x, direction.y, direction.z, 1.0f));        // lastPdfW = 1
-        stStream(prec(paths, R_TP, slot), f4(1.0f, 1.0f, 1.0f, 1.0f));
-        stStream(prec(paths, R_RESULT, slot), f4(0.0f, 0.0f, 0.0f, fbits(pix)));
-        stStream(prec(paths, R_SH_TP, slot), f4(0.0f, 0.0f, 0.0f, fbits(slot)));                    // .w: the path's home
-        storeSampler(sampler, paths, slot, 0.0f, 0u);
+        if (fullRecords != 0u)
+        {
+            // (the consumers that do not rebuild a fresh path's other records from its slot: see denseShadeVertex)
+            stStream(prec(paths, R_TP, slot), f4(1.0f, 1.0f, 1.0f, 1.0f));
+            stStream(prec(paths, R_RESULT, slot), f4(0.0f, 0.0f, 0.0f, fbits(pix)));
+            stStream(prec(paths, R_SH_TP, slot), f4(0.0f, 0.0f, 0.0f, fbits(slot)));                    // .w: the path's home
+            storeSampler(sampler, paths, slot, 0.0f, 0u);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < RT_DENSE_SHARDS)
     {
@@ -71,16 +75,30 @@ struct DenseVertex
 template <int kLean, bool kPlain, bool kAll>
 __device__ __forceinline__ static void denseShadeVertex(const RtSceneDesc& scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const DevPass& pass, const Paths& in,
                                                         uint32_t slot, bool zombie, V4 lightSamplingWeight, V4 bsdfSamplingWeight, float lightPickProbability,
-                                                        float4 (*stage)[RT_BLOCK], float4* __restrict__ home, Counters& cnt, DenseVertex& v)
+                                                        float4 (*stage)[RT_BLOCK], float4* __restrict__ home, Counters& cnt, DenseVertex& v,
+                                                        const uint32_t* __restrict__ primarySlotPixel = nullptr)
 {
-    const float4 rResult = ldStream(prec(in, R_RESULT, slot)), rSampler = ldStream(prec(in, R_SAMPLER, slot)), rShTp = ldStream(prec(in, R_SH_TP, slot));
+    // Bounce 0 (primarySlotPixel != null): k_generate_dense stores only what depends on the camera sample -- origin and direction.  The other five
+    // records of a fresh path are functions of its slot (radiance 0 | pixel, throughput 1, home = slot, the sampler and the per-pixel generator as
+    // the camera left them) and are rebuilt here instead of being written and read back: 80 of 112 bytes per path in each direction.
+    const bool primary = primarySlotPixel != nullptr;
+    float4 rResult, rSampler, rShTp;
+    if (primary)
+    {
+        rResult = f4(0.0f, 0.0f, 0.0f, fbits(primarySlotPixel[slot - (slot / slotsPerPass) * slotsPerPass]));
+        rSampler = f4(prec(in, R_SAMPLER, slot).x, 0.0f, 0.0f, fbits(0u));   // .x: the hit's v, written by the traversal; no request is pending
+        rShTp = f4(0.0f, 0.0f, 0.0f, fbits(slot));
+    }
+    else { rResult = ldStream(prec(in, R_RESULT, slot)); rSampler = ldStream(prec(in, R_SAMPLER, slot)); rShTp = ldStream(prec(in, R_SH_TP, slot)); }
     const uint32_t pix = ubits(rResult.w), homeIndex = ubits(rShTp.w);
     v.oHome = homeIndex;
     V4 resultColor(rResult.x, rResult.y, rResult.z, 0.0f);
     resolvePendingLightSamples(in, slot, ubits(rSampler.w), lightSamplingWeight, resultColor, cnt);   // NEE of the previous vertex
     if (!zombie)
     {
-        const float4 rOrigin = ldStream(prec(in, R_ORIGIN, slot)), rDir = ldStream(prec(in, R_DIR, slot)), rTp = ldStream(prec(in, R_TP, slot)), rHit = ldStream(prec(in, R_HIT, slot));
+        const float4 rOrigin = ldStream(prec(in, R_ORIGIN, slot)), rDir = ldStream(prec(in, R_DIR, slot)), rHit = ldStream(prec(in, R_HIT, slot));
+        float4 rTp = f4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (!primary) rTp = ldStream(prec(in, R_TP, slot));
         const uint32_t flags = ubits(rOrigin.w);
         const uint32_t depth = flags & 0xFFu;
         const bool lastSpecular = (flags & 0x100u) != 0;
@@ -148,8 +166,20 @@ __device__ __forceinline__ static void denseShadeVertex(const RtSceneDesc& scene
             materialEvaluateShadingData<kLean>(scene, mat, sd);
             resultColor = mulAdd(throughput, kPlain ? sd.mp.emission : sd.mp.emission * bsdfSamplingWeight, resultColor);   // emission, :309-317
 
-            Sampler sampler; loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise);
-            sampler.seed = passes[homeIndex / slotsPerPass].seed;
+            Sampler sampler;
+            if (primary)
+            {
+                // the sampler and the per-pixel generator as Camera::GenerateRay left them: reset as k_generate_dense does and let the camera draw again
+                const DevPass& own = passes[homeIndex / slotsPerPass];
+                const uint32_t x = pix & 0xFFFFu, y = pix >> 16;
+                sampler.seed = own.seed; sampler.numDims = own.numDimensions; sampler.blueNoiseLayers = own.blueNoiseLayers; sampler.blueNoise = scene.blueNoise;
+                sampler.resetPixel(x, y, own.rngKey[0], own.rngKey[1]);
+                const float invW = 1.0f / (float)(int32_t)own.width, invH = 1.0f / (float)(int32_t)own.height;
+                const V4 coords(((float)(int32_t)x + own.sampleOffset[0]) * invW, ((float)(int32_t)(own.height - 1u - y) + own.sampleOffset[1]) * invH, 0.0f, 0.0f);
+                V4 cameraOrigin, cameraDirection;
+                cameraGenerateRayParts(own.camera, coords, sampler, cameraOrigin, cameraDirection);
+            }
+            else { loadSampler(sampler, in, slot, pix, rSampler, pass, scene.blueNoise); sampler.seed = passes[homeIndex / slotsPerPass].seed; }
 
             // SampleLights (next event estimation), PathTracerMIS.cpp:125-155
             if (!kPlain && kAll && scene.numLights != 0)
@@ -325,7 +355,8 @@ __global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense(const RtSceneDesc
             bool zombie;
             const uint32_t slot = vertexSlot(i, zombie);
             inSlot = slot;
-            denseShadeVertex<kLean, kPlain, kAll>(scene, passes, slotsPerPass, pass, in, slot, zombie, lightSamplingWeight, bsdfSamplingWeight, lightPickProbability, sStage, home, cnt, v);
+            denseShadeVertex<kLean, kPlain, kAll>(scene, passes, slotsPerPass, pass, in, slot, zombie, lightSamplingWeight, bsdfSamplingWeight, lightPickProbability, sStage, home, cnt, v,
+                                                  dense.primarySlotPixel);
         }
         uint32_t outcome = v.outcome;
 

@@ -139,6 +139,7 @@ struct DenseCounts
     uint32_t* out;          // the same for the arena being written (zeroed by the host)
     uint32_t shardCapacity;
     uint32_t* errorFlags;   // host-visible words of the context (RtgpuContext::deviceFlags): [0] != 0 = a region of the arena overflowed
+    const uint32_t* primarySlotPixel;   // bounce 0 of a batch whose k_generate_dense stored origin and direction only: the slot -> pixel table; else null
 };
 
 // prefix sums of the 16 region counts into LDS (prefix[16] = total); all threads of the block call it

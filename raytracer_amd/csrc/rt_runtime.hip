@@ -1193,10 +1193,15 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
     {
         const uint32_t shardCapacity = (totalSlots + RT_DENSE_SHARDS - 1u) / RT_DENSE_SHARDS + 65536u;
         const uint32_t plane = 2u * RT_DENSE_SHARDS;
+        // a fresh path's records: only origin and direction are stored, bounce 0's shade rebuilds the rest from the slot (rt_dense.inl); RTGPU_FULL_PRIMARY=1: all seven.
+        // (the tail kernel never sees bounce 0 -- tailDepthFor returns >= 1 -- and the traversal kernels read origin and direction only)
+        static const bool fullPrimaryEnv = getenv("RTGPU_FULL_PRIMARY") && atoi(getenv("RTGPU_FULL_PRIMARY")) != 0;
+        const bool leanPrimary = !fullPrimaryEnv;
         HIP_TRY(hipMemsetAsync(l.denseCounts, 0, (size_t)plane * (l.queueCountCapacity + 1u) * sizeof(uint32_t), l.stream));
         {
             LaunchTimer t(c, l.stream, KC_GENERATE);
-            hipLaunchKernelGGL(k_generate_dense, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters);
+            hipLaunchKernelGGL(k_generate_dense, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters,
+                               leanPrimary ? 0u : 1u);
         }
         const bool haveNee = c->numLights != 0 && !c->plainPathTracer;
         // The fused tail (rt_tail.hip): from bounce `tailDepth` on, one persistent launch takes the batch's remaining paths to their end.  Single-mesh
@@ -1254,7 +1259,8 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 #undef RT_LAUNCH_TRACE_DENSE
             }
             // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
-            const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags };
+            const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags,
+                                     leanPrimary && depth == 0u ? c->slotPixel : nullptr };
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
                                                      l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters, c->sortShadeKinds ? 1u : 0u)

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_accumulate(const Paths paths, uint
                                                          unsigned long long* counters);
 __global__ void __launch_bounds__(RT_BLOCK) k_generate_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths,
                                                              const uint32_t* __restrict__ slotPixel, uint32_t numSlots, uint32_t shardCapacity, uint32_t* __restrict__ counts,
-                                                             unsigned long long* counters);
+                                                             unsigned long long* counters, uint32_t fullRecords);
 template <int kLean, bool kPlain = false, bool kAll = false>
 __global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense RT_K_SHADE_DENSE_ARGS;
 __global__ void __launch_bounds__(RT_BLOCK) k_accumulate_home(const float4* __restrict__ home, const uint32_t* __restrict__ slotPixel, uint32_t slotsPerPass, uint32_t numPasses,
