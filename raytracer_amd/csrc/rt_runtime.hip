@@ -968,7 +968,8 @@ RTGPU_API int rtgpu_reset(RtgpuContext* c)
 static uint32_t maxStreamingBatch(const RtgpuContext* c)
 {
     const size_t perPass = (size_t)(c->numSlots ? c->numSlots : 1) * ((size_t)R_NUM_BASE + RT_SHADOW_RECORDS) * sizeof(float4);
-    uint32_t batch = 24u;
+    static const uint32_t most = getenv("RTGPU_MAX_STREAM_BATCH") ? (uint32_t)atoi(getenv("RTGPU_MAX_STREAM_BATCH")) : 24u;   // tuning knob (a multiple of 8, at most 64)
+    uint32_t batch = most < 8u ? 8u : (most > RT_SEED_RING / 2 ? RT_SEED_RING / 2 : most);
     while (batch > 8u && perPass * batch > ((size_t)24 << 30)) batch -= 8u;
     return batch;
 }
