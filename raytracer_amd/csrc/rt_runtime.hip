@@ -1080,16 +1080,18 @@ static bool useWide(const RtgpuContext* c) { return (c->wide.nodes != nullptr ||
 
 static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset,
-                            const uint32_t* denseCounts, uint32_t denseShardCapacity, bool mayTraceUndecidedRaysItself = true)
+                            const uint32_t* denseCounts, uint32_t denseShardCapacity, bool mayTraceUndecidedRaysItself = true, uint32_t bounce = 0u)
 {
     // A block traces the rays its walk does not decide itself (rt_trace_wide.inl) where launches are short: a 1/8 shard of a full-HD frame gains 10 %
     // (ten launches per batch less to wait for), a full frame loses 1.4 % (a block holds its slot of the CU while one wave walks; the separate launch
     // ran beside the other lanes' kernels) -- profiles/r04_local_exact_ab.txt.  RTGPU_LOCAL_EXACT=0 / 1 forces it.
     static const int localExactEnv = getenv("RTGPU_LOCAL_EXACT") ? atoi(getenv("RTGPU_LOCAL_EXACT")) : -1;
+    // (larger frames: from this bounce on -- the late launches of a batch are short whatever the frame; 255 = never)
+    static const uint32_t localExactFromBounce = getenv("RTGPU_LOCAL_EXACT_FROM") ? (uint32_t)atoi(getenv("RTGPU_LOCAL_EXACT_FROM")) : 255u;
     // (the second walk runs on the kernel's 24-entry stacks: scenes whose binary trees need deeper ones keep the separate launch)
     // (never in front of the bidirectional integrator: its light paths produce degenerate closest-hit rays -- an emitted direction that is exactly a coordinate
     //  axis -- which only the separate launch hands on to k_trace_monster; in a block they walk alone for milliseconds: 16.5 -> 26 ms per pass, profiles/r04_vcm_wide_ab.txt)
-    const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : c->numSlots < 700000u));   // (a 1/4 shard, 518 k pixels: +0 ... 2 %, with the tail +4 %; halves: 0)
+    const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : (c->numSlots < 700000u || bounce >= localExactFromBounce)));   // (a 1/4 shard, 518 k pixels: +0 ... 2 %, with the tail +4 %; halves: 0)
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
                         chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u };
@@ -1244,7 +1246,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                     uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
                     uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
                     launchTraceWide(c, l.stream, in, nullptr, nullptr, tsq, tsc, cursors + depth, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, 0.0001f,
-                                    tune.denseCounts, shardCapacity);
+                                    tune.denseCounts, shardCapacity, true, depth);
                     TravTuning exactTune = c->tune;
                     LaunchTimer t(c, l.stream, KC_RETRACE);
                     const dim3 retraceGrid(c->numCUs);
