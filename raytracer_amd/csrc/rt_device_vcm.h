@@ -178,6 +178,7 @@ RT_DEV float uniformSpherePdf() { return RTD_INV_PI / 4.0f; }                   
 RT_DEV float uniformCirclePdf(float radius) { return 1.0f / (RTD_PI * Sqr(radius)); }   // Geometry.h:32-35
 
 // ILight::Illuminate with rendererSupportsSolidAngleSampling = false; also returns IlluminateResult::emissionPdfW
+template <int kClass = 0>
 RT_DEV V4 lightIlluminateBidir(const RtSceneDesc& d, const RtLight& L, const Intersection& isect, const float u[3], IlluminateResult& out, float& outEmissionPdfW)
 {
     outEmissionPdfW = -1.0f;
@@ -201,7 +202,7 @@ RT_DEV V4 lightIlluminateBidir(const RtSceneDesc& d, const RtLight& L, const Int
         outEmissionPdfW = cosNormalDir * invArea * RTD_INV_PI;
         return load4(L.color);
     }
-    const V4 radiance = lightIlluminate<false>(d, L, isect, u, out);
+    const V4 radiance = lightIlluminate<kClass>(d, L, isect, u, out);
     switch (L.type)
     {
     case RT_LIGHT_BACKGROUND: outEmissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius); break;   // BackgroundLight.cpp:68
@@ -213,6 +214,7 @@ RT_DEV V4 lightIlluminateBidir(const RtSceneDesc& d, const RtLight& L, const Int
 }
 
 // ILight::GetRadiance with rendererSupportsSolidAngleSampling = false, plus *outEmissionPdfW
+template <int kClass = 0>
 RT_DEV V4 lightGetRadianceBidir(const RtSceneDesc& d, const RtLight& L, const Ray& lray, V4 hitPoint, float cosAtLight, float& outDirectPdfA, float& outEmissionPdfW)
 {
     switch (L.type)
@@ -228,7 +230,7 @@ RT_DEV V4 lightGetRadianceBidir(const RtSceneDesc& d, const RtLight& L, const Ra
     case RT_LIGHT_BACKGROUND:    // BackgroundLight.cpp:78-92
         outDirectPdfA = uniformHemispherePdf();
         outEmissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius);
-        return backgroundColor<false>(d, L, lray.dir);
+        return backgroundColor<kClass>(d, L, lray.dir);
     case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:94-121
         if (L.isDelta) return zero4();
         if (dot3(lray.dir, V4(0, 0, 1, 0)) > -L.cosAngle) return zero4();
@@ -242,6 +244,7 @@ RT_DEV V4 lightGetRadianceBidir(const RtSceneDesc& d, const RtLight& L, const Ra
 
 // ILight::Emit
 struct EmitResult { V4 position, direction; float directPdfA, emissionPdfW, cosAtLight; };
+template <int kClass = 0>
 RT_DEV V4 lightEmit(const RtSceneDesc& d, const RtLight& L, const float up[3], const float ud[2], EmitResult& out)
 {
     const M4 lightToWorld = loadM4(L.transform);
@@ -274,7 +277,7 @@ RT_DEV V4 lightEmit(const RtSceneDesc& d, const RtLight& L, const float up[3], c
         out.directPdfA = uniformHemispherePdf();
         out.emissionPdfW = uniformSpherePdf() * uniformCirclePdf(kSceneRadius);
         out.cosAtLight = 1.0f;
-        return backgroundColor<false>(d, L, neg(out.direction));
+        return backgroundColor<kClass>(d, L, neg(out.direction));
     }
     case RT_LIGHT_DIRECTIONAL:   // DirectionalLight.cpp:120-135 (SampleDirection :47-78); the origin disc is NOT transformed
     {

@@ -6,6 +6,14 @@
 #define RT_VCM_COUNT_PLANE (RT_VCM_MAX_PATH_LENGTH + 4u)
 #define RT_VCM_NUM_COUNT_PLANES 16u   // 0-9 as before; 10-11 / 12-13 / 14-15: per trace launch the hand-over counts (closest, any-hit) and cursor of the 4-wide walks
 
+// the kernels of rt_vcm.inl that may evaluate textures exist per scene class (rt_shade_kernels.h): a scene without textures takes class 3
+// (RTGPU_VCM_CLASS=0: the generic kernels for every scene)
+#define RT_LAUNCH_VCM(K, ...) { if (vcmUntextured(c)) hipLaunchKernelGGL((K<3>), __VA_ARGS__); else hipLaunchKernelGGL((K<0>), __VA_ARGS__); }
+static bool vcmUntextured(const RtgpuContext* c)
+{
+    static const bool allow = !(getenv("RTGPU_VCM_CLASS") && atoi(getenv("RTGPU_VCM_CLASS")) == 0);
+    return allow && (c->leanScene == 1 || c->leanScene == 3);
+}
 static void freeVcm(RtgpuContext* c)
 {
     RtgpuContext::Vcm& v = c->vcm;
@@ -215,7 +223,7 @@ static int vcmFlush(RtgpuContext* c)
     {
         LaunchTimer t(c, stream, KC_GENERATE);
         hipLaunchKernelGGL(k_generate, grid1, block, 0, stream, c->sceneDev, v.passDev, c->numSlots, v.cameraPaths, c->slotPixel, totalSlots, cq[0], cpc + 0, c->counters);
-        hipLaunchKernelGGL(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, totalSlots, lq[0], lpc + 0);
+        RT_LAUNCH_VCM(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, totalSlots, lq[0], lpc + 0);
     }
     // light sub-paths of every pass of the batch
     for (uint32_t b = 0; b < maxLV; ++b)
@@ -224,7 +232,7 @@ static int vcmFlush(RtgpuContext* c)
         launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0001f,
                     v.overflowQueue, v.counts + 7 * RT_VCM_COUNT_PLANE + b);
         LaunchTimer t(c, stream, KC_SHADE);
-        hipLaunchKernelGGL(k_vcm_light_shade, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
+        RT_LAUNCH_VCM(k_vcm_light_shade, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
                            lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);
     }
     if (vp.useVertexConnection)
@@ -251,7 +259,7 @@ static int vcmFlush(RtgpuContext* c)
         launchTrace(c, stream, v.cameraPaths, cq[d & 1u], cpc + d, haveShadow ? csq[(d - 1u) & 1u] : nullptr, haveShadow ? csc + (d - 1u) : nullptr, ccur + d, 0.0001f,
                     v.overflowQueue, v.counts + 8 * RT_VCM_COUNT_PLANE + d);
         LaunchTimer t(c, stream, KC_SHADE);
-        hipLaunchKernelGGL(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, batch, v.cameraPaths, v.arena, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
+        RT_LAUNCH_VCM(k_vcm_camera_shade, grid1, block, 0, stream, c->sceneDev, batch, v.cameraPaths, v.arena, cq[d & 1u], cpc + d, cq[(d + 1u) & 1u], cpc + d + 1,
                            csq[d & 1u], csc + d, v.mergeQueue, cmc + d, v.connectQueue, ccc + d, c->counters);
         if (vp.useVertexConnection && maxLV > 0u && d + 1u < vp.maxPathLength)
             hipLaunchKernelGGL(k_vcm_connect, grid1, block, 0, stream, c->sceneDev, batch, v.cameraPaths, v.arena, v.connectQueue, ccc + d, csq[d & 1u], csc + d);
@@ -332,7 +340,7 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
         LaunchTimer t(c, stream, KC_GENERATE);
         // the camera ray is generated (it consumes the pixel's lens samples and counts as a primary ray) and then ignored, Viewport.cpp:305-331
         hipLaunchKernelGGL(k_generate, grid1, block, 0, stream, c->sceneDev, v.passDev, c->numSlots, v.cameraPaths, c->slotPixel, c->numSlots, v.queues[2], cpc + 0, c->counters);
-        hipLaunchKernelGGL(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, c->numSlots, lq[0], lpc + 0);
+        RT_LAUNCH_VCM(k_vcm_emit, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.cameraPaths, v.arena, c->slotPixel, c->numSlots, lq[0], lpc + 0);
     }
     for (uint32_t b = 0; b <= p->maxRayDepth; ++b)
     {
@@ -340,7 +348,7 @@ static int lightTracerRenderPass(RtgpuContext* c, const RtPassParams* p)
         launchTrace(c, stream, v.lightPaths, lq[b & 1u], lpc + b, haveShadow ? lsq[(b - 1u) & 1u] : nullptr, haveShadow ? lsc + (b - 1u) : nullptr, lcur + b, 0.0f,
                     v.overflowQueue, v.counts + 7 * RT_VCM_COUNT_PLANE + b);
         LaunchTimer t(c, stream, KC_SHADE);
-        hipLaunchKernelGGL(k_lt_shade, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
+        RT_LAUNCH_VCM(k_lt_shade, grid1, block, 0, stream, c->sceneDev, batch, v.lightPaths, v.arena, lq[b & 1u], lpc + b, lq[(b + 1u) & 1u], lpc + b + 1,
                            lsq[b & 1u], lsc + b, c->sum, c->secondary, c->counters);
     }
     launchTrace(c, stream, v.lightPaths, nullptr, nullptr, lsq[p->maxRayDepth & 1u], lsc + p->maxRayDepth, lcur + p->maxRayDepth + 1u, 0.0f);

@@ -23,3 +23,9 @@ RT_K_SHADE_DENSE_INSTANCES(RT_X)
 #define RT_X(L, P) template __global__ void __launch_bounds__(RT_BLOCK) k_shade<L, P> RT_K_SHADE_ARGS;
 RT_K_SHADE_INSTANCES(RT_X)
 #undef RT_X
+#define RT_X(C) template __global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit<C> RT_K_VCM_EMIT_ARGS; \
+                template __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade<C> RT_K_VCM_LIGHT_SHADE_ARGS; \
+                template __global__ void __launch_bounds__(RT_BLOCK) k_lt_shade<C> RT_K_LT_SHADE_ARGS; \
+                template __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade<C> RT_K_VCM_CAMERA_SHADE_ARGS;
+RT_VCM_CLASSES(RT_X)
+#undef RT_X

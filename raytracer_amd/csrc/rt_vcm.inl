@@ -84,7 +84,8 @@ RT_DEV void loadLightVertex(const RtSceneDesc& scene, const VcmArena& a, uint32_
 
 // GenerateLightSample, :428-491.  The scalar generator (Random::GetInt) is the pixel's Sampler::fallback stream, which lives in
 // the CAMERA arena's R_RNG record (k_generate has reset it for this pass).
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const Paths cp,
+template <int kClass>
+__global__ void RT_VCM_ATTR(k_vcm_emit) k_vcm_emit(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const Paths cp,
                                                        const VcmArena a, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
                                                        uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount)
 {
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_emit(const RtSceneDesc scene, 
                 const V4 ps = simd.getVector4(); const V4 ds = simd.getVector4();
                 const float up[3] = { ps.x, ps.y, ps.z }, ud[2] = { ds.x, ds.y };
                 EmitResult er; er.position = zero4(); er.direction = zero4(); er.directPdfA = er.emissionPdfW = er.cosAtLight = 0.0f;
-                const V4 emitted = lightEmit(scene, light, up, ud, er);
+                const V4 emitted = lightEmit<kClass>(scene, light, up, ud, er);
                 if (!almostZero4(emitted))
                 {
                     er.directPdfA *= lightPickProbability;
@@ -203,7 +204,8 @@ RT_DEV bool vcmAdvancePath(const RtSceneDesc& scene, const VcmDev& vcm, const Pa
 }
 
 // One vertex of TraceLightPath's loop, :334-425
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
+template <int kClass>
+__global__ void RT_VCM_ATTR(k_vcm_light_shade) k_vcm_light_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
                                                               const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                               uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -241,10 +243,10 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
             if (hit.objectId != RT_INVALID_OBJECT && hit.subObjectId != RT_LIGHT_OBJECT)
             {
                 ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
-                sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                sceneEvaluateIntersection<kClass>(scene, ray, hit, sd.intersection, cnt);
                 sd.outgoingDirWorldSpace = neg(ray.dir);
                 const RtMaterial& mat = scene.materials[sd.intersection.material];
-                materialEvaluateShadingData<false>(scene, mat, sd);
+                materialEvaluateShadingData<kClass>(scene, mat, sd);
                 {
                     if (length > 1u || isFiniteLight) dVCM *= Sqr(hit.distance);
                     const float cosTheta = dot3(ray.dir, sd.intersection.frame.r[2]);
@@ -331,7 +333,8 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_light_shade(const RtSceneDesc 
 // One vertex of LightTracer::RenderPixel's loop (Core/Rendering/LightTracer.cpp:69-181; renderer "Light Tracer"): like k_vcm_light_shade
 // without MIS quantities, light vertices and photons; every vertex below maxRayDepth is connected to the camera with
 // contribution = bsdf * throughput * PdfW / distance^2, and the shadow ray starts at samplePos + normal * 1e-4 (:138).
-__global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
+template <int kClass>
+__global__ void RT_VCM_ATTR(k_lt_shade) k_lt_shade(const RtSceneDesc scene, const VcmBatch b, const Paths lp, const VcmArena a,
                                                        const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                        uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                        uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -368,9 +371,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_lt_shade(const RtSceneDesc scene, 
                 ShadingData sd; sd.intersection.material = RT_NO_MATERIAL;
                 if (hit.distance < FLT_MAX)
                 {
-                    sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                    sceneEvaluateIntersection<kClass>(scene, ray, hit, sd.intersection, cnt);
                     sd.outgoingDirWorldSpace = neg(ray.dir);
-                    materialEvaluateShadingData<false>(scene, scene.materials[sd.intersection.material], sd);
+                    materialEvaluateShadingData<kClass>(scene, scene.materials[sd.intersection.material], sd);
                 }
                 if (depth < maxRayDepth)
                 {
@@ -506,6 +509,7 @@ RT_DEV void vcmResolvePending(const Paths& cp, const VcmArena& a, const VcmDev& 
 }
 
 // EvaluateLight, :580-635 (isect == nullptr for global lights)
+template <int kClass>
 RT_DEV V4 vcmEvaluateLight(const RtSceneDesc& scene, const VcmDev& vcm, const RtLight& light, const float* invTransform, const Intersection* isect, const Ray& ray,
                            uint32_t length, bool lastSpecular, float dVC, float dVCM)
 {
@@ -514,7 +518,7 @@ RT_DEV V4 vcmEvaluateLight(const RtSceneDesc& scene, const VcmDev& vcm, const Rt
     const float cosAtLight = isect ? -dot3(isect->frame.r[2], ray.dir) : 1.0f;
     const V4 lightSpaceHitPoint = isect ? transformPoint(worldToLight, isect->frame.r[3]) : zero4();
     float directPdfA = 0.0f, emissionPdfW = 0.0f;
-    V4 lightContribution = lightGetRadianceBidir(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA, emissionPdfW);
+    V4 lightContribution = lightGetRadianceBidir<kClass>(scene, light, lightSpaceRay, lightSpaceHitPoint, cosAtLight, directPdfA, emissionPdfW);
     if (almostZero4(lightContribution)) return zero4();
     if (length > 1u)
     {
@@ -535,7 +539,8 @@ RT_DEV V4 vcmEvaluateLight(const RtSceneDesc& scene, const VcmDev& vcm, const Rt
 }
 
 // One vertex of RenderPixel's loop, :201-314
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
+template <int kClass>
+__global__ void RT_VCM_ATTR(k_vcm_camera_shade) k_vcm_camera_shade(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
                                                                const uint32_t* __restrict__ queueIn, const uint32_t* __restrict__ countIn,
                                                                uint32_t* __restrict__ queueOut, uint32_t* __restrict__ countOut,
                                                                uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
@@ -590,14 +595,14 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                     for (uint32_t g = 0; g < scene.numGlobalLights; ++g)
                     {
                         const RtLight& light = scene.lights[scene.globalLights[g]];
-                        result = result + vcmEvaluateLight(scene, vcm, light, light.invTransform, nullptr, ray, length, lastSpecular, dVC, dVCM);
+                        result = result + vcmEvaluateLight<kClass>(scene, vcm, light, light.invTransform, nullptr, ray, length, lastSpecular, dVC, dVCM);
                     }
                     resultColor = mulAdd(throughput, result, resultColor);
                     break;
                 }
                 ShadingData sd;
                 sd.intersection.material = (flags >> 9) - 1u;   // the path's one ShadingData keeps the previous vertex's material (see k_shade)
-                sceneEvaluateIntersection<false>(scene, ray, hit, sd.intersection, cnt);
+                sceneEvaluateIntersection<kClass>(scene, ray, hit, sd.intersection, cnt);
                 {
                     const float cosTheta = dot3(ray.dir, sd.intersection.frame.r[2]);
                     const float invMis = 1.0f / Abs(cosTheta);
@@ -607,13 +612,13 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                 if (hit.subObjectId == RT_LIGHT_OBJECT)
                 {
                     const RtObject& obj = scene.objects[hit.objectId];
-                    const V4 lightColor = vcmEvaluateLight(scene, vcm, scene.lights[obj.lightIndex], obj.invTransform, &sd.intersection, ray, length, lastSpecular, dVC, dVCM);
+                    const V4 lightColor = vcmEvaluateLight<kClass>(scene, vcm, scene.lights[obj.lightIndex], obj.invTransform, &sd.intersection, ray, length, lastSpecular, dVC, dVCM);
                     resultColor = mulAdd(throughput, lightColor, resultColor);
                     break;
                 }
                 sd.outgoingDirWorldSpace = neg(ray.dir);
                 const RtMaterial& mat = scene.materials[sd.intersection.material];
-                materialEvaluateShadingData<false>(scene, mat, sd);
+                materialEvaluateShadingData<kClass>(scene, mat, sd);
                 resultColor = mulAdd(throughput, sd.mp.emission, resultColor);
                 if (length >= vcm.maxPathLength) break;
                 const bool isDeltaBsdf = bsdfIsDelta(mat.bsdf);
@@ -631,7 +636,7 @@ __global__ void __launch_bounds__(RT_BLOCK) k_vcm_camera_shade(const RtSceneDesc
                         float u[3]; u[0] = sampler.getFloat(); u[1] = sampler.getFloat(); u[2] = sampler.getFloat();
                         float tmax = -1.0f; V4 dir = zero4(); V4 contribution = zero4();
                         IlluminateResult ir; float emissionPdfW;
-                        const V4 radiance = lightIlluminateBidir(scene, light, sd.intersection, u, ir, emissionPdfW);
+                        const V4 radiance = lightIlluminateBidir<kClass>(scene, light, sd.intersection, u, ir, emissionPdfW);
                         if (!almostZero4(radiance))
                         {
                             float bsdfPdfW = 0.0f, bsdfRevPdfW = 0.0f;
@@ -789,7 +794,7 @@ RT_DEV void loadCameraVertex(const RtSceneDesc& scene, const VcmArena& a, uint32
 // request (direction | tmax, contribution | vertex) after the vertex's next-event requests; the visibility rays ride in the next k_trace
 // launch and vcmResolvePending folds the visible ones in.  Reads the 96-byte vertex record the merge kernel uses, plus dVC and the path
 // length from the spare lanes of R_SH_P / R_SH_TP.
-__global__ void __launch_bounds__(RT_BLOCK) k_vcm_connect(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
+__global__ void RT_VCM_CONNECT_ATTR k_vcm_connect(const RtSceneDesc scene, const VcmBatch b, const Paths cp, const VcmArena a,
                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                           uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount)
 {
