@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; T=gpurun_out/s5; mkdir -p $T
+ENVS=""
+for r in 12 20 28 36; do for o in 16 24 32 40; do ENVS="$ENVS RTGPU_REFILL_MIN_IDLE=$r,RTGPU_OTHER_MIN_LANES=$o"; done; done
+for rep in 1 2; do for E in $ENVS; do
+  env $(echo $E | tr ',' ' ') python bench.py --steps 64 --warmup 5 --no-pmc --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); kt = d.get('kernel_time_ms', {})
+print('%-52s %8.1f Msamples/s %7.3f ms/pass trace %.1f' % ('$E', d['value'], d['ms_per_step'], kt.get('trace', 0)))"
+done; done > $T/knob_sweep.txt
+sort $T/knob_sweep.txt | cut -c1-110
