@@ -1106,6 +1106,15 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
         return;
     }
     static const bool diag = getenv("RTGPU_WIDE_DIAG") != nullptr;       // walk statistics in the spare counters (tools/wide_diag.py)
+    // the camera rays of a dense batch walk the tree as packets (rt_trace_packet.inl: a wave = an 8 x 8 pixel block, the node is uniform); RTGPU_PACKET=0: off
+    const char* const packetEnv = getenv("RTGPU_PACKET");   // (read per launch: the tests switch it)
+    const bool packets = !(packetEnv && atoi(packetEnv) == 0);
+    if (packets && !diag && bounce == 0u && denseCounts != nullptr && tsq == nullptr && tq == nullptr)
+    {
+        static const uint32_t packetBlocksPerCU = getenv("RTGPU_PACKET_BLOCKS") ? (uint32_t)atoi(getenv("RTGPU_PACKET_BLOCKS")) : 8u;
+        hipLaunchKernelGGL(k_trace_packet, dim3(c->numCUs * packetBlocksPerCU), block, 0, stream, c->sceneDev, c->wide, paths, cursor, c->counters, tune);
+        return;
+    }
     if (diag) hipLaunchKernelGGL((k_trace_wide<24, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
     else hipLaunchKernelGGL((k_trace_wide<24, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
 }

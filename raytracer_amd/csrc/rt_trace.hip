@@ -2,6 +2,7 @@
 //   rt_trace_binary.inl   k_trace (the reference's walk: binary BVH, near child first), k_trace_monster
 //   rt_trace_quant.inl    k_trace_quant (16-bit child pairs: an experiment, opt-in)
 //   rt_trace_wide.inl     k_trace_wide (4-wide tree of a single-mesh scene; the rays it does not decide go through the reference's walk in the same launch)
+//   rt_trace_packet.inl   k_trace_packet (the camera rays of a dense batch: one wave walks the 4-wide tree for an 8 x 8 pixel block, the node is uniform)
 //   rt_trace_wide2.inl    k_trace_wide2 (4-wide top-level tree over 4-wide mesh trees)
 //   rt_generate.inl       k_generate (camera rays, slot-per-pixel pipeline)
 //   rt_post.inl           post-process, bloom, block errors, texture evaluation
@@ -23,6 +24,7 @@ using namespace rtd;
 #include "rt_trace_binary.inl"
 #include "rt_trace_quant.inl"
 #include "rt_trace_wide.inl"
+#include "rt_trace_packet.inl"
 #include "rt_trace_wide2.inl"
 #include "rt_kat.inl"
 #include "rt_post.inl"

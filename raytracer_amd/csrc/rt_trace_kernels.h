@@ -43,6 +43,7 @@ template <int kStack, bool kCount, bool kLdsTop = false> __global__ void RT_TRAC
 template <int kStack> __global__ void RT_TRACE_ATTR(kStack) k_trace_quant RT_K_TRACE_QUANT_ARGS;
 template <int kStack, bool kDiag = false> __global__ void RT_TRACE_ATTR(kStack) k_trace_wide RT_K_TRACE_WIDE_ARGS;
 template <int kStack> __global__ void RT_TRACE_ATTR(kStack) k_trace_wide2 RT_K_TRACE_WIDE2_ARGS;
+__global__ void __launch_bounds__(RT_BLOCK) k_trace_packet(const RtSceneDesc scene, const WideBvh bvh, const Paths paths, uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune);
 __global__ void __launch_bounds__(RT_BLOCK) k_generate(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass,
                                                        const Paths paths, const uint32_t* __restrict__ slotPixel, uint32_t numSlots,
                                                        uint32_t* __restrict__ queue, uint32_t* __restrict__ queueCount,

@@ -853,11 +853,32 @@ def test_fused_tail_and_block_local_retrace_are_invisible(built):
     assert np.array_equal(plain[0][0].view(np.uint32), plain[1][0].view(np.uint32)) and plain[0][1] == plain[1][1]
 
 
-def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
+@pytest.mark.parametrize("packets", ["0", "1"])
+def test_packet_walk_of_the_camera_rays_gives_the_reference_hits(built, monkeypatch, packets):
+    """rt_trace_packet.inl: the camera rays of a dense batch walk the 4-wide tree one 8 x 8 pixel block per wave (uniform node, shared stack, a child is
+    entered if any lane's ray enters it).  Images and ray / shadow-ray / hit counters are the oracle's with it and without it (RTGPU_PACKET=0: k_trace_wide
+    serves bounce 0 too): a frame whose last packet is ragged, a thin-lens camera (64 different origins per packet), a shard (packets of owned tiles only),
+    and a batch of several passes."""
+    monkeypatch.setenv("RTGPU_PACKET", packets)
+    w, h = 150, 90     # 13 500 paths per pass: 210 full packets and one of 60
+    scene, camera = scenes.sponza_class(w / h, 60000)
+    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=6)
+    assert_quant_identical(*out)
+    camera.set_dof(True, 9.0, 0.25)
+    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=4)
+    assert_quant_identical(*out)
+    camera.set_dof(False)
+    out = run_quant(scene, camera, 192, 128, passes=2, max_ray_depth=5, shard=(1, 3))
+    assert_quant_identical(*out)
+
+
+def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built, monkeypatch):
     """A pathological mesh -- 64 nested sheets around the camera axis, sizes and distances growing by 1.6 from one to the next: the SAH
     builder peels them off a few at a time (a tree 22 levels deep for 128 triangles), and a ray through the stack of sheets enters every
     child on its way down and defers more of them than a 24-entry stack holds (17 000 of 30 000 rays from the near side).  Such rays
-    go to the binary-tree kernel (the uploaded depth picks its stack class); images and ray counters stay the oracle's, from both sides."""
+    go to the binary-tree kernel (the uploaded depth picks its stack class); images and ray counters stay the oracle's, from both sides.
+    The camera rays are the ones that overflow: they take k_trace_wide with RTGPU_PACKET=0 (the hand-over under test) and the packet walk
+    of rt_trace_packet.inl by default (its shared stack holds them: no hand-over, the same image)."""
     n = 64
     pos, idx = [], []
     for k in range(n):
@@ -877,7 +898,8 @@ def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built):
     w, h = 96, 64
     far = float(1.6 ** n)
     overflows = 0
-    for camera in (ra.Camera((0.0, 0.0, 3.0), (0.0, 180.0, 0.0), w / h, 50.0), ra.Camera((0.0, 0.0, -3.0 * far), (0.0, 0.0, 0.0), w / h, 50.0)):
+    for packets, camera in [(p, c) for p in ("0", "1") for c in (ra.Camera((0.0, 0.0, 3.0), (0.0, 180.0, 0.0), w / h, 50.0), ra.Camera((0.0, 0.0, -3.0 * far), (0.0, 0.0, 0.0), w / h, 50.0))]:
+        monkeypatch.setenv("RTGPU_PACKET", packets)
         out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=4)
         assert_quant_identical(*out)
         print("stack overflows: %d, untrusted: %d, re-traced: %d of %d rays" % (out[2]["numStackOverflowRays"], out[2]["numUntrustedRays"], out[2]["numRetracedRays"],
