@@ -147,7 +147,7 @@ def algorithmic_bytes(c):
 
 
 # kernel-name prefix (as rocprofv3 reports it) -> kernel class of rtgpu_get_kernel_times
-KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_tail", "tail"), ("k_trace_wide", "trace"), ("k_trace_quant", "trace"), ("k_trace", "trace"), ("k_shade", "shade"),
+KERNEL_CLASS_PREFIXES = (("k_trace_monster", None), ("k_tail", "tail"), ("k_trace_wide", "trace"), ("k_trace_packet", "trace"), ("k_trace_quant", "trace"), ("k_trace", "trace"), ("k_shade", "shade"),
                          ("k_vcm_light_finish", "accumulate"), ("k_vcm_camera_finish", "accumulate"), ("k_vcm_emit", "generate"), ("k_vcm_", "shade"),
                          ("k_lt_shade", "shade"), ("k_generate", "generate"), ("k_accumulate", "accumulate"))
 
@@ -200,7 +200,7 @@ def pmc_child_sums(args, counter, timeout_s):
             pass
         if not rows:
             return None, "no %s rows in the rocprofv3 database" % label
-        reencoded = any(n.replace("void ", "").strip().startswith(("k_trace_wide", "k_trace_quant")) for n, _, _, _ in rows)
+        reencoded = any(n.replace("void ", "").strip().startswith(("k_trace_wide", "k_trace_quant", "k_trace_packet")) for n, _, _, _ in rows)
         multi = {}
         for name, cname, launches, total in rows:
             cls = kernel_class(name, reencoded)
@@ -522,7 +522,7 @@ def main():
             algorithmic_gbs = per_launch_bytes / per_launch_s / 1e9
             kernel_name = "k_" + dom
             if dom == "trace" and c1.get("numRetracedRays", 0) > 0:
-                kernel_name = "k_trace_wide"   # the 4-wide walk served the launches (it hands a few rays to k_trace: class "retrace")
+                kernel_name = "k_trace_wide"   # the 4-wide walk served the launches (it hands a few rays to k_trace: class "retrace"); bounce 0's launch of a batch is k_trace_packet, the same tree walked one 8 x 8 pixel block per wave (one launch in ten of the class)
             # achieved / peak / frac / traffic: the HBM roof, as the contract words it (measured fabric traffic / launch time / 8 TB/s).  `bound` says
             # which ceiling the kernel is actually nearest to -- decided below from the counters -- and `ceilings` holds the evidence.
             # reference_walk_*: SURVEY 8(d)'s byte model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk, ...): what
