@@ -20,6 +20,9 @@ typedef uint32_t PacketU4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) PacketU4* PacketConst4;    // constant address space: a uniform address is a scalar load
 typedef const __attribute__((address_space(4))) float* PacketConstF;
 
+// a 16-bit plane of a node word in a SCALAR register as a float: the sub-word select of the conversion reads the scalar register directly (no unpacking)
+RT_DEV float packetPlaneLo(uint32_t w) { float f; asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "s"(w)); return f; }
+RT_DEV float packetPlaneHi(uint32_t w) { float f; asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "s"(w)); return f; }
 #define RT_PACKET_CE(ka, ra, kb, rb) { if (ka > kb) { const uint32_t tk_ = ka, tr_ = ra; ka = kb; ra = rb; kb = tk_; rb = tr_; } }
 
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_packet(const RtSceneDesc scene, const WideBvh bvh, const Paths paths, uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
@@ -101,9 +104,9 @@ __global__ void __launch_bounds__(RT_BLOCK) k_trace_packet(const RtSceneDesc sce
                         const PacketU4 q0 = nodes[4u * cur], q1 = nodes[4u * cur + 1u], q2 = nodes[4u * cur + 2u], q3 = nodes[4u * cur + 3u];   // one 64-byte scalar load
 #define RT_PACKET_CHILD(q, key, ref)                                                                                                             \
                         {                                                                                                                        \
-                            const float nx0 = __fmaf_rn((float)(q.x & 0xFFFFu), ax, bx), nx1 = __fmaf_rn((float)(q.y >> 16), ax, bx);            \
-                            const float ny0 = __fmaf_rn((float)(q.x >> 16), ay, by), ny1 = __fmaf_rn((float)(q.z & 0xFFFFu), ay, by);            \
-                            const float nz0 = __fmaf_rn((float)(q.y & 0xFFFFu), az, bz), nz1 = __fmaf_rn((float)(q.z >> 16), az, bz);            \
+                            const float nx0 = __fmaf_rn(packetPlaneLo(q.x), ax, bx), nx1 = __fmaf_rn(packetPlaneHi(q.y), ax, bx);            \
+                            const float ny0 = __fmaf_rn(packetPlaneHi(q.x), ay, by), ny1 = __fmaf_rn(packetPlaneLo(q.z), ay, by);            \
+                            const float nz0 = __fmaf_rn(packetPlaneLo(q.y), az, bz), nz1 = __fmaf_rn(packetPlaneHi(q.z), az, bz);            \
                             const float n = fmaxf(fmaxf(fminf(nx0, nx1), fminf(ny0, ny1)), fmaxf(fminf(nz0, nz1), 0.0f));                         \
                             const float f = fminf(fminf(fmaxf(nx0, nx1), fmaxf(ny0, ny1)), fmaxf(nz0, nz1));                                      \
                             const unsigned long long m = __ballot(act && f >= n && n < limit);                                                   \
