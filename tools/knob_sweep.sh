@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; T=gpurun_out/s5; mkdir -p $T
+# 2-D sweep of the traversal kernels' scheduling knobs, two runs each (gpurun -- 'bash tools/knob_sweep.sh'; profiles/r04_interior_step_probes.txt, section 4)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; T=gpurun_out/probes; mkdir -p $T
 ENVS=""
 for r in 12 20 28 36; do for o in 16 24 32 40; do ENVS="$ENVS RTGPU_REFILL_MIN_IDLE=$r,RTGPU_OTHER_MIN_LANES=$o"; done; done
 for rep in 1 2; do for E in $ENVS; do
