@@ -3,10 +3,12 @@
 //
 // Why.  k_trace_wide's step is paced by its dependent node fetch (profiles/r04_interior_step_probes.txt): every lane fetches its own 64-byte node, a
 // wave step ends when the last of ~36 lines has arrived.  Camera rays of neighbouring pixels visit nearly the same nodes, so here the NODE IS UNIFORM:
-// the wave keeps one current node and one stack (wave-uniform values: scalar registers, the stack in the lanes of one vector register), a node is one
+// the wave keeps one current node and one stack (wave-uniform values: scalar registers, the stack in the lanes of two vector registers), a node is one
 // scalar load of 64 bytes through the constant cache, a leaf's triangles and exact box likewise, and every lane tests its own ray against them -- no
 // divergent fetch, no per-lane stack, no idle lanes inside a step.  A child is entered if ANY lane's ray enters it; the order is that of the first lane
 // that does.  The first launch of a batch is 10 % of its traversal time (profiles/r03_timeline_serial_start_of_round.txt).
+// Measured (profiles/r04_packet_ab.txt): 20.5 interior + 3.8 leaf steps per packet on the benchmark frame (one ray: 17 + 2), first launch of a five-pass batch
+// 1.41 -> 1.02-1.2 ms, +2 % end to end; the launch is bound by the ~1.2 G instructions it issues (~240 per step, vector and scalar alike).
 //
 // Exactness: k_trace_wide's argument unchanged.  A lane sees a SUPERSET of the leaves its own walk would visit (the packet's union), in another order;
 // a leaf's triangles count for a lane only behind the leaf's exact box and the `lo < best + tol` test, every candidate has the reference's (t, u, v), the
@@ -14,7 +16,7 @@
 // -- goes to the exact queue for the reference's own walk (the k_trace launch behind this one).  Any-hit rays never come here (bounce 0 has none).
 
 #ifdef RT_DEVICE_KERNELS
-#define RT_PACKET_CLAIM 4u            // packets a wave claims per atomic
+#define RT_PACKET_CLAIM 4u            // packets a wave claims per atomic (1: +1 ms per launch in atomics; 16: uneven tails; profiles/r04_packet_ab.txt)
 #define RT_PACKET_STACK 128u          // entries: two vector registers' lanes (a 4-wide tree of depth d defers at most 3 d nodes)
 typedef uint32_t PacketU4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) PacketU4* PacketConst4;    // constant address space: a uniform address is a scalar load
