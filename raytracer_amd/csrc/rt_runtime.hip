@@ -1115,8 +1115,37 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
         hipLaunchKernelGGL(k_trace_packet, dim3(c->numCUs * packetBlocksPerCU), block, 0, stream, c->sceneDev, c->wide, paths, cursor, c->counters, tune);
         return;
     }
-    if (diag) hipLaunchKernelGGL((k_trace_wide<24, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
-    else hipLaunchKernelGGL((k_trace_wide<24, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+    if (diag) tune.localExact = (uint32_t)atoi(getenv("RTGPU_WIDE_DIAG"));   // 2: stack-depth histogram instead of the visit counts (tools/wide_diag.py)
+    if (diag) hipLaunchKernelGGL((k_trace_wide<24, true, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+    else if (localExact) hipLaunchKernelGGL((k_trace_wide<24, false, true>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+    else hipLaunchKernelGGL((k_trace_wide<24, false, false>), grid, block, 0, stream, c->sceneDev, c->wide, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune);
+}
+
+// The re-trace launch behind a 4-wide walk: the reference's own walk (k_trace) over the rays the walk handed over (0.1 % of a launch), and -- single-mesh
+// scenes -- k_trace_monster behind it for the closest-hit rays among them that k_trace gave up on: a direction that is exactly a coordinate axis turns
+// two of three slab tests into inf - inf and the ray walks most of the tree, alone in its wave (1.0-1.6 ms launches at bounce 1 where an ordinary one
+// takes 0.1-0.2 ms, profiles/r04_timeline_serial.txt); a whole block finds the same hit cooperatively.  `overflowQueue`: a queue of the lane nobody
+// uses during this bounce's trace (dense path state: none of the slot queues is in use; slot-per-pixel: the one the next shade will fill).
+static void launchRetrace(RtgpuContext* c, BatchLane& l, hipStream_t stream, const Paths& paths, uint32_t depth, uint32_t stackClass, uint32_t* overflowQueue)
+{
+    uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
+    uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
+    uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
+    uint32_t* overflowCounts = l.queueCounts + 7 * l.queueCountCapacity;
+    const char* const abortText = getenv("RTGPU_ABORT_RETRACE_AFTER");   // test hook, read per launch (0: every closest-hit ray in flight when its wave's queue runs dry goes to k_trace_monster)
+    const int abortEnv = abortText ? atoi(abortText) : -1;
+    static const bool monstersAllowed = !(getenv("RTGPU_RETRACE_MONSTERS") && atoi(getenv("RTGPU_RETRACE_MONSTERS")) == 0);
+    const bool monsters = monstersAllowed && overflowQueue != nullptr && c->wide.nodes != nullptr && c->sceneDev.numObjects == 1u && !c->countIntersections;
+    TravTuning exactTune = c->tune;
+    exactTune.overflowQueue = monsters ? overflowQueue : nullptr; exactTune.overflowCount = monsters ? overflowCounts + depth : nullptr;
+    exactTune.abortClosestAfter = abortEnv >= 0 ? (uint32_t)abortEnv : RT_ABORT_RETRACE_AFTER;
+    exactTune.denseCounts = nullptr; exactTune.denseShardCapacity = 0u;
+    LaunchTimer t(c, stream, KC_RETRACE);
+    const dim3 retraceGrid(c->numCUs), block(RT_BLOCK);
+#define RT_LAUNCH_RETRACE(S) hipLaunchKernelGGL((k_trace<S, false>), retraceGrid, block, 0, stream, c->sceneDev, paths, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune)
+    if (stackClass == 24u) RT_LAUNCH_RETRACE(24); else if (stackClass == 32u) RT_LAUNCH_RETRACE(32); else RT_LAUNCH_RETRACE(64);
+#undef RT_LAUNCH_RETRACE
+    if (monsters) hipLaunchKernelGGL(k_trace_monster, dim3(64), dim3(RT_MONSTER_BLOCK), 0, stream, c->sceneDev, paths, overflowQueue, overflowCounts + depth);
 }
 
 // The bounce at which a dense batch hands its remaining paths to k_tail (0: never).  RTGPU_TAIL_DEPTH=n forces bounce n (0: off).
@@ -1227,7 +1256,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             const Paths& out = (depth & 1u) ? l.paths : l.paths2;
             if (tailDepth != 0u && depth == tailDepth)
             {
-                const TailArgs args = { l.denseCounts + (size_t)plane * depth, shardCapacity, cursors + depth, c->tune.refillMinIdle, c->tune.otherMinLanes };
+                const TailArgs args = { l.denseCounts + (size_t)plane * depth, shardCapacity, cursors + depth, c->tune.refillMinIdle, c->tune.otherMinLanes, c->deviceFlags };
                 static const uint32_t tailBlocksPerCU = getenv("RTGPU_TAIL_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_TAIL_BLOCKS_PER_CU")) : 4u;   // tuning knob
                 uint32_t tailBlocks = (totalSlots + RT_TAIL_PATHS - 1u) / RT_TAIL_PATHS;   // never more blocks than chunks of the whole batch
                 if (tailBlocks > c->numCUs * tailBlocksPerCU) tailBlocks = c->numCUs * tailBlocksPerCU;
@@ -1256,12 +1285,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                     uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
                     launchTraceWide(c, l.stream, in, nullptr, nullptr, tsq, tsc, cursors + depth, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, 0.0001f,
                                     tune.denseCounts, shardCapacity, true, depth);
-                    TravTuning exactTune = c->tune;
-                    LaunchTimer t(c, l.stream, KC_RETRACE);
-                    const dim3 retraceGrid(c->numCUs);
-                    if (stackClass == 24u) hipLaunchKernelGGL((k_trace<24, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
-                    else if (stackClass == 32u) hipLaunchKernelGGL((k_trace<32, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
-                    else hipLaunchKernelGGL((k_trace<64, false>), retraceGrid, block, 0, l.stream, c->sceneDev, in, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune);
+                    launchRetrace(c, l, l.stream, in, depth, stackClass, l.queues[0]);
                 }
                 else
                 {
@@ -1321,10 +1345,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                 if (useWide(c)) launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f, nullptr, 0u);
                 else
                 launchTraceQuant(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
-                tq = l.exactQueue; tqc = exactCounts + launchIndex; tsq = l.exactShadowQueue; tsc = exactShadowCounts + launchIndex;
-                uint32_t* cursors = exactCursors;
-                LaunchTimer t(c, l.stream, KC_RETRACE);
-                if (stackClass == 24u) RT_LAUNCH_TRACE(24, false); else if (stackClass == 32u) RT_LAUNCH_TRACE(32, false); else RT_LAUNCH_TRACE(64, false);
+                launchRetrace(c, l, l.stream, l.paths, launchIndex, stackClass, l.queues[(depth + 1u) & 1u]);
             }
             else
             {

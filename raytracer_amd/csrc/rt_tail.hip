@@ -38,6 +38,10 @@ using namespace rtd;
 #include "rt_shade.inl"
 #include "rt_dense.inl"
 
+// Invariant the hand-over lists rest on: a chunk holds RT_TAIL_PATHS vertices, each with at most ONE closest-hit ray and ONE next-event request
+// (LightSamplingStrategy::Single or none), so a walk never hands over more than RT_TAIL_PATHS entries of a kind and widePushExact never needs the
+// launch-wide queues, which this kernel does not have (WideTuning's queue pointers are null; widePushExact drops the request and raises nothing
+// if that ever changed -- kAll in the tail or a larger chunk needs queues of its own).
 // LDS of a block: the walks' stacks (24 entries x 256 lanes = 24 KB; the shade phase stages its next-event records in the same memory), five
 // lists of RT_TAIL_PATHS slots (live / zombie vertices of this round and the next, shadow requests; the lists of the NEXT round double as the
 // hand-over lists of the walks, which run when those are empty) -- 35 KB, four blocks per CU.
@@ -56,7 +60,13 @@ __global__ void RT_TAIL_ATTR(kLean, kPlain) k_tail RT_K_TAIL_ARGS
     if (threadIdx.x == 64)
     {
         uint32_t sum = 0;
-        for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s) { sZombiePrefix[s] = sum; sum += args.denseCounts[RT_DENSE_SHARDS + s]; }
+        for (uint32_t s = 0; s < RT_DENSE_SHARDS; ++s)
+        {
+            sZombiePrefix[s] = sum; sum += args.denseCounts[RT_DENSE_SHARDS + s];
+            // the launch before this one overfilled region s (live paths growing up met the zombies growing down): k_shade_dense's prologue check, which the
+            // hand-over bounce would otherwise lose
+            if (blockIdx.x == 0 && args.denseCounts[s] + args.denseCounts[RT_DENSE_SHARDS + s] > args.shardCapacity) args.errorFlags[0] = 1u;
+        }
         sZombiePrefix[RT_DENSE_SHARDS] = sum;
     }
     __syncthreads();

@@ -36,7 +36,7 @@ RT_K_TRACE_INSTANCES(RT_X)
 #define RT_X(S) template __global__ void RT_TRACE_ATTR(S) k_trace_quant<S> RT_K_TRACE_QUANT_ARGS;
 RT_K_TRACE_QUANT_INSTANCES(RT_X)
 #undef RT_X
-#define RT_X(S, D) template __global__ void RT_TRACE_ATTR(S) k_trace_wide<S, D> RT_K_TRACE_WIDE_ARGS;
+#define RT_X(S, D, L) template __global__ void RT_TRACE_ATTR(S) k_trace_wide<S, D, L> RT_K_TRACE_WIDE_ARGS;
 RT_K_TRACE_WIDE_INSTANCES(RT_X)
 #undef RT_X
 #define RT_X(S) template __global__ void RT_TRACE_ATTR(S) k_trace_wide2<S> RT_K_TRACE_WIDE2_ARGS;

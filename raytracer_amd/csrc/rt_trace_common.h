@@ -50,6 +50,9 @@ struct TravTuning
     uint32_t denseShardCapacity;
 };
 #define RT_ABORT_CLOSEST_AFTER 768u
+// the same hand-over in the re-trace launches behind the 4-wide walks (PathTracerMIS) and in a block's local second walk: their queues hold a few
+// thousand rays, a wave's queue is dry after its first claim, an ordinary ray is done within ~10 rounds (a round = a run of interior steps + a leaf)
+#define RT_ABORT_RETRACE_AFTER 96u
 
 #define RT_COUNTER_RETRACED 12   // counters[]: rays the 4-wide walks handed to the binary-tree walk (RtCounters::numRetracedRays)
 #define RT_LDS_TOP_NODES 224u    // 7 KB: the stack class of 24 entries leaves 7.4 KB per block at five blocks per CU

@@ -82,6 +82,7 @@ RT_DEV void widePushExact(const WideTuning& tune, const WideLocal& local, bool s
         const uint32_t i = atomicAdd(shadowRequest ? local.shadowCount : local.exactCount, 1u);   // (the consumer clamps the count to the capacity)
         if (i < local.capacity) { (shadowRequest ? local.shadow : local.exact)[i] = request; return; }
     }
+    if (tune.exactQueue == nullptr) return;   // k_tail: its lists hold every request a chunk can produce (rt_tail.hip states the invariant)
     if (shadowRequest) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
     else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = request;
 }
@@ -111,6 +112,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
+    uint32_t diagMaxSp = 0, diagDeep[3] = { 0u, 0u, 0u };     // kDiag, RTGPU_WIDE_DIAG=2: rays whose stack held more than 9 / 13 / 17 entries (what a 12 / 16 / 20-entry stack would hand over)
 
     uint32_t chunkSize = count / (sharingWaves * 4u);
     chunkSize = chunkSize < tune.chunkMin ? tune.chunkMin : (chunkSize > 1024u ? 1024u : chunkSize);
@@ -189,6 +191,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                     tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
                     best = maxDistance; second = inf; occluded = false; overflow = false;
                     sp = 0u; cur = 0u;   // node 0 holds the children of the binary tree's root
+                    if (kDiag) diagMaxSp = 0u;
                     have = true;
                     if (shadow) numShadowRays++;   // (a request handed to the binary-tree kernel is counted there)
                 }
@@ -228,6 +231,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                         if (numHit != 0u) { cur = numHit == 1u ? r0 : (numHit == 2u ? r1 : (numHit == 3u ? r2 : r3)); sp += numHit - 1u; }
                         else if (sp == 0u) cur = RT_QUANT_DONE;
                         else { --sp; cur = stack[sp * RT_BLOCK]; }
+                    if (kDiag && sp > diagMaxSp) diagMaxSp = sp;
                     if (sp + 3u > (uint32_t)kStack) { overflow = true; cur = RT_QUANT_DONE; }   // the next step could not push: the binary-tree kernel takes the ray
                 }
                 in = in && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
@@ -288,6 +292,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
             if (cur == RT_QUANT_DONE)
             {
                 // ---- finished ----
+                if (kDiag) { if (diagMaxSp > 9u) diagDeep[0]++; if (diagMaxSp > 13u) diagDeep[1]++; if (diagMaxSp > 17u) diagDeep[2]++; }
                 if (overflow)
                 {
                     widePushExact(tune, handOver, shadow, shadow ? light * paths.capacity + slot : slot);
@@ -327,9 +332,10 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     else
     {
         // RTGPU_WIDE_DIAG=1: the three spare counters hold the walk's statistics instead
-        atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)diagVisits);
-        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)diagSlots);
-        atomicAdd(&counters[RT_COUNTER_RETRACED + 3], (unsigned long long)diagLeaves);
+        const bool deep = tune.localExact == 2u;   // (the diagnostic kernel has no block-local lists: the field carries RTGPU_WIDE_DIAG's mode)
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)(deep ? diagDeep[0] : diagVisits));
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)(deep ? diagDeep[1] : diagSlots));
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 3], (unsigned long long)(deep ? diagDeep[2] : diagLeaves));
         if ((threadIdx.x & 63u) == 0u)
         {
             // the reference's intersection counters are not used by this walk: per-wave clocks and phase counts ride in their slots
@@ -344,7 +350,10 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
 }
 
 
-template <int kStack, bool kDiag = false>
+// kLocalExact: the block traces the rays its walk does not decide itself (small frames: rtgpu_set_schedule / launchTraceWide's policy).  A template
+// parameter, not a run-time switch: the second walk's state cost the full-frame instantiation 148 bytes of scratch per lane and 2 KB of LDS
+// (profiles/r04_kernel_stats_serial.txt against r03's) although a full frame never runs it.
+template <int kStack, bool kDiag = false, bool kLocalExact = false>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_wide(const RtSceneDesc scene, const WideBvh bvh, const Paths paths,
                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
@@ -352,21 +361,30 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    __shared__ uint32_t sLocalExact[RT_WIDE_LOCAL_EXACT], sLocalShadow[RT_WIDE_LOCAL_EXACT], sLocalCounts[4];   // counts: closest, any-hit, work cursor of the second walk
-    const bool localLists = tune.localExact != 0u && !kDiag;
-    if (threadIdx.x < 4u) sLocalCounts[threadIdx.x] = 0u;
-    __syncthreads();
-    const WideLocal local = { sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], localLists ? RT_WIDE_LOCAL_EXACT : 0u };
-    traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, local, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
-    // the rays this block's walk did not decide, by the reference's own walk (block-uniform branch: the counts are final behind the walk's barrier)
-    __syncthreads();
-    if (threadIdx.x < 2u && sLocalCounts[threadIdx.x] > RT_WIDE_LOCAL_EXACT) sLocalCounts[threadIdx.x] = RT_WIDE_LOCAL_EXACT;
-    __syncthreads();
-    if (sLocalCounts[0] + sLocalCounts[1] != 0u)
+    if constexpr (!kLocalExact)
     {
-        const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };
-        traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
-                                              (uint32_t)RT_BLOCK / 64u);
+        const WideLocal none = { nullptr, nullptr, nullptr, nullptr, 0u };
+        traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, none, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
+    }
+    else
+    {
+        __shared__ uint32_t sLocalExact[RT_WIDE_LOCAL_EXACT], sLocalShadow[RT_WIDE_LOCAL_EXACT], sLocalCounts[4];   // counts: closest, any-hit, work cursor of the second walk
+        if (threadIdx.x < 4u) sLocalCounts[threadIdx.x] = 0u;
+        __syncthreads();
+        const WideLocal local = { sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], RT_WIDE_LOCAL_EXACT };
+        traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, local, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
+        // the rays this block's walk did not decide, by the reference's own walk (block-uniform branch: the counts are final behind the walk's barrier)
+        __syncthreads();
+        if (threadIdx.x < 2u && sLocalCounts[threadIdx.x] > RT_WIDE_LOCAL_EXACT) sLocalCounts[threadIdx.x] = RT_WIDE_LOCAL_EXACT;
+        __syncthreads();
+        if (sLocalCounts[0] + sLocalCounts[1] != 0u)
+        {
+            // a degenerate closest-hit ray (an axis-parallel direction: it walks most of the tree) does not keep the block: past RT_ABORT_RETRACE_AFTER rounds
+            // it goes to the launch's exact queue, i.e. to the re-trace launch behind this one, which hands it on to k_trace_monster
+            const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, tune.exactQueue, tune.exactCount, RT_ABORT_RETRACE_AFTER, nullptr, 0u };
+            traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
+                                                  (uint32_t)RT_BLOCK / 64u);
+        }
     }
 }
 #endif   // RT_DEVICE_KERNELS

@@ -872,6 +872,47 @@ def test_packet_walk_of_the_camera_rays_gives_the_reference_hits(built, monkeypa
     assert_quant_identical(*out)
 
 
+@pytest.mark.parametrize("abort_after", ["0", "3", None])
+def test_retrace_launch_hands_long_closest_hit_rays_to_the_cooperative_walker(built, monkeypatch, abort_after):
+    """Round 5: the re-trace launch behind k_trace_wide (the reference's own walk over the 0.1 % of the rays the 4-wide walk does not decide) hands
+    closest-hit rays that are still walking RT_ABORT_RETRACE_AFTER scheduling rounds after their wave's queue ran dry to k_trace_monster, which finds
+    the same hit with a whole block (degenerate axis-parallel rays walk most of the tree: 1-1.6 ms alone in a wave).  RTGPU_ABORT_RETRACE_AFTER=0 sends
+    EVERY ray in flight at that moment down that path, 3 the slower ones, the default only pathological ones: images and counters are the oracle's in all
+    three -- separate re-trace launch and block-local second walk (whose aborted rays go to the launch's exact queue, then re-trace launch, then monster),
+    dense and slot-per-pixel path state."""
+    if abort_after is not None:
+        monkeypatch.setenv("RTGPU_ABORT_RETRACE_AFTER", abort_after)
+    w, h = 160, 96
+    scene, camera = scenes.sponza_class(w / h, 30000)
+    desc = scene.desc
+    bn = ra.load_blue_noise()
+    desc.contents.blueNoise = bn.ctypes.data
+    lib = ra.rtgpu_lib()
+    reference = None
+    for local_retrace, no_dense in ((0, False), (1, False), (0, True)):
+        if no_dense:
+            monkeypatch.setenv("RTGPU_NO_DENSE", "1")
+        vp = ra.Viewport(w, h, seed=777, max_ray_depth=6)
+        vp.set_renderer(scene)
+        ctx = vp.device_context()
+        assert lib.rtgpu_set_intersection_counters(ctx, 0) == 0
+        assert lib.rtgpu_set_schedule(ctx, C.c_uint32(0), C.c_int32(0)) == 0 and lib.rtgpu_set_schedule(ctx, C.c_uint32(1), C.c_int32(local_retrace)) == 0
+        if reference is None:
+            ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
+            cnt = np.zeros(16, dtype=np.uint64)
+            for _ in range(3):
+                p = vp.next_pass_params(camera)
+                vp.render_pass_with(p)
+                oracle_lib.render_pass(desc, p, w, h, ref, ref2, cnt, threads=8)
+            reference = (ref, ref2, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES)})
+        else:
+            vp.render(camera, 3)    # the same seed => the same per-pass constants
+        img, img2 = vp.sum_buffer(secondary=True)
+        counters = vp.counters()
+        assert_quant_identical(img, img2, counters, *reference)
+        assert counters["numRetracedRays"] > 0
+
+
 def test_wide_traversal_hands_over_rays_whose_stack_would_overflow(built, monkeypatch):
     """A pathological mesh -- 64 nested sheets around the camera axis, sizes and distances growing by 1.6 from one to the next: the SAH
     builder peels them off a few at a time (a tree 22 levels deep for 128 triangles), and a ray through the stack of sheets enters every

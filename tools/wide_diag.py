@@ -10,7 +10,10 @@ ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 1 if os.envi
 vp.render(camera,4); c=vp.counters()
 rays=c["numRays"]+c["numShadowRays"]
 print({k:c[k] for k in ("numPassedRayBoxTests","numPassedRayTriangleTests","numMeshHits","numAnalyticHits","numPrimaryRays","numShadowRaysHit","numRays","numShadowRays","numRetracedRays","numUntrustedRays","numStackOverflowRays","diag2","numRayBoxTests","numShadowRayBoxTests","numRayTriangleTests","numShadowRayTriangleTests")})
-if os.environ.get("RTGPU_WIDE_DIAG"):
+if os.environ.get("RTGPU_WIDE_DIAG") == "2":
+    print("stack depth: rays whose stack held more than 9 / 13 / 17 entries (a 12 / 16 / 20-entry stack hands them over): %d / %d / %d of %d rays = %.4f %% / %.4f %% / %.4f %%" % (
+        c["numUntrustedRays"], c["numStackOverflowRays"], c["diag2"], rays, 100.0*c["numUntrustedRays"]/rays, 100.0*c["numStackOverflowRays"]/rays, 100.0*c["diag2"]/rays))
+elif os.environ.get("RTGPU_WIDE_DIAG"):
     print("interior visits/ray %.2f  interior-loop lane utilisation %.3f  leaf visits/ray %.2f" % (c["numUntrustedRays"]/rays, c["numUntrustedRays"]/max(1,c["numStackOverflowRays"]), c["diag2"]/rays))
     tot = c["numPassedRayTriangleTests"]
     print("wave clocks: refill %.1f %%  interior %.1f %%  leaf/finish %.1f %%  (sum %.1f %% of the waves' lifetime)" % (100*c["numRayBoxTests"]/tot, 100*c["numPassedRayBoxTests"]/tot, 100*c["numRayTriangleTests"]/tot, 100*(c["numRayBoxTests"]+c["numPassedRayBoxTests"]+c["numRayTriangleTests"])/tot))
