@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of a bench run
+    ap.add_argument("--walk-diag-child", action="store_true", help=argparse.SUPPRESS)   # internal: the instrumented-walk child (RTGPU_WIDE_DIAG=3)
     return ap.parse_args()
 
 
@@ -315,6 +316,41 @@ def measure_traffic(args):
     return out, None
 
 
+def walk_byte_model(args):
+    """The bytes the 4-wide walk ITSELF asks for (round-4 review, item 2b): a child process renders this command's warm-up + timed passes on one batch lane
+    with the walk's diagnostic instantiation (RTGPU_WIDE_DIAG=3: every bounce through k_trace_wide, which counts interior visits, leaf visits, exact-box
+    fetches and hit records written through), priced at what the kernel loads per event:
+      interior visit 64 B (one node = four 16-byte child records), leaf visit 72 B (the leaf's two triangle slots), exact box 32 B, a closest-hit ray's
+      refill 32 B (origin + direction records), an any-hit ray's 36 B (queue entry + shading point + direction / length records), a hit record 20 B.
+    (Not counted: the 16 / 4 bytes a ray writes when it ends without a hit / occluded, the 4-byte entries of the few rays handed to the re-trace.)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--walk-diag-child", "--steps", str(args.steps), "--warmup", str(args.warmup), "--width", str(args.width),
+           "--height", str(args.height), "--depth", str(args.depth), "--triangles", str(args.triangles), "--workload", args.workload]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, RTGPU_WIDE_DIAG="3", RTGPU_LANES="1"), capture_output=True, text=True, timeout=max(120.0, 6.0 * (args.steps + args.warmup)))
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{"walk_diag"')]
+        if r.returncode != 0 or not lines:
+            return None, "walk-diag child failed (rc %d): %s" % (r.returncode, (r.stderr or "")[-300:])
+        d = json.loads(lines[-1])["walk_diag"]
+        if not d["interior_visits"]:
+            return None, "this scene's launches are not served by k_trace_wide (no diagnostic counts)"
+        per_event = {"interior_visits": 64, "leaf_visits": 72, "exact_box_fetches": 32, "closest_rays": 32, "shadow_rays": 36, "hit_records_written": 20}
+        d["bytes_per_event"] = per_event
+        d["bytes"] = sum(per_event[k] * d[k] for k in per_event)
+        rays = d["closest_rays"] + d["shadow_rays"]
+        d["per_ray"] = {"interior_visits": d["interior_visits"] / max(1, rays), "leaf_visits": d["leaf_visits"] / max(1, rays), "bytes": d["bytes"] / max(1, rays)}
+        return d, None
+    except subprocess.TimeoutExpired:
+        return None, "walk-diag child timed out"
+    except Exception as e:
+        return None, "walk-diag child: %r" % (e,)
+
+
+def work_changing_env():
+    """Every environment switch that changes what a bench line measured: the bench's own aids (BENCH_*) and any RTGPU_* knob of the library that is
+    set -- a line produced under one of them must say so (config.env), and an emulated shard is not the whole frame (config.emulated_shard, metric)."""
+    return {k: os.environ[k] for k in sorted(os.environ) if k.startswith(("BENCH_", "RTGPU_")) or k in ("GPU_MAX_HW_QUEUES",)}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -328,7 +364,7 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
-    if rank == 0 and not args.pmc_child:
+    if rank == 0 and not args.pmc_child and not args.walk_diag_child:
         entry.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -355,7 +391,7 @@ def main():
     host = ra.host_lib()
     ctx = vp.device_context()
 
-    if args.pmc_child:
+    if args.pmc_child or args.walk_diag_child:
         # the profiled child: exactly the parent's passes, strictly serial kernels, nothing else
         lib.rtgpu_set_concurrency(ctx, 1)
         lib.rtgpu_set_intersection_counters(ctx, 0)
@@ -363,6 +399,12 @@ def main():
         vp.counters()            # the parent's replay reads the counters here (a synchronising call: the pass batches start over)
         vp.render(camera, args.steps)
         lib.rtgpu_synchronize(ctx)
+        if args.walk_diag_child:
+            # RTGPU_WIDE_DIAG=3 (set by the parent): the 4-wide walk counted its own fetches in the spare counters (rt_trace_wide.inl)
+            c = vp.counters()
+            print(json.dumps({"walk_diag": {"interior_visits": c["numUntrustedRays"], "leaf_visits": c["diag2"], "exact_box_fetches": c["numStackOverflowRays"] & 0xFFFFFFFF,
+                                            "hit_records_written": c["numStackOverflowRays"] >> 32, "closest_rays": c["numRays"], "shadow_rays": c["numShadowRays"],
+                                            "retraced_rays": c["numRetracedRays"]}}), flush=True)
         return
 
     def sync_all():
@@ -413,7 +455,8 @@ def main():
 
     if os.environ.get("BENCH_TIMED_ONLY"):   # profiling aid (tools/concurrency.py): the trace ends with the timed region, no replays behind it
         if rank == 0:
-            print(json.dumps({"value": delta["numRays"] / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "timed_only": True}))
+            print(json.dumps({"value": delta["numRays"] / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "timed_only": True,
+                              "config": {"env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None}}))
         return
     def kernel_times(context):
         ms = (C.c_double * 8)(); launches = (C.c_uint64 * 8)(); names = (C.c_char_p * 8)()
@@ -501,13 +544,20 @@ def main():
             "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world,
-                       "timed_region": "K passes + gather of owned tiles (N > 1) + read-back of the float3 sum buffer to host"},
+                       "timed_region": "K passes + gather of owned tiles (N > 1) + read-back of the float3 sum buffer to host",
+                       # what changed this line's work, if anything: environment switches of the bench (BENCH_*) and of the library (RTGPU_*)
+                       "env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None,
+                       "dist_backend": backend if world > 1 else None},
             "counters": {k: delta[k] for k in ("numRays", "numPrimaryRays", "numShadowRays", "numRayBoxTests", "numRayTriangleTests",
                                                "numShadowRayBoxTests", "numShadowRayTriangleTests", "numMeshHits", "numAnalyticHits")},
             "mrays_per_s_incl_shadow": (delta["numRays"] + delta["numShadowRays"]) / elapsed / 1e6,
             "intersection_counters": "off in the timed region (reference default); counts from an identical instrumented replay",
             "image": {"finite": image_ok, "mean_per_pass": image_mean},
         }
+        if emulate > 1:
+            # NOT the whole frame: the tiles rank 0 of `emulate` ranks would own, rendered alone on this device (a tuning aid for the N > 1 path)
+            out["metric"] += " -- EMULATED SHARD: 1/%d of the frame (rank 0's tiles of %d), one device" % (emulate, emulate)
+            out["config"]["parallelism"] = "emulated shard 0 of %d (tile-interleaved), 1 device" % emulate
         if scaling_report:
             out["multi_gpu"] = scaling_report
         # roofline of the dominant kernel class (rank 0's own launches and rank 0's own counters)

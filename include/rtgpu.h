@@ -583,6 +583,29 @@ typedef struct RtWalkInfo
 } RtWalkInfo;
 int rtgpu_get_walk_info(RtgpuContext* ctx, RtWalkInfo* out);
 
+/* How a multi-device context (rtgpu_create_multi) exchanges the peers' tiles at read-back, and why -- so that a first run on a real multi-GPU node
+ * explains itself (the reference has no counterpart: its only fan-out is Core/Utils/ThreadPool.cpp:57-117 under Viewport.cpp:244-262).
+ *   gatherMode    0 one device (nothing to gather), 1 a kernel on the first device reads the peers' sum buffers in place (peer access over xGMI),
+ *                 2 hipMemcpyPeerAsync into staging buffers of the first device, then the same kernel
+ *   gatherReason  why mode 2: 0 not staged, 1 RTGPU_MULTI_STAGED=1, 2 hipDeviceCanAccessPeer said no for `reasonDevice`,
+ *                 3 hipDeviceEnablePeerAccess failed for `reasonDevice` (reasonError = the HIP error code)
+ *   devices       the HIP device index of every shard (an index may repeat); peerAccess[k]: the first device addresses device k's memory
+ *   gathers / lastGatherMs / totalGatherMs   exchanges so far and their host-side wall time (submission to completion on the first device's stream) */
+#define RTGPU_GATHER_NONE 0u
+#define RTGPU_GATHER_PEER_KERNEL 1u
+#define RTGPU_GATHER_STAGED_COPY 2u
+typedef struct RtMultiInfo
+{
+    uint32_t numDevices, gatherMode, gatherReason;
+    int32_t  reasonDevice, reasonError;
+    int32_t  devices[16];
+    uint32_t peerAccess[16];
+    uint32_t reserved;
+    uint64_t gathers;
+    double   lastGatherMs, totalGatherMs;
+} RtMultiInfo;
+int rtgpu_get_multi_info(RtgpuContext* ctx, RtMultiInfo* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,23 @@ class RtCamera(C.Structure):
                 ("worldToScreen", C.c_float * 16)]
 
 
+class RtMultiInfo(C.Structure):
+    _fields_ = [("numDevices", C.c_uint32), ("gatherMode", C.c_uint32), ("gatherReason", C.c_uint32), ("reasonDevice", C.c_int32), ("reasonError", C.c_int32),
+                ("devices", C.c_int32 * 16), ("peerAccess", C.c_uint32 * 16), ("reserved", C.c_uint32), ("gathers", C.c_uint64),
+                ("lastGatherMs", C.c_double), ("totalGatherMs", C.c_double)]
+
+
+def multi_info(ctx):
+    """rtgpu_get_multi_info as a dict: how a (multi-device) context gathers the peers' tiles at read-back, and why."""
+    m = RtMultiInfo()
+    if rtgpu_lib().rtgpu_get_multi_info(ctx, C.byref(m)) != 0:
+        raise RuntimeError("rtgpu_get_multi_info failed")
+    n = int(m.numDevices)
+    return {"numDevices": n, "gatherMode": ["none", "peer-kernel", "staged-copy"][m.gatherMode], "gatherReason": ["", "RTGPU_MULTI_STAGED=1", "hipDeviceCanAccessPeer: no", "hipDeviceEnablePeerAccess failed"][m.gatherReason],
+            "reasonDevice": int(m.reasonDevice), "reasonError": int(m.reasonError), "devices": [int(m.devices[i]) for i in range(n)], "peerAccess": [bool(m.peerAccess[i]) for i in range(n)],
+            "gathers": int(m.gathers), "lastGatherMs": float(m.lastGatherMs), "totalGatherMs": float(m.totalGatherMs)}
+
+
 class RtPassParams(C.Structure):
     _fields_ = [("camera", RtCamera), ("seed", C.POINTER(C.c_uint32)), ("numDimensions", C.c_uint32), ("useBlueNoise", C.c_uint32),
                 ("sampleOffset", C.c_float * 2), ("passIndex", C.c_uint32), ("maxRayDepth", C.c_uint32),

@@ -257,31 +257,6 @@ __device__ __forceinline__ static void denseShadeVertex(const RtSceneDesc& scene
 // The body of PathTracerMIS::RenderPixel's loop for one path vertex (PathTracerMIS.cpp:276-395), as k_shade, reading arena `in`
 // and writing the survivors densely into arena `out`.  kPlain: PathTracer::RenderPixel (Core/Rendering/PathTracer.cpp:73-171).
 //
-// Hit-kind sort (generic variant, `sortKinds`).  Material::Sample / Evaluate dispatch over nine BSDF classes (Material.cpp:40-83, :182-232), a
-// vertex may instead have left the scene (EvaluateGlobalLights) or hit a light (EvaluateLight), and a zombie only resolves its request: a
-// wave whose 64 vertices mix these kinds executes every branch one after the other.  The 256 vertices a block takes per round are
-// therefore dealt to its threads by KIND -- a counting sort in LDS over twelve keys (zombie, miss, light hit, BSDF 0-8): the first waves of
-// the block get the cheap kinds, the others one or two BSDFs each.  Which thread shades a vertex changes nothing in its arithmetic.
-#define RT_SHADE_KINDS 16u
-RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t slot, bool zombie)
-{
-    if (zombie) return 0u;
-    const float4 rHit = ldStream(prec(in, R_HIT, slot));
-    const uint32_t objectId = ubits(rHit.x);
-    if (objectId == RT_INVALID_OBJECT) return 1u;
-    const RtObject& obj = scene.objects[objectId];
-    if (obj.objectKind == RT_OBJECT_LIGHT) return 2u;
-    uint32_t material = obj.materialIndex;
-    if (obj.shapeKind == RT_SHAPE_MESH)
-    {
-        const RtMesh& mesh = scene.meshes[obj.meshIndex];
-        const uint32_t ofTriangle = reinterpret_cast<const TriangleShading*>(scene.vertexIndices)[mesh.firstTriangle + ubits(rHit.y)].materialIndex;   // as meshEvaluateIntersection
-        if (ofTriangle != RT_NO_MATERIAL) material = ofTriangle;
-    }
-    return material == RT_NO_MATERIAL ? 3u : 3u + (scene.materials[material].bsdf & 15u) % (RT_SHADE_KINDS - 4u);
-}
-
-//
 // kAll: LightSamplingStrategy::All (PathTracerMIS.cpp:141-147: every light is sampled at every vertex, up to RT_DENSE_MAX_LIGHTS of them here).
 // The 2 x numLights request records of a vertex cannot wait in registers or LDS for its output slot, so they are written to the vertex's OWN
 // slot of the input arena first -- its previous requests were folded in at the top of the iteration, the space is free -- and copied to the
@@ -289,9 +264,8 @@ RT_DEV uint32_t shadeKindOf(const RtSceneDesc& scene, const Paths& in, uint32_t 
 template <int kLean, bool kPlain = false, bool kAll = false>
 __global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense(const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out,
                                                           const DenseCounts dense, uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount,
-                                                          float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds)
+                                                          float4* __restrict__ home, unsigned long long* counters)
 {
-    __shared__ uint32_t sKindCount[RT_SHADE_KINDS], sKindBase[RT_SHADE_KINDS], sDealt[RT_BLOCK];
     __shared__ uint32_t sShadowBuf[RT_APPEND_BUFFER];
     // The four records of a vertex's next-event request are known long before the vertex knows whether and where it survives (Russian roulette,
     // BSDF sampling and the block's slot allocation come after): they wait in LDS instead of 16 registers.  142 -> 127 VGPRs for the lean
@@ -301,7 +275,6 @@ __global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense(const RtSceneDesc
     __shared__ uint32_t sLive, sZombies, sLiveBase, sZombieBase;
     __shared__ uint32_t sLivePrefix[RT_DENSE_SHARDS + 1u], sZombiePrefix[RT_DENSE_SHARDS + 1u];
     if (threadIdx.x == 0) { sShadowCount = 0; sLive = 0; sZombies = 0; }
-    if (threadIdx.x < RT_SHADE_KINDS) sKindCount[threadIdx.x] = 0u;
     denseLoadPrefix(dense.in, sLivePrefix);
     if (threadIdx.x == 64)
     {
@@ -332,20 +305,7 @@ __global__ void RT_SHADE_DENSE_ATTR(kLean, kAll) k_shade_dense(const RtSceneDesc
     };
     for (uint32_t first = blockIdx.x * blockDim.x; first < rounded; first += stride)
     {
-        uint32_t i = first + threadIdx.x;
-        if (!RT_LEAN(kLean) && sortKinds != 0u)
-        {
-            // deal the round's vertices to the threads by kind
-            bool z = false;
-            const uint32_t kind = i < count ? shadeKindOf(scene, in, vertexSlot(i, z), i >= numLive) : RT_SHADE_KINDS - 1u;
-            const uint32_t rankInKind = atomicAdd(&sKindCount[kind], 1u);
-            __syncthreads();
-            if (threadIdx.x == 0) { uint32_t sum = 0; for (uint32_t k = 0; k < RT_SHADE_KINDS; ++k) { sKindBase[k] = sum; sum += sKindCount[k]; sKindCount[k] = 0u; } }
-            __syncthreads();
-            sDealt[sKindBase[kind] + rankInKind] = i;
-            __syncthreads();
-            i = sDealt[threadIdx.x];
-        }
+        const uint32_t i = first + threadIdx.x;
         // what this vertex leaves behind: 0 nothing (radiance parked), 1 a live path, 2 a zombie (radiance + one pending request)
         DenseVertex v;
         v.outcome = 0; v.stagedShTp = false; v.rayNeeded = false; v.oHome = 0u; v.rayMask = 0u;

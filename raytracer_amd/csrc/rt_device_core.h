@@ -325,6 +325,24 @@ RT_DEV bool intersectBoxRayNoNaN(const Ray& ray, float minx, float miny, float m
     outDistance = nearD;
     return (farD >= nearD) && (farD >= 0.0f);
 }
+// A ray with a direction component of exactly zero keeps that coordinate for its whole length, and the reference's slab test says nothing about it:
+// box * inf - origin * inf is NaN whenever box plane and origin have the same sign, and _mm_min_ps / _mm_max_ps then drop the axis -- the ray is tested
+// against the OTHER two slabs only and walks every node of the scene's whole column there (a next-event ray towards a light whose direction lies in a
+// coordinate plane, from a wall: tens of thousands of nodes; with sponza.json's light orientation [80, 0, 0] 360 such rays per pass, 2 ms per re-trace
+// launch, profiles/r05_degenerate_axis_rays.txt).  No triangle of a box that is clearly off the ray's fixed coordinate can be hit -- a node's box bounds
+// its triangles' vertices exactly, and Moeller-Trumbore only accepts points inside the triangle -- so such boxes are skipped: the walk visits a SUBSET of
+// the reference's nodes in the reference's order, every leaf that holds a hit is still visited, the accepted hits and their order are the reference's.
+// "Clearly off": by more than 2^-7 of the magnitudes involved (>= the box's extent in that axis), five decimal orders above the rounding of the tests.
+// Not applied when the intersection counters are on (they count the reference's own box tests).
+RT_DEV bool boxNearDegenerateAxes(const Ray& r, float minx, float miny, float minz, float maxx, float maxy, float maxz)
+{
+    const uint32_t inf = 0x7f800000u;
+    bool near = true;
+    if ((__float_as_uint(r.invDir.x) & 0x7fffffffu) == inf) { const float m = (fabsf(r.origin.x) + fabsf(minx) + fabsf(maxx)) * 0.0078125f; near = near && r.origin.x >= minx - m && r.origin.x <= maxx + m; }
+    if ((__float_as_uint(r.invDir.y) & 0x7fffffffu) == inf) { const float m = (fabsf(r.origin.y) + fabsf(miny) + fabsf(maxy)) * 0.0078125f; near = near && r.origin.y >= miny - m && r.origin.y <= maxy + m; }
+    if ((__float_as_uint(r.invDir.z) & 0x7fffffffu) == inf) { const float m = (fabsf(r.origin.z) + fabsf(minz) + fabsf(maxz)) * 0.0078125f; near = near && r.origin.z >= minz - m && r.origin.z <= maxz + m; }
+    return near;
+}
 RT_DEV bool rayIsNaNFree(const Ray& r)
 {
     const uint32_t inf = 0x7f800000u;

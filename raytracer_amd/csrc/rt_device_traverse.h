@@ -88,22 +88,24 @@ RT_DEV void travBegin(TravState& s, const RtSceneDesc& d, const Ray& worldRay, f
 // INTERIOR step: test both children, descend / push / pop (Traversal_Single.h:44-91 and :127-170).
 // Precondition: travIsInterior(s).  kExactMinMax selects the compare+select slab test that reproduces the
 // _mm_min_ps/_mm_max_ps NaN behaviour; the caller uses it whenever a lane of the wave is not nanFree.
-// LDS copy of the first nodes of a breadth-first ordered mesh tree (nodes [2, 2 + count)): the top levels every ray walks through
-struct LdsTop { const float4* nodes; uint32_t count; };
 
 template <bool kCount, bool kExactMinMax>
-RT_DEV void travStepInterior(TravState& s, const LdsStack& stack, Counters& cnt, const LdsTop top = { nullptr, 0u })
+RT_DEV void travStepInterior(TravState& s, const LdsStack& stack, Counters& cnt)
 {
     const uint32_t firstChild = s.cur & RT_NODE_CHILD_MASK;
-    NodePair n;
-    if (firstChild - 2u < top.count) { const float4* p = top.nodes + (firstChild - 2u) * 2u; n.a0 = p[0]; n.a1 = p[1]; n.b0 = p[2]; n.b1 = p[3]; }
-    else n = loadNodePair(s.nodes, firstChild);
+    const NodePair n = loadNodePair(s.nodes, firstChild);
     float distanceA, distanceB;
     bool hitA, hitB;
     if (kExactMinMax)
     {
         hitA = intersectBoxRay(s.ray, V4(n.a0.x, n.a0.y, n.a0.z, 0.0f), V4(n.a1.x, n.a1.y, n.a1.z, 0.0f), distanceA);
         hitB = intersectBoxRay(s.ray, V4(n.b0.x, n.b0.y, n.b0.z, 0.0f), V4(n.b1.x, n.b1.y, n.b1.z, 0.0f), distanceB);
+        if (!kCount && !s.nanFree)
+        {
+            // an axis-parallel ray: boxes clearly off its fixed coordinate hold nothing it can hit (rt_device_core.h, boxNearDegenerateAxes)
+            hitA = hitA && boxNearDegenerateAxes(s.ray, n.a0.x, n.a0.y, n.a0.z, n.a1.x, n.a1.y, n.a1.z);
+            hitB = hitB && boxNearDegenerateAxes(s.ray, n.b0.x, n.b0.y, n.b0.z, n.b1.x, n.b1.y, n.b1.z);
+        }
     }
     else
     {

@@ -51,6 +51,7 @@ static int gatherPeers(RtgpuContext* c)
     const uint32_t world = (uint32_t)c->peers.size() + 1u;
     const size_t floats = (size_t)c->width * c->height * 3;
     hipStream_t st = c->lanes[0].stream;
+    const auto gatherStart = std::chrono::steady_clock::now();
     PeerFilms films;
     memset(&films, 0, sizeof(films));
     if (c->stagedGather)
@@ -79,5 +80,7 @@ static int gatherPeers(RtgpuContext* c)
     hipLaunchKernelGGL(k_gather_tiles, dim3(blocks), dim3(RT_BLOCK), 0, st, c->sum, c->secondary, films, c->width, c->height, world);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - gatherStart).count();
+    c->multiInfo.gathers++; c->multiInfo.lastGatherMs = ms; c->multiInfo.totalGatherMs += ms;
     return RTGPU_OK;
 }

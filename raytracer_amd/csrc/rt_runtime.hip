@@ -31,6 +31,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -125,7 +126,7 @@ struct BatchLane
     Paths paths = { nullptr, 0, 0 };
     uint32_t* queues[2] = { nullptr, nullptr };
     uint32_t* shadowQueues[2] = { nullptr, nullptr };   // capacity * maxLights NEE ray requests each, ping-pong per bounce
-    uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests k_trace_quant hands to the binary-tree kernel
+    uint32_t* exactQueue = nullptr;        // closest-hit rays / any-hit requests the 4-wide walks hand to the binary-tree kernel
     uint32_t* exactShadowQueue = nullptr;
     // dense path state (rt_dense.inl, LightSamplingStrategy::Single): the second arena of the ping-pong, the parked radiance of
     // finished paths, per bounce the live / zombie counts of the arena's regions (2 * RT_DENSE_SHARDS words per bounce)
@@ -160,6 +161,7 @@ struct RtgpuContext
     bool isPeer = false;
     bool stagedGather = false;         // no peer access between the devices (or RTGPU_MULTI_STAGED=1): hipMemcpyPeerAsync into staging buffers, then the gather
     float* gatherStage = nullptr; size_t gatherStageFloats = 0;
+    RtMultiInfo multiInfo = {};        // rtgpu_get_multi_info: which gather was chosen and why, its timings
     float* sum = nullptr;
     float* secondary = nullptr;
     uint32_t* slotPixel = nullptr;
@@ -177,20 +179,16 @@ struct RtgpuContext
     uint32_t nextLane = 0;
     int lastAccumulateLane = -1;
     uint32_t traversalStackNeed = 0;   // deepest top-level + mesh stack the uploaded scene can produce
-    QuantBvh quant;                    // 32-byte child pairs of a single-mesh scene (rt_trace_quant.inl); pairs == nullptr: none
     WideBvh wide;                      // 4-wide collapse of the same tree (rt_trace_wide.inl); nodes == nullptr: none
     WideScene wide2;                   // two-level scenes: 4-wide top-level tree over 4-wide mesh trees (rt_trace_wide2.inl); nodes == nullptr: none
     bool wide2Allowed = true;          // RTGPU_WIDE2=0: two-level scenes keep the binary walk
     uint64_t walkNodeBytes[3] = { 0, 0, 0 }, walkLeafBoxBytes[3] = { 0, 0, 0 }, walkTriangleBytes = 0;   // rtgpu_get_walk_info, per RTGPU_WALK_* kernel
     bool wideAllowed = true;           // RTGPU_WIDE=0: single-mesh scenes walk the binary tree (k_trace) even with the intersection counters off
-    bool quantAllowed = false;         // RTGPU_QUANT=1: k_trace_quant serves single-mesh scenes (an experiment that did not pay, rt_trace_quant.inl)
     bool denseAllowed = true;          // RTGPU_NO_DENSE=1: path state stays in the pixel's slot for the whole path (the first layout)
-    bool ldsTopAllowed = false;        // RTGPU_LDS_TOP=1: k_trace serves the top levels of a single mesh's tree from LDS (measured 12 % slower than the L1)
     TravTuning tune = { 28u, 32u, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };   // scheduling: measured plateau on MI355X (profiles/r01_tuning_sweep.txt)
     uint32_t travBlocksPerCU = 0;      // 0 = default
     int32_t tailBounce = -1;           // rtgpu_set_schedule: the bounce at which a dense batch hands over to k_tail (rt_tail.hip); 0 = never, -1 = policy
     int32_t localRetrace = -1;         // rtgpu_set_schedule: the 4-wide walks trace their undecided rays themselves; 0 / 1, -1 = policy
-    bool sortShadeKinds = false;       // RTGPU_SHADE_SORT=1: the generic k_shade_dense deals a block's vertices to its threads by hit kind (measured 4 % slower: off)
     int leanScene = 0;                 // the scene class of rt_device_core.h (kLean): 0 anything, 1 lean, 2 lean + textures, 3 anything without textures, 4 lean + simple bitmaps only
     bool countIntersections = false;   // box / triangle test counters: RT_ENABLE_INTERSECTION_COUNTERS of the reference, off by default like there (Core/Config.h:4);
                                        // rtgpu_set_intersection_counters, or RTGPU_INTERSECTION_COUNTERS=1 for the default of new contexts
@@ -449,14 +447,11 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_OTHER_MIN_LANES")) c->tune.otherMinLanes = (uint32_t)atoi(e);
     if (const char* e = getenv("RTGPU_TRAV_BLOCKS_PER_CU")) c->travBlocksPerCU = (uint32_t)atoi(e);
-    if (const char* e = getenv("RTGPU_QUANT")) c->quantAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_WIDE")) c->wideAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_INTERSECTION_COUNTERS")) c->countIntersections = atoi(e) != 0;
     memset(&c->wide, 0, sizeof(c->wide));
-    if (const char* e = getenv("RTGPU_LDS_TOP")) c->ldsTopAllowed = atoi(e) != 0;
     if (const char* e = getenv("RTGPU_NO_DENSE")) c->denseAllowed = atoi(e) == 0;
     if (const char* e = getenv("RTGPU_WIDE2")) c->wide2Allowed = atoi(e) != 0;
-    memset(&c->quant, 0, sizeof(c->quant));
     if (const char* e = getenv("RTGPU_PASS_BATCH")) { c->passBatch = (uint32_t)atoi(e); c->passBatchFromEnv = true; }
     if (c->passBatch < 1) c->passBatch = 1;
     if (c->passBatch > RT_SEED_RING / 2) c->passBatch = RT_SEED_RING / 2;
@@ -507,6 +502,9 @@ RTGPU_API int rtgpu_create_multi(const int* deviceIndices, uint32_t numDevices, 
     const uint32_t world = (uint32_t)devices.size();
     c->shard = { 0u, world };
     if (const char* e = getenv("RTGPU_MULTI_STAGED")) c->stagedGather = atoi(e) != 0;
+    RtMultiInfo& info = c->multiInfo;
+    info.numDevices = world; info.reasonDevice = -1; info.gatherReason = c->stagedGather ? 1u : 0u;
+    for (uint32_t k = 0; k < world; ++k) { info.devices[k] = devices[k]; info.peerAccess[k] = devices[k] == devices[0] ? 1u : 0u; }
     for (uint32_t k = 1; k < world; ++k)
     {
         RtgpuContext* p = nullptr;
@@ -519,17 +517,35 @@ RTGPU_API int rtgpu_create_multi(const int* deviceIndices, uint32_t numDevices, 
             // the gather kernel on device 0 reads the peers' sum buffers in place
             int can = 0;
             (void)hipSetDevice(devices[0]);
-            if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) != hipSuccess || !can) c->stagedGather = true;
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[k]) != hipSuccess || !can) { c->stagedGather = true; info.gatherReason = 2u; info.reasonDevice = devices[k]; }
             else
             {
                 const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) c->stagedGather = true;
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { c->stagedGather = true; info.gatherReason = 3u; info.reasonDevice = devices[k]; info.reasonError = (int32_t)e; }
+                else info.peerAccess[k] = 1u;
                 (void)hipGetLastError();
             }
         }
     }
     (void)hipSetDevice(devices[0]);
+    info.gatherMode = world == 1u ? RTGPU_GATHER_NONE : (c->stagedGather ? RTGPU_GATHER_STAGED_COPY : RTGPU_GATHER_PEER_KERNEL);
+    if (getenv("RTGPU_VERBOSE") && atoi(getenv("RTGPU_VERBOSE")) != 0)
+    {
+        static const char* const why[] = { "", " (RTGPU_MULTI_STAGED=1)", " (hipDeviceCanAccessPeer: no)", " (hipDeviceEnablePeerAccess failed)" };
+        fprintf(stderr, "[rtgpu] multi-device context: %u devices [", world);
+        for (uint32_t k = 0; k < world; ++k) fprintf(stderr, "%s%d", k ? " " : "", devices[k]);
+        fprintf(stderr, "], read-back gather = %s%s\n", world == 1u ? "none" : (c->stagedGather ? "hipMemcpyPeerAsync into staging buffers + kernel" : "kernel reading the peers' buffers in place (peer access)"),
+                why[info.gatherReason < 4u ? info.gatherReason : 0u]);
+    }
     *outCtx = c;
+    return RTGPU_OK;
+}
+
+RTGPU_API int rtgpu_get_multi_info(RtgpuContext* c, RtMultiInfo* out)
+{
+    if (!c || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = c->multiInfo;
+    if (out->numDevices == 0u) { out->numDevices = 1u; out->devices[0] = c->device; out->peerAccess[0] = 1u; out->reasonDevice = -1; }   // a one-device context (rtgpu_create)
     return RTGPU_OK;
 }
 
@@ -740,7 +756,6 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
     if ((r = uploadArray(c, s->textures, s->numTextures, &d.textures))) return r;
     if ((r = uploadArray(c, s->texelData, s->numTextures ? (size_t)s->texelBytes : 0, &d.texelData))) return r;
     // single-mesh scenes (Scene::Traverse's one-object bypass): the re-encoded tree of the default traversal kernel
-    memset(&c->quant, 0, sizeof(c->quant));
     memset(&c->wide, 0, sizeof(c->wide));
     memset(&c->wide2, 0, sizeof(c->wide2));
     const bool singleMesh = s->numObjects == 1u && s->objects[0].objectKind == RT_OBJECT_SHAPE && s->objects[0].shapeKind == RT_SHAPE_MESH;
@@ -797,11 +812,8 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         const QuantBuild q = buildQuantBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, mesh.numTriangles, maxMeshDepth);
         if (q.ok)
         {
-            const float4* devPairs = nullptr; const float4* devGate = nullptr;
-            if ((r = uploadArray(c, q.pairs.data(), q.pairs.size(), &devPairs))) return r;
+            const float4* devGate = nullptr;
             if ((r = uploadArray(c, q.gate.data(), q.gate.size(), &devGate))) return r;
-            c->quant.pairs = devPairs; c->quant.gate = devGate; c->quant.root = q.root; c->quant.stackNeed = q.stackNeed;
-            memcpy(c->quant.base, q.base, sizeof(q.base)); memcpy(c->quant.step, q.step, sizeof(q.step)); memcpy(c->quant.bound, q.bound, sizeof(q.bound));
             const WideBuild w = buildWideBvh(s->meshNodes + mesh.firstNode, mesh.numNodes, q);
             if (w.ok)
             {
@@ -832,19 +844,6 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         bool simple = c->leanScene == 2 && s->numTextures != 0u && !(getenv("RTGPU_NO_SIMPLE_TEXTURES") && atoi(getenv("RTGPU_NO_SIMPLE_TEXTURES")) != 0);
         for (uint32_t i = 0; i < s->numTextures && simple; ++i) simple = s->textures[i].kind == RT_TEXTURE_BITMAP && RT_FORMAT_IS_SIMPLE(s->textures[i].format);
         if (simple) c->leanScene = 4;
-    }
-    {
-        // kinds a vertex of this scene can be: BSDF classes in use, light objects; (misses and zombies exist everywhere)
-        uint32_t bsdfMask = 0u; bool lightObjects = false;
-        for (uint32_t i = 0; i < s->numMaterials; ++i) bsdfMask |= 1u << (s->materials[i].bsdf & 15u);
-        for (uint32_t i = 0; i < s->numObjects; ++i) lightObjects = lightObjects || s->objects[i].objectKind == RT_OBJECT_LIGHT;
-        // Measured (profiles/r03_shade_variants.txt): the sort makes k_shade_dense 4-7 % SLOWER on the Cornell box and on the all-BSDF scene -- the
-        // kernel waits on dependent gathers, it does not issue-stall on divergent branches, and the key costs a second walk hit -> object ->
-        // triangle -> material plus three block barriers.  What did pay on those scenes is occupancy (scene class 3: 196 -> 167 VGPRs, -17 ... -21 %).
-        // So the sort is built, bit-exact (tests) and OFF unless RTGPU_SHADE_SORT=1.
-        const bool mixed = !lean && ((bsdfMask & (bsdfMask - 1u)) != 0u || lightObjects);
-        c->sortShadeKinds = false;
-        if (const char* e = getenv("RTGPU_SHADE_SORT")) c->sortShadeKinds = mixed && atoi(e) != 0;
     }
     c->sceneReady = true;
     c->vcm.havePhotons = false;   // photons of another scene
@@ -1056,22 +1055,6 @@ static int ensurePaths(RtgpuContext* c, BatchLane& l, uint32_t maxLights, uint32
         HIP_TRY(hipMalloc((void**)&l.denseCounts, (size_t)2 * RT_DENSE_SHARDS * (l.queueCountCapacity + 1u) * sizeof(uint32_t)));
     }
     return RTGPU_OK;
-}
-
-// The re-encoded tree serves single-mesh scenes unless the reference's box / triangle test counters are wanted (they belong to the
-// reference's walk) or it was switched off.
-static bool useQuant(const RtgpuContext* c) { return c->quant.pairs != nullptr && c->quantAllowed && !c->countIntersections; }
-
-static void launchTraceQuant(RtgpuContext* c, hipStream_t stream, const Paths& paths, const uint32_t* tq, const uint32_t* tqc, const uint32_t* tsq, const uint32_t* tsc,
-                             uint32_t* cursor, uint32_t* exactQueue, uint32_t* exactCount, uint32_t* exactShadowQueue, uint32_t* exactShadowCount, float shadowOffset)
-{
-    QuantTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount };
-    const uint32_t stackClass = c->quant.stackNeed <= 24u ? 24u : (c->quant.stackNeed <= 32u ? 32u : 64u);
-    const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)))), block(RT_BLOCK);
-    LaunchTimer t(c, stream, KC_TRACE);
-#define RT_LAUNCH_QUANT(S) hipLaunchKernelGGL((k_trace_quant<S>), grid, block, 0, stream, c->sceneDev, c->quant, paths, tq, tqc, tsq, tsc, cursor, c->counters, tune)
-    if (stackClass == 24u) RT_LAUNCH_QUANT(24); else if (stackClass == 32u) RT_LAUNCH_QUANT(32); else RT_LAUNCH_QUANT(64);
-#undef RT_LAUNCH_QUANT
 }
 
 // The 4-wide tree: single-mesh scenes, intersection counters off (they belong to the reference's walk).  Stack: 24 entries per lane, a
@@ -1301,7 +1284,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                                      leanPrimary && depth == 0u ? c->slotPixel : nullptr };
             LaunchTimer t(c, l.stream, KC_SHADE);
 #define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
-                                                     l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters, c->sortShadeKinds ? 1u : 0u)
+                                                     l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters)
             if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true, false);
             else if (denseAll) { if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, true); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, true); else if (c->leanScene == 4) RT_LAUNCH_SHADE_DENSE(4, false, true); else RT_LAUNCH_SHADE_DENSE(0, false, true); }
             else if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, false); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, false);
@@ -1321,7 +1304,6 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
         hipLaunchKernelGGL(k_generate, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, l.queues[0], pathCounts + 0, c->counters);
     }
 #define RT_LAUNCH_TRACE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune)
-    const bool ldsTop = stackClass == 24u && !c->countIntersections && c->ldsTopAllowed && c->sceneDev.numObjects == 1u;
     // bounce k: trace {closest rays of bounce k, NEE rays of bounce k-1} -> shade k; one last trace for the NEE rays of
     // the final bounce
     const uint32_t lastDepth = c->debugMode >= 0 ? 0u : maxRayDepth + 1u;
@@ -1336,22 +1318,19 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
             const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
             const uint32_t launchIndex = depth;
-            if (useWide(c) || useQuant(c))
+            if (useWide(c))
             {
                 // the re-encoded tree serves the launch; what it does not trust goes through the binary-tree kernel right behind it
                 uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
                 uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
                 uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
-                if (useWide(c)) launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f, nullptr, 0u);
-                else
-                launchTraceQuant(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f);
+                launchTraceWide(c, l.stream, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, l.exactQueue, exactCounts + launchIndex, l.exactShadowQueue, exactShadowCounts + launchIndex, 0.0001f, nullptr, 0u);
                 launchRetrace(c, l, l.stream, l.paths, launchIndex, stackClass, l.queues[(depth + 1u) & 1u]);
             }
             else
             {
                 LaunchTimer t(c, l.stream, KC_TRACE);
-                if (ldsTop) hipLaunchKernelGGL((k_trace<24, false, true>), travGrid, block, 0, l.stream, c->sceneDev, l.paths, tq, tqc, tsq, tsc, cursors + launchIndex, c->counters, c->tune);
-                else if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
+                if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE(24, true); else RT_LAUNCH_TRACE(24, false); }
                 else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE(32, true); else RT_LAUNCH_TRACE(32, false); }
                 else { if (c->countIntersections) RT_LAUNCH_TRACE(64, true); else RT_LAUNCH_TRACE(64, false); }
             }

@@ -6,7 +6,7 @@
 // rt_shade.hip; the launch ladder of flushBatch (rt_runtime.hip) picks among exactly these
 #define RT_SHADE_DENSE_ATTR(kLean, kAll) __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_SHADE_MIN_WAVES(kLean, kAll), RT_SHADE_MIN_WAVES(kLean, kAll) > 1 ? RT_SHADE_MIN_WAVES(kLean, kAll) : 10)))
 #define RT_K_SHADE_DENSE_ARGS (const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths in, const Paths out, const DenseCounts dense, \
-                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount, float4* __restrict__ home, unsigned long long* counters, uint32_t sortKinds)
+                               uint32_t* __restrict__ shadowQueue, uint32_t* __restrict__ shadowCount, float4* __restrict__ home, unsigned long long* counters)
 #define RT_K_SHADE_DENSE_INSTANCES(X) X(0, true, false) X(1, false, true) X(2, false, true) X(4, false, true) X(0, false, true) \
                                       X(1, false, false) X(2, false, false) X(3, false, false) X(4, false, false) X(0, false, false)
 #define RT_K_SHADE_ARGS (const RtSceneDesc scene, const DevPass* __restrict__ passes, uint32_t slotsPerPass, const Paths paths, const uint32_t* __restrict__ queueIn, \

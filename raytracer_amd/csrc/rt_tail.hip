@@ -50,7 +50,8 @@ enum { TN_LIVE = 0, TN_ZOMBIES, TN_SHADOW, TN_NEXT_LIVE, TN_NEXT_ZOMBIES, TN_CUR
 template <int kLean, bool kPlain>
 __global__ void RT_TAIL_ATTR(kLean, kPlain) k_tail RT_K_TAIL_ARGS
 {
-    __shared__ __attribute__((aligned(16))) uint32_t sStack[24 * RT_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint32_t sStack[24 * RT_BLOCK];   // (the 4-wide walk uses RT_WIDE_STACK entries + RT_WIDE_PARK parked words of it, the reference's walk all 24)
+    static_assert(RT_WIDE_STACK + (int)RT_WIDE_PARK <= 24, "the 4-wide walk's stack and parked words share the 24-entry stack memory");
     __shared__ uint32_t sLists[5][RT_TAIL_PATHS];
     __shared__ uint32_t sLivePrefix[RT_DENSE_SHARDS + 1u], sZombiePrefix[RT_DENSE_SHARDS + 1u];
     __shared__ uint32_t sN[TN_COUNT];
@@ -115,14 +116,14 @@ __global__ void RT_TAIL_ATTR(kLean, kPlain) k_tail RT_K_TAIL_ARGS
             {
                 // ---- T: the 4-wide walk; what it does not decide waits in the (still empty) lists of the next round ----
                 const WideLocal handOver = { nextLive, &sN[TN_NEXT_LIVE], nextZombies, &sN[TN_NEXT_ZOMBIES], RT_TAIL_PATHS };
-                traceWideLoop<24, false>(scene, bvh, paths, live, &sN[TN_LIVE], sLists[4], &sN[TN_SHADOW], &sN[TN_CURSOR], counters, wideTune, handOver, sStack, sLivePrefix, blockWaves);
+                traceWideLoop<RT_WIDE_STACK, false>(scene, bvh, paths, live, &sN[TN_LIVE], sLists[4], &sN[TN_SHADOW], &sN[TN_CURSOR], counters, wideTune, handOver, sStack, sLivePrefix, blockWaves);
                 __syncthreads();
                 if (sN[TN_NEXT_LIVE] + sN[TN_NEXT_ZOMBIES] != 0u)
                 {
                     // ---- X: the reference's own walk for those ----
                     if (threadIdx.x == 0) sN[TN_CURSOR] = 0u;
                     __syncthreads();
-                    traceBinaryLoop<24, false, false>(scene, paths, nextLive, &sN[TN_NEXT_LIVE], nextZombies, &sN[TN_NEXT_ZOMBIES], &sN[TN_CURSOR], counters, exactTune, sStack, nullptr, sLivePrefix, blockWaves);
+                    traceBinaryLoop<24, false>(scene, paths, nextLive, &sN[TN_NEXT_LIVE], nextZombies, &sN[TN_NEXT_ZOMBIES], &sN[TN_CURSOR], counters, exactTune, sStack, sLivePrefix, blockWaves);
                     __syncthreads();
                 }
             }

@@ -12,10 +12,10 @@
 // The loop itself is a device function: k_trace runs it over the launch's queues with its own LDS; k_trace_wide runs it over the block's own
 // list of undecided rays when its walk is done (rt_trace_wide.inl), and k_tail between its block-local trace and shade phases (rt_tail.hip).
 // `queue`, `shadowQueue`, the counts and `cursor` may live in LDS (generic pointers); `sharingWaves` = the waves that claim from `cursor`.
-template <int kStack, bool kCount, bool kLdsTop = false>
+template <int kStack, bool kCount>
 RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const uint32_t* queue, const uint32_t* queueCount,
                             const uint32_t* shadowQueue, const uint32_t* shadowCount, uint32_t* cursor, unsigned long long* counters, const TravTuning& tune,
-                            uint32_t* sStack, float4* sTop, uint32_t* sDensePrefix, uint32_t sharingWaves)
+                            uint32_t* sStack, uint32_t* sDensePrefix, uint32_t sharingWaves)
 {
     const LdsStack stack = { sStack + threadIdx.x, RT_BLOCK };
     Counters cnt; zeroCounters(cnt);
@@ -75,16 +75,6 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
             bypassTriBase = mesh.firstTriangle;
             bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
         }
-    }
-    // LDS-staged node packets: the device copy of a mesh tree is in breadth-first order, so its top levels are its first nodes
-    LdsTop top = { sTop, 0u };
-    if (kLdsTop && bypassMesh)
-    {
-        const uint32_t numNodes = scene.meshes[scene.objects[0].meshIndex].numNodes;
-        top.count = numNodes > 2u ? (numNodes - 2u < RT_LDS_TOP_NODES ? numNodes - 2u : RT_LDS_TOP_NODES) : 0u;
-        const float4* src = reinterpret_cast<const float4*>(bypassNodes + 2);
-        for (uint32_t i = threadIdx.x; i < top.count * 2u; i += RT_BLOCK) sTop[i] = src[i];
-        __syncthreads();
     }
     uint32_t drainIterations = 0, closestDrain = 0;
     for (;;)
@@ -222,7 +212,7 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
             {
                 for (;;)
                 {
-                    if (in) travStepInterior<kCount, false>(s, stack, cnt, top);
+                    if (in) travStepInterior<kCount, false>(s, stack, cnt);
                     in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
@@ -232,7 +222,7 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
             {
                 for (;;)
                 {
-                    if (in) travStepInterior<kCount, true>(s, stack, cnt, top);
+                    if (in) travStepInterior<kCount, true>(s, stack, cnt);
                     in = in && (s.cur >> RT_NODE_LEAVES_SHIFT) == 0u;   // the mode does not change in here
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
@@ -260,16 +250,15 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
     flushCounters(cnt, counters);
 }
 
-template <int kStack, bool kCount, bool kLdsTop = false>
+template <int kStack, bool kCount>
 __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace(const RtSceneDesc scene, const Paths paths,
                                                     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
                                                     const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                     uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
-    __shared__ float4 sTop[kLdsTop ? RT_LDS_TOP_NODES * 2u : 1u];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    traceBinaryLoop<kStack, kCount, kLdsTop>(scene, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, sStack, sTop, sDensePrefix, gridDim.x * (RT_BLOCK / 64u));
+    traceBinaryLoop<kStack, kCount>(scene, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, sStack, sDensePrefix, gridDim.x * (RT_BLOCK / 64u));
 }
 
 #ifndef RT_TRACE_FUNCTIONS_ONLY   // (rt_tail.hip takes the walk above and not this kernel)
@@ -323,8 +312,10 @@ __global__ void __launch_bounds__(RT_MONSTER_BLOCK) k_trace_monster(const RtScen
                 {
                     const NodePair np = loadNodePair(nodes, first);
                     float distanceA, distanceB;
-                    const bool hitA = intersectBoxRay(ray, V4(np.a0.x, np.a0.y, np.a0.z, 0.0f), V4(np.a1.x, np.a1.y, np.a1.z, 0.0f), distanceA) && distanceA <= best;
-                    const bool hitB = intersectBoxRay(ray, V4(np.b0.x, np.b0.y, np.b0.z, 0.0f), V4(np.b1.x, np.b1.y, np.b1.z, 0.0f), distanceB) && distanceB <= best;
+                    const bool hitA = intersectBoxRay(ray, V4(np.a0.x, np.a0.y, np.a0.z, 0.0f), V4(np.a1.x, np.a1.y, np.a1.z, 0.0f), distanceA) && distanceA <= best &&
+                                      boxNearDegenerateAxes(ray, np.a0.x, np.a0.y, np.a0.z, np.a1.x, np.a1.y, np.a1.z);
+                    const bool hitB = intersectBoxRay(ray, V4(np.b0.x, np.b0.y, np.b0.z, 0.0f), V4(np.b1.x, np.b1.y, np.b1.z, 0.0f), distanceB) && distanceB <= best &&
+                                      boxNearDegenerateAxes(ray, np.b0.x, np.b0.y, np.b0.z, np.b1.x, np.b1.y, np.b1.z);
                     const uint32_t pushes = (hitA ? 1u : 0u) + (hitB ? 1u : 0u);
                     if (pushes != 0u)
                     {

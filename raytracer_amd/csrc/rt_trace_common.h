@@ -27,7 +27,7 @@ RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSiz
 {
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == 0u) base = atomicAdd(cursor, chunkSize);
-    base = __shfl(base, 0);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);   // wave-uniform: the chunk lives in scalar registers (every lane is active here; lane 0 claimed)
     chunk.next = base < count ? base : count;
     chunk.end = base + chunkSize < count ? base + chunkSize : count;
     if (chunk.end < chunk.next) chunk.end = chunk.next;
@@ -55,6 +55,5 @@ struct TravTuning
 #define RT_ABORT_RETRACE_AFTER 96u
 
 #define RT_COUNTER_RETRACED 12   // counters[]: rays the 4-wide walks handed to the binary-tree walk (RtCounters::numRetracedRays)
-#define RT_LDS_TOP_NODES 224u    // 7 KB: the stack class of 24 entries leaves 7.4 KB per block at five blocks per CU
 #define RT_MONSTER_BLOCK 512
 #define RT_MONSTER_STACK 8192

@@ -23,24 +23,20 @@ struct BlurPlan { uint32_t n, wl, wu; float m; };
 struct BloomLevels { const float* level[5]; };
 struct ErrorRow { uint32_t block, y; };
 
-// one list of the traversal kernels' instantiations: X(stack entries per lane, intersection counters, top levels in LDS) etc.
+// one list of the traversal kernels' instantiations: X(stack entries per lane, intersection counters) etc.
 #define RT_TRACE_ATTR(kStack) __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1)))
 #define RT_K_TRACE_ARGS (const RtSceneDesc scene, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, \
                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount, uint32_t* __restrict__ cursor, unsigned long long* counters, const TravTuning tune)
-#define RT_K_TRACE_QUANT_ARGS (const RtSceneDesc scene, const QuantBvh bvh, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, \
-                               const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount, uint32_t* __restrict__ cursor, unsigned long long* counters, const QuantTuning tune)
 #define RT_K_TRACE_WIDE_ARGS (const RtSceneDesc scene, const WideBvh bvh, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, \
                               const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount, uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
 #define RT_K_TRACE_WIDE2_ARGS (const RtSceneDesc scene, const WideScene wide, const Paths paths, const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount, \
                                const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount, uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
-#define RT_K_TRACE_INSTANCES(X) X(24, false, false) X(24, true, false) X(32, false, false) X(32, true, false) X(64, false, false) X(64, true, false) X(24, false, true)
-#define RT_K_TRACE_QUANT_INSTANCES(X) X(24) X(32) X(64)
+#define RT_K_TRACE_INSTANCES(X) X(24, false) X(24, true) X(32, false) X(32, true) X(64, false) X(64, true)
 #define RT_K_TRACE_WIDE_INSTANCES(X) X(24, false, false) X(24, false, true) X(24, true, false)
 #define RT_K_TRACE_WIDE2_INSTANCES(X) X(24)
 
 #ifndef RT_DEVICE_KERNELS
-template <int kStack, bool kCount, bool kLdsTop = false> __global__ void RT_TRACE_ATTR(kStack) k_trace RT_K_TRACE_ARGS;
-template <int kStack> __global__ void RT_TRACE_ATTR(kStack) k_trace_quant RT_K_TRACE_QUANT_ARGS;
+template <int kStack, bool kCount> __global__ void RT_TRACE_ATTR(kStack) k_trace RT_K_TRACE_ARGS;
 template <int kStack, bool kDiag = false, bool kLocalExact = false> __global__ void RT_TRACE_ATTR(kStack) k_trace_wide RT_K_TRACE_WIDE_ARGS;
 template <int kStack> __global__ void RT_TRACE_ATTR(kStack) k_trace_wide2 RT_K_TRACE_WIDE2_ARGS;
 __global__ void __launch_bounds__(RT_BLOCK) k_trace_packet(const RtSceneDesc scene, const WideBvh bvh, const Paths paths, uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune);

@@ -1,31 +1,24 @@
-// rt_trace_quant.inl -- an EXPERIMENT (RTGPU_QUANT=1; measured no faster than k_trace: 182 vs 183 ms) and the home of what the default
-// walk of single-mesh scenes, k_trace_wide (rt_trace_wide.inl), shares with it: the 16-bit grid, the per-leaf exact boxes and the
-// exactness argument below.  The kernel here walks the binary tree of the reference with its child pairs re-encoded in 32 bytes.
-// Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS).
+// rt_trace_quant.inl -- what the 4-wide walks (rt_trace_wide.inl, rt_trace_wide2.inl, rt_trace_packet.inl) share: the 16-bit grid of conservative boxes, the
+// per-leaf exact boxes ("gates") and the exactness argument below.  Included by rt_trace.hip / rt_tail.hip (RT_DEVICE_KERNELS) and rt_runtime.hip (tree
+// builders: RT_HOST_BUILDERS).
+// (Round 2 also had a kernel here, k_trace_quant: the reference's BINARY tree with its child pairs re-encoded in 32 bytes -- two accesses per visit instead
+// of four, no decode step.  Bit-exact, and no faster than k_trace: 182 vs 183 ms, the twelve conversions per visit ate what the L1 gave back.  Removed in
+// round 5 with the other measured-slower opt-in paths; the patch that restores it is profiles/r05_removed_optin_paths.patch.)
 //
-// Why.  k_trace (rt_device_traverse.h) is bound by the vector L1: a lane fetches its 64-byte node pair with four 16-byte loads, and a
-// divergent 16-byte access occupies the texture-cache pipeline for a cycle whatever it uses of the line -- 0.71 accesses per clock and
-// CU measured against a ceiling of one (profiles/r02_diag0_pmc_3.txt), vector ALU issue at 54 %, the memory behind it mostly idle;
-// fetching the same pair twice makes the kernel 49 % slower.  A first attempt to cut accesses by giving each ray a quad of lanes over a
-// 4-wide tree (one fully coalesced access per node) was bit-exact and 1.7x SLOWER: a quarter of the rays per wave at the same
-// instruction count per step, 96 % vector-ALU issue (profiles/r02_quadwide_pmc_*.txt).  This kernel keeps one ray per lane and
-// halves the bytes instead:
-//   * a child pair is two 16-byte records {min.xyz, max.xyz as 16-bit grid coordinates, child reference}: two accesses per visit
-//     instead of four; the grid spans the mesh's bounds, planes are rounded OUTWARDS with a step to spare, so a stored box always
-//     contains the reference's box;
-//   * the slab test needs no decode step: t = fma(float(q), step * invDir, base * invDir - origin * invDir), two constants per axis
-//     and ray, so a visit costs the twelve integer-to-float conversions on top of the old twelve fmas;
-//   * boxes that are only conservative cannot decide what the reference tests, so a leaf's triangles count only if the ray also passes
-//     the leaf's EXACT box (the test the reference's walk performs before it reaches them) -- fetched only when a triangle was
-//     actually hit.
+// The re-encoding:
+//   * a child record is 16 bytes {min.xyz, max.xyz as 16-bit grid coordinates, child reference}; the grid spans the mesh's bounds, planes are
+//     rounded OUTWARDS with a step to spare, so a stored box always contains the reference's box;
+//   * the slab test needs no decode step: t = fma(float(q), step * invDir, base * invDir - origin * invDir), two constants per axis and ray;
+//   * boxes that are only conservative cannot decide what the reference tests, so a leaf's triangles count only if the ray also passes the
+//     leaf's EXACT box (the test the reference's walk performs before it reaches them) -- fetched only when a triangle was actually hit.
 //
 // Exactness.  Same argument as for any walk that visits a superset of the reference's leaves in another order: every candidate hit
 // (a triangle the ray intersects inside a leaf whose exact box it passes) has the same (t, u, v) as in the reference's walk, because
 // the triangle test and the exact box test are the reference's arithmetic; the slab test is monotone in the box planes, so passing a
 // leaf's exact box implies passing every ancestor's box with a smaller entry distance, i.e. the reference's walk reaches exactly these
 // candidates unless its running hit distance culls one -- which can only change the result when two candidates are closer together than
-// the disagreement between a box's entry distance and its triangle's hit distance.  The kernel culls with a slack (near < best + 2 tol),
-// tracks the SECOND smallest candidate distance, and a ray whose runner-up lies within tol of its best (tol = 16 ulps of the largest
+// the disagreement between a box's entry distance and its triangle's hit distance.  The walks cull with a slack (near < best + 2 tol),
+// track the SECOND smallest candidate distance, and a ray whose runner-up lies within tol of its best (tol = 16 ulps of the largest
 // term of its slab tests) is not trusted: it goes to the exact queue and is traced again by k_trace in the reference's order.  So do
 // rays with a zero direction component (their slab tests produce NaNs, which the reference's min/max operand order resolves in its
 // own way) and rays that start so far outside the mesh that the folded slab test's rounding could eat the spare grid step.  Any-hit rays
@@ -35,228 +28,6 @@
 
 #define RT_QUANT_DONE 0xFFFFFFFFu   // cur: the ray is finished (same value as RT_LEVEL_EXHAUSTED: the mesh level has no node left)
 #define RT_QUANT_GRID 65535.0f
-
-struct QuantBvh
-{
-    const float4* pairs;     // record c of pair (childIndex, childIndex + 1) at pairs[childIndex + c]: {minx | miny << 16, minz | maxx << 16, maxy | maxz << 16, ref}
-    const float4* gate;      // exact box of the leaf whose first triangle is t: gate[2 t] = {min.xyz, -}, gate[2 t + 1] = {max.xyz, -}
-    uint32_t root;           // packed reference of the root node
-    uint32_t stackNeed;
-    float base[3], step[3];  // plane(q) = base + q * step
-    float bound[3];          // largest |coordinate| of the mesh per axis (for the per-ray tolerance)
-};
-
-struct QuantTuning
-{
-    uint32_t refillMinIdle, otherMinLanes;
-    float shadowOffset;
-    uint32_t* exactQueue; uint32_t* exactCount;               // closest-hit rays handed to the binary-tree kernel
-    uint32_t* exactShadowQueue; uint32_t* exactShadowCount;   // any-hit requests handed to it
-};
-
-#ifdef RT_DEVICE_KERNELS
-template <int kStack>
-__global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(kStack <= 24 ? 5 : 1))) k_trace_quant(const RtSceneDesc scene, const QuantBvh bvh, const Paths paths,
-                                                          const uint32_t* __restrict__ queue, const uint32_t* __restrict__ queueCount,
-                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
-                                                          uint32_t* __restrict__ cursor, unsigned long long* counters, const QuantTuning tune)
-{
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
-    uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
-    const uint32_t numClosest = queueCount ? *queueCount : 0u;
-    const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
-    const M4 invTransform = loadM4(scene.objects[0].invTransform);
-    const RtTriangle* const tris = scene.triangles + scene.meshes[scene.objects[0].meshIndex].firstTriangle;
-    const float inf = __uint_as_float(0x7f800000u);
-
-    // per-lane ray state
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;     // local ray (triangle tests, leaf gate)
-    float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;     // folded slab constants: t(q) = fma(q, a, b)
-    float best = 0, second = 0, tol = 0;
-    uint32_t cur = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;
-    bool have = false, shadow = false, occluded = false, exhausted = false;
-    uint32_t numRetraced = 0, numShadowRays = 0;
-
-    uint32_t chunkSize = count / (gridDim.x * (RT_BLOCK / 64u) * 4u);
-    chunkSize = chunkSize < 64u ? 64u : (chunkSize > 1024u ? 1024u : chunkSize);
-    WaveChunk chunk = { 0u, 0u };
-
-    for (;;)
-    {
-        const bool interior = have && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
-        const bool other = have && !interior;      // at a leaf, or finished
-        const unsigned long long mI = __ballot(interior), mO = __ballot(other);
-        const uint32_t nIdle = 64u - (uint32_t)__popcll(mI) - (uint32_t)__popcll(mO);
-        if (!exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle))
-        {
-            // ---- refill ----
-            if (chunk.next >= chunk.end)
-            {
-                waveClaimChunk(chunk, cursor, chunkSize, count);
-                if (chunk.next >= chunk.end) { exhausted = true; continue; }
-            }
-            const uint32_t idx = waveTake(!have, chunk);
-            if (idx != 0xFFFFFFFFu)
-            {
-                shadow = idx >= numClosest;
-                const uint32_t request = shadow ? shadowQueue[idx - numClosest] : (queue ? queue[idx] : idx);
-                Ray world;
-                float maxDistance = inf;
-                if (shadow)
-                {
-                    light = request / paths.capacity; slot = request - light * paths.capacity;
-                    const float4 origin = prec(paths, R_SH_P, slot), dirTmax = pshadow(paths, light, 0, slot);
-                    world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dirTmax.x, dirTmax.y, dirTmax.z, 0.0f));
-                    world.origin = world.origin + world.dir * tune.shadowOffset;   // PathTracerMIS.cpp:86
-                    maxDistance = dirTmax.w;                                       // hitPoint.distance = illuminateResult.distance * 0.999f
-                }
-                else
-                {
-                    slot = request; light = 0u;
-                    const float4 origin = prec(paths, R_ORIGIN, slot), dir = prec(paths, R_DIR, slot);
-                    world = makePathRay(origin, dir, ubits(origin.w) & 0xFFu);
-                }
-                const Ray local = transformRayUnsafe(invTransform, world);   // MeshShape is entered in object space, Scene.cpp:128-145
-                // largest magnitude a slab test of this ray can produce, per axis; 2^-21 of it bounds the folded test's rounding
-                const float mx = fabsf(local.originDivDir.x) + bvh.bound[0] * fabsf(local.invDir.x);
-                const float my = fabsf(local.originDivDir.y) + bvh.bound[1] * fabsf(local.invDir.y);
-                const float mz = fabsf(local.originDivDir.z) + bvh.bound[2] * fabsf(local.invDir.z);
-                const float fold = 4.76837158203125e-07f;   // 2^-21
-                const bool trusted = rayIsNaNFree(local) &&
-                                     mx * fold < bvh.step[0] * fabsf(local.invDir.x) && my * fold < bvh.step[1] * fabsf(local.invDir.y) && mz * fold < bvh.step[2] * fabsf(local.invDir.z);
-                if (!trusted)
-                {
-                    // a zero direction component (NaNs in the reference's slab test) or an origin far outside the mesh: the reference's walk only
-                    if (shadow) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
-                    else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;
-                    numRetraced++;
-                }
-                else
-                {
-                    ox = local.origin.x; oy = local.origin.y; oz = local.origin.z; dx = local.dir.x; dy = local.dir.y; dz = local.dir.z;
-                    ax = bvh.step[0] * local.invDir.x; ay = bvh.step[1] * local.invDir.y; az = bvh.step[2] * local.invDir.z;
-                    bx = __fmaf_rn(bvh.base[0], local.invDir.x, -local.originDivDir.x);
-                    by = __fmaf_rn(bvh.base[1], local.invDir.y, -local.originDivDir.y);
-                    bz = __fmaf_rn(bvh.base[2], local.invDir.z, -local.originDivDir.z);
-                    tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
-                    best = maxDistance; second = inf; occluded = false;
-                    sp = 0u; cur = bvh.root;
-                    have = true;
-                    if (shadow) numShadowRays++;   // (a request handed to the binary-tree kernel is counted there)
-                }
-            }
-            continue;
-        }
-        if ((mI | mO) == 0ull) break;
-        if (mI != 0ull && (uint32_t)__popcll(mO) < tune.otherMinLanes)
-        {
-            // ---- interior phase: two conservative slab tests per step, until enough lanes wait at a leaf or are finished ----
-            bool in = interior;
-            const float limit = best + (tol + tol);   // box occlusion with the slack that keeps every candidate within tol of the final hit in the walk
-            for (;;)
-            {
-                if (in)
-                {
-                    const float4* p = bvh.pairs + (cur & RT_NODE_CHILD_MASK);
-                    const float4 qa = p[0], qb = p[1];
-                    const uint32_t a0 = ubits(qa.x), a1 = ubits(qa.y), a2 = ubits(qa.z), b0 = ubits(qb.x), b1 = ubits(qb.y), b2 = ubits(qb.z);
-                    const float aNx = __fmaf_rn((float)(a0 & 0xFFFFu), ax, bx), aNy = __fmaf_rn((float)(a0 >> 16), ay, by), aNz = __fmaf_rn((float)(a1 & 0xFFFFu), az, bz);
-                    const float aXx = __fmaf_rn((float)(a1 >> 16), ax, bx), aXy = __fmaf_rn((float)(a2 & 0xFFFFu), ay, by), aXz = __fmaf_rn((float)(a2 >> 16), az, bz);
-                    const float bNx = __fmaf_rn((float)(b0 & 0xFFFFu), ax, bx), bNy = __fmaf_rn((float)(b0 >> 16), ay, by), bNz = __fmaf_rn((float)(b1 & 0xFFFFu), az, bz);
-                    const float bXx = __fmaf_rn((float)(b1 >> 16), ax, bx), bXy = __fmaf_rn((float)(b2 & 0xFFFFu), ay, by), bXz = __fmaf_rn((float)(b2 >> 16), az, bz);
-                    const float nearA = fmaxf(fmaxf(fminf(aNx, aXx), fminf(aNy, aXy)), fminf(aNz, aXz));
-                    const float farA = fminf(fminf(fmaxf(aNx, aXx), fmaxf(aNy, aXy)), fmaxf(aNz, aXz));
-                    const float nearB = fmaxf(fmaxf(fminf(bNx, bXx), fminf(bNy, bXy)), fminf(bNz, bXz));
-                    const float farB = fminf(fminf(fmaxf(bNx, bXx), fmaxf(bNy, bXy)), fmaxf(bNz, bXz));
-                    const bool hitA = (farA >= nearA) && (farA >= 0.0f) && (nearA < limit);
-                    const bool hitB = (farB >= nearB) && (farB >= 0.0f) && (nearB < limit);
-                    const uint32_t a = ubits(qa.w), b = ubits(qb.w);
-                    const bool both = hitA && hitB;
-                    const bool swap = both && (nearB < nearA);   // nearer child first (any order gives the same candidates)
-                    if (both) { stack[sp * RT_BLOCK] = swap ? a : b; ++sp; }
-                    if (hitA || hitB) cur = (hitA && !swap) ? a : b;
-                    else if (sp == 0u) cur = RT_QUANT_DONE;
-                    else { --sp; cur = stack[sp * RT_BLOCK]; }
-                }
-                in = in && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
-                const unsigned long long m = __ballot(in);
-                if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
-            }
-        }
-        else if (other)
-        {
-            if (cur != RT_QUANT_DONE)
-            {
-                // ---- leaf: MeshShape::Traverse_Leaf(_Shadow), MeshShape.cpp:134-207 ----
-                const uint32_t numLeaves = cur >> RT_NODE_LEAVES_SHIFT, first = cur & RT_NODE_CHILD_MASK;
-                Ray ray; ray.origin = V4(ox, oy, oz, 0.0f); ray.dir = V4(dx, dy, dz, 0.0f);
-                V4 v0, e1, e2, nv0, ne1, ne2;
-                loadTriangle(tris + first, v0, e1, e2);
-                loadTriangle(tris + first + (numLeaves > 1u ? 1u : 0u), nv0, ne1, ne2);   // the second triangle of the leaf rides in the same round trip
-                float u0, v0_, t0, u1 = 0.0f, v1 = 0.0f, t1 = inf;
-                if (!intersectTriangleRay(ray, v0, e1, e2, u0, v0_, t0)) t0 = inf;
-                if (numLeaves > 1u && !intersectTriangleRay(ray, nv0, ne1, ne2, u1, v1, t1)) t1 = inf;
-                const float lo = fminf(t0, t1);
-                if (lo < best + tol)
-                {
-                    // a hit that matters: it counts only if the ray passes the leaf's exact box, as in the reference's walk
-                    const float4 gmin = bvh.gate[2u * first], gmax = bvh.gate[2u * first + 1u];
-                    const Ray gateRay = makeRayUnsafe(ray.origin, ray.dir);   // = the ray transformRayUnsafe built
-                    float nearD;
-                    const bool pass = intersectBoxRayNoNaN(gateRay, gmin.x, gmin.y, gmin.z, gmax.x, gmax.y, gmax.z, nearD) && (!shadow || nearD < best);
-                    if (pass)
-                    {
-                        if (shadow) { if (lo < best) { occluded = true; cur = RT_QUANT_DONE; } }
-                        else
-                        {
-                            const float hi = fmaxf(t0, t1);
-                            if (lo < best)
-                            {
-                                second = fminf(best, hi);
-                                best = lo;
-                                const bool firstWins = t0 <= t1;   // HitPoint written through (an exact tie is retraced anyway)
-                                prec(paths, R_HIT, slot) = f4(fbits(0u), fbits(first + (firstWins ? 0u : 1u)), lo, firstWins ? u0 : u1);
-                                prec(paths, R_SAMPLER, slot).x = firstWins ? v0_ : v1;
-                            }
-                            else second = fminf(second, lo);
-                        }
-                    }
-                }
-                if (cur != RT_QUANT_DONE)
-                {
-                    if (sp == 0u) cur = RT_QUANT_DONE;
-                    else { --sp; cur = stack[sp * RT_BLOCK]; }
-                }
-            }
-            if (cur == RT_QUANT_DONE)
-            {
-                // ---- finished ----
-                if (shadow)
-                {
-                    if (occluded) pshadow(paths, light, 0, slot).w = -1.0f;   // unoccluded requests are tallied when they are resolved
-                }
-                else if (best == inf) prec(paths, R_HIT, slot) = f4(fbits(RT_INVALID_OBJECT), fbits(0u), inf, 0.0f);   // HitPoint.h:14-51
-                else if (second <= best + tol)
-                {
-                    tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = slot;   // a runner-up too close to call: the reference's own walk decides
-                    numRetraced++;
-                }
-                have = false;
-            }
-        }
-    }
-    // counters: shadow rays traced here, rays handed to the binary-tree kernel
-    __shared__ uint32_t sTally[2];
-    if (threadIdx.x < 2u) sTally[threadIdx.x] = 0u;
-    __syncthreads();
-    if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
-    if (numRetraced) atomicAdd(&sTally[1], numRetraced);
-    __syncthreads();
-    if (threadIdx.x == 0u && sTally[0]) atomicAdd(&counters[C_SHADOW], (unsigned long long)sTally[0]);
-    if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
-}
-
-#endif   // RT_DEVICE_KERNELS
 
 #ifdef RT_HOST_BUILDERS
 // ---- host: the reference's binary BVH (BVH::Node, 32 bytes, children adjacent) re-encoded ----

@@ -86,6 +86,8 @@ RT_DEV void widePushExact(const WideTuning& tune, const WideLocal& local, bool s
     if (shadowRequest) tune.exactShadowQueue[atomicAdd(tune.exactShadowCount, 1u)] = request;
     else tune.exactQueue[atomicAdd(tune.exactCount, 1u)] = request;
 }
+#define RT_WIDE_STACK 16           // stack entries per lane of the 4-wide walk
+#define RT_WIDE_PARK 6u            // words per lane behind the stack (traceWideLoop's `park`)
 #define RT_WIDE_LOCAL_EXACT 256u   // per block and kind: ~40 x what a block of the benchmark hands over per launch
 
 // The walk as a device function (k_trace_wide below; k_tail, rt_tail.hip, runs it over a block's own queues in LDS: `queue`, `shadowQueue`,
@@ -96,6 +98,10 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                           const WideLocal& handOver, uint32_t* sStack, uint32_t* sDensePrefix, uint32_t sharingWaves)
 {
     uint32_t* const stack = sStack + threadIdx.x;   // entry e at stack[e * RT_BLOCK]: bank = lane, conflict free at any depth
+    // Behind the stack's kStack entries: RT_WIDE_PARK words per lane that only the leaf phase reads -- the local ray's invDir and originDivDir, which the
+    // exact box test of a leaf needs (round 5: rebuilding them there cost three IEEE divisions, ~100 of the leaf phase's 320 instructions, every time
+    // some lane of the wave had a triangle hit to confirm)
+    float* const park = reinterpret_cast<float*>(sStack + kStack * RT_BLOCK) + threadIdx.x;
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
     const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
     const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
@@ -107,11 +113,12 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;     // local ray (triangle tests, leaf gate)
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;     // folded slab constants: t(q) = fma(q, a, b)
     float best = 0, second = 0, tol = 0;
-    uint32_t selX = RT_WIDE_SEL_X_POS, selY = RT_WIDE_SEL_Y_POS, selZ = RT_WIDE_SEL_Z_POS;   // which plane of an axis the ray meets first
     uint32_t cur = RT_QUANT_DONE, sp = 0, slot = 0, light = 0;
     bool have = false, shadow = false, occluded = false, exhausted = false, overflow = false;
+    // tallies per WAVE (ballots at wave-uniform points of the loop: scalar registers; as per-lane counters they were four of the 96 vector registers)
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
+    uint32_t diagGates = 0, diagHitWrites = 0;                // kDiag, RTGPU_WIDE_DIAG=3: exact-box fetches and hit records written through (the walk's byte model, bench.py)
     uint32_t diagMaxSp = 0, diagDeep[3] = { 0u, 0u, 0u };     // kDiag, RTGPU_WIDE_DIAG=2: rays whose stack held more than 9 / 13 / 17 entries (what a 12 / 16 / 20-entry stack would hand over)
 
     uint32_t chunkSize = count / (sharingWaves * 4u);
@@ -141,6 +148,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 if (chunk.next >= chunk.end) { exhausted = true; if (kDiag) diagExhausted = (unsigned long long)clock64(); continue; }
             }
             const uint32_t idx = waveTake(!have, chunk);
+            bool tookUntrusted = false, tookShadow = false;
             if (idx != 0xFFFFFFFFu)
             {
                 shadow = idx >= numClosest;
@@ -178,7 +186,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 {
                     // a zero direction component (NaNs in the reference's slab test) or an origin far outside the mesh: the reference's walk only
                     widePushExact(tune, handOver, shadow, shadow ? request : slot);
-                    numRetraced++; numUntrusted++;
+                    tookUntrusted = true;
                 }
                 else
                 {
@@ -187,15 +195,17 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                     bx = __fmaf_rn(bvh.base[0], local.invDir.x, -local.originDivDir.x);
                     by = __fmaf_rn(bvh.base[1], local.invDir.y, -local.originDivDir.y);
                     bz = __fmaf_rn(bvh.base[2], local.invDir.z, -local.originDivDir.z);
-                    selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
+                    park[0] = local.invDir.x; park[RT_BLOCK] = local.invDir.y; park[2 * RT_BLOCK] = local.invDir.z;
+                    park[3 * RT_BLOCK] = local.originDivDir.x; park[4 * RT_BLOCK] = local.originDivDir.y; park[5 * RT_BLOCK] = local.originDivDir.z;
                     tol = shadow ? 0.0f : fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f;   // 2^-19: 16 ulps
                     best = maxDistance; second = inf; occluded = false; overflow = false;
                     sp = 0u; cur = 0u;   // node 0 holds the children of the binary tree's root
                     if (kDiag) diagMaxSp = 0u;
                     have = true;
-                    if (shadow) numShadowRays++;   // (a request handed to the binary-tree kernel is counted there)
+                    tookShadow = shadow;   // (a request handed to the binary-tree kernel is counted there)
                 }
             }
+            { const uint32_t n = (uint32_t)__popcll(__ballot(tookUntrusted)); numRetraced += n; numUntrusted += n; numShadowRays += (uint32_t)__popcll(__ballot(tookShadow)); }
             continue;
         }
         if ((mI | mO) == 0ull) break;
@@ -205,6 +215,8 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
             if (kDiag) { diagPhase = 1u; diagRuns[1]++; }
             bool in = interior;
             const float limit = best + (tol + tol);   // box occlusion with the slack that keeps every candidate within tol of the final hit in the walk
+            // which plane of an axis the ray meets first: byte selectors of the slab test, rebuilt per phase (three registers less across the leaf and refill phases)
+            const uint32_t selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS, selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS, selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
             for (;;)
             {
                 if (kDiag) { diagSlots++; if (in) diagVisits++; }
@@ -239,8 +251,11 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
             }
         }
-        else if (kDiag && (diagPhase = 2u, diagRuns[2]++, false)) {}
-        else if (other)
+        else
+        {
+        if (kDiag) { diagPhase = 2u; diagRuns[2]++; }
+        bool handedOver = false, overflowed = false, uncountShadow = false;
+        if (other)
         {
             // ---- leaves (the current one and the one set aside): MeshShape::Traverse_Leaf(_Shadow), MeshShape.cpp:134-207 ----
             for (int once = 0; once < 1; ++once)
@@ -261,7 +276,11 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 {
                     // a hit that matters: it counts only if the ray passes the leaf's exact box, as in the reference's walk
                     const float4 gmin = bvh.gate[2u * first], gmax = bvh.gate[2u * first + 1u];
-                    const Ray gateRay = makeRayUnsafe3(ray.origin, ray.dir);   // = the ray transformRayUnsafe built
+                    if (kDiag) diagGates++;
+                    Ray gateRay;   // = the ray transformRayUnsafe built at refill (makeRayUnsafe3 of the same origin and direction: its quotients were parked then)
+                    gateRay.origin = ray.origin; gateRay.dir = ray.dir;
+                    gateRay.invDir = V4(park[0], park[RT_BLOCK], park[2 * RT_BLOCK], 0.0f);
+                    gateRay.originDivDir = V4(park[3 * RT_BLOCK], park[4 * RT_BLOCK], park[5 * RT_BLOCK], 0.0f);
                     float nearD;
                     const bool pass = intersectBoxRayNoNaN(gateRay, gmin.x, gmin.y, gmin.z, gmax.x, gmax.y, gmax.z, nearD) && (!shadow || nearD < best);
                     if (pass)
@@ -277,6 +296,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                                 const bool firstWins = t0 <= t1;   // HitPoint written through (an exact tie is retraced anyway)
                                 prec(paths, R_HIT, slot) = f4(fbits(0u), fbits(first + (firstWins ? 0u : 1u)), lo, firstWins ? u0 : u1);
                                 prec(paths, R_SAMPLER, slot).x = firstWins ? v0_ : v1;
+                                if (kDiag) diagHitWrites++;
                             }
                             else second = fminf(second, lo);
                         }
@@ -296,8 +316,8 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 if (overflow)
                 {
                     widePushExact(tune, handOver, shadow, shadow ? light * paths.capacity + slot : slot);
-                    numRetraced++; numOverflow++;
-                    if (shadow) numShadowRays--;   // counted by the kernel that resolves it
+                    handedOver = true; overflowed = true;
+                    uncountShadow = shadow;   // counted by the kernel that resolves it
                 }
                 else if (shadow)
                 {
@@ -307,20 +327,25 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 else if (second <= best + tol)
                 {
                     widePushExact(tune, handOver, false, slot);   // a runner-up too close to call: the reference's own walk decides
-                    numRetraced++;
+                    handedOver = true;
                 }
                 have = false;
             }
+        }
+        numRetraced += (uint32_t)__popcll(__ballot(handedOver)); numOverflow += (uint32_t)__popcll(__ballot(overflowed)); numShadowRays -= (uint32_t)__popcll(__ballot(uncountShadow));
         }
     }
     // counters: shadow rays traced here, rays handed to the binary-tree kernel
     __shared__ uint32_t sTally[4];
     if (threadIdx.x < 4u) sTally[threadIdx.x] = 0u;
     __syncthreads();
-    if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
-    if (numRetraced) atomicAdd(&sTally[1], numRetraced);
-    if (numUntrusted) atomicAdd(&sTally[2], numUntrusted);
-    if (numOverflow) atomicAdd(&sTally[3], numOverflow);
+    if ((threadIdx.x & 63u) == 0u)
+    {
+        if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
+        if (numRetraced) atomicAdd(&sTally[1], numRetraced);
+        if (numUntrusted) atomicAdd(&sTally[2], numUntrusted);
+        if (numOverflow) atomicAdd(&sTally[3], numOverflow);
+    }
     __syncthreads();
     if (threadIdx.x == 0u && sTally[0]) atomicAdd(&counters[C_SHADOW], (unsigned long long)sTally[0]);
     if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
@@ -332,9 +357,9 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     else
     {
         // RTGPU_WIDE_DIAG=1: the three spare counters hold the walk's statistics instead
-        const bool deep = tune.localExact == 2u;   // (the diagnostic kernel has no block-local lists: the field carries RTGPU_WIDE_DIAG's mode)
+        const bool deep = tune.localExact == 2u, bytes = tune.localExact == 3u;   // (the diagnostic kernel has no block-local lists: the field carries RTGPU_WIDE_DIAG's mode)
         atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)(deep ? diagDeep[0] : diagVisits));
-        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)(deep ? diagDeep[1] : diagSlots));
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], bytes ? (unsigned long long)diagGates | ((unsigned long long)diagHitWrites << 32) : (unsigned long long)(deep ? diagDeep[1] : diagSlots));   // 3: exact-box fetches | hit records << 32 (each below 2^32 over a run of a few dozen passes)
         atomicAdd(&counters[RT_COUNTER_RETRACED + 3], (unsigned long long)(deep ? diagDeep[2] : diagLeaves));
         if ((threadIdx.x & 63u) == 0u)
         {
@@ -359,12 +384,16 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                                                          const uint32_t* __restrict__ shadowQueue, const uint32_t* __restrict__ shadowCount,
                                                          uint32_t* __restrict__ cursor, unsigned long long* counters, const WideTuning tune)
 {
-    __shared__ uint32_t sStack[kStack * RT_BLOCK];
+    // the 4-wide walk's own stack: RT_WIDE_STACK entries per lane (measured on the benchmark frame, RTGPU_WIDE_DIAG=2: 18 of 48.8 M rays ever hold
+    // more than 13 deferred children, none more than 17 -- profiles/r05_wide_diag_phases.txt; a ray that would need more goes to the re-trace launch)
+    // + the parked words; the block-local second walk runs the reference's binary walk on kStack entries of the same memory
+    constexpr int kWords = kLocalExact && kStack > RT_WIDE_STACK + (int)RT_WIDE_PARK ? kStack : RT_WIDE_STACK + (int)RT_WIDE_PARK;
+    __shared__ uint32_t sStack[kWords * RT_BLOCK];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
     if constexpr (!kLocalExact)
     {
         const WideLocal none = { nullptr, nullptr, nullptr, nullptr, 0u };
-        traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, none, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
+        traceWideLoop<RT_WIDE_STACK, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, none, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
     }
     else
     {
@@ -372,7 +401,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         if (threadIdx.x < 4u) sLocalCounts[threadIdx.x] = 0u;
         __syncthreads();
         const WideLocal local = { sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], RT_WIDE_LOCAL_EXACT };
-        traceWideLoop<kStack, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, local, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
+        traceWideLoop<RT_WIDE_STACK, kDiag>(scene, bvh, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, local, sStack, sDensePrefix, gridDim.x * ((uint32_t)RT_BLOCK / 64u));
         // the rays this block's walk did not decide, by the reference's own walk (block-uniform branch: the counts are final behind the walk's barrier)
         __syncthreads();
         if (threadIdx.x < 2u && sLocalCounts[threadIdx.x] > RT_WIDE_LOCAL_EXACT) sLocalCounts[threadIdx.x] = RT_WIDE_LOCAL_EXACT;
@@ -382,7 +411,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             // a degenerate closest-hit ray (an axis-parallel direction: it walks most of the tree) does not keep the block: past RT_ABORT_RETRACE_AFTER rounds
             // it goes to the launch's exact queue, i.e. to the re-trace launch behind this one, which hands it on to k_trace_monster
             const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, tune.exactQueue, tune.exactCount, RT_ABORT_RETRACE_AFTER, nullptr, 0u };
-            traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
+            traceBinaryLoop<kStack, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, sDensePrefix,
                                                   (uint32_t)RT_BLOCK / 64u);
         }
     }

@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     if (sLocalCounts[0] + sLocalCounts[1] != 0u)
     {
         const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };
-        traceBinaryLoop<kStack, false, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, nullptr, sDensePrefix,
+        traceBinaryLoop<kStack, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, sDensePrefix,
                                               (uint32_t)RT_BLOCK / 64u);
     }
 }

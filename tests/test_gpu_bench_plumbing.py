@@ -58,3 +58,27 @@ def test_bench_two_ranks_on_one_device(built, tmp_path):
     assert d2["n_gpus"] == 2 and d2["image"]["finite"] and d2["value"] > 0
     assert d2["counters"]["numRays"] == d1["counters"]["numRays"] and d2["counters"]["numShadowRays"] == d1["counters"]["numShadowRays"]
     assert d2["image"]["mean_per_pass"] == d1["image"]["mean_per_pass"]
+    # a line says which switches changed its work: the two-rank run names its backend and BENCH_DIST_BACKEND, the one-rank run nothing of the kind
+    assert d2["config"]["env"].get("BENCH_DIST_BACKEND") == "gloo" and d2["config"]["dist_backend"] == "gloo" and d2["config"]["emulated_shard"] is None
+    assert "BENCH_DIST_BACKEND" not in d1["config"]["env"] and d1["config"]["emulated_shard"] is None and "EMULATED" not in d1["metric"]
+
+
+def test_bench_line_names_every_switch_that_changed_its_work(built):
+    """Round-4 review item 7: an emulated-shard line (BENCH_EMULATE_SHARD=N renders 1/N of the frame) must not be readable as a whole-frame line, and any
+    RTGPU_* / BENCH_* variable in the environment goes into config.env -- also on the reduced BENCH_TIMED_ONLY line."""
+    import json
+    import subprocess
+    common = ["--steps", "4", "--warmup", "2", "--width", "640", "--height", "360", "--triangles", "20000", "--no-pmc", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("BENCH_", "RTGPU_"))}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=dict(env, BENCH_EMULATE_SHARD="4", RTGPU_PACKET="0"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["emulated_shard"] == [0, 4] and "EMULATED SHARD: 1/4 of the frame" in d["metric"] and d["config"]["parallelism"].startswith("emulated shard 0 of 4")
+    assert d["config"]["env"] == {"BENCH_EMULATE_SHARD": "4", "RTGPU_PACKET": "0"} and d["n_gpus"] == 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=dict(env, BENCH_TIMED_ONLY="1", BENCH_EMULATE_SHARD="2"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["timed_only"] and d["config"]["emulated_shard"] == [0, 2] and d["config"]["env"] == {"BENCH_EMULATE_SHARD": "2", "BENCH_TIMED_ONLY": "1"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["env"] == {} and d["config"]["emulated_shard"] is None and "EMULATED" not in d["metric"]

@@ -54,6 +54,12 @@ def test_shards_of_one_context_reproduce_the_single_device_frame(built, shards):
     assert one["devices"] == 1 and many["devices"] == shards
     assert one["sum"].any()
     assert_same(one, many)
+    # rtgpu_get_multi_info: which gather the context chose and why (shards of one device address each other: the in-place kernel), its timings
+    info = ra.multi_info(many["vp"].device_context())
+    assert info["numDevices"] == shards and info["devices"] == [0] * shards and all(info["peerAccess"])
+    assert info["gatherMode"] == "peer-kernel" and info["gatherReason"] == "" and info["gathers"] >= 1 and info["lastGatherMs"] > 0.0
+    single = ra.multi_info(one["vp"].device_context())
+    assert single["numDevices"] == 1 and single["gatherMode"] == "none" and single["gathers"] == 0
 
 
 def test_staged_gather_and_the_all_lights_strategy(built, monkeypatch):
@@ -63,6 +69,8 @@ def test_staged_gather_and_the_all_lights_strategy(built, monkeypatch):
     monkeypatch.setenv("RTGPU_MULTI_STAGED", "1")     # hipMemcpyPeerAsync into staging buffers, then the same gather kernel
     many = render(scene, camera, w, h, 5, devices=[0, 0, 0], all_lights=True)
     assert_same(one, many)
+    info = ra.multi_info(many["vp"].device_context())
+    assert info["gatherMode"] == "staged-copy" and info["gatherReason"] == "RTGPU_MULTI_STAGED=1" and info["gathers"] >= 1
 
 
 def test_mesh_scene_and_the_other_per_pixel_integrators(built):

@@ -206,17 +206,6 @@ def test_single_object_scene_bypasses_top_bvh(built, walk):
     assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=8))
 
 
-def test_hit_kind_sort_is_invisible(built, monkeypatch):
-    """RTGPU_SHADE_SORT=1: the generic shading kernel deals the 256 vertices a block takes per round to its threads by KIND (zombie / miss /
-    light hit / one of the nine BSDF classes: a counting sort in LDS).  Which thread shades a vertex changes nothing: Cornell box (analytic
-    shapes, glass / metal / diffuse, area light) and the all-lights x all-BSDFs scene are bit-identical to the oracle with it on."""
-    monkeypatch.setenv("RTGPU_SHADE_SORT", "1")
-    w, h = 128, 96
-    for make, args in ((scenes.cornell_box, dict(max_ray_depth=6)), (scene_zoo.all_lights_scene, dict(max_ray_depth=6, dimensions=16))):
-        scene, camera = make(w / h)
-        assert_identical(*run_both(scene, camera, w, h, walk="default", passes=3, **args))
-
-
 def test_lean_and_generic_shade_variants_agree(built, monkeypatch):
     """Scenes with only meshes / diffuse materials / background + directional lights run a feature-specialised shade
     kernel; it must produce exactly what the generic kernel produces (RTGPU_NO_LEAN forces the generic one)."""
@@ -733,8 +722,8 @@ def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
 
 # ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_trace_quant.inl) -------
 def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_args):
-    """Like run_both, with the intersection counters OFF (the reference's default) and RTGPU_QUANT=1 set by the caller: single-mesh
-    scenes then run k_trace_quant, and what it does not trust is traced again by the binary-tree kernel."""
+    """Like run_both, with the intersection counters OFF (the reference's default): single-mesh scenes then run the 4-wide walk over the re-encoded
+    ("quantised") tree, and what it does not trust is traced again by the binary-tree kernel."""
     desc = scene.desc
     bn = ra.load_blue_noise()
     desc.contents.blueNoise = bn.ctypes.data
@@ -761,26 +750,6 @@ def assert_quant_identical(img, img2, counters, ref, ref2, ref_counters):
     for n in NOT_INTERSECTION:
         assert counters[n] == ref_counters[n], (n, counters[n], ref_counters[n])
     assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0   # the reference's counters belong to its own walk
-
-
-def test_quantized_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch):
-    """The walk over the conservatively re-encoded tree (exact leaf gate, runner-up tracking, exact re-trace) gives the reference's hits: images and ray / shadow-ray / hit counters
-    identical to the oracle's binary-tree walk on a small and a mid-size mesh, under both light sampling strategies, and only a
-    small fraction of the rays needs the exact re-trace."""
-    monkeypatch.setenv("RTGPU_QUANT", "1")
-    monkeypatch.setenv("RTGPU_WIDE", "0")
-    monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
-    w, h = 128, 72
-    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
-    out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
-    assert_quant_identical(*out)
-    traced = out[2]["numRays"] + out[2]["numShadowRays"]
-    assert 0 < out[2]["numRetracedRays"] < 0.02 * traced, (out[2]["numRetracedRays"], traced)
-    scene, camera = scenes.sponza_class(w / h, 60000)
-    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=8, light_sampling_all=True, dimensions=128)
-    assert_quant_identical(*out)
-    out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=3, min_russian_roulette_depth=8)
-    assert_quant_identical(*out)
 
 
 @pytest.mark.parametrize("dense", ["0", "1"])
@@ -1055,47 +1024,15 @@ def test_wide_and_exact_traversal_agree_at_full_size(built, monkeypatch):
     print("retraced %d of %d rays" % (ca["numRetracedRays"], traced))
 
 
-def test_quantized_and_exact_traversal_agree_at_full_size(built, monkeypatch):
-    """1920x1080, the benchmark's 262 176-triangle mesh, depth 8, counters off: the frame rendered with the re-encoded tree equals the
-    frame rendered with the binary-tree kernel alone bit for bit, ray counters included, and 1/48 of its tiles equal
-    the oracle; the exact re-trace serves well under 1 % of the rays."""
-    w, h, depth, passes = 1920, 1080, 8, 2
-    scene, camera = scenes.sponza_class(w / h)
-    monkeypatch.setenv("RTGPU_NO_DENSE", "1")   # the experiment lives in the slot-per-pixel pipeline
-    monkeypatch.setenv("RTGPU_WIDE", "0")
-    frames = []
-    for quant in ("1", "0"):
-        monkeypatch.setenv("RTGPU_QUANT", quant)
-        vp = ra.Viewport(w, h, seed=515, max_ray_depth=depth)
-        vp.set_renderer(scene)
-        assert ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0) == 0
-        vp.render(camera, passes)
-        frames.append((vp.sum_buffer(), vp.counters()))
-    monkeypatch.setenv("RTGPU_QUANT", "1")
-    (wide, cw), (binary, cb) = frames
-    assert np.isfinite(wide).all() and float(wide.max()) > 0.0
-    assert np.array_equal(wide.view(np.uint32), binary.view(np.uint32))
-    for n in NOT_INTERSECTION:
-        assert cw[n] == cb[n], (n, cw[n], cb[n])
-    assert cb["numRetracedRays"] == 0 and 0 < cw["numRetracedRays"] < 0.01 * (cw["numRays"] + cw["numShadowRays"]), cw["numRetracedRays"]
-    out = run_quant(scene, camera, w, h, passes=2, seed=515, threads=16, shard=(5, 48), max_ray_depth=depth)
-    assert_quant_identical(*out)
-
-
-def test_lds_staged_top_levels_bit_exact(built, monkeypatch):
-    """Intersection counters off (the reference's default, what bench.py times) on a single-mesh scene, whose tree the device holds in
-    breadth-first order: same images and ray counters as the oracle -- with the plain k_trace and with the variant that serves the top
-    levels from an LDS copy (RTGPU_LDS_TOP=1; slower than the L1 on this chip, kept as an option)."""
+def test_binary_walk_with_the_counters_off_bit_exact(built, monkeypatch):
+    """Intersection counters off (the reference's default) on a single-mesh scene, whose tree the device holds in breadth-first order, with the 4-wide
+    walk switched off (RTGPU_WIDE=0): the reference's own binary walk alone gives the oracle's image and ray counters, and hands nothing over."""
     w, h = 128, 72
     monkeypatch.setenv("RTGPU_WIDE", "0")      # the binary-tree walk, not the 4-wide one
     scene, camera = scenes.sponza_class(w / h, 60000)
     a = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
     assert_quant_identical(*a)
     assert a[2]["numRetracedRays"] == 0
-    monkeypatch.setenv("RTGPU_LDS_TOP", "1")
-    b = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
-    assert_quant_identical(*b)
-    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
 
 
 def test_dense_and_slot_per_pixel_path_state_agree(built, monkeypatch, walk):
