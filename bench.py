@@ -119,8 +119,32 @@ class TileGather:
         self.recv = [torch.zeros((self.pad, 3), dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
         self.peers = [torch.from_numpy(owned_pixel_indices(width, height, r, world)).to(device) for r in range(world)] if rank == 0 else None
 
-    def run(self):
-        self.send[:len(self.own)] = self.image.index_select(0, self.own)
+    mode = "gather"            # "gather": one dist.gather to rank 0; "send_recv": grouped point-to-point transfers (the fallback)
+    mode_reason = "default"
+
+    def choose_mode(self):
+        """Outside the timed region: tries the gather collective once on every rank; if ANY rank's attempt fails, all ranks fall back to grouped
+        isend / irecv (dist.batch_isend_irecv), and the reason is kept for the JSON line.  BENCH_GATHER=send_recv forces the fallback."""
+        forced = os.environ.get("BENCH_GATHER", "")
+        ok, why = 1.0, ""
+        if forced == "send_recv":
+            ok, why = 0.0, "BENCH_GATHER=send_recv"
+        else:
+            try:
+                self._gather()
+                if self.send.is_cuda:
+                    self.torch.cuda.synchronize()
+            except Exception as e:   # a collective that does not come up on this fabric must not take the measurement down
+                ok, why = 0.0, "dist.gather failed on rank %d: %r" % (self.rank, e)
+        flag = self.torch.tensor([ok], dtype=self.torch.float32, device=self.send.device if self.dist.get_backend() == "nccl" else "cpu")
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            TileGather.mode = self.mode = "send_recv"
+            self.mode_reason = why or "another rank's dist.gather failed"
+            sys.stderr.write("[bench] rank %d: tile exchange falls back to grouped send / recv (%s)\n" % (self.rank, self.mode_reason))
+        return self.mode
+
+    def _gather(self):
         if self.send.is_cuda and self.dist.get_backend() != "nccl":
             # BENCH_DIST_BACKEND=gloo (the N > 1 code path exercised on a 1-GPU box): gloo gathers host tensors
             recv = [t.cpu() for t in self.recv] if self.rank == 0 else None
@@ -130,6 +154,27 @@ class TileGather:
                     self.recv[r].copy_(recv[r])
         else:
             self.dist.gather(self.send, self.recv, dst=0)
+
+    def _send_recv(self):
+        host = self.send.is_cuda and self.dist.get_backend() != "nccl"
+        if self.rank == 0:
+            bufs = [(t.cpu() if host else t) for t in self.recv]
+            ops = [self.dist.P2POp(self.dist.irecv, bufs[r], r) for r in range(1, self.world)]
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+            if host:
+                for r in range(1, self.world):
+                    self.recv[r].copy_(bufs[r])
+        else:
+            for w in self.dist.batch_isend_irecv([self.dist.P2POp(self.dist.isend, self.send.cpu() if host else self.send, 0)]):
+                w.wait()
+
+    def run(self):
+        self.send[:len(self.own)] = self.image.index_select(0, self.own)
+        if self.mode == "send_recv":
+            self._send_recv()
+        else:
+            self._gather()
         if self.rank == 0:
             for r in range(1, self.world):
                 self.image.index_copy_(0, self.peers[r], self.recv[r][:len(self.peers[r])])
@@ -295,12 +340,25 @@ def measure_pipes(args, num_cus, footprint_bytes=None):
     return out, None
 
 
+# FETCH_SIZE / WRITE_SIZE on gfx950, calibrated on known byte counts in THIS library's access patterns (tools/microbench/fetch_calib.hip over a 2 GB table,
+# profiles/r05_fetch_calibration.json): FETCH_SIZE = fabric read requests x 64 B whatever their size.  A wide coalesced stream (16 B per lane, consecutive)
+# makes 128-byte requests and is reported at HALF its bytes -- the guide's factor 2; a random 64-byte node (four 16-byte loads of one half line), a random
+# 16-byte load and a random 72-byte triangle pair make 64-byte requests and are reported at 1.00 / 1.00 / 1.05 of the lines they touch.  WRITE_SIZE reports
+# coalesced 16-byte stores exactly and a random 16-byte store as 32 bytes.  So: the traversal classes (random node / triangle / box fetches; their streamed
+# ray records corrected separately from the walk's own counts) take FETCH_SIZE as it is, the streaming classes (path records) take it doubled.
+CALIBRATION = {
+    "source": "profiles/r05_fetch_calibration.json (tools/microbench/fetch_calib.hip, tools/fetch_calib.sh; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over known byte counts, 2 GB table)",
+    "FETCH_SIZE_true_bytes_per_reported_byte": {"coalesced 16 B/lane stream": 2.0, "random 64-byte node (4 x 16 B)": 1.0, "random 16 B load (per 64-byte line touched)": 1.0,
+                                                "random 72-byte triangle pair (per 64-byte line touched)": 1.05},
+    "WRITE_SIZE_true_bytes_per_reported_byte": {"coalesced 16 B/lane stores": 1.0, "random 16 B store": 0.5},
+    "fetch_factor_by_class": {"trace": 1.0, "retrace": 1.0, "tail": 1.0, "shade": 2.0, "generate": 2.0, "accumulate": 2.0},
+}
+
+
 def measure_traffic(args):
-    """HBM-side bytes per launch of every kernel class from two separate --pmc child runs (the guide's recipe: FETCH_SIZE and
-    WRITE_SIZE do not fit one pass).  rocprofv3 reports both in KiB.  gfx950 correction: FETCH_SIZE counts a 128-byte request of
-    16-byte-per-lane loads as 64 bytes, so the fetched bytes are 2 x FETCH_SIZE for such loads -- every record / node / triangle
-    load of these kernels is a 16-byte load, so the doubled figure is used (an upper bound where narrower loads are mixed in).
-    Infinity-Cache hits are included in both counters (fabric requests)."""
+    """Fabric-side bytes per launch of every kernel class from two separate --pmc child runs (the guide's recipe: FETCH_SIZE and WRITE_SIZE do not fit
+    one pass; rocprofv3 reports both in KiB), corrected per kernel class by CALIBRATION.  Infinity-Cache hits are included in both counters (they are L2 <->
+    fabric requests): an upper bound of the DRAM bytes."""
     budget = max(120.0, 6.0 * (args.steps + args.warmup))
     fetch, err_f = pmc_child_sums(args, "FETCH_SIZE", budget)
     write, err_w = pmc_child_sums(args, "WRITE_SIZE", budget)
@@ -310,8 +368,9 @@ def measure_traffic(args):
     for cls in fetch:
         if cls in write and fetch[cls][1] == write[cls][1] and fetch[cls][1] > 0:
             n = fetch[cls][1]
-            out[cls] = {"launches": n, "fetch_size_bytes": 1024.0 * fetch[cls][0] / n, "write_size_bytes": 1024.0 * write[cls][0] / n,
-                        "hbm_bytes": (2.0 * 1024.0 * fetch[cls][0] + 1024.0 * write[cls][0]) / n,
+            factor = CALIBRATION["fetch_factor_by_class"].get(cls, 2.0)
+            out[cls] = {"launches": n, "fetch_size_bytes": 1024.0 * fetch[cls][0] / n, "write_size_bytes": 1024.0 * write[cls][0] / n, "fetch_factor": factor,
+                        "hbm_bytes": (factor * 1024.0 * fetch[cls][0] + 1024.0 * write[cls][0]) / n,
                         "profiled_avg_launch_ms": fetch[cls][2] / n / 1e6 if fetch[cls][2] else None}
     return out, None
 
@@ -374,12 +433,23 @@ def main():
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    init_s = 0.0
     if world > 1:
+        t_init = time.perf_counter()
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
         dist.barrier()
+        torch.cuda.synchronize()
+        init_s = time.perf_counter() - t_init    # communicator set-up + the first barrier: outside the timed region, reported per rank
+        props = torch.cuda.get_device_properties(local_rank)
+        try:
+            peer0 = bool(torch.cuda.can_device_access_peer(local_rank, 0)) if local_rank != 0 else True
+        except Exception:
+            peer0 = None
+        sys.stderr.write("[bench] rank %d / %d: device %d (%s, %d CUs, %.0f GB), peer access to device 0: %s, backend %s, process group up in %.2f s\n"
+                         % (rank, world, local_rank, props.name, props.multi_processor_count, props.total_memory / 2**30, peer0, backend, init_s))
     import raytracer_amd as ra
 
     w, h = args.width, args.height
@@ -427,7 +497,11 @@ def main():
         lib.rtgpu_get_device_sum(ctx, C.byref(sum_ptr), C.byref(sec_ptr), C.byref(nfl))
         gather = TileGather(torch, dist, w, h, rank, world, device_tensor(sum_ptr.value, nfl.value, torch))
         sync_all()
-        gather.run()            # warm-up of the collective (channel set-up) outside the timed region; it moves the warm-up image
+        t_warm = time.perf_counter()
+        gather.choose_mode()    # warm-up of the collective (channel set-up) outside the timed region, and the decision gather / grouped send-recv
+        gather.run()            # (it moves the warm-up image)
+        torch.cuda.synchronize()
+        gather_warmup_s = time.perf_counter() - t_warm
     sync_all()
     c0 = vp.counters()
 
@@ -494,7 +568,8 @@ def main():
     if world > 1:
         # what a first measured curve needs to explain itself: every rank's share of the work and of the time, the exchange, and the proof that the
         # assembled frame is the one-GPU frame
-        mine = torch.tensor([float(own_counts["numRays"]), float(own_counts["numShadowRays"]), render_s, gather_s, elapsed], dtype=torch.float64, device="cuda")
+        mine = torch.tensor([float(own_counts["numRays"]), float(own_counts["numShadowRays"]), render_s, gather_s, elapsed, init_s, gather_warmup_s, float(local_rank),
+                             float(torch.cuda.can_device_access_peer(local_rank, 0)) if local_rank != 0 else 1.0], dtype=torch.float64, device="cuda")
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(per_rank, mine)
         per_rank = [t.tolist() for t in per_rank]
@@ -504,6 +579,9 @@ def main():
             "per_rank_timed_region_ms": [round(1000.0 * r[4], 3) for r in per_rank],
             "load_imbalance_numRays": max(r[0] for r in per_rank) / (sum(r[0] for r in per_rank) / world),
             "gather_bytes_per_peer": int(gather.pad * 12),
+            "per_rank_device": [int(r[7]) for r in per_rank], "per_rank_peer_access_to_device_0": [bool(r[8]) for r in per_rank],
+            "per_rank_process_group_init_s": [round(r[5], 3) for r in per_rank], "per_rank_gather_warmup_s": [round(r[6], 3) for r in per_rank],
+            "exchange": {"mode": gather.mode, "reason": gather.mode_reason, "backend": backend},
         }
         if rank == 0:
             # the same warm-up + timed passes on ONE device, whole frame: the gathered frame must be that frame, bit for bit
@@ -578,12 +656,21 @@ def main():
             # reference_walk_*: SURVEY 8(d)'s byte model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk, ...): what
             # the reference's algorithm would move if nothing were cached -- a work measure, not HBM traffic (the caches serve ~4/5 of it and the
             # 4-wide walk visits fewer nodes), which is why it may exceed the HBM peak.
+            # The contract's fields: `achieved` = ALGORITHMIC bytes per launch / average launch time, `frac` = achieved / 8 TB/s, `traffic` = the bytes that
+            # crossed the L2 <-> fabric boundary per launch (PMC, calibrated).  Algorithmic bytes of the dominant class:
+            #   trace, served by k_trace_wide: the walk's OWN fetches, counted on the device by its diagnostic instantiation (walk_byte_model);
+            #   trace, binary walk / shade / accumulate: SURVEY 8(d)'s per-unit figures x the units the replay counted (algorithmic_bytes);
+            #   classes without a byte model (tail, retrace, generate): no roofline fraction is claimed ("n/a").
+            # reference_walk_*: SURVEY 8(d)'s model of the REFERENCE'S binary walk (32 B per box test + 36 B per triangle test): a work measure -- the
+            # 4-wide walk makes 17 node visits where the binary walk makes 29 -- kept beside the kernel's own bytes, not used for `frac`.
             roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
                     "reference_walk_bytes_per_launch": per_launch_bytes, "reference_walk_GBs": algorithmic_gbs,
-                    "reference_walk_frac_of_l2_peak": algorithmic_gbs / L2_PEAK_GBS,
+                    "calibration": CALIBRATION,
                     "measured": "launch time: HIP events around every launch of a one-lane (serial kernels) replay of the warm-up and timed passes; "
-                                "traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the same passes, 2 x FETCH_SIZE + WRITE_SIZE per launch; "
+                                "algorithmic bytes: the walk's own event counts (a child run of the same passes with its diagnostic instantiation) x bytes per event; "
+                                "traffic: two rocprofv3 --pmc child runs (FETCH_SIZE, WRITE_SIZE) of the same passes, fetch_factor x FETCH_SIZE + WRITE_SIZE per launch "
+                                "(factor per kernel class from the calibration run; the traversal class adds the uncounted half of its streamed ray records); "
                                 "ceilings: a third child run (SQ / GRBM / TCP counters), cadence and L1 peak from tools/microbench/cadence.hip"}
             t = traffic.get(dom) if traffic else None
             if t and t["launches"] != launches and t["profiled_avg_launch_ms"]:
@@ -594,14 +681,31 @@ def main():
                 per_launch_bytes = abytes_replay[dom] / max(1, launches)
                 roof["reference_walk_bytes_per_launch"] = per_launch_bytes
                 roof["measured"] += "; this class's event pairs span several kernels, so launch time and count are the profiled child's"
+            walk_model, walk_error = (None, "skipped (--no-pmc)")
+            if dom == "trace" and kernel_name == "k_trace_wide" and not args.no_pmc and world == 1:
+                walk_model, walk_error = walk_byte_model(args)
+            if walk_model:
+                algorithmic = walk_model["bytes"] / max(1, launches)
+                roof["algorithmic_model"] = walk_model
+            elif dom in ("tail", "retrace", "generate") or abytes_replay.get(dom, 0) == 0:
+                algorithmic = None
+                roof["algorithmic_model"] = "n/a: class '%s' has no byte model (%s)" % (dom, walk_error)
+            else:
+                algorithmic = per_launch_bytes
+                roof["algorithmic_model"] = "SURVEY 8(d) per-unit bytes x the replay's counters (%s)" % (walk_error if dom == "trace" else "class " + dom)
+            roof["algorithmic_bytes_per_launch"] = algorithmic
+            roof["achieved"] = algorithmic / per_launch_s / 1e9 if algorithmic else None
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if algorithmic else None
             if t and t["launches"] == launches:
-                # `achieved` is what crossed the L2 <-> fabric boundary per second while the kernel ran: <= peak by construction.  The
-                # algorithmic byte model of SURVEY 8(d) (every node visit fetched from memory) is reported beside it: caches serve most of it.
-                roof.update({"achieved": t["hbm_bytes"] / per_launch_s / 1e9, "traffic": t["hbm_bytes"],
-                             "traffic_fetch_size_bytes": t["fetch_size_bytes"], "traffic_write_size_bytes": t["write_size_bytes"],
+                hbm_bytes = t["hbm_bytes"]
+                if walk_model:
+                    # the ray records a refill reads are a coalesced stream inside a class whose FETCH_SIZE is otherwise taken as it is: add the half the counter missed
+                    hbm_bytes += 0.5 * (32.0 * walk_model["closest_rays"] + 32.0 * walk_model["shadow_rays"]) / max(1, launches)
+                roof.update({"traffic": hbm_bytes, "traffic_GBs": hbm_bytes / per_launch_s / 1e9, "traffic_frac": hbm_bytes / per_launch_s / 1e9 / HBM_PEAK_GBS,
+                             "traffic_over_algorithmic": hbm_bytes / algorithmic if algorithmic else None,
+                             "traffic_fetch_size_bytes": t["fetch_size_bytes"], "traffic_write_size_bytes": t["write_size_bytes"], "traffic_fetch_factor": t["fetch_factor"],
                              "profiled_avg_launch_ms": t["profiled_avg_launch_ms"]})
-                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-                roof["traffic_over_reference_walk_bytes"] = t["hbm_bytes"] / per_launch_bytes if per_launch_bytes else None
+                roof["traffic_over_reference_walk_bytes"] = hbm_bytes / per_launch_bytes if per_launch_bytes else None
                 out["traffic_per_launch"] = {k: {"launches": v["launches"], "hbm_bytes": v["hbm_bytes"],
                                                  "GBs": (v["hbm_bytes"] / (ktimes[k][0] / 1000.0 / max(1, ktimes[k][1])) / 1e9) if k in ktimes and ktimes[k][0] > 0 else None,
                                                  "reference_walk_bytes": abytes_replay.get(k, 0) / max(1, v["launches"])}
@@ -616,7 +720,7 @@ def main():
                 pipes, pipes_error = measure_pipes(args, torch.cuda.get_device_properties(local_rank).multi_processor_count, footprint)
                 if pipes and dom in pipes:
                     pd = pipes[dom]
-                    fracs = {"hbm": roof["frac"], "valu_issue": pd["valu_issue"]["frac"],
+                    fracs = {"hbm": roof["traffic_frac"], "valu_issue": pd["valu_issue"]["frac"],
                              "cache_fetch": pd["l1_access"]["frac_at_footprint"] if pd["l1_access"]["frac_at_footprint"] is not None else pd["l1_access"]["frac"]}
                     nearest = max(fracs, key=lambda k: fracs[k])
                     # cache_fetch: the kernel's vector-L1 accesses per clock and CU over what the divergent-fetch microbenchmark sustains from a table of
@@ -632,8 +736,7 @@ def main():
                 else:
                     roof["ceilings_error"] = pipes_error or "no counters for the dominant kernel class"
             else:
-                roof.update({"achieved": None, "traffic": None, "frac": None,
-                             "traffic_error": traffic_error or ("launch population mismatch: %s" % (t,))})
+                roof.update({"traffic": None, "traffic_error": traffic_error or ("launch population mismatch: %s" % (t,))})
             out["roofline"] = roof
             out["kernel_time_ms"] = {k: round(v[0], 3) for k, v in ktimes.items()}
             out["kernel_launches"] = {k: v[1] for k, v in ktimes.items()}

@@ -37,6 +37,8 @@ own = bench.owned_pixel_indices(w, h, rank, world)
 others = np.setdiff1d(np.arange(w * h), own)
 assert not img.reshape(-1, 3)[others].any()            # a shard never touches a pixel it does not own
 gather = bench.TileGather(torch, dist, w, h, rank, world, t.view(-1), device="cpu")
+mode = gather.choose_mode()                            # the bench's warm-up: tries the collective, agrees on gather / grouped send-recv across the ranks
+assert mode == os.environ.get("EXPECT_MODE", "gather"), (mode, gather.mode_reason)
 gather.run()
 gather.run()                                           # idempotent: the bench warms the collective with one extra call
 rays = torch.tensor([int(cnt[0])], dtype=torch.int64)
@@ -48,7 +50,13 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("exchange", ["gather", "send_recv"])
+def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path, exchange):
+    """exchange = send_recv: the fallback bench.py takes when the gather collective does not come up on a fabric (BENCH_GATHER=send_recv forces it):
+    grouped isend / irecv of the same packed tiles -- the same frame."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import raytracer_amd as ra
     from raytracer_amd import scenes
@@ -66,9 +74,11 @@ def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "reduced.npy")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", EXPECT_MODE=exchange)
+    if exchange == "send_recv":
+        env["BENCH_GATHER"] = "send_recv"
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29541", str(script), ROOT, out], env=env, timeout=600)
+                           "--master-port", "29541" if exchange == "gather" else "29543", str(script), ROOT, out], env=env, timeout=600)
     data = np.load(out)
     reduced = data[:-1].reshape(h, w, 3)
     assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))
