@@ -1,6 +1,7 @@
 """The reference's RenderingTest.* suite compiled against the C++ mirror of the reference API
 (tests/cpp/rendering_tests.cpp).  CPU: must compile and link; GPU: must pass."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -131,12 +132,19 @@ def test_reference_test_file_passes_on_gpu(built):
         _build_reference_tests()
     env = dict(os.environ, RT_DATA_DIR=os.path.join(ROOT, "raytracer_amd", "data"))
     # The reference seeds its generators from the system's entropy (Random::Reset, Viewport's constructor) and its furnace tests compare a Monte Carlo
-    # estimate with a fixed tolerance: a run can miss it by a hair (seen once in ~10 runs here: 0.0764 against 0.075 in one channel).  A second, independent
-    # run has to pass then.
-    for attempt in range(2):
+    # estimate with a fixed tolerance: a run can miss it by a hair (seen once in ~10 runs: 0.0764 against 0.075 in one channel).  ONE repeat is allowed, and
+    # only for exactly that: every failed case is a furnace test and every EXPECT_NEAR that fired exceeded its tolerance by less than 10 %.  Anything else
+    # (a crash, another test, a real bias) fails at once; a repeat is logged.
+    out = subprocess.run([REF_EXE], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(REF_EXE))
+    print(out.stdout[-3000:], out.stderr[-2000:])
+    if out.returncode != 0:
+        failed = set(re.findall(r"\[  FAILED  \] (RenderingTest\.\w+)", out.stdout))
+        # gtest's EXPECT_NEAR message: "The difference between A and B is D, which exceeds maxError, where\n A evaluates to ..,\n B evaluates to .., and\n maxError evaluates to T."
+        misses = [(float(d), float(t)) for d, t in re.findall(r"is ([0-9.eE+-]+),\s+which exceeds [^\n]*?\n(?:.*\n)*?maxError evaluates to ([0-9.eE+-]+)\.", out.stdout)]
+        marginal = bool(failed) and all("FurnaceTest" in name for name in failed) and bool(misses) and all(tol < delta < 1.1 * tol for delta, tol in misses)
+        assert marginal, "not the known marginal furnace-tolerance miss (failed: %s, deltas / tolerances: %s)\n%s" % (sorted(failed), misses, out.stdout[-3000:] + out.stderr[-2000:])
+        print("RETRY: the reference's stochastic furnace test missed its tolerance by < 10 %% (%s: %s); running it once more" % (sorted(failed), misses))
         out = subprocess.run([REF_EXE], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(REF_EXE))
         print(out.stdout[-3000:], out.stderr[-2000:])
-        if out.returncode == 0:
-            break
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "[  PASSED  ] 6 tests." in out.stdout

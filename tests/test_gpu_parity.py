@@ -87,6 +87,37 @@ def test_single_strategy_many_lights_and_dimension_overflow(built, walk):
     assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=5, dimensions=16, use_blue_noise=False))
 
 
+def _mesh_under_a_delta_sun(aspect, orientation, triangles=20000, angle_degrees=0.0):
+    """The Sponza-class mesh under ONE directional light (delta for angle 0) with the given Euler orientation, plus the background light."""
+    pos, idx, nrm, tan, uv, mat = scenes.sponza_class_mesh(triangles, 7, refine=True)
+    scene = ra.Scene()
+    mats = [scene.add_material("diffuse", c) for _, c in scenes.SPONZA_MATERIALS]
+    scene.add_mesh(pos, idx, nrm, tan, uv, mat, mats)
+    scene.add_background_light((0.3, 0.4, 0.5))
+    scene.add_directional_light((8.0, 7.5, 7.0), np.float32(angle_degrees) / np.float32(180.0) * np.float32(3.14159265359), ra.transform_from_euler((0.0, 0.0, 0.0), orientation))
+    scene.build()
+    return scene, ra.Camera((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), aspect, 65.0)
+
+
+@pytest.mark.parametrize("orientation", [(0.0, 0.0, 0.0), (90.0, 0.0, 0.0), (0.0, 90.0, 0.0), (45.0, 0.0, 0.0), (80.0, 0.0, 0.0)])
+def test_axis_parallel_next_event_rays(built, walk, orientation):
+    """Round 5.  A sun that shines exactly along z (identity orientation): EVERY next-event ray towards it has two direction components of exactly zero; pitched or turned by 90 degrees the Euler matrix leaves one exact zero and one of 1e-7; a sun in a
+    coordinate plane (pitch 45 / 80 degrees: sponza.json's orientation) gives one.  The reference's slab test drops such an axis (inf - inf) and its walk
+    visits the scene's whole column there -- or, depending on the signs of plane and origin, rejects every box that reaches across zero (operand order of
+    _mm_min_ps / _mm_max_ps: a ray with a negative coordinate on the dropped axis passes through most of the scene).  With the counters off such rays go from the
+    4-wide walk to the re-trace launch, whose binary walk skips boxes clearly off the ray's fixed coordinate (boxNearDegenerateAxes); with the counters on the
+    reference's walk runs untouched.  Images and ray / shadow-ray / hit counters are the oracle's either
+    way, and the delta sun must actually light the frame (rays that are dropped or always occluded would pass a comparison of two black images)."""
+    w, h = 160, 96
+    scene, camera = _mesh_under_a_delta_sun(w / h, orientation)
+    out = run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=5)
+    assert_identical(*out)
+    assert out[2]["numShadowRays"] > out[2]["numShadowRaysHit"] > 0
+    # the same with a one-degree sun (cone samples around the axis: a few rays with an exactly-zero component among ordinary ones) under `All`
+    scene, camera = _mesh_under_a_delta_sun(w / h, orientation, angle_degrees=1.0)
+    assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=4, light_sampling_all=True, dimensions=64))
+
+
 def test_mesh_two_level_bvh_bit_exact(built, walk):
     """Triangle mesh instance + analytic instances: mesh BVH traversal, Moller-Trumbore, barycentric frames."""
     w, h = 160, 90
