@@ -687,9 +687,10 @@ def main():
             if walk_model:
                 algorithmic = walk_model["bytes"] / max(1, launches)
                 roof["algorithmic_model"] = walk_model
-            elif dom in ("tail", "retrace", "generate") or abytes_replay.get(dom, 0) == 0:
+            elif dom in ("tail", "retrace", "generate") or abytes_replay.get(dom, 0) == 0 or (dom == "trace" and kernel_name == "k_trace_wide"):
+                # (the 4-wide walk without its own counts -- --no-pmc, N > 1 -- claims nothing: SURVEY 8(d)'s model of the reference's BINARY walk is not what it fetches)
                 algorithmic = None
-                roof["algorithmic_model"] = "n/a: class '%s' has no byte model (%s)" % (dom, walk_error)
+                roof["algorithmic_model"] = "n/a: class '%s' has no byte model here (%s)" % (dom, walk_error)
             else:
                 algorithmic = per_launch_bytes
                 roof["algorithmic_model"] = "SURVEY 8(d) per-unit bytes x the replay's counters (%s)" % (walk_error if dom == "trace" else "class " + dom)

@@ -63,14 +63,17 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
     // needs to enter the mesh is the same for all rays, so it is fetched ONCE per wave (uniform -> scalar registers) instead
     // of through three dependent loads (object -> mesh -> root node) behind every refill.
     bool bypassMesh = false;
-    M4 bypassInvTransform; const RtNode* bypassNodes = nullptr; uint32_t bypassTriBase = 0, bypassRoot = 0;
+    // (the object's inverse transform is fetched per refill through the constant address space -- scalar loads of a uniform address -- instead of living in
+    //  sixteen scalar registers across the loop, whose header spilled two dozen of them into vector lanes every iteration)
+    typedef const __attribute__((address_space(4))) float* ConstF;
+    const ConstF bypassInvTransformWords = (ConstF)(uintptr_t)scene.objects[0].invTransform;
+    const RtNode* bypassNodes = nullptr; uint32_t bypassTriBase = 0, bypassRoot = 0;
     if (scene.numObjects == 1u && scene.objects[0].objectKind == RT_OBJECT_SHAPE && scene.objects[0].shapeKind == RT_SHAPE_MESH)
     {
         const RtMesh& mesh = scene.meshes[scene.objects[0].meshIndex];
         if (mesh.numNodes != 0u)
         {
             bypassMesh = true;
-            bypassInvTransform = loadM4(scene.objects[0].invTransform);
             bypassNodes = scene.meshNodes + mesh.firstNode;
             bypassTriBase = mesh.firstTriangle;
             bypassRoot = packNode(bypassNodes[0].childIndex, bypassNodes[0].leaves);
@@ -172,6 +175,8 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
                 if (bypassMesh)
                 {
                     // = travBegin + the object step of travStepOther for the one mesh object
+                    M4 bypassInvTransform;
+                    for (int r = 0; r < 4; ++r) bypassInvTransform.r[r] = V4(bypassInvTransformWords[4 * r], bypassInvTransformWords[4 * r + 1], bypassInvTransformWords[4 * r + 2], bypassInvTransformWords[4 * r + 3]);
                     s.ray = transformRayUnsafe(bypassInvTransform, loadWorldRay());
                     s.nanFree = rayIsNaNFree(s.ray);
                     s.hitDistance = maxDistance;

@@ -105,7 +105,10 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     if (tune.denseCounts) { denseLoadPrefix(tune.denseCounts, sDensePrefix); __syncthreads(); }
     const uint32_t numClosest = tune.denseCounts ? sDensePrefix[RT_DENSE_SHARDS] : (queueCount ? *queueCount : 0u);
     const uint32_t count = numClosest + (shadowCount ? *shadowCount : 0u);
-    const M4 invTransform = loadM4(scene.objects[0].invTransform);
+    // the mesh object's inverse transform is fetched per refill through the constant address space (scalar loads of a uniform address): sixteen scalar registers
+    // less across the whole loop, whose header spilled a dozen of them into vector lanes every iteration
+    typedef const __attribute__((address_space(4))) float* ConstF;
+    const ConstF invTransformWords = (ConstF)(uintptr_t)scene.objects[0].invTransform;
     const RtTriangle* const tris = scene.triangles + scene.meshes[scene.objects[0].meshIndex].firstTriangle;
     const float inf = __uint_as_float(0x7f800000u);
 
@@ -161,7 +164,8 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 float4 origin, dir;
                 if (shadow)
                 {
-                    light = request / paths.capacity; slot = request - light * paths.capacity;
+                    // request = light * capacity + slot; one request per vertex (LightSamplingStrategy::Single: the arena holds one light's records) needs no division
+                    if (paths.maxLights == 1u) { light = 0u; slot = request; } else { light = request / paths.capacity; slot = request - light * paths.capacity; }
                     origin = ldStream(prec(paths, R_SH_P, slot)); dir = ldStream(pshadow(paths, light, 0, slot));
                     maxDistance = dir.w;           // hitPoint.distance = illuminateResult.distance * 0.999f
                     offset = tune.shadowOffset;
@@ -174,6 +178,8 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 }
                 Ray world = makeRay(V4(origin.x, origin.y, origin.z, 0.0f), V4(dir.x, dir.y, dir.z, 0.0f));
                 if (shadow || (ubits(origin.w) & 0xFFu) != 0u) world.origin = world.origin + world.dir * offset;
+                M4 invTransform;
+                for (int r = 0; r < 4; ++r) invTransform.r[r] = V4(invTransformWords[4 * r], invTransformWords[4 * r + 1], invTransformWords[4 * r + 2], invTransformWords[4 * r + 3]);
                 const Ray local = makeRayUnsafe3(transformPoint(invTransform, world.origin), transformVector(invTransform, world.dir));   // = transformRayUnsafe: MeshShape is entered in object space, Scene.cpp:128-145
                 // largest magnitude a slab test of this ray can produce, per axis; 2^-21 of it bounds the folded test's rounding
                 const float mx = fabsf(local.originDivDir.x) + bvh.bound[0] * fabsf(local.invDir.x);
