@@ -82,3 +82,9 @@ def test_bench_line_names_every_switch_that_changed_its_work(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["env"] == {} and d["config"]["emulated_shard"] is None and "EMULATED" not in d["metric"]
+    # the roofline of a --no-pmc line: launch time and the calibration are there, but a 4-wide walk without its own counts (they come from a child run the
+    # flag skips) claims no fraction -- SURVEY 8(d)'s model of the reference's BINARY walk exceeds the HBM peak and is kept as a work measure only
+    r = d["roofline"]
+    assert r["kernel"] == "k_trace_wide" and r["avg_launch_ms"] > 0 and "FETCH_SIZE_true_bytes_per_reported_byte" in r["calibration"]
+    assert r["frac"] is None and r["achieved"] is None and r["algorithmic_bytes_per_launch"] is None and str(r["algorithmic_model"]).startswith("n/a")
+    assert r["traffic"] is None and r["reference_walk_bytes_per_launch"] > 0
