@@ -1123,6 +1123,11 @@ static void launchRetrace(RtgpuContext* c, BatchLane& l, hipStream_t stream, con
     exactTune.overflowQueue = monsters ? overflowQueue : nullptr; exactTune.overflowCount = monsters ? overflowCounts + depth : nullptr;
     exactTune.abortClosestAfter = abortEnv >= 0 ? (uint32_t)abortEnv : RT_ABORT_RETRACE_AFTER;
     exactTune.denseCounts = nullptr; exactTune.denseShardCapacity = 0u;
+    // a re-trace launch's queue is dry after the first claim and its duration is its longest ray: an any-hit ray that slides along a wall it started on (a sun in a
+    // coordinate plane: the ray lies IN the wall's plane, Moeller-Trumbore never accepts the coplanar triangles) walks ~170 nodes = 250 us alone.  Idle lanes take its
+    // deferred subtrees after RT_RETRACE_SPLIT_AFTER drain iterations instead of the 32 of a full launch.
+    static const uint32_t splitEnv = getenv("RTGPU_RETRACE_SPLIT_AFTER") ? (uint32_t)atoi(getenv("RTGPU_RETRACE_SPLIT_AFTER")) : 0u;   // tuning knob
+    exactTune.splitAfter = splitEnv ? splitEnv : RT_RETRACE_SPLIT_AFTER;
     LaunchTimer t(c, stream, KC_RETRACE);
     const dim3 retraceGrid(c->numCUs), block(RT_BLOCK);
 #define RT_LAUNCH_RETRACE(S) hipLaunchKernelGGL((k_trace<S, false>), retraceGrid, block, 0, stream, c->sceneDev, paths, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune)

@@ -108,7 +108,7 @@ RT_DEV void traceBinaryLoop(const RtSceneDesc& scene, const Paths& paths, const 
         const bool refill = !exhausted && (nIdle == 64u || nIdle >= tune.refillMinIdle);
         unsigned long long mDonors = 0ull;
         const bool canDonate = have && s.shadow && s.mode == TRAV_MESH && s.stackSize > s.levelBase;
-        if (splitShadowRays && exhausted && nIdle != 0u && ++drainIterations > RT_SPLIT_AFTER) mDonors = __ballot(canDonate);
+        if (splitShadowRays && exhausted && nIdle != 0u && ++drainIterations > (tune.splitAfter ? tune.splitAfter : RT_SPLIT_AFTER)) mDonors = __ballot(canDonate);
         if (refill || mDonors != 0ull)
         {
             uint32_t request = 0xFFFFFFFFu, donated = 0u, meshContextObject = 0u;

@@ -35,6 +35,7 @@ RT_DEV void waveClaimChunk(WaveChunk& chunk, uint32_t* cursor, uint32_t chunkSiz
 
 
 #define RT_SPLIT_AFTER 32u   // drain iterations of a wave before its shadow rays start sharing subtrees
+#define RT_RETRACE_SPLIT_AFTER 2u   // ... in the re-trace launches behind the 4-wide walks (TravTuning::splitAfter)
 
 // Wave scheduling knobs of the persistent traversal kernel (wave-uniform, passed as kernel arguments)
 struct TravTuning
@@ -48,6 +49,7 @@ struct TravTuning
     uint32_t abortClosestAfter;   // ... measured in scheduling rounds of the wave after its queue is exhausted
     const uint32_t* denseCounts;  // dense path state: the closest-hit rays are the live paths of the arena's regions (no queue); else null
     uint32_t denseShardCapacity;
+    uint32_t splitAfter;      // drain iterations of a wave before its any-hit rays start sharing subtrees (0: RT_SPLIT_AFTER)
 };
 #define RT_ABORT_CLOSEST_AFTER 768u
 // the same hand-over in the re-trace launches behind the 4-wide walks (PathTracerMIS) and in a block's local second walk: their queues hold a few

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         {
             // a degenerate closest-hit ray (an axis-parallel direction: it walks most of the tree) does not keep the block: past RT_ABORT_RETRACE_AFTER rounds
             // it goes to the launch's exact queue, i.e. to the re-trace launch behind this one, which hands it on to k_trace_monster
-            const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, tune.exactQueue, tune.exactCount, RT_ABORT_RETRACE_AFTER, nullptr, 0u };
+            const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, tune.exactQueue, tune.exactCount, RT_ABORT_RETRACE_AFTER, nullptr, 0u, RT_RETRACE_SPLIT_AFTER };
             traceBinaryLoop<kStack, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, sDensePrefix,
                                                   (uint32_t)RT_BLOCK / 64u);
         }

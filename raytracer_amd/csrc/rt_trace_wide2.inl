@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     __syncthreads();
     if (sLocalCounts[0] + sLocalCounts[1] != 0u)
     {
-        const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u };
+        const TravTuning exactTune = { tune.refillMinIdle, tune.otherMinLanes, tune.shadowOffset, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u, RT_RETRACE_SPLIT_AFTER };
         traceBinaryLoop<kStack, false>(scene, paths, sLocalExact, &sLocalCounts[0], sLocalShadow, &sLocalCounts[1], &sLocalCounts[2], counters, exactTune, sStack, sDensePrefix,
                                               (uint32_t)RT_BLOCK / 64u);
     }
