@@ -481,9 +481,9 @@ int rtgpu_set_concurrency(RtgpuContext* ctx, uint32_t lanes);
  * every setting against the oracle).  Synchronises.
  *   RTGPU_SCHEDULE_TAIL_BOUNCE   the bounce at which a batch with dense path state hands its remaining paths to the fused tail kernel
  *                                (k_tail, rt_tail.hip: trace + the reference's own walk + shade in one persistent launch, per block);
- *                                0 = never, -1 = the library's policy (frames under 400 k owned pixels: bounce 5, under 700 k: 6, else never).
+ *                                0 = never, -1 = the library's policy (frames under 700 k owned pixels: bounce 6, else never).
  *   RTGPU_SCHEDULE_LOCAL_RETRACE 1 = a block of the 4-wide walks traces the rays it does not decide itself instead of handing them to a
- *                                launch of their own, 0 = never, -1 = the library's policy (frames under 700 k owned pixels). */
+ *                                launch of their own, 0 = never, -1 = the library's policy (frames under 400 k owned pixels). */
 enum { RTGPU_SCHEDULE_TAIL_BOUNCE = 0, RTGPU_SCHEDULE_LOCAL_RETRACE = 1 };
 int rtgpu_set_schedule(RtgpuContext* ctx, uint32_t knob, int32_t value);
 

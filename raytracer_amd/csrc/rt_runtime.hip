@@ -1074,7 +1074,7 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     // (the second walk runs on the kernel's 24-entry stacks: scenes whose binary trees need deeper ones keep the separate launch)
     // (never in front of the bidirectional integrator: its light paths produce degenerate closest-hit rays -- an emitted direction that is exactly a coordinate
     //  axis -- which only the separate launch hands on to k_trace_monster; in a block they walk alone for milliseconds: 16.5 -> 26 ms per pass, profiles/r04_vcm_wide_ab.txt)
-    const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : (c->numSlots < 700000u || bounce >= localExactFromBounce)));   // (a 1/4 shard, 518 k pixels: +0 ... 2 %, with the tail +4 %; halves: 0)
+    const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : (c->numSlots < 400000u || bounce >= localExactFromBounce)));   // (round 5, with re-trace launches that hand long rays on and share subtrees early: a 1/8 shard still gains 3 % from it, a 1/4 shard (518 k pixels) now LOSES 2 %, halves 0: profiles/r05_shard_policy.txt)
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
                         chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u };
@@ -1143,8 +1143,9 @@ static uint32_t tailDepthFor(const RtgpuContext* c, uint32_t totalSlots, uint32_
     if (env == 0 || c->tailBounce == 0 || denseAll || c->wide.nodes == nullptr || !useWide(c) || stackClass != 24u || c->debugMode >= 0) return 0u;
     // Measured (profiles/r04_tail_sweep.txt, 20 passes): a 1/8 shard of the full-HD benchmark frame gains 6-8 % with the hand-over at bounce 4 or 5 (0.580 ->
     // 0.544 ms per pass, with 20-pass batches 0.575-0.606 -> 0.526-0.558; bounce 2: -20 %, 3: 0), a 1/4 shard +2 % at bounce 5 and +4 % at bounce 6 together with the block-local re-trace, halves and full frames lose 1-5 % at any bounce: the block-local
-    // rounds pay a drain each and only beat the launch sequence where that is all floors.  So: small frames only.
-    uint32_t depth = env > 0 ? (uint32_t)env : (c->tailBounce > 0 ? (uint32_t)c->tailBounce : (c->numSlots < 400000u ? 5u : (c->numSlots < 700000u ? 6u : 0u)));
+    // rounds pay a drain each and only beat the launch sequence where that is all floors.  So: small frames only.  Round 5 (faster traversal and re-trace launches,
+    // profiles/r05_shard_policy.txt): bounce 6 beats 5 on the 1/8 shard too (0.499 -> 0.488 ms per pass), 4 loses everywhere, halves gain 0.6 % at 6 (left off).
+    uint32_t depth = env > 0 ? (uint32_t)env : (c->tailBounce > 0 ? (uint32_t)c->tailBounce : (c->numSlots < 700000u ? 6u : 0u));
     (void)totalSlots;
     if (depth > maxRayDepth + 1u) return 0u;
     return depth;

@@ -68,12 +68,11 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
     float ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
     float best = 0, second = 0, tol = 0;
-    uint32_t selX = RT_WIDE_SEL_X_POS, selY = RT_WIDE_SEL_Y_POS, selZ = RT_WIDE_SEL_Z_POS;
     uint32_t cur = RT_QUANT_DONE, sp = 0, levelBase = 0, nodeBase = 0, slot = 0, light = 0;
     uint32_t objectId = 0;     // the mesh object being walked
     uint32_t leafRest = 0;     // objects of the current top-level leaf not yet visited: next index | how many << 30 (0: none)
     bool have = false, shadow = false, occluded = false, handOver = false, inMesh = false, exhausted = false;
-    uint32_t numRetraced = 0, numShadowRays = 0;
+    uint32_t numRetraced = 0, numShadowRays = 0;   // per WAVE (ballots at wave-uniform points: scalar registers)
 
     uint32_t chunkSize = count / (gridDim.x * ((uint32_t)RT_BLOCK / 64u) * 4u);
     chunkSize = chunkSize < tune.chunkMin ? tune.chunkMin : (chunkSize > 1024u ? 1024u : chunkSize);
@@ -104,7 +103,6 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
         bx = __fmaf_rn(level.base[0], ray.invDir.x, -ray.originDivDir.x);
         by = __fmaf_rn(level.base[1], ray.invDir.y, -ray.originDivDir.y);
         bz = __fmaf_rn(level.base[2], ray.invDir.z, -ray.originDivDir.z);
-        selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
         if (!shadow) tol = fmaxf(tol, fmaxf(fmaxf(mx, my), mz) * 1.9073486328125e-06f);   // 2^-19
         nodeBase = level.nodeBase;
         return true;
@@ -132,6 +130,7 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 if (chunk.next >= chunk.end) { exhausted = true; continue; }
             }
             const uint32_t idx = waveTake(!have, chunk);
+            bool tookShadow = false;
             if (idx != 0xFFFFFFFFu)
             {
                 shadow = idx >= numClosest;
@@ -156,8 +155,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     // of such a ray is that offset plus the rounding term (found by bench.py's replay check on the Cornell box: 5 of 600 000 paths).
                     if (!shadow && (ubits(prec(paths, R_ORIGIN, slot).w) & 0xFFu) != 0u) tol += 0.00100098f;
                 }
-                if (shadow) numShadowRays++;
+                tookShadow = shadow;
             }
+            numShadowRays += (uint32_t)__popcll(__ballot(tookShadow));
             continue;
         }
         if ((mI | mO) == 0ull) break;
@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             // ---- interior phase (either level): four conservative slab tests per step ----
             bool in = interior;
             const float limit = best + (tol + tol);
+            // byte selectors of the slab test, rebuilt per phase from the current level's constants (as k_trace_wide since round 5: three registers less across the other phases)
+            const uint32_t selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS, selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS, selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
             for (;;)
             {
                 if (in)
@@ -194,7 +196,10 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 if (m == 0ull || 64u - nIdle - (uint32_t)__popcll(m) >= tune.otherMinLanes) break;
             }
         }
-        else if (other)
+        else
+        {
+        bool handedOver = false, uncountShadow = false;
+        if (other)
         {
             // ---- everything else, one step per round: a mesh leaf, leaving a mesh, a top-level leaf, the next object of it, finishing ----
             bool finish = handOver;
@@ -255,7 +260,6 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                             bx = __fmaf_rn(topLevel->base[0], world.invDir.x, -world.originDivDir.x);
                             by = __fmaf_rn(topLevel->base[1], world.invDir.y, -world.originDivDir.y);
                             bz = __fmaf_rn(topLevel->base[2], world.invDir.z, -world.originDivDir.z);
-                            selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS; selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS; selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
                             nodeBase = topLevel->nodeBase;
                         }
                         if (leafRest == 0u) { popOrDone(); if (cur == RT_QUANT_DONE) finish = true; }
@@ -332,9 +336,9 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
             {
                 if (handOver)
                 {
-                    if (shadow) { widePushExact(tune, localLists, true, light * paths.capacity + slot); numShadowRays--; }   // counted by the kernel that resolves it
+                    if (shadow) { widePushExact(tune, localLists, true, light * paths.capacity + slot); uncountShadow = true; }   // counted by the kernel that resolves it
                     else widePushExact(tune, localLists, false, slot);
-                    numRetraced++;
+                    handedOver = true;
                 }
                 else if (shadow)
                 {
@@ -344,17 +348,22 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 else if (second <= best + tol)
                 {
                     widePushExact(tune, localLists, false, slot);   // a runner-up too close to call: the reference's own walk decides
-                    numRetraced++;
+                    handedOver = true;
                 }
                 have = false; cur = RT_QUANT_DONE; leafRest = 0u; inMesh = false;
             }
+        }
+        numRetraced += (uint32_t)__popcll(__ballot(handedOver)); numShadowRays -= (uint32_t)__popcll(__ballot(uncountShadow));
         }
     }
     __shared__ uint32_t sTally[2];
     if (threadIdx.x < 2u) sTally[threadIdx.x] = 0u;
     __syncthreads();
-    if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
-    if (numRetraced) atomicAdd(&sTally[1], numRetraced);
+    if ((threadIdx.x & 63u) == 0u)
+    {
+        if (numShadowRays) atomicAdd(&sTally[0], numShadowRays);
+        if (numRetraced) atomicAdd(&sTally[1], numRetraced);
+    }
     __syncthreads();
     if (threadIdx.x == 0u && sTally[0]) atomicAdd(&counters[C_SHADOW], (unsigned long long)sTally[0]);
     if (threadIdx.x == 1u && sTally[1]) atomicAdd(&counters[RT_COUNTER_RETRACED], (unsigned long long)sTally[1]);
