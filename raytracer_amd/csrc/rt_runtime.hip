@@ -161,6 +161,7 @@ struct RtgpuContext
     bool isPeer = false;
     bool stagedGather = false;         // no peer access between the devices (or RTGPU_MULTI_STAGED=1): hipMemcpyPeerAsync into staging buffers, then the gather
     float* gatherStage = nullptr; size_t gatherStageFloats = 0;
+    bool axisParallelSun = false;      // the scene has a delta directional light along a coordinate plane / axis: its next-event rays fill the re-trace launches (full grid there)
     RtMultiInfo multiInfo = {};        // rtgpu_get_multi_info: which gather was chosen and why, its timings
     float* sum = nullptr;
     float* secondary = nullptr;
@@ -845,6 +846,10 @@ RTGPU_API int rtgpu_upload_scene(RtgpuContext* c, const RtSceneDesc* s)
         for (uint32_t i = 0; i < s->numTextures && simple; ++i) simple = s->textures[i].kind == RT_TEXTURE_BITMAP && RT_FORMAT_IS_SIMPLE(s->textures[i].format);
         if (simple) c->leanScene = 4;
     }
+    // a delta directional light whose direction has an exactly-zero component: EVERY next-event ray towards it is axis-parallel and goes through the re-trace launches (launchRetrace)
+    c->axisParallelSun = false;
+    for (uint32_t i = 0; i < s->numLights; ++i)
+        if (s->lights[i].type == RT_LIGHT_DIRECTIONAL && s->lights[i].isDelta && (s->lights[i].transform[8] == 0.0f || s->lights[i].transform[9] == 0.0f || s->lights[i].transform[10] == 0.0f)) c->axisParallelSun = true;
     c->sceneReady = true;
     c->vcm.havePhotons = false;   // photons of another scene
     return RTGPU_OK;
@@ -1129,7 +1134,14 @@ static void launchRetrace(RtgpuContext* c, BatchLane& l, hipStream_t stream, con
     static const uint32_t splitEnv = getenv("RTGPU_RETRACE_SPLIT_AFTER") ? (uint32_t)atoi(getenv("RTGPU_RETRACE_SPLIT_AFTER")) : 0u;   // tuning knob
     exactTune.splitAfter = splitEnv ? splitEnv : RT_RETRACE_SPLIT_AFTER;
     LaunchTimer t(c, stream, KC_RETRACE);
-    const dim3 retraceGrid(c->numCUs), block(RT_BLOCK);
+    // one block per CU serves the usual few thousand requests; above 64 per such block the whole traversal grid works (decided on the device from the counts)
+    // (only where the scene can produce such queues -- a delta sun with an exactly-zero direction component, c->axisParallelSun: the 1024 extra blocks that read two
+    //  counts and leave cost an ordinary scene ~0.5 % end to end, profiles/r05_retrace_grid_ab.txt; RTGPU_RETRACE_FULL_GRID=0 / 1 forces it)
+    static const int gridEnv = getenv("RTGPU_RETRACE_FULL_GRID") ? atoi(getenv("RTGPU_RETRACE_FULL_GRID")) : -1;
+    const bool adaptiveGrid = gridEnv >= 0 ? gridEnv != 0 : c->axisParallelSun;
+    const uint32_t fullBlocks = c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u)));
+    exactTune.baseBlocks = adaptiveGrid ? c->numCUs : 0u; exactTune.fullGridAbove = c->numCUs * 256u * 4u;
+    const dim3 retraceGrid(adaptiveGrid ? fullBlocks : c->numCUs), block(RT_BLOCK);
 #define RT_LAUNCH_RETRACE(S) hipLaunchKernelGGL((k_trace<S, false>), retraceGrid, block, 0, stream, c->sceneDev, paths, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, exactCursors + depth, c->counters, exactTune)
     if (stackClass == 24u) RT_LAUNCH_RETRACE(24); else if (stackClass == 32u) RT_LAUNCH_RETRACE(32); else RT_LAUNCH_RETRACE(64);
 #undef RT_LAUNCH_RETRACE

@@ -263,7 +263,14 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
 {
     __shared__ uint32_t sStack[kStack * RT_BLOCK];
     __shared__ uint32_t sDensePrefix[RT_DENSE_SHARDS + 1u];
-    traceBinaryLoop<kStack, kCount>(scene, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, sStack, sDensePrefix, gridDim.x * (RT_BLOCK / 64u));
+    uint32_t blocks = gridDim.x;
+    if (tune.baseBlocks != 0u && tune.baseBlocks < gridDim.x && !tune.denseCounts)
+    {
+        // a re-trace launch is issued with a full grid; for its usual few thousand rays only the first `baseBlocks` blocks stay (block-uniform decision)
+        const uint32_t requests = (queueCount ? *queueCount : 0u) + (shadowCount ? *shadowCount : 0u);
+        if (requests <= tune.fullGridAbove) { if (blockIdx.x >= tune.baseBlocks) return; blocks = tune.baseBlocks; }
+    }
+    traceBinaryLoop<kStack, kCount>(scene, paths, queue, queueCount, shadowQueue, shadowCount, cursor, counters, tune, sStack, sDensePrefix, blocks * (RT_BLOCK / 64u));
 }
 
 #ifndef RT_TRACE_FUNCTIONS_ONLY   // (rt_tail.hip takes the walk above and not this kernel)

@@ -50,6 +50,9 @@ struct TravTuning
     const uint32_t* denseCounts;  // dense path state: the closest-hit rays are the live paths of the arena's regions (no queue); else null
     uint32_t denseShardCapacity;
     uint32_t splitAfter;      // drain iterations of a wave before its any-hit rays start sharing subtrees (0: RT_SPLIT_AFTER)
+    uint32_t baseBlocks;      // re-trace launches: blocks beyond this many leave at once unless the queues hold more than `fullGridAbove` requests
+    uint32_t fullGridAbove;   // (0 / 0: every block works).  A re-trace launch usually holds a few thousand rays -- one block per CU --, but a scene whose sun
+                              // shines exactly along an axis hands it a fifth of all next-event rays (tests/test_gpu_parity.py, test_axis_parallel_next_event_rays)
 };
 #define RT_ABORT_CLOSEST_AFTER 768u
 // the same hand-over in the re-trace launches behind the 4-wide walks (PathTracerMIS) and in a block's local second walk: their queues hold a few
