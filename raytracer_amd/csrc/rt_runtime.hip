@@ -1122,8 +1122,13 @@ static void launchRetrace(RtgpuContext* c, BatchLane& l, hipStream_t stream, con
     uint32_t* overflowCounts = l.queueCounts + 7 * l.queueCountCapacity;
     const char* const abortText = getenv("RTGPU_ABORT_RETRACE_AFTER");   // test hook, read per launch (0: every closest-hit ray in flight when its wave's queue runs dry goes to k_trace_monster)
     const int abortEnv = abortText ? atoi(abortText) : -1;
-    static const bool monstersAllowed = !(getenv("RTGPU_RETRACE_MONSTERS") && atoi(getenv("RTGPU_RETRACE_MONSTERS")) == 0);
-    const bool monsters = monstersAllowed && overflowQueue != nullptr && c->wide.nodes != nullptr && c->sceneDev.numObjects == 1u && !c->countIntersections;
+    // OFF by default since the axis-parallel prune (boxNearDegenerateAxes) made the rays it was built for short: on the benchmark frame no ray is handed over any more,
+    // and the EMPTY k_trace_monster launch behind every re-trace launch is not free under concurrency -- its 64 blocks of 512 threads / 33 KB LDS wait for CU slots that the other
+    // lanes' persistent traversal kernels hold: 27.7 ms summed over the 40 launches of the driver's timed region (profiles/r05_concurrency.txt), 2 % end to end
+    // (profiles/r05_monsters_under_concurrency_ab.txt).  RTGPU_RETRACE_MONSTERS=1 (or the test hook RTGPU_ABORT_RETRACE_AFTER) switches the hand-over on; read per launch.
+    const char* const monstersText = getenv("RTGPU_RETRACE_MONSTERS");
+    const bool monstersWanted = monstersText ? atoi(monstersText) != 0 : abortText != nullptr;
+    const bool monsters = monstersWanted && overflowQueue != nullptr && c->wide.nodes != nullptr && c->sceneDev.numObjects == 1u && !c->countIntersections;
     TravTuning exactTune = c->tune;
     exactTune.overflowQueue = monsters ? overflowQueue : nullptr; exactTune.overflowCount = monsters ? overflowCounts + depth : nullptr;
     exactTune.abortClosestAfter = abortEnv >= 0 ? (uint32_t)abortEnv : RT_ABORT_RETRACE_AFTER;
