@@ -424,7 +424,9 @@ def main():
     import torch.distributed as dist
     import __graft_entry__ as entry
     if rank == 0 and not args.pmc_child and not args.walk_diag_child:
-        entry.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):   # stdout carries the one JSON line and nothing else
+            entry.build()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; BENCH_DIST_BACKEND=gloo with ranks sharing a device exists only to exercise the N>1 code path
@@ -697,6 +699,14 @@ def main():
             roof["algorithmic_bytes_per_launch"] = algorithmic
             roof["achieved"] = algorithmic / per_launch_s / 1e9 if algorithmic else None
             roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if algorithmic else None
+            if walk_model:
+                # The walk's own fetches are REQUESTS: every node, gate and triangle a lane asks for, whichever cache level answers.  ~4/5 of them are
+                # answered by L1 / L2 (`traffic_over_algorithmic`), so with large batches (`python bench.py` without flags: 17 passes per launch) the
+                # kernel asks faster than HBM could deliver and `frac` passes 1 -- no roof is broken, `traffic_frac` is the share of the HBM roof in use.
+                # compulsory_*: the bytes one launch cannot avoid moving across the fabric -- each ray's record in, each hit record out, the walked
+                # tree's footprint once -- the floor `traffic` is to be read against (above it: nodes re-fetched because 22 MB of tree do not fit a 4 MB L2).
+                roof["frac_reads_as"] = ("requests per second over the HBM peak: the walk's fetches are counted where the lanes issue them and the caches answer "
+                                         "most of them (traffic_over_algorithmic), so a value above 1 means cache-served, not a broken roof; traffic_frac is the HBM roof in use")
             if t and t["launches"] == launches:
                 hbm_bytes = t["hbm_bytes"]
                 if walk_model:
@@ -718,6 +728,10 @@ def main():
                 footprint = int(wi.nodeBytes + wi.leafBoxBytes + wi.triangleBytes) if dom in ("trace",) else None
                 out["walk"] = {"kernel": ["k_trace (binary tree)", "k_trace_wide", "k_trace_wide2"][wi.kernel], "node_bytes": int(wi.nodeBytes),
                                "leaf_box_bytes": int(wi.leafBoxBytes), "triangle_bytes": int(wi.triangleBytes)}
+                if walk_model and footprint:
+                    compulsory = (32.0 * walk_model["closest_rays"] + 36.0 * walk_model["shadow_rays"] + 20.0 * walk_model["hit_records_written"]) / max(1, launches) + footprint
+                    roof["compulsory_bytes_per_launch"] = compulsory
+                    roof["traffic_over_compulsory"] = hbm_bytes / compulsory
                 pipes, pipes_error = measure_pipes(args, torch.cuda.get_device_properties(local_rank).multi_processor_count, footprint)
                 if pipes and dom in pipes:
                     pd = pipes[dom]

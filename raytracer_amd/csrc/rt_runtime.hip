@@ -1082,7 +1082,16 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : (c->numSlots < 400000u || bounce >= localExactFromBounce)));   // (round 5, with re-trace launches that hand long rays on and share subtrees early: a 1/8 shard still gains 3 % from it, a 1/4 shard (518 k pixels) now LOSES 2 %, halves 0: profiles/r05_shard_policy.txt)
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
-                        chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u };
+                        chunkMin < 64u ? 64u : chunkMin, localExact ? 1u : 0u, 0u };
+    // test hook, read per launch: a wave whose work queue ran dry N loop iterations ago hands the rays it still walks -- hits half found, written through -- to the
+    // re-trace launch (the stack-overflow path, which the benchmark frame never takes).  As a schedule it moves time, it does not save any: what k_trace_wide's drain
+    // loses (-5.6 % at N = 8) the re-trace launches gain, with or without k_trace_monster behind them (profiles/r05_drain_abort_ab.txt)
+    if (const char* e = getenv("RTGPU_WIDE_DRAIN_ABORT")) tune.drainAbortAfter = (uint32_t)atoi(e);
+    // the work queue is taken from its END: the any-hit requests first, the closest-hit rays last.  A launch ends with the drain of its last rays, and unoccluded
+    // next-event rays -- no hit ever shortens them -- are the long ones: trace -1 %, 1/8 and 1/4 shards +2 % end to end (profiles/r05_claim_order_ab.txt).
+    // RTGPU_WIDE_REVERSE=0: front to back (read per launch: the tests run both orders)
+    tune.reverseOrder = 1u;
+    if (const char* e = getenv("RTGPU_WIDE_REVERSE")) tune.reverseOrder = (uint32_t)atoi(e);
     const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
     if (c->wide.nodes == nullptr)

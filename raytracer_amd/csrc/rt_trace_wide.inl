@@ -40,6 +40,8 @@ struct WideTuning
     const uint32_t* denseCounts; uint32_t denseShardCapacity; // dense path state (TravTuning)
     uint32_t chunkMin;                                        // smallest piece of the work queue a wave claims at once
     uint32_t localExact;                                      // != 0: a block traces the rays its walk does not decide itself (k_trace_wide; RTGPU_LOCAL_EXACT=0: off)
+    uint32_t drainAbortAfter;                                 // != 0: a wave whose work queue ran dry this many loop iterations ago hands the rays it still walks to the binary-tree kernel
+    uint32_t reverseOrder;                                    // != 0: the queue is taken from its end (any-hit requests first, closest-hit rays last: the launch's drain is then made of rays that hits shorten)
 };
 
 #ifdef RT_DEVICE_KERNELS
@@ -132,9 +134,11 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     unsigned long long diagClock[3] = { 0ull, 0ull, 0ull }, diagPrev = kDiag ? (unsigned long long)clock64() : 0ull, diagStart = diagPrev;
     uint32_t diagRuns[3] = { 0u, 0u, 0u }, diagPhase = 0u, diagClaims = 0u;
     unsigned long long diagClaimClock = 0ull, diagExhausted = 0ull;   // when this wave found the work queue empty   // inside the refill phase: waiting for the work cursor's atomic
+    uint32_t drainIterations = 0u;   // (wave-uniform) loop iterations since the work queue ran dry
     for (;;)
     {
         if (kDiag) { const unsigned long long now = (unsigned long long)clock64(); diagClock[diagPhase] += now - diagPrev; diagPrev = now; }
+        if (exhausted && tune.drainAbortAfter != 0u && ++drainIterations == tune.drainAbortAfter && have) { overflow = true; cur = RT_QUANT_DONE; }
         const bool interior = have && (cur >> RT_NODE_LEAVES_SHIFT) == 0u;
         const bool other = have && !interior;      // at a leaf, or finished
         const unsigned long long mI = __ballot(interior), mO = __ballot(other);
@@ -150,7 +154,8 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                 if (kDiag) { diagClaimClock += (unsigned long long)clock64() - claim0; diagClaims++; }
                 if (chunk.next >= chunk.end) { exhausted = true; if (kDiag) diagExhausted = (unsigned long long)clock64(); continue; }
             }
-            const uint32_t idx = waveTake(!have, chunk);
+            uint32_t idx = waveTake(!have, chunk);
+            if (tune.reverseOrder != 0u && idx != 0xFFFFFFFFu) idx = count - 1u - idx;
             bool tookUntrusted = false, tookShadow = false;
             if (idx != 0xFFFFFFFFu)
             {

@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                 waveClaimChunk(chunk, cursor, chunkSize, count);
                 if (chunk.next >= chunk.end) { exhausted = true; continue; }
             }
-            const uint32_t idx = waveTake(!have, chunk);
+            uint32_t idx = waveTake(!have, chunk);
+            if (tune.reverseOrder != 0u && idx != 0xFFFFFFFFu) idx = count - 1u - idx;   // (as in k_trace_wide: the any-hit requests first)
             bool tookShadow = false;
             if (idx != 0xFFFFFFFFu)
             {

@@ -752,7 +752,7 @@ def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
 
 
 # ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_trace_quant.inl) -------
-def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_args):
+def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, schedule=None, **vp_args):
     """Like run_both, with the intersection counters OFF (the reference's default): single-mesh scenes then run the 4-wide walk over the re-encoded
     ("quantised") tree, and what it does not trust is traced again by the binary-tree kernel."""
     desc = scene.desc
@@ -763,6 +763,9 @@ def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, **vp_
     if shard:
         vp.set_shard(*shard)
     assert ra.rtgpu_lib().rtgpu_set_intersection_counters(vp.device_context(), 0) == 0
+    if schedule:   # (tail bounce, block-local re-trace): rtgpu_set_schedule
+        for what, value in enumerate(schedule):
+            assert ra.rtgpu_lib().rtgpu_set_schedule(vp.device_context(), C.c_uint32(what), C.c_int32(value)) == 0
     ref = np.zeros((h, w, 3), dtype=np.float32); ref2 = np.zeros((h, w, 3), dtype=np.float32)
     cnt = np.zeros(16, dtype=np.uint64)
     for _ in range(passes):
@@ -783,13 +786,15 @@ def assert_quant_identical(img, img2, counters, ref, ref2, ref_counters):
     assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0   # the reference's counters belong to its own walk
 
 
-@pytest.mark.parametrize("dense", ["0", "1"])
+@pytest.mark.parametrize("dense", ["0", "1", "front-to-back"])
 def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dense):
     """k_trace_wide (4-wide collapse of the same tree, conservative 16-bit boxes, exact leaf gate, runner-up tracking, exact re-trace,
     stack-overflow hand-over) gives the reference's hits: images and ray / shadow-ray / hit counters identical to the oracle's binary-tree
     walk, with the dense and with the slot-per-pixel path state, and only a small fraction of the rays needs the exact re-trace."""
     monkeypatch.setenv("RTGPU_WIDE", "1")
-    monkeypatch.setenv("RTGPU_NO_DENSE", "0" if dense == "1" else "1")
+    monkeypatch.setenv("RTGPU_NO_DENSE", "1" if dense == "0" else "0")
+    if dense == "front-to-back":
+        monkeypatch.setenv("RTGPU_WIDE_REVERSE", "0")   # (the default takes a launch's queue from its end)
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
     out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
@@ -808,6 +813,23 @@ def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dens
     box.add_background_light((1.0, 1.5, 2.0))
     box.build()
     assert_quant_identical(*run_quant(box, ra.Camera((0.0, 2.5, 6.0), (20.0, 180.0, 0.0), w / h, 45.0), w, h, passes=2, max_ray_depth=4))
+
+
+@pytest.mark.parametrize("after", ["1", "3", "12"])
+def test_rays_handed_over_in_mid_walk_bit_exact(built, monkeypatch, after):
+    """RTGPU_WIDE_DRAIN_ABORT=N: a wave of k_trace_wide whose work queue ran dry N loop iterations ago gives up the rays it still walks -- closest-hit rays
+    whose best hit so far is already written through, any-hit rays half way -- and the re-trace launch (the reference's own walk) redoes them from the start:
+    the stack-overflow hand-over taken by a large share of a small frame's rays instead of by none.  Images and counters stay the oracle's."""
+    monkeypatch.setenv("RTGPU_WIDE", "1")
+    monkeypatch.setenv("RTGPU_WIDE_DRAIN_ABORT", after)
+    w, h = 128, 72
+    scene, camera = scenes.sponza_class(w / h, 60000)
+    for local_retrace in (0, 1):
+        out = run_quant(scene, camera, w, h, passes=2, max_ray_depth=8, schedule=(0, local_retrace))   # (no fused tail: every bounce through k_trace_wide)
+        assert_quant_identical(*out)
+        assert out[2]["numRetracedRays"] > 0
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
+    assert_quant_identical(*run_quant(scene, camera, w, h, passes=2, max_ray_depth=8, light_sampling_all=True, dimensions=128))
 
 
 def test_fused_tail_and_block_local_retrace_are_invisible(built):
