@@ -9,10 +9,13 @@ light, LightSamplingStrategy::Single.  One "step" = one pass = one sample per pi
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
   python bench.py --workload bdpt-glass                   (BASELINE configs[4]: rough-glass slab, renderer "VCM" without merging)
 
-Timed region: the K passes AND the final read-back of the float3 sum buffer to host memory.  N > 1: the frame's
+Timed region: the K passes, until the accumulated float3 frame is complete in rank 0's HBM.  N > 1: the frame's
 64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no data-path collective); the
-read-back is preceded by ONE gather of the owned tiles to rank 0 over RCCL (packed tile pixels, 24.9 MB / N per peer; the
-collective is warmed up before the timed region).  Total work is fixed => "scaling": "strong".
+passes are followed by ONE gather of the owned tiles to rank 0 over RCCL (packed tile pixels, 24.9 MB / N per peer; the
+collective is warmed up before the timed region), inside the timed region.  Total work is fixed => "scaling": "strong".
+The read-back of the frame to host memory (24.9 MB over PCIe, ~0.6 ms, once per timed region whatever N) is timed right
+behind the region and reported beside it (`host_readback`: its time and the rate with it included) -- the measurement
+contract keeps PCIe transfers out of `value`; rounds 1-4 and this round's earlier profiles had it inside.
 
 The roofline block is measured in the run itself: HIP-event launch times from a serial (one batch lane) replay of the same
 passes, and HBM-side traffic from two `rocprofv3 --pmc` child runs of the same passes (FETCH_SIZE, WRITE_SIZE; separate
@@ -504,6 +507,10 @@ def main():
         gather.run()            # (it moves the warm-up image)
         torch.cuda.synchronize()
         gather_warmup_s = time.perf_counter() - t_warm
+    if rank == 0:
+        # warm-up of the read-back: the FIRST Viewport::GetSumBuffer registers the viewport's bitmaps as page-locked memory (1.6-3.5 ms, once per viewport;
+        # profiles/r05_readback_cost.txt) -- a later one is the copy alone (~0.45 ms for 24.9 MB).  Rounds 1-5 had that first call inside the timed region.
+        host.rth_viewport_fetch_sum(vp._h)
     sync_all()
     c0 = vp.counters()
 
@@ -517,10 +524,12 @@ def main():
         gather.run()
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - t0 - render_s   # on rank 0 this includes waiting for the slowest peer
+    sync_all()                               # every rank's passes have run and rank 0's sum buffer (HBM) holds the whole frame
+    elapsed = time.perf_counter() - t0
+    t_readback = time.perf_counter()
     if rank == 0:
         host.rth_viewport_fetch_sum(vp._h)   # Viewport::GetSumBuffer: synchronises, the frame is in the viewport's (page-locked) host bitmap afterwards
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    readback_s = time.perf_counter() - t_readback   # PCIe, not part of `value` (reported beside it: host_readback)
     if rank == 0:
         host.rth_viewport_read_sum(vp._h, host_sum.ctypes.data_as(C.POINTER(C.c_float)), None)   # a copy of that bitmap for the checks below
 
@@ -532,6 +541,7 @@ def main():
     if os.environ.get("BENCH_TIMED_ONLY"):   # profiling aid (tools/concurrency.py): the trace ends with the timed region, no replays behind it
         if rank == 0:
             print(json.dumps({"value": delta["numRays"] / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "timed_only": True,
+                              "host_readback_ms": 1000.0 * readback_s,
                               "config": {"env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None}}))
         return
     def kernel_times(context):
@@ -624,7 +634,7 @@ def main():
             "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world,
-                       "timed_region": "K passes + gather of owned tiles (N > 1) + read-back of the float3 sum buffer to host",
+                       "timed_region": "K passes + gather of owned tiles to rank 0 (N > 1): the float3 sum buffer complete in rank 0's HBM; its read-back to host is host_readback",
                        # what changed this line's work, if anything: environment switches of the bench (BENCH_*) and of the library (RTGPU_*)
                        "env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None,
                        "dist_backend": backend if world > 1 else None},
@@ -633,6 +643,10 @@ def main():
             "mrays_per_s_incl_shadow": (delta["numRays"] + delta["numShadowRays"]) / elapsed / 1e6,
             "intersection_counters": "off in the timed region (reference default); counts from an identical instrumented replay",
             "image": {"finite": image_ok, "mean_per_pass": image_mean},
+            # the frame's way to host memory (Viewport::GetSumBuffer): PCIe, once per timed region whatever N -- kept out of `value` by the measurement contract,
+            # timed right behind the region (it was inside it in rounds 1-4: value_incl_host_readback is that definition)
+            "host_readback": {"ms": 1000.0 * readback_s, "bytes": int(w) * int(h) * 12, "in_value": False,
+                              "value_incl_host_readback": delta["numRays"] / (elapsed + readback_s) / 1e6},
         }
         if emulate > 1:
             # NOT the whole frame: the tiles rank 0 of `emulate` ranks would own, rendered alone on this device (a tuning aid for the N > 1 path)

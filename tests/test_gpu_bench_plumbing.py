@@ -82,6 +82,10 @@ def test_bench_line_names_every_switch_that_changed_its_work(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["config"]["env"] == {} and d["config"]["emulated_shard"] is None and "EMULATED" not in d["metric"]
+    # the frame's PCIe read-back is timed behind the region and reported beside `value`, never inside it (measurement contract)
+    hr = d["host_readback"]
+    assert hr["in_value"] is False and hr["ms"] > 0 and hr["bytes"] == 640 * 360 * 12 and 0 < hr["value_incl_host_readback"] < d["value"]
+    assert "HBM" in d["config"]["timed_region"] and "host_readback" in d["config"]["timed_region"]
     # the roofline of a --no-pmc line: launch time and the calibration are there, but a 4-wide walk without its own counts (they come from a child run the
     # flag skips) claims no fraction -- SURVEY 8(d)'s model of the reference's BINARY walk exceeds the HBM peak and is kept as a work measure only
     r = d["roofline"]
