@@ -92,6 +92,31 @@ def make_viewport(ra, args, scene, device, shard=None):
     return vp
 
 
+def init_process_group(dist, backend, device=None, timeout_s=300):
+    """The N > 1 run's process group: RCCL (`nccl`) as asked, and -- if the communicator does not come up on this node (initialisation or the first barrier
+    raises) -- gloo with host-staged tile exchange instead of no measurement at all: the exchange is 24.9 MB once per timed region, the passes do not
+    communicate.  Returns (backend in use, reason for a fallback or None).  A rank whose peers failed sees its own barrier time out and falls back too."""
+    import datetime
+    if backend != "nccl":
+        dist.init_process_group(backend)
+        return backend, None
+    try:
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=timeout_s))
+        dist.barrier()
+        return "nccl", None
+    except Exception as e:   # noqa: BLE001 -- whatever the communication library throws: the fallback decides, the reason goes into the JSON line
+        reason = "nccl process group failed on rank %s: %r" % (os.environ.get("RANK", "?"), e)
+        sys.stderr.write("[bench] %s -- falling back to gloo (host-staged tile exchange)\n" % reason)
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass
+        dist.init_process_group("gloo")
+        dist.barrier()
+        return "gloo", reason[:500]
+
+
 def device_tensor(ptr, num_floats, torch):
     """torch view of a hipMalloc'ed float buffer owned by librtgpu (plumbing for the RCCL gather)."""
     class _Buf:
@@ -434,17 +459,16 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; BENCH_DIST_BACKEND=gloo with ranks sharing a device exists only to exercise the N>1 code path
     # on a 1-GPU box (RCCL refuses two ranks on one device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only: RCCL's peer buffers need it (exported on the GPU boxes; kept here for any other launcher)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    backend_fallback = None
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     init_s = 0.0
     if world > 1:
         t_init = time.perf_counter()
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        backend, backend_fallback = init_process_group(dist, backend, torch.device("cuda", local_rank))
         dist.barrier()
         torch.cuda.synchronize()
         init_s = time.perf_counter() - t_init    # communicator set-up + the first barrier: outside the timed region, reported per rank
@@ -593,7 +617,7 @@ def main():
             "gather_bytes_per_peer": int(gather.pad * 12),
             "per_rank_device": [int(r[7]) for r in per_rank], "per_rank_peer_access_to_device_0": [bool(r[8]) for r in per_rank],
             "per_rank_process_group_init_s": [round(r[5], 3) for r in per_rank], "per_rank_gather_warmup_s": [round(r[6], 3) for r in per_rank],
-            "exchange": {"mode": gather.mode, "reason": gather.mode_reason, "backend": backend},
+            "exchange": {"mode": gather.mode, "reason": gather.mode_reason, "backend": backend, "backend_fallback": backend_fallback},
         }
         if rank == 0:
             # the same warm-up + timed passes on ONE device, whole frame: the gathered frame must be that frame, bit for bit

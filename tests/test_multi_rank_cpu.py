@@ -20,7 +20,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import raytracer_amd as ra
 from raytracer_amd import scenes
 import oracle_lib
-dist.init_process_group("gloo")
+import bench
+# bench.py's own set-up of the process group: RCCL as asked, gloo (host-staged exchange) if the communicator does not come up -- which is the case here (no GPU)
+backend, why = bench.init_process_group(dist, os.environ.get("WORKER_BACKEND", "gloo"), timeout_s=60)
+if os.environ.get("WORKER_BACKEND") == "nccl":
+    assert backend == "gloo" and why and "nccl process group failed" in why, (backend, why)
+else:
+    assert backend == "gloo" and why is None
 rank, world = dist.get_rank(), dist.get_world_size()
 w, h = 200, 136
 scene, camera = scenes.cornell_box(w / h)
@@ -31,7 +37,6 @@ cnt = np.zeros(16, dtype=np.uint64)
 for _ in range(2):
     p = vp.next_pass_params(camera)
     oracle_lib.render_pass(scene.desc, p, w, h, img, None, cnt, shard=(rank, world), threads=2)
-import bench
 t = torch.from_numpy(img)
 own = bench.owned_pixel_indices(w, h, rank, world)
 others = np.setdiff1d(np.arange(w * h), own)
@@ -53,10 +58,11 @@ dist.destroy_process_group()
 import pytest
 
 
-@pytest.mark.parametrize("exchange", ["gather", "send_recv"])
+@pytest.mark.parametrize("exchange", ["gather", "send_recv", "nccl_fallback"])
 def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path, exchange):
     """exchange = send_recv: the fallback bench.py takes when the gather collective does not come up on a fabric (BENCH_GATHER=send_recv forces it):
-    grouped isend / irecv of the same packed tiles -- the same frame."""
+    grouped isend / irecv of the same packed tiles -- the same frame.  nccl_fallback: the ranks ask for RCCL where there is none (this container has no
+    GPU): bench.init_process_group falls back to gloo on every rank, says why, and the frame is the same."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import raytracer_amd as ra
     from raytracer_amd import scenes
@@ -74,11 +80,13 @@ def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path, exchange):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "reduced.npy")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", EXPECT_MODE=exchange)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", EXPECT_MODE="send_recv" if exchange == "send_recv" else "gather")
     if exchange == "send_recv":
         env["BENCH_GATHER"] = "send_recv"
+    if exchange == "nccl_fallback":
+        env["WORKER_BACKEND"] = "nccl"
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29541" if exchange == "gather" else "29543", str(script), ROOT, out], env=env, timeout=600)
+                           "--master-port", {"gather": "29541", "send_recv": "29543", "nccl_fallback": "29545"}[exchange], str(script), ROOT, out], env=env, timeout=600)
     data = np.load(out)
     reduced = data[:-1].reshape(h, w, 3)
     assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))
