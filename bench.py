@@ -462,7 +462,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver supports dmabuf IPC only: RCCL's peer buffers need it (exported on the GPU boxes; kept here for any other launcher)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     backend_fallback = None
-    if backend != "nccl":
+    if local_rank >= torch.cuda.device_count():
+        # fewer visible devices than ranks: BENCH_DIST_BACKEND=gloo on a 1-GPU box (the N > 1 code path exercised with ranks sharing a device), or a launcher
+        # that shows every rank only its own device (HIP_VISIBLE_DEVICES per rank: the rank's device is then index 0)
+        sys.stderr.write("[bench] rank %d: local rank %d but %d visible device(s): using device %d\n" % (rank, local_rank, torch.cuda.device_count(), local_rank % torch.cuda.device_count()))
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     init_s = 0.0
