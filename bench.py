@@ -13,7 +13,7 @@ Timed region: the K passes, until the accumulated float3 frame is co
 64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no data-path collective); the
 passes are followed by ONE gather of the owned tiles to rank 0 over RCCL (packed tile pixels, 24.9 MB / N per peer; the
 collective is warmed up before the timed region), inside the timed region.  Total work is fixed => "scaling": "strong".
-The read-back of the frame to host memory (24.9 MB over PCIe, ~0.6 ms, once per timed region whatever N) is timed right
+The read-back of the frame to host memory (24.9 MB over PCIe, ~0.45 ms once the bitmaps are page-locked, once per timed region whatever N) is timed right
 behind the region and reported beside it (`host_readback`: its time and the rate with it included) -- the measurement
 contract keeps PCIe transfers out of `value`; rounds 1-4 and this round's earlier profiles had it inside.
 
