@@ -9,16 +9,17 @@ light, LightSamplingStrategy::Single.  One "step" = one pass = one sample per pi
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
   python bench.py --workload bdpt-glass                   (BASELINE configs[4]: rough-glass slab, renderer "VCM" without merging)
 
-Timed region: the K passes, until the accumulated float3 frame is complete in rank 0's HBM.  N > 1: the frame's
-64x64 tiles are interleaved across ranks (tile % N == rank, identical scene on every GPU, no data-path collective); the
-passes are followed by ONE gather of the owned tiles to rank 0 over RCCL (packed tile pixels, 24.9 MB / N per peer; the
-collective is warmed up before the timed region), inside the timed region.  Total work is fixed => "scaling": "strong".
-The read-back of the frame to host memory (24.9 MB over PCIe, ~0.45 ms once the bitmaps are page-locked, once per timed region whatever N) is timed right
-behind the region and reported beside it (`host_readback`: its time and the rate with it included) -- the measurement
-contract keeps PCIe transfers out of `value`; rounds 1-4 and this round's earlier profiles had it inside.
+Timed region (SURVEY 8d): the K passes + (N > 1) the gather + the final Viewport::GetSumBuffer (read_sum): the clock stops when the accumulated
+float3 frame lies in the viewport's page-locked host bitmap.  N > 1: the frame's 64x64 tiles are interleaved across ranks (tile % N == rank,
+identical scene on every GPU, no data-path collective); the passes are followed by ONE gather of the owned tiles to rank 0 over RCCL (packed tile
+pixels, 24.9 MB / N per peer; the collective is warmed up before the timed region), inside the timed region.  Total work is fixed => "scaling":
+"strong".  The read-back (24.9 MB over PCIe, ~0.45 ms; the bitmaps are page-locked by a warm-up read-back in front of the region) is the region's
+last step on rank 0; the rate without it -- the frame complete in rank 0's HBM, what BENCH_r05.json's `value` was -- is printed beside `value` as
+`frame_in_hbm`, the copy's own time as `host_readback`, and `config.value_definition` names the definition ("survey-8d/r6").
 
 The roofline block is measured in the run itself: HIP-event launch times from a serial (one batch lane) replay of the same
-passes, and HBM-side traffic from two `rocprofv3 --pmc` child runs of the same passes (FETCH_SIZE, WRITE_SIZE; separate
+passes; `roofline.frac` = HBM-side traffic of the dominant kernel from two `rocprofv3 --pmc` child runs of the same passes
+(FETCH_SIZE, WRITE_SIZE, calibrated per kernel class; separate
 passes, kernel-trace only).  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -38,6 +39,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# What `value` times.  "survey-8d/r6": SURVEY 8(d)'s region -- K x Viewport::Render (+ the gather, N > 1) + the final Viewport::GetSumBuffer -- with the
+# viewport's bitmaps page-locked by a warm-up read-back in front (BENCH_r01..r04: the same region, but with that one-time page-locking inside it;
+# BENCH_r05: the region ended with the frame complete in HBM -- this line's frame_in_hbm.value).
+VALUE_DEFINITION = "survey-8d/r6"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth, same guide
 SEED = 20260928
@@ -420,6 +425,13 @@ def walk_byte_model(args):
         d = json.loads(lines[-1])["walk_diag"]
         if not d["interior_visits"]:
             return None, "this scene's launches are not served by k_trace_wide (no diagnostic counts)"
+        # exact-box fetches and hit records share one 64-bit counter (low / high half, rt_trace_wide.inl).  An exact box is fetched inside a leaf visit and a hit
+        # record is written behind an exact box, so hit records <= exact boxes <= leaf visits: with fewer than 2^32 leaf visits neither half can have wrapped
+        # into the other.  A run long enough to get there (~400 full-HD passes) is refused instead of priced with corrupt counts.
+        if d["leaf_visits"] >= 2 ** 32:
+            return None, "walk-diag counters: %d leaf visits, the packed exact-box / hit-record counter may have wrapped (use fewer passes)" % d["leaf_visits"]
+        if not (d["hit_records_written"] <= d["exact_box_fetches"] <= d["leaf_visits"]):
+            return None, "walk-diag counters inconsistent (hit records %d, exact boxes %d, leaf visits %d)" % (d["hit_records_written"], d["exact_box_fetches"], d["leaf_visits"])
         per_event = {"interior_visits": 64, "leaf_visits": 72, "exact_box_fetches": 32, "closest_rays": 32, "shadow_rays": 36, "hit_records_written": 20}
         d["bytes_per_event"] = per_event
         d["bytes"] = sum(per_event[k] * d[k] for k in per_event)
@@ -552,11 +564,11 @@ def main():
         torch.cuda.synchronize()
         gather_s = time.perf_counter() - t0 - render_s   # on rank 0 this includes waiting for the slowest peer
     sync_all()                               # every rank's passes have run and rank 0's sum buffer (HBM) holds the whole frame
-    elapsed = time.perf_counter() - t0
-    t_readback = time.perf_counter()
+    elapsed_hbm = time.perf_counter() - t0   # reported beside `value` (frame_in_hbm): the region without the PCIe copy
     if rank == 0:
-        host.rth_viewport_fetch_sum(vp._h)   # Viewport::GetSumBuffer: synchronises, the frame is in the viewport's (page-locked) host bitmap afterwards
-    readback_s = time.perf_counter() - t_readback   # PCIe, not part of `value` (reported beside it: host_readback)
+        host.rth_viewport_fetch_sum(vp._h)   # Viewport::GetSumBuffer = the final read_sum of SURVEY 8(d): the frame is in the viewport's (page-locked) host bitmap afterwards
+    elapsed = time.perf_counter() - t0       # the timed region of SURVEY 8(d): render_pass x K (+ gather) + the final read_sum
+    readback_s = elapsed - elapsed_hbm
     if rank == 0:
         host.rth_viewport_read_sum(vp._h, host_sum.ctypes.data_as(C.POINTER(C.c_float)), None)   # a copy of that bitmap for the checks below
 
@@ -568,7 +580,8 @@ def main():
     if os.environ.get("BENCH_TIMED_ONLY"):   # profiling aid (tools/concurrency.py): the trace ends with the timed region, no replays behind it
         if rank == 0:
             print(json.dumps({"value": delta["numRays"] / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "timed_only": True,
-                              "host_readback_ms": 1000.0 * readback_s,
+                              "host_readback_ms": 1000.0 * readback_s, "value_frame_in_hbm": delta["numRays"] / elapsed_hbm / 1e6,
+                              "ms_per_step_frame_in_hbm": 1000.0 * elapsed_hbm / max(1, args.steps), "value_definition": VALUE_DEFINITION,
                               "config": {"env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None}}))
         return
     def kernel_times(context):
@@ -637,9 +650,9 @@ def main():
             if scaling_report["frame_check"]["equal_to_one_gpu_replay"] is False:
                 # reported, not fatal: the line below still carries the measurement, with the failed check in it for whoever reads the curve
                 sys.stderr.write("WARNING: the gathered frame differs from the one-GPU replay: %r\n" % (scaling_report["frame_check"],))
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, elapsed_hbm], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_hbm = (float(x) for x in t.tolist())
         keys = sorted(delta)
         tc = torch.tensor([delta[k] for k in keys], dtype=torch.int64, device="cuda")
         dist.all_reduce(tc, op=dist.ReduceOp.SUM)
@@ -661,7 +674,8 @@ def main():
             "ms_per_step": 1000.0 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "spp_timed": args.steps, "parallelism": "tile-interleaved x%d" % world,
-                       "timed_region": "K passes + gather of owned tiles to rank 0 (N > 1): the float3 sum buffer complete in rank 0's HBM; its read-back to host is host_readback",
+                       "timed_region": "SURVEY 8(d): K x Viewport::Render + (N > 1) the gather of owned tiles to rank 0 + the final Viewport::GetSumBuffer (read_sum: 24.9 MB to page-locked host memory); frame_in_hbm is the region without that copy",
+                       "value_definition": VALUE_DEFINITION,
                        # what changed this line's work, if anything: environment switches of the bench (BENCH_*) and of the library (RTGPU_*)
                        "env": work_changing_env(), "emulated_shard": [0, emulate] if emulate > 1 else None,
                        "dist_backend": backend if world > 1 else None},
@@ -670,10 +684,9 @@ def main():
             "mrays_per_s_incl_shadow": (delta["numRays"] + delta["numShadowRays"]) / elapsed / 1e6,
             "intersection_counters": "off in the timed region (reference default); counts from an identical instrumented replay",
             "image": {"finite": image_ok, "mean_per_pass": image_mean},
-            # the frame's way to host memory (Viewport::GetSumBuffer): PCIe, once per timed region whatever N -- kept out of `value` by the measurement contract,
-            # timed right behind the region (it was inside it in rounds 1-4: value_incl_host_readback is that definition)
-            "host_readback": {"ms": 1000.0 * readback_s, "bytes": int(w) * int(h) * 12, "in_value": False,
-                              "value_incl_host_readback": delta["numRays"] / (elapsed + readback_s) / 1e6},
+            # the region without its last step: the frame complete in rank 0's HBM (what BENCH_r05.json called `value`; rounds 1-4 and this round: read-back inside)
+            "frame_in_hbm": {"value": delta["numRays"] / elapsed_hbm / 1e6, "ms_per_step": 1000.0 * elapsed_hbm / max(1, args.steps)},
+            "host_readback": {"ms": 1000.0 * readback_s, "bytes": int(w) * int(h) * 12, "in_value": True},
         }
         if emulate > 1:
             # NOT the whole frame: the tiles rank 0 of `emulate` ranks would own, rendered alone on this device (a tuning aid for the N > 1 path)
@@ -694,19 +707,18 @@ def main():
             kernel_name = "k_" + dom
             if dom == "trace" and c1.get("numRetracedRays", 0) > 0:
                 kernel_name = "k_trace_wide"   # the 4-wide walk served the launches (it hands a few rays to k_trace: class "retrace"); bounce 0's launch of a batch is k_trace_packet, the same tree walked one 8 x 8 pixel block per wave (one launch in ten of the class)
-            # achieved / peak / frac / traffic: the HBM roof, as the contract words it (measured fabric traffic / launch time / 8 TB/s).  `bound` says
-            # which ceiling the kernel is actually nearest to -- decided below from the counters -- and `ceilings` holds the evidence.
-            # reference_walk_*: SURVEY 8(d)'s byte model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk, ...): what
-            # the reference's algorithm would move if nothing were cached -- a work measure, not HBM traffic (the caches serve ~4/5 of it and the
-            # 4-wide walk visits fewer nodes), which is why it may exceed the HBM peak.
-            # The contract's fields: `achieved` = ALGORITHMIC bytes per launch / average launch time, `frac` = achieved / 8 TB/s, `traffic` = the bytes that
-            # crossed the L2 <-> fabric boundary per launch (PMC, calibrated).  Algorithmic bytes of the dominant class:
-            #   trace, served by k_trace_wide: the walk's OWN fetches, counted on the device by its diagnostic instantiation (walk_byte_model);
-            #   trace, binary walk / shade / accumulate: SURVEY 8(d)'s per-unit figures x the units the replay counted (algorithmic_bytes);
-            #   classes without a byte model (tail, retrace, generate): no roofline fraction is claimed ("n/a").
-            # reference_walk_*: SURVEY 8(d)'s model of the REFERENCE'S binary walk (32 B per box test + 36 B per triangle test): a work measure -- the
-            # 4-wide walk makes 17 node visits where the binary walk makes 29 -- kept beside the kernel's own bytes, not used for `frac`.
-            roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # Round 6 (review item 2): the block says what it measures.
+            #   achieved / frac          the HBM roofline: calibrated fabric bytes per launch (`traffic`: FETCH_SIZE + WRITE_SIZE of two --pmc child runs of the same
+            #                            launches) / average launch time, over 8 TB/s.  A fraction of a roof: 0 < frac <= 1 at any batch size (asserted by
+            #                            tests/test_gpu_bench_plumbing.py at 20 and at 256 passes); null without PMC (--no-pmc, N > 1).
+            #   request_rate_*           the ALGORITHMIC bytes the kernel asks for / launch time.  trace served by k_trace_wide: the walk's OWN fetches, counted on the
+            #                            device by its diagnostic instantiation (walk_byte_model); binary walk / shade / accumulate: SURVEY 8(d)'s per-unit figures x the
+            #                            replay's counters; classes without a byte model (tail, retrace, generate): "n/a".  These are requests, answered by L1 / L2 /
+            #                            Infinity Cache four times out of five -- not bounded by the HBM peak (1.06 x at 256 passes), so the field is not called frac.
+            #   reference_walk_*         SURVEY 8(d)'s literal model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk): a work measure,
+            #                            non-physical as a rate (> 1 x peak: this kernel walks another tree -- 17 visits where the binary walk makes 29 -- out of the caches).
+            #   bound / ceilings / frac_of_binding_ceiling   which measured ceiling (HBM, VALU issue, cache fetch) the kernel is nearest to, and the counters behind it.
+            roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "definition": "r6: frac = measured HBM traffic fraction (BENCH_r05's frac is request_rate_over_hbm_peak here)",
                     "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
                     "reference_walk_bytes_per_launch": per_launch_bytes, "reference_walk_GBs": algorithmic_gbs,
                     "calibration": CALIBRATION,
@@ -738,16 +750,16 @@ def main():
                 algorithmic = per_launch_bytes
                 roof["algorithmic_model"] = "SURVEY 8(d) per-unit bytes x the replay's counters (%s)" % (walk_error if dom == "trace" else "class " + dom)
             roof["algorithmic_bytes_per_launch"] = algorithmic
-            roof["achieved"] = algorithmic / per_launch_s / 1e9 if algorithmic else None
-            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if algorithmic else None
-            if walk_model:
-                # The walk's own fetches are REQUESTS: every node, gate and triangle a lane asks for, whichever cache level answers.  ~4/5 of them are
-                # answered by L1 / L2 (`traffic_over_algorithmic`), so with large batches (`python bench.py` without flags: 17 passes per launch) the
-                # kernel asks faster than HBM could deliver and `frac` passes 1 -- no roof is broken, `traffic_frac` is the share of the HBM roof in use.
-                # compulsory_*: the bytes one launch cannot avoid moving across the fabric -- each ray's record in, each hit record out, the walked
-                # tree's footprint once -- the floor `traffic` is to be read against (above it: nodes re-fetched because 22 MB of tree do not fit a 4 MB L2).
-                roof["frac_reads_as"] = ("requests per second over the HBM peak: the walk's fetches are counted where the lanes issue them and the caches answer "
-                                         "most of them (traffic_over_algorithmic), so a value above 1 means cache-served, not a broken roof; traffic_frac is the HBM roof in use")
+            roof["request_rate_GBs"] = algorithmic / per_launch_s / 1e9 if algorithmic else None
+            roof["request_rate_over_hbm_peak"] = roof["request_rate_GBs"] / HBM_PEAK_GBS if algorithmic else None
+            roof["request_rate_reads_as"] = ("algorithmic bytes the lanes ask for per second over the HBM peak; the caches answer most of them (traffic_over_algorithmic), "
+                                             "so this may exceed 1 -- it is not a fraction of a roof; `frac` is")
+            roof["reference_walk_frac"] = algorithmic_gbs / HBM_PEAK_GBS
+            roof["reference_walk_note"] = ("SURVEY 8(d) literal: 32 B x box tests + 36 B x triangle tests of the reference's BINARY walk per launch / launch time / 8 TB/s; "
+                                           "non-physical (> 1 possible): the timed kernel walks a different, cache-resident tree")
+            roof["achieved"] = None; roof["frac"] = None   # the HBM roofline proper: set from the PMC traffic below, null without it
+            # compulsory_*: the bytes one launch cannot avoid moving across the fabric -- each ray's record in, each hit record out, the walked tree's
+            # footprint once -- the floor `traffic` is to be read against (above it: nodes re-fetched because 22 MB of tree do not fit a 4 MB L2).
             if t and t["launches"] == launches:
                 hbm_bytes = t["hbm_bytes"]
                 if walk_model:
@@ -757,6 +769,8 @@ def main():
                              "traffic_over_algorithmic": hbm_bytes / algorithmic if algorithmic else None,
                              "traffic_fetch_size_bytes": t["fetch_size_bytes"], "traffic_write_size_bytes": t["write_size_bytes"], "traffic_fetch_factor": t["fetch_factor"],
                              "profiled_avg_launch_ms": t["profiled_avg_launch_ms"]})
+                roof["achieved"] = roof["traffic_GBs"]; roof["frac"] = roof["traffic_frac"]
+                roof["frac_is"] = "traffic / avg launch time / 8 TB/s: calibrated FETCH_SIZE + WRITE_SIZE (rocprofv3 --pmc, separate passes) of the same launches -- the share of the HBM roof in use"
                 roof["traffic_over_reference_walk_bytes"] = hbm_bytes / per_launch_bytes if per_launch_bytes else None
                 out["traffic_per_launch"] = {k: {"launches": v["launches"], "hbm_bytes": v["hbm_bytes"],
                                                  "GBs": (v["hbm_bytes"] / (ktimes[k][0] / 1000.0 / max(1, ktimes[k][1])) / 1e9) if k in ktimes and ktimes[k][0] > 0 else None,
@@ -786,6 +800,11 @@ def main():
                     # Below 0.6 of every ceiling the kernel is called latency-bound.
                     roof["bound"] = nearest if fracs[nearest] >= 0.6 else "latency"
                     roof["ceilings"] = {"fracs": fracs, "nearest": nearest, **pd}
+                    roof["frac_of_binding_ceiling"] = fracs[nearest]
+                    roof["binding_ceiling"] = {"name": nearest, "counters": {
+                        "hbm": "FETCH_SIZE, WRITE_SIZE (calibrated per kernel class) / launch time / 8 TB/s",
+                        "valu_issue": "SQ_INSTS_VALU x 2.1 clocks / (4 SIMDs x CUs x GRBM_GUI_ACTIVE / 8 XCDs); lane utilisation SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)",
+                        "cache_fetch": "TCP_TOTAL_CACHE_ACCESSES_sum / (CUs x GRBM_GUI_ACTIVE / 8) over the divergent-fetch microbenchmark's rate at the walk's footprint"}[nearest]}
                     out["pipes_per_kernel_class"] = {k: {"valu_issue_frac": v["valu_issue"]["frac"], "lane_utilisation": v["valu_issue"]["lane_utilisation"],
                                                          "l1_access_frac": v["l1_access"]["frac"], "waiting_for_memory": v["wave_time"]["waiting_for_memory"]}
                                                      for k, v in pipes.items()}

@@ -640,6 +640,22 @@ static void genIntegers()
     }
 }
 
+
+// A BVH's node array as eight words per node {min.xyz, childIndex, max.xyz, numLeaves | splitAxis << 30}.  Two things the reference's builder leaves
+// UNINITIALISED are written as zero so that a regenerated fixture is byte-identical to the committed one (tests/test_golden_regeneration.py):
+// node 1 (the root is node 0 and child pairs start at 2: BVHBuilder.cpp never writes it) and the splitAxis bits of a leaf.
+static void pushNodes(std::vector<uint32_t>& blob, const BVH& bvh)
+{
+    for (uint32_t i = 0; i < bvh.GetNumNodes(); ++i)
+    {
+        if (i == 1u) { for (int k = 0; k < 8; ++k) blob.push_back(0u); continue; }
+        const BVH::Node& nd = bvh.GetNodes()[i];
+        blob.push_back(fbits(nd.min.x)); blob.push_back(fbits(nd.min.y)); blob.push_back(fbits(nd.min.z)); blob.push_back(nd.childIndex);
+        blob.push_back(fbits(nd.max.x)); blob.push_back(fbits(nd.max.y)); blob.push_back(fbits(nd.max.z));
+        blob.push_back(nd.numLeaves | ((nd.numLeaves == 0 ? nd.splitAxis : 0u) << 30));
+    }
+}
+
 static void genHost()
 {
     // ---- transforms: Euler (degrees, JSON convention) -> matrix, and the general inverse
@@ -676,13 +692,7 @@ static void genHost()
             builder.Build(boxes.Data(), n, BvhBuildingParams(), order);
             blob.push_back(n); blob.push_back(bvh.GetNumNodes());
             for (uint32_t i = 0; i < n; ++i) { const float f[6] = { boxes[i].min.x, boxes[i].min.y, boxes[i].min.z, boxes[i].max.x, boxes[i].max.y, boxes[i].max.z }; for (float v : f) blob.push_back(fbits(v)); }
-            for (uint32_t i = 0; i < bvh.GetNumNodes(); ++i)
-            {
-                const BVH::Node& nd = bvh.GetNodes()[i];
-                blob.push_back(fbits(nd.min.x)); blob.push_back(fbits(nd.min.y)); blob.push_back(fbits(nd.min.z)); blob.push_back(nd.childIndex);
-                blob.push_back(fbits(nd.max.x)); blob.push_back(fbits(nd.max.y)); blob.push_back(fbits(nd.max.z));
-                blob.push_back(nd.numLeaves | ((nd.numLeaves == 0 ? nd.splitAxis : 0u) << 30));   // splitAxis of leaves is uninitialised in the reference
-            }
+            pushNodes(blob, bvh);
             for (uint32_t i = 0; i < n; ++i) blob.push_back(order[i]);
         }
         writeRaw("bvh_builder.bin", blob.data(), blob.size() * 4);
@@ -720,13 +730,7 @@ static void genMesh()
     // BVH nodes + triangles (leaf order) + vertex indices
     const BVH& bvh = mesh.mBVH;
     blob.push_back(bvh.GetNumNodes()); blob.push_back(nt);
-    for (uint32_t i = 0; i < bvh.GetNumNodes(); ++i)
-    {
-        const BVH::Node& nd = bvh.GetNodes()[i];
-        blob.push_back(fbits(nd.min.x)); blob.push_back(fbits(nd.min.y)); blob.push_back(fbits(nd.min.z)); blob.push_back(nd.childIndex);
-        blob.push_back(fbits(nd.max.x)); blob.push_back(fbits(nd.max.y)); blob.push_back(fbits(nd.max.z));
-        blob.push_back(nd.numLeaves | ((nd.numLeaves == 0 ? nd.splitAxis : 0u) << 30));
-    }
+    pushNodes(blob, bvh);
     for (uint32_t i = 0; i < nt; ++i)
     {
         const ProcessedTriangle& t = mesh.mVertexBuffer.GetTriangle(i);
@@ -992,13 +996,7 @@ static void genObjMesh()
     const uint32_t nt = mesh.mVertexBuffer.GetNumTriangles();
     const uint32_t nmat = (uint32_t)mesh.mVertexBuffer.mMaterials.Size();
     blob.push_back(bvh.GetNumNodes()); blob.push_back(nt); blob.push_back(nmat);
-    for (uint32_t i = 0; i < bvh.GetNumNodes(); ++i)
-    {
-        const BVH::Node& nd = bvh.GetNodes()[i];
-        blob.push_back(fbits(nd.min.x)); blob.push_back(fbits(nd.min.y)); blob.push_back(fbits(nd.min.z)); blob.push_back(nd.childIndex);
-        blob.push_back(fbits(nd.max.x)); blob.push_back(fbits(nd.max.y)); blob.push_back(fbits(nd.max.z));
-        blob.push_back(nd.numLeaves | ((nd.numLeaves == 0 ? nd.splitAxis : 0u) << 30));
-    }
+    pushNodes(blob, bvh);
     for (uint32_t i = 0; i < nt; ++i)
     {
         const ProcessedTriangle& t = mesh.mVertexBuffer.GetTriangle(i);

@@ -39,7 +39,7 @@
 using namespace rtd;
 
 #define RT_HOST_BUILDERS 1
-#include "rt_trace_quant.inl"
+#include "rt_wide_grid.inl"
 #include "rt_trace_wide.inl"
 #include "rt_trace_wide2.inl"
 #include "rt_trace_kernels.h"
@@ -443,6 +443,14 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
         // six lanes (the most rtgpu_set_concurrency allows) plus scene, film and the bidirectional integrator's arenas must fit what is free now
         size_t freeBytes = 0, totalBytes = 0;
         if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes / 8u < c->laneBudgetBytes) c->laneBudgetBytes = freeBytes / 8u > ((size_t)64 << 20) ? freeBytes / 8u : ((size_t)64 << 20);
+        // RTGPU_LANE_BUDGET_MB: the device memory ONE batch lane may take for its path-state arenas (a co-tenant's knob: four lanes of a full-HD frame reach
+        // ~70 GB with the default; 4096 holds them to 16 GB at 5-pass batches).  Only ever lowers the budget; results do not depend on it (the batch a lane
+        // holds shrinks, maxBatchFor / ensurePaths).
+        if (const char* e = getenv("RTGPU_LANE_BUDGET_MB"))
+        {
+            const size_t asked = (size_t)strtoull(e, nullptr, 10) << 20;
+            if (asked >= ((size_t)64 << 20) && asked < c->laneBudgetBytes) c->laneBudgetBytes = asked;
+        }
     }
     // scheduling knobs (performance only; results do not depend on them)
     if (const char* e = getenv("RTGPU_REFILL_MIN_IDLE")) c->tune.refillMinIdle = (uint32_t)atoi(e);
@@ -1078,7 +1086,9 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     static const uint32_t localExactFromBounce = getenv("RTGPU_LOCAL_EXACT_FROM") ? (uint32_t)atoi(getenv("RTGPU_LOCAL_EXACT_FROM")) : 255u;
     // (the second walk runs on the kernel's 24-entry stacks: scenes whose binary trees need deeper ones keep the separate launch)
     // (never in front of the bidirectional integrator: its light paths produce degenerate closest-hit rays -- an emitted direction that is exactly a coordinate
-    //  axis -- which only the separate launch hands on to k_trace_monster; in a block they walk alone for milliseconds: 16.5 -> 26 ms per pass, profiles/r04_vcm_wide_ab.txt)
+    //  axis -- which walk alone for milliseconds and would hold a whole block's slot of the CU meanwhile: 16.5 -> 26 ms per pass, profiles/r04_vcm_wide_ab.txt, measured
+    //  when the separate launch still handed them on to k_trace_monster; that hand-over is opt-in since round 5 (launchRetrace), the separate launch stays: it
+    //  holds one block per CU instead of the traversal grid)
     const bool localExact = mayTraceUndecidedRaysItself && c->traversalStackNeed <= 24u && (localExactEnv >= 0 ? localExactEnv != 0 : (c->localRetrace >= 0 ? c->localRetrace != 0 : (c->numSlots < 400000u || bounce >= localExactFromBounce)));   // (round 5, with re-trace launches that hand long rays on and share subtrees early: a 1/8 shard still gains 3 % from it, a 1/4 shard (518 k pixels) now LOSES 2 %, halves 0: profiles/r05_shard_policy.txt)
     static const uint32_t chunkMin = getenv("RTGPU_WIDE_CHUNK_MIN") ? (uint32_t)atoi(getenv("RTGPU_WIDE_CHUNK_MIN")) : 64u;   // tuning knob
     WideTuning tune = { c->tune.refillMinIdle, c->tune.otherMinLanes, shadowOffset, exactQueue, exactCount, exactShadowQueue, exactShadowCount, denseCounts, denseShardCapacity,
@@ -1148,7 +1158,8 @@ static void launchRetrace(RtgpuContext* c, BatchLane& l, hipStream_t stream, con
     static const uint32_t splitEnv = getenv("RTGPU_RETRACE_SPLIT_AFTER") ? (uint32_t)atoi(getenv("RTGPU_RETRACE_SPLIT_AFTER")) : 0u;   // tuning knob
     exactTune.splitAfter = splitEnv ? splitEnv : RT_RETRACE_SPLIT_AFTER;
     LaunchTimer t(c, stream, KC_RETRACE);
-    // one block per CU serves the usual few thousand requests; above 64 per such block the whole traversal grid works (decided on the device from the counts)
+    // one block per CU serves the usual few thousand requests; above 1024 requests per CU (exactTune.fullGridAbove = numCUs * 1024) the whole traversal grid works
+    // (decided on the device from the counts)
     // (only where the scene can produce such queues -- a delta sun with an exactly-zero direction component, c->axisParallelSun: the 1024 extra blocks that read two
     //  counts and leave cost an ordinary scene ~0.5 % end to end, profiles/r05_retrace_grid_ab.txt; RTGPU_RETRACE_FULL_GRID=0 / 1 forces it)
     static const int gridEnv = getenv("RTGPU_RETRACE_FULL_GRID") ? atoi(getenv("RTGPU_RETRACE_FULL_GRID")) : -1;

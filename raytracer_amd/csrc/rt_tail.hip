@@ -33,7 +33,7 @@
 using namespace rtd;
 
 #include "rt_trace_binary.inl"
-#include "rt_trace_quant.inl"
+#include "rt_wide_grid.inl"
 #include "rt_trace_wide.inl"
 #include "rt_shade.inl"
 #include "rt_dense.inl"

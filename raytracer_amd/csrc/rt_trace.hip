@@ -1,6 +1,6 @@
 // rt_trace.hip -- the traversal kernels of the library and the small kernels around them, a translation unit of their own:
 //   rt_trace_binary.inl   k_trace (the reference's walk: binary BVH, near child first), k_trace_monster
-//   rt_trace_quant.inl    the 16-bit grid, the leaf gates and the exactness argument the 4-wide walks share
+//   rt_wide_grid.inl    the 16-bit grid, the leaf gates and the exactness argument the 4-wide walks share
 //   rt_trace_wide.inl     k_trace_wide (4-wide tree of a single-mesh scene; the rays it does not decide go through the reference's walk in the same launch)
 //   rt_trace_packet.inl   k_trace_packet (the camera rays of a dense batch: one wave walks the 4-wide tree for an 8 x 8 pixel block, the node is uniform)
 //   rt_trace_wide2.inl    k_trace_wide2 (4-wide top-level tree over 4-wide mesh trees)
@@ -22,7 +22,7 @@ using namespace rtd;
 
 #include "rt_generate.inl"
 #include "rt_trace_binary.inl"
-#include "rt_trace_quant.inl"
+#include "rt_wide_grid.inl"
 #include "rt_trace_wide.inl"
 #include "rt_trace_packet.inl"
 #include "rt_trace_wide2.inl"

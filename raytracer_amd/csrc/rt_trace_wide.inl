@@ -1,5 +1,5 @@
 // rt_trace_wide.inl -- traversal of single-mesh scenes over a 4-WIDE tree collapsed from the reference's binary tree (same SAH splits,
-// same leaves), one ray per lane.  Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS) after rt_trace_quant.inl, whose grid, leaf gates and exactness argument it
+// same leaves), one ray per lane.  Included by rt_trace.hip (kernels: RT_DEVICE_KERNELS) and rt_runtime.hip (tree builders: RT_HOST_BUILDERS) after rt_wide_grid.inl, whose grid, leaf gates and exactness argument it
 // shares.
 //
 // Why.  k_trace waits ~0.8 us per dependent node fetch with 20 waves per CU to hide it: the walk is a chain of ~29 round

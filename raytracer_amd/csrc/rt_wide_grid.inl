@@ -1,4 +1,4 @@
-// rt_trace_quant.inl -- what the 4-wide walks (rt_trace_wide.inl, rt_trace_wide2.inl, rt_trace_packet.inl) share: the 16-bit grid of conservative boxes, the
+// rt_wide_grid.inl -- what the 4-wide walks (rt_trace_wide.inl, rt_trace_wide2.inl, rt_trace_packet.inl) share: the 16-bit grid of conservative boxes, the
 // per-leaf exact boxes ("gates") and the exactness argument below.  Included by rt_trace.hip / rt_tail.hip (RT_DEVICE_KERNELS) and rt_runtime.hip (tree
 // builders: RT_HOST_BUILDERS).
 // (Round 2 also had a kernel here, k_trace_quant: the reference's BINARY tree with its child pairs re-encoded in 32 bytes -- two accesses per visit instead
@@ -33,7 +33,7 @@
 // ---- host: the reference's binary BVH (BVH::Node, 32 bytes, children adjacent) re-encoded ----
 struct QuantBuild
 {
-    std::vector<float4> pairs, gate;
+    std::vector<float4> pairs, gate;   // pairs: one 16-byte record per BINARY node, host-side only -- buildWideBvh / buildWide2 copy them into the 4-wide nodes they upload; gate: uploaded
     uint32_t root = 0, stackNeed = 0;
     float base[3] = { 0, 0, 0 }, step[3] = { 0, 0, 0 }, bound[3] = { 0, 0, 0 };
     bool ok = false;

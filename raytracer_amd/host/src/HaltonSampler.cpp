@@ -46,28 +46,27 @@ void HaltonSequence::InitPrimes()
     }
 }
 
-// random start index per dimension: digits of a uniform double in the dimension's base (:160-183)
+// Start index of a dimension = a uniform double written out digit by digit in the dimension's base (HaltonSampler.cpp:160-183): the digit of
+// weight base^-(k+1) is peeled off the remainder while that is still above 1e-16 and enters the index with weight base^k.  mStarts must be the
+// reference's integers, so the three double expressions keep the reference's operations in its order: the quotient 1.0 / place, the product
+// remainder * place under floor, and digit * 1.0 / place subtracted from the remainder.
+static uint64 RadicalDigitsOf(double remainder, const uint64 base)
+{
+    uint64 index = 0;
+    for (uint64 place = base; remainder > 1.0e-16; place *= base)
+    {
+        const double placeAsDouble = (double)place;
+        if (remainder < 1.0 / placeAsDouble) continue;   // digit 0 at this place
+        const uint64 digit = (uint64)floor(remainder * placeAsDouble);
+        remainder -= (double)digit * 1.0 / placeAsDouble;
+        index += digit * place / base;
+    }
+    return index;
+}
+
 void HaltonSequence::InitStart()
 {
-    for (uint32 i = 0; i < mDimensions; i++)
-    {
-        double r = mRandom.GetDouble();
-        const uint64 base = mBase[i];
-        uint64 z = 0;
-        uint64 b = base;
-        while (r > 1.0e-16)
-        {
-            uint64 cnt = 0;
-            if (r >= 1.0 / b)
-            {
-                cnt = (uint64)floor(r * b);
-                r = r - cnt * 1.0 / b;
-                z += cnt * b / base;
-            }
-            b *= base;
-        }
-        mStarts[i] = z;
-    }
+    for (uint32 d = 0; d < mDimensions; d++) mStarts[d] = RadicalDigitsOf(mRandom.GetDouble(), mBase[d]);
 }
 
 void HaltonSequence::InitPowerBuffer()   // :31-59

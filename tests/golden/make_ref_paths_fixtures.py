@@ -17,6 +17,7 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("RT_FIXTURE_OUT", HERE)   # tests/test_golden_regeneration.py regenerates into a scratch directory and compares
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_render   # noqa: E402
@@ -45,7 +46,7 @@ def run_paths(scene_path, w, h):
 
 if __name__ == "__main__":
     w, h = SIZE
-    os.makedirs(os.path.join(HERE, "ref_paths"), exist_ok=True)
+    os.makedirs(os.path.join(OUT, "ref_paths"), exist_ok=True)
     for name in SCENES:
         make, _, _, _, depth, sampling_all, dims = ref_scenes.FIXTURES[name]
         scene, camera = make(w / h)
@@ -53,7 +54,7 @@ if __name__ == "__main__":
         ref_render.export_scene(path, scene, camera, w, h, 1, 1, depth, dimensions=dims, light_sampling_all=sampling_all, seed=ref_scenes.SEED)
         v = run_paths(path, w, h)
         os.remove(path)
-        with open(os.path.join(HERE, "ref_paths", name + ".bin"), "wb") as f:
+        with open(os.path.join(OUT, "ref_paths", name + ".bin"), "wb") as f:
             f.write(struct.pack("<8I", 0x31565052, w, h, depth, int(sampling_all), dims, len(v), 0))
             f.write(v.astype("<f4").tobytes())
         print(name, len(v), "vertices")

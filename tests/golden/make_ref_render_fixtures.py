@@ -12,13 +12,14 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("RT_FIXTURE_OUT", HERE)   # tests/test_golden_regeneration.py regenerates into a scratch directory and compares
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import ref_render   # noqa: E402
 import ref_scenes   # noqa: E402
 
 def write_fixture(name, w, h, passes, depth, sampling_all, dims, out):
-    with open(os.path.join(HERE, "ref_render", name + ".bin"), "wb") as f:
+    with open(os.path.join(OUT, "ref_render", name + ".bin"), "wb") as f:
         f.write(struct.pack("<8I", 0x31465252, w, h, passes, depth, int(sampling_all), dims, len(out["first_pass_seeds"])))
         f.write(struct.pack("<4Q", out["numRays"], out["numPrimaryRays"], out["numShadowRays"], out["numShadowRaysHit"]))
         f.write(out["first_pass_sample_offset"].astype("<f4").tobytes())
@@ -40,8 +41,12 @@ def make_statistical(names=None):
 
 
 if __name__ == "__main__":
-    make_statistical()
-    if len(sys.argv) > 1 and sys.argv[1] == "statistical":
+    # no argument: everything; "statistical": only the entropy-seeded fixture (NOT reproducible byte for byte: the reference's per-thread generator is seeded
+    # from std::random_device); "exact": only the fixtures that are a function of the seed (what tests/test_golden_regeneration.py byte-compares)
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "statistical"):
+        make_statistical()
+    if which == "statistical":
         sys.exit(0)
     for name, (make, w, h, passes, depth, sampling_all, dims) in ref_scenes.FIXTURES.items():
         scene, camera = make(w / h)

@@ -1,5 +1,6 @@
-"""The reference's RenderingTest.* suite compiled against the C++ mirror of the reference API
-(tests/cpp/rendering_tests.cpp).  CPU: must compile and link; GPU: must pass."""
+"""The C++ mirror of the reference API from C++: the reference's OWN Tests/RaytracingTests.cpp compiled unchanged against it (below), the headless Demo,
+and tests/cpp/front_buffer_test.cpp for what the reference's file does not touch (unknown renderer names, Viewport::GetFrontBuffer).
+CPU: must compile and link; GPU: must pass."""
 import os
 import re
 import subprocess
@@ -8,30 +9,30 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cpp", "_build", "rendering_tests")
+EXE = os.path.join(ROOT, "tests", "cpp", "_build", "front_buffer_test")
 
 
 def _build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
     lib = os.path.join(ROOT, "raytracer_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(ROOT, "raytracer_amd", "host"),
-                           os.path.join(ROOT, "tests", "cpp", "rendering_tests.cpp"), "-o", EXE, "-L" + lib,
+                           os.path.join(ROOT, "tests", "cpp", "front_buffer_test.cpp"), "-o", EXE, "-L" + lib,
                            "-lraytracer_amd_host", "-lrtgpu", "-Wl,-rpath," + lib])
 
 
-def test_reference_style_cpp_tests_compile_and_link(built):
+def test_front_buffer_test_compiles_and_links(built):
     _build()
     assert os.path.exists(EXE)
 
 
 @pytest.mark.gpu
-def test_reference_rendering_tests_pass_on_gpu(built):
+def test_front_buffer_and_unknown_renderer_names_on_gpu(built):
     _build()
     env = dict(os.environ, RT_DATA_DIR=os.path.join(ROOT, "raytracer_amd", "data"), RT_SEED="12345")
     out = subprocess.run([EXE], env=env, capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "0 test(s) failed" in out.stdout
+    assert "0 check(s) failed" in out.stdout
 
 
 DEMO = os.path.join(ROOT, "raytracer_amd", "lib", "rt_demo")

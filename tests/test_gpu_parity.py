@@ -294,6 +294,24 @@ def test_batch_lanes_are_invisible(built, monkeypatch):
     assert ra.rtgpu_lib().rtgpu_set_concurrency(vp.device_context(), 7) == -1   # RTGPU_ERR_INVALID_ARGUMENT
 
 
+def test_lane_memory_budget_is_invisible(built, monkeypatch):
+    """RTGPU_LANE_BUDGET_MB (a co-tenant's knob) bounds the device memory a batch lane takes for its path-state arenas; the batch a
+    lane holds shrinks to fit.  640x360 needs ~95 MB per pass and lane, so 128 MB means one pass per launch where the default streams 20: same bits, same counters."""
+    w, h = 640, 360
+    scene, camera = scenes.sponza_class(w / h, 20000)
+    results = []
+    for budget in (None, "128"):
+        if budget:
+            monkeypatch.setenv("RTGPU_LANE_BUDGET_MB", budget)
+        vp = ra.Viewport(w, h, seed=91, max_ray_depth=5)
+        vp.set_renderer(scene)
+        vp.render(camera, 7)
+        results.append((vp.sum_buffer(secondary=True), vp.counters()))
+    assert np.array_equal(results[1][0][0].view(np.uint32), results[0][0][0].view(np.uint32))
+    assert np.array_equal(results[1][0][1].view(np.uint32), results[0][0][1].view(np.uint32))
+    assert results[1][1] == results[0][1]
+
+
 def test_front_buffer_postprocess_matches_oracle(built):
     """Viewport::PostProcessTile on the device (rtgpu_postprocess) against the oracle's restatement (itself pinned to the
     reference's FastLog / FastExp / ToneMap / ToBGR by postprocess_kat.bin) on a rendered sum buffer: identical 8-bit
@@ -751,7 +769,7 @@ def test_frames_beyond_full_hd_stream_in_smaller_batches(built):
     assert np.array_equal(whole[owned].view(np.uint32), ref[owned].view(np.uint32))
 
 
-# ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_trace_quant.inl) -------
+# ---- the default traversal of single-mesh scenes: the reference's tree re-encoded in 32-byte child pairs (rt_wide_grid.inl) -------
 def run_quant(scene, camera, w, h, passes, seed=99, threads=8, shard=None, schedule=None, **vp_args):
     """Like run_both, with the intersection counters OFF (the reference's default): single-mesh scenes then run the 4-wide walk over the re-encoded
     ("quantised") tree, and what it does not trust is traced again by the binary-tree kernel."""
@@ -894,14 +912,18 @@ def test_packet_walk_of_the_camera_rays_gives_the_reference_hits(built, monkeypa
     assert_quant_identical(*out)
 
 
-@pytest.mark.parametrize("abort_after", ["0", "3", None])
+@pytest.mark.parametrize("abort_after", ["0", "3", None, "monsters"])
 def test_retrace_launch_hands_long_closest_hit_rays_to_the_cooperative_walker(built, monkeypatch, abort_after):
-    """Round 5: the re-trace launch behind k_trace_wide (the reference's own walk over the 0.1 % of the rays the 4-wide walk does not decide) hands
+    """Round 5: the re-trace launch behind k_trace_wide (the reference's own walk over the 0.1 % of the rays the 4-wide walk does not decide) CAN hand
     closest-hit rays that are still walking RT_ABORT_RETRACE_AFTER scheduling rounds after their wave's queue ran dry to k_trace_monster, which finds
-    the same hit with a whole block (degenerate axis-parallel rays walk most of the tree: 1-1.6 ms alone in a wave).  RTGPU_ABORT_RETRACE_AFTER=0 sends
-    EVERY ray in flight at that moment down that path, 3 the slower ones, the default only pathological ones: images and counters are the oracle's in all
-    three -- separate re-trace launch and block-local second walk (whose aborted rays go to the launch's exact queue, then re-trace launch, then monster),
-    dense and slot-per-pixel path state."""
+    the same hit with a whole block (degenerate axis-parallel rays walk most of the tree: 1-1.6 ms alone in a wave).  The hand-over is OFF by default since
+    the axis-parallel prune (rt_runtime.hip launchRetrace); setting RTGPU_ABORT_RETRACE_AFTER switches it on: 0 sends EVERY ray in flight at that moment down
+    that path, 3 the slower ones.  The `None` case is the product default (no hand-over, no k_trace_monster launch) and RTGPU_RETRACE_MONSTERS=1 with the
+    default threshold is covered by the fourth case.  Images and counters are the oracle's in all of them -- separate re-trace launch and block-local second
+    walk (whose aborted rays go to the launch's exact queue, then re-trace launch, then monster), dense and slot-per-pixel path state."""
+    if abort_after == "monsters":
+        monkeypatch.setenv("RTGPU_RETRACE_MONSTERS", "1")
+        abort_after = None
     if abort_after is not None:
         monkeypatch.setenv("RTGPU_ABORT_RETRACE_AFTER", abort_after)
     w, h = 160, 96
