@@ -425,11 +425,7 @@ def walk_byte_model(args):
         d = json.loads(lines[-1])["walk_diag"]
         if not d["interior_visits"]:
             return None, "this scene's launches are not served by k_trace_wide (no diagnostic counts)"
-        # exact-box fetches and hit records share one 64-bit counter (low / high half, rt_trace_wide.inl).  An exact box is fetched inside a leaf visit and a hit
-        # record is written behind an exact box, so hit records <= exact boxes <= leaf visits: with fewer than 2^32 leaf visits neither half can have wrapped
-        # into the other.  A run long enough to get there (~400 full-HD passes) is refused instead of priced with corrupt counts.
-        if d["leaf_visits"] >= 2 ** 32:
-            return None, "walk-diag counters: %d leaf visits, the packed exact-box / hit-record counter may have wrapped (use fewer passes)" % d["leaf_visits"]
+        # sanity of the device counts (64-bit slots each since round 6): an exact box is fetched inside a leaf visit, a hit record is written behind an exact box
         if not (d["hit_records_written"] <= d["exact_box_fetches"] <= d["leaf_visits"]):
             return None, "walk-diag counters inconsistent (hit records %d, exact boxes %d, leaf visits %d)" % (d["hit_records_written"], d["exact_box_fetches"], d["leaf_visits"])
         per_event = {"interior_visits": 64, "leaf_visits": 72, "exact_box_fetches": 32, "closest_rays": 32, "shadow_rays": 36, "hit_records_written": 20}
@@ -516,8 +512,8 @@ def main():
         if args.walk_diag_child:
             # RTGPU_WIDE_DIAG=3 (set by the parent): the 4-wide walk counted its own fetches in the spare counters (rt_trace_wide.inl)
             c = vp.counters()
-            print(json.dumps({"walk_diag": {"interior_visits": c["numUntrustedRays"], "leaf_visits": c["diag2"], "exact_box_fetches": c["numStackOverflowRays"] & 0xFFFFFFFF,
-                                            "hit_records_written": c["numStackOverflowRays"] >> 32, "closest_rays": c["numRays"], "shadow_rays": c["numShadowRays"],
+            print(json.dumps({"walk_diag": {"interior_visits": c["numUntrustedRays"], "leaf_visits": c["diag2"], "exact_box_fetches": c["numStackOverflowRays"],
+                                            "hit_records_written": c["numShadowRayTriangleTests"],   # (the diagnostic walk's own 64-bit slot, rt_trace_wide.inl) "closest_rays": c["numRays"], "shadow_rays": c["numShadowRays"],
                                             "retraced_rays": c["numRetracedRays"]}}), flush=True)
         return
 

@@ -123,7 +123,7 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
     // tallies per WAVE (ballots at wave-uniform points of the loop: scalar registers; as per-lane counters they were four of the 96 vector registers)
     uint32_t numRetraced = 0, numShadowRays = 0, numUntrusted = 0, numOverflow = 0;
     uint32_t diagVisits = 0, diagSlots = 0, diagLeaves = 0;   // kDiag: interior visits, lane slots of the interior loop (64 per wave step), leaf visits
-    uint32_t diagGates = 0, diagHitWrites = 0;                // kDiag, RTGPU_WIDE_DIAG=3: exact-box fetches and hit records written through (the walk's byte model, bench.py)
+    uint32_t diagGates = 0, diagHitWrites = 0;                // kDiag, RTGPU_WIDE_DIAG=3: exact-box fetches and hit records written through, per lane and launch (the walk's byte model, bench.py)
     uint32_t diagMaxSp = 0, diagDeep[3] = { 0u, 0u, 0u };     // kDiag, RTGPU_WIDE_DIAG=2: rays whose stack held more than 9 / 13 / 17 entries (what a 12 / 16 / 20-entry stack would hand over)
 
     uint32_t chunkSize = count / (sharingWaves * 4u);
@@ -370,9 +370,13 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
         // RTGPU_WIDE_DIAG=1: the three spare counters hold the walk's statistics instead
         const bool deep = tune.localExact == 2u, bytes = tune.localExact == 3u;   // (the diagnostic kernel has no block-local lists: the field carries RTGPU_WIDE_DIAG's mode)
         atomicAdd(&counters[RT_COUNTER_RETRACED + 1], (unsigned long long)(deep ? diagDeep[0] : diagVisits));
-        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], bytes ? (unsigned long long)diagGates | ((unsigned long long)diagHitWrites << 32) : (unsigned long long)(deep ? diagDeep[1] : diagSlots));   // 3: exact-box fetches | hit records << 32 (each below 2^32 over a run of a few dozen passes)
+        atomicAdd(&counters[RT_COUNTER_RETRACED + 2], (unsigned long long)(bytes ? diagGates : (deep ? diagDeep[1] : diagSlots)));   // 3: exact-box fetches
         atomicAdd(&counters[RT_COUNTER_RETRACED + 3], (unsigned long long)(deep ? diagDeep[2] : diagLeaves));
-        if ((threadIdx.x & 63u) == 0u)
+        // 3: the hit records written through get a 64-bit slot of their own (round 5 packed them into the upper half of the exact-box count, which wraps into
+        // them past 2^32 boxes -- a 256-pass bench run is within a factor of two of that): the reference's shadow triangle-test counter, free in this walk; the
+        // phase clocks that otherwise ride in these slots are not written in this mode
+        if (bytes) atomicAdd(&counters[C_TRI_SHADOW], (unsigned long long)diagHitWrites);
+        else if ((threadIdx.x & 63u) == 0u)
         {
             // the reference's intersection counters are not used by this walk: per-wave clocks and phase counts ride in their slots
             atomicAdd(&counters[C_BOX], diagClock[0]); atomicAdd(&counters[C_BOX_PASS], diagClock[1]); atomicAdd(&counters[C_TRI], diagClock[2]);

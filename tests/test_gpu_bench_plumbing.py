@@ -131,6 +131,7 @@ def test_roofline_block_is_a_fraction_of_a_roof(built, steps, warmup):
                                                 "frac_of_binding_ceiling", "bound", "traffic_over_compulsory")}), d["value"], d["frame_in_hbm"])
     assert roof["kernel"] == "k_trace_wide" and roof["traffic"] is not None, roof.get("traffic_error")
     assert 0.0 < roof["frac"] <= 1.0 and roof["frac"] == roof["traffic_frac"] and abs(roof["achieved"] - roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    assert roof["request_rate_over_hbm_peak"] is not None, roof.get("algorithmic_model")
     assert roof["request_rate_over_hbm_peak"] > roof["frac"]            # the caches answer most requests
     assert 0.0 < roof["frac_of_binding_ceiling"] <= 1.0 and roof["binding_ceiling"]["name"] in ("hbm", "valu_issue", "cache_fetch")
     assert roof["frac_of_binding_ceiling"] >= roof["frac"]
