@@ -513,7 +513,8 @@ def main():
             # RTGPU_WIDE_DIAG=3 (set by the parent): the 4-wide walk counted its own fetches in the spare counters (rt_trace_wide.inl)
             c = vp.counters()
             print(json.dumps({"walk_diag": {"interior_visits": c["numUntrustedRays"], "leaf_visits": c["diag2"], "exact_box_fetches": c["numStackOverflowRays"],
-                                            "hit_records_written": c["numShadowRayTriangleTests"],   # (the diagnostic walk's own 64-bit slot, rt_trace_wide.inl) "closest_rays": c["numRays"], "shadow_rays": c["numShadowRays"],
+                                            "hit_records_written": c["numShadowRayTriangleTests"],   # (the diagnostic walk's own 64-bit slot, rt_trace_wide.inl)
+                                            "closest_rays": c["numRays"], "shadow_rays": c["numShadowRays"],
                                             "retraced_rays": c["numRetracedRays"]}}), flush=True)
         return
 
