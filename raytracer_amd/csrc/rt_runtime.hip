@@ -1142,6 +1142,10 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     // RTGPU_WIDE_REVERSE=0: front to back (read per launch: the tests run both orders)
     tune.reverseOrder = 1u;
     if (const char* e = getenv("RTGPU_WIDE_REVERSE")) tune.reverseOrder = (uint32_t)atoi(e);
+    // any-hit rays walk the FARTHEST child they enter first (rt_trace_wide.inl: occlusion is an OR over the candidates, and the occluders of a ray that starts on a
+    // surface are far from it); RTGPU_ANYHIT_FAR_FIRST=0: nearest first like closest-hit rays (read per launch: the tests run both orders)
+    tune.anyHitFarFirst = 1u;
+    if (const char* e = getenv("RTGPU_ANYHIT_FAR_FIRST")) tune.anyHitFarFirst = (uint32_t)atoi(e);
     const dim3 grid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : 5u)), block(RT_BLOCK);
     LaunchTimer t(c, stream, KC_TRACE);
     if (c->wide.nodes == nullptr)
@@ -1339,7 +1343,8 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             const Paths& out = (depth & 1u) ? l.paths : l.paths2;
             if (tailDepth != 0u && depth == tailDepth)
             {
-                const TailArgs args = { l.denseCounts + (size_t)plane * depth, shardCapacity, cursors + depth, c->tune.refillMinIdle, c->tune.otherMinLanes, c->deviceFlags };
+                const TailArgs args = { l.denseCounts + (size_t)plane * depth, shardCapacity, cursors + depth, c->tune.refillMinIdle, c->tune.otherMinLanes, c->deviceFlags,
+                                        (getenv("RTGPU_ANYHIT_FAR_FIRST") && atoi(getenv("RTGPU_ANYHIT_FAR_FIRST")) == 0) ? 0u : 1u };
                 static const uint32_t tailBlocksPerCU = getenv("RTGPU_TAIL_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_TAIL_BLOCKS_PER_CU")) : 4u;   // tuning knob
                 uint32_t tailBlocks = (totalSlots + RT_TAIL_PATHS - 1u) / RT_TAIL_PATHS;   // never more blocks than chunks of the whole batch
                 if (tailBlocks > travCUs * tailBlocksPerCU) tailBlocks = travCUs * tailBlocksPerCU;

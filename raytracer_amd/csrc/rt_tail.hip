@@ -84,7 +84,7 @@ __global__ void RT_TAIL_ATTR(kLean, kPlain) k_tail RT_K_TAIL_ARGS
     const DevPass pass = passes[0];   // the structural parameters are those of every pass of the batch
     const V4 lightSamplingWeight = load4(pass.lightSamplingWeight), bsdfSamplingWeight = load4(pass.bsdfSamplingWeight);
     const float lightPickProbability = 1.0f / (float)(scene.numLights ? scene.numLights : 1u);   // GetLightPickingProbability, PathTracerMIS.cpp:157-172 (Single)
-    const WideTuning wideTune = { args.refillMinIdle, args.otherMinLanes, 0.0001f, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 64u, 1u };
+    const WideTuning wideTune = { args.refillMinIdle, args.otherMinLanes, 0.0001f, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, 64u, 1u, 0u, 0u, args.anyHitFarFirst };
     const TravTuning exactTune = { args.refillMinIdle, args.otherMinLanes, 0.0001f, nullptr, nullptr, RT_ABORT_CLOSEST_AFTER, nullptr, 0u, RT_RETRACE_SPLIT_AFTER };
     const uint32_t blockWaves = (uint32_t)RT_BLOCK / 64u;
     uint32_t cur = 0u;   // which pair of (live, zombie) lists is this round's; block-uniform

@@ -11,6 +11,7 @@ struct TailArgs
     uint32_t* cursor;              // work cursor over the hand-over bounce's vertices (zeroed by the host)
     uint32_t refillMinIdle, otherMinLanes;
     uint32_t* errorFlags;          // RtgpuContext::deviceFlags: [0] = a region of the arena overflowed (checked here as k_shade_dense's prologue does)
+    uint32_t anyHitFarFirst;       // WideTuning::anyHitFarFirst for the walks of this launch
 };
 
 // X(scene class of rt_device_core.h, plain path tracer)

@@ -42,6 +42,7 @@ struct WideTuning
     uint32_t localExact;                                      // != 0: a block traces the rays its walk does not decide itself (k_trace_wide; RTGPU_LOCAL_EXACT=0: off)
     uint32_t drainAbortAfter;                                 // != 0: a wave whose work queue ran dry this many loop iterations ago hands the rays it still walks to the binary-tree kernel
     uint32_t reverseOrder;                                    // != 0: the queue is taken from its end (any-hit requests first, closest-hit rays last: the launch's drain is then made of rays that hits shorten)
+    uint32_t anyHitFarFirst;                                  // != 0: an any-hit ray walks the FARTHEST child it enters next (round 6; RTGPU_ANYHIT_FAR_FIRST=0: nearest, as closest-hit rays do)
 };
 
 #ifdef RT_DEVICE_KERNELS
@@ -228,6 +229,14 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
             const float limit = best + (tol + tol);   // box occlusion with the slack that keeps every candidate within tol of the final hit in the walk
             // which plane of an axis the ray meets first: byte selectors of the slab test, rebuilt per phase (three registers less across the leaf and refill phases)
             const uint32_t selX = ax < 0.0f ? RT_WIDE_SEL_X_NEG : RT_WIDE_SEL_X_POS, selY = ay < 0.0f ? RT_WIDE_SEL_Y_NEG : RT_WIDE_SEL_Y_POS, selZ = az < 0.0f ? RT_WIDE_SEL_Z_NEG : RT_WIDE_SEL_Z_POS;
+            // Visiting order (round 6).  A closest-hit ray walks its NEAREST entered child next (hits shorten it).  An any-hit ray has nothing to shorten -- it ends
+            // with the first occluder, wherever that lies -- and nearest-first is the worst order for it: a next-event ray starts ON a surface, so the nearest
+            // boxes hold that surface's neighbours, which never occlude it.  FARTHEST child first finds the walls and roofs that do: the step model over the
+            // benchmark's rays (tools/wide8/walk_model.cpp, profiles/r06_wide8_step_model.txt) gives 9.9 interior + 1.5 leaf visits per any-hit ray instead of
+            // 16.0 + 2.6.  Occlusion is an OR over the same candidates: the result does not depend on the order.  Same instruction count: the sort key
+            // 0x7FFFFFFF - bits(entry) = 0x7FFFFFFF ^ bits(entry) (entry >= 0: no borrow), and an any-hit lane xors with 0 instead.
+            // (The flip is rebuilt in every iteration from `tol`, which is zero for any-hit rays only, behind an optimisation barrier: as a loop-invariant value
+            //  it would be one more vector register live across the loop -- the 97th: 20 bytes of scratch -- for three instructions per visit saved.)
             for (;;)
             {
                 if (kDiag) { diagSlots++; if (in) diagVisits++; }
@@ -237,11 +246,15 @@ RT_DEV void traceWideLoop(const RtSceneDesc& scene, const WideBvh& bvh, const Pa
                     const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                     float n0, f0, n1, f1, n2, f2, n3, f3;
                     RT_WIDE_SLAB(q0, n0, f0); RT_WIDE_SLAB(q1, n1, f1); RT_WIDE_SLAB(q2, n2, f2); RT_WIDE_SLAB(q3, n3, f3);
-                        // (key, reference) pairs sorted so that the children the ray enters come first, farthest first, and the ones it misses
-                        // last: key = 0x7FFFFFFF - bits(entry distance) (the distance is >= 0, so its bits order like the float), miss = all ones
+                        // (key, reference) pairs sorted so that the children the ray enters come first -- farthest first for a closest-hit ray, nearest
+                        // first for an any-hit ray: the LAST entered one is walked next -- and the ones it misses last: key = orderFlip ^ bits(entry
+                        // distance) (the distance is >= 0, so its bits order like the float), miss = all ones
                         const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
-                        uint32_t k0 = h0 ? 0x7FFFFFFFu - ubits(n0) : 0xFFFFFFFFu, k1 = h1 ? 0x7FFFFFFFu - ubits(n1) : 0xFFFFFFFFu;
-                        uint32_t k2 = h2 ? 0x7FFFFFFFu - ubits(n2) : 0xFFFFFFFFu, k3 = h3 ? 0x7FFFFFFFu - ubits(n3) : 0xFFFFFFFFu;
+                        float tolNow = tol;
+                        asm volatile("" : "+v"(tolNow));
+                        const uint32_t orderFlip = (tolNow == 0.0f && tune.anyHitFarFirst != 0u) ? 0u : 0x7FFFFFFFu;
+                        uint32_t k0 = h0 ? orderFlip ^ ubits(n0) : 0xFFFFFFFFu, k1 = h1 ? orderFlip ^ ubits(n1) : 0xFFFFFFFFu;
+                        uint32_t k2 = h2 ? orderFlip ^ ubits(n2) : 0xFFFFFFFFu, k3 = h3 ? orderFlip ^ ubits(n3) : 0xFFFFFFFFu;
                         uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
 #define RT_WIDE_CE(ka, ra, kb, rb) { const bool c_ = ka > kb; const uint32_t lo_ = min(ka, kb), hi_ = max(ka, kb), rl_ = c_ ? rb : ra, rh_ = c_ ? ra : rb; ka = lo_; kb = hi_; ra = rl_; rb = rh_; }
                         RT_WIDE_CE(k0, r0, k1, r1) RT_WIDE_CE(k2, r2, k3, r3) RT_WIDE_CE(k0, r0, k2, r2) RT_WIDE_CE(k1, r1, k3, r3) RT_WIDE_CE(k1, r1, k2, r2)

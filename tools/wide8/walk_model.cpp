@@ -92,7 +92,7 @@ static WTree collapse(int width, bool octantSlots, bool planes8)
             {
                 int bc = -1, bs = -1; float bestCost = -INFINITY;
                 for (int k = 0; k < num; ++k) if (!usedC[k])
-                    for (int s = 0; s < width; ++s) if (!usedS[s])
+                    for (int s = 0; s < 8; ++s) if (!usedS[s])
                     {
                         float cost = 0.0f;
                         for (int a = 0; a < 3; ++a) { const float d = 0.5f * (gNodes[list[k]].mn[a] + gNodes[list[k]].mx[a]) - cen[a]; cost += ((s >> a) & 1) ? d : -d; }
@@ -193,6 +193,17 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             st.entered += numHit;
             // order: the LAST element is visited next
             if (order == 0) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD < hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); } }
+            else if (order == 2) { std::reverse(hit, hit + numHit); }   // storage order (slot 0 first)
+            else if (order == 6) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD > hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); } }   // FARTHEST first
+            else if (order == 4) { }                                    // reverse storage order (the highest slot first)
+            else if (order == 5) { static uint32_t lc = 12345u; for (int i = numHit - 1; i > 0; --i) { lc = lc * 1664525u + 1013904223u; std::swap(hit[i], hit[(lc >> 16) % (uint32_t)(i + 1)]); } }   // random order
+            else if (order == 3)
+            {
+                // largest box first (any-hit rays: the child most likely to hold an occluder) -- keys ride in nearD
+                for (int i = 0; i < numHit; ++i) for (int k = 0; k < 8; ++k) if (n.c[k].valid && n.c[k].ref == hit[i].ref && n.c[k].leaf == hit[i].leaf)
+                { const float ex = n.c[k].hi[0] - n.c[k].lo[0], ey = n.c[k].hi[1] - n.c[k].lo[1], ez = n.c[k].hi[2] - n.c[k].lo[2]; hit[i].nearD = ex * ey + ey * ez + ez * ex; }
+                for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD > hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); }
+            }
             else { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && slotKey[j - 1] < slotKey[j]; --j) { std::swap(hit[j - 1], hit[j]); std::swap(slotKey[j - 1], slotKey[j]); } }
             if (numHit == 0)
             {
@@ -281,6 +292,15 @@ int main(int argc, char** argv)
         { "W8  16-bit planes, octant order", 8, true, false, 1, true },
         { "W8  8-bit planes, distance order", 8, false, true, 0, true },
         { "W8  8-bit planes, octant order (the 64-byte node)", 8, true, true, 1, true },
+        { "W6  8-bit planes, octant order (header + 6 x 8 B)", 6, true, true, 1, true },
+        { "W6  8-bit planes, distance order", 6, false, true, 0, true },
+        { "W4  16-bit planes, STORAGE order (no sort at all; any-hit rays only are meaningful)", 4, false, false, 2, false },
+        { "W4  16-bit planes, LARGEST child first (any-hit rays only are meaningful)", 4, false, false, 3, false },
+        { "W4  16-bit planes, REVERSE storage order", 4, false, false, 4, false },
+        { "W4  16-bit planes, RANDOM order", 4, false, false, 5, false },
+        { "W4  16-bit planes, FARTHEST child first", 4, false, false, 6, false },
+        { "W8  8-bit planes, FARTHEST child first", 8, false, true, 6, true },
+        { "W8  8-bit planes, REVERSE storage order", 8, false, true, 4, true },
     };
     double base[2] = { 0, 0 };
     for (const Variant& v : variants)
