@@ -178,8 +178,12 @@ __global__ void __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(k
                     float n0, f0, n1, f1, n2, f2, n3, f3;
                     RT_WIDE_SLAB(q0, n0, f0); RT_WIDE_SLAB(q1, n1, f1); RT_WIDE_SLAB(q2, n2, f2); RT_WIDE_SLAB(q3, n3, f3);
                     const bool h0 = f0 >= n0 && n0 < limit, h1 = f1 >= n1 && n1 < limit, h2 = f2 >= n2 && n2 < limit, h3 = f3 >= n3 && n3 < limit;
-                    uint32_t k0 = h0 ? 0x7FFFFFFFu - ubits(n0) : 0xFFFFFFFFu, k1 = h1 ? 0x7FFFFFFFu - ubits(n1) : 0xFFFFFFFFu;
-                    uint32_t k2 = h2 ? 0x7FFFFFFFu - ubits(n2) : 0xFFFFFFFFu, k3 = h3 ? 0x7FFFFFFFu - ubits(n3) : 0xFFFFFFFFu;
+                    // any-hit rays walk the FARTHEST entered child next (rt_trace_wide.inl has the reasoning and the barrier's); `tol` is zero for any-hit rays only
+                    float tolNow = tol;
+                    asm volatile("" : "+v"(tolNow));
+                    const uint32_t orderFlip = (tolNow == 0.0f && tune.anyHitFarFirst != 0u) ? 0u : 0x7FFFFFFFu;
+                    uint32_t k0 = h0 ? orderFlip ^ ubits(n0) : 0xFFFFFFFFu, k1 = h1 ? orderFlip ^ ubits(n1) : 0xFFFFFFFFu;
+                    uint32_t k2 = h2 ? orderFlip ^ ubits(n2) : 0xFFFFFFFFu, k3 = h3 ? orderFlip ^ ubits(n3) : 0xFFFFFFFFu;
                     uint32_t r0 = ubits(q0.w), r1 = ubits(q1.w), r2 = ubits(q2.w), r3 = ubits(q3.w);
 #define RT_WIDE_CE(ka, ra, kb, rb) { const bool c_ = ka > kb; const uint32_t lo_ = min(ka, kb), hi_ = max(ka, kb), rl_ = c_ ? rb : ra, rh_ = c_ ? ra : rb; ka = lo_; kb = hi_; ra = rl_; rb = rh_; }
                     RT_WIDE_CE(k0, r0, k1, r1) RT_WIDE_CE(k2, r2, k3, r3) RT_WIDE_CE(k0, r0, k2, r2) RT_WIDE_CE(k1, r1, k3, r3) RT_WIDE_CE(k1, r1, k2, r2)

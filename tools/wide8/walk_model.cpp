@@ -28,6 +28,7 @@ struct Tri { float v0[3], e1[3], e2[3]; };
 struct RayIn { float o[3], d[3], dist, bounce, p[3], n[3]; };
 struct Ray { float o[3], d[3], inv[3], tmax; bool anyHit; uint32_t oct; };
 
+static bool gCullOnPop = false;   // the deferred entry carries its entry distance and is dropped at the pop if a hit found meanwhile lies in front of it
 static std::vector<Node> gNodes;
 static std::vector<Tri> gTris;
 
@@ -131,7 +132,7 @@ static WTree collapse(int width, bool octantSlots, bool planes8)
 }
 
 // ---- tests ----
-static inline bool slab(const Ray& r, const float lo[3], const float hi[3], float& nearOut)
+static inline bool slab(const Ray& r, const float lo[3], const float hi[3], float& nearOut, float& farOut)
 {
     float tn = 0.0f, tf = INFINITY;
     for (int a = 0; a < 3; ++a)
@@ -139,7 +140,7 @@ static inline bool slab(const Ray& r, const float lo[3], const float hi[3], floa
         const float t0 = (lo[a] - r.o[a]) * r.inv[a], t1 = (hi[a] - r.o[a]) * r.inv[a];
         tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
     }
-    nearOut = tn;
+    nearOut = tn; farOut = tf;
     return tf >= tn;
 }
 static inline bool triHit(const Ray& r, const Tri& t, float& dist)
@@ -169,11 +170,11 @@ struct Stats
 // groupStack: deferred work is counted in node groups (a node with children still to visit = one entry) instead of single children.
 static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stats& st)
 {
-    struct Entry { uint32_t ref; bool leaf; float nearD; };
+    struct Entry { uint32_t ref; bool leaf; float nearD; float farD; };
     std::vector<Entry> stack; stack.reserve(64);
     std::vector<int> groupSizes;   // groupStack: children still deferred per group (for the depth statistic)
     float best = r.tmax;
-    Entry cur = { 0u, false, 0.0f };
+    Entry cur = { 0u, false, 0.0f, 0.0f };
     bool have = true;
     size_t deepest = 0;
     while (have)
@@ -187,14 +188,16 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             {
                 if (!n.c[k].valid) continue;
                 st.boxTests++;
-                float nd;
-                if (slab(r, n.c[k].lo, n.c[k].hi, nd) && nd < best) { hit[numHit] = { n.c[k].ref, n.c[k].leaf, nd }; slotKey[numHit] = k ^ (int)r.oct; numHit++; }
+                float nd, fd;
+                if (slab(r, n.c[k].lo, n.c[k].hi, nd, fd) && nd < best) { hit[numHit] = { n.c[k].ref, n.c[k].leaf, nd, fminf(fd, best) }; slotKey[numHit] = k ^ (int)r.oct; numHit++; }
             }
             st.entered += numHit;
             // order: the LAST element is visited next
             if (order == 0) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD < hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); } }
             else if (order == 2) { std::reverse(hit, hit + numHit); }   // storage order (slot 0 first)
             else if (order == 6) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD > hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); } }   // FARTHEST first
+            else if (order == 7) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && (hit[j - 1].farD - hit[j - 1].nearD) > (hit[j].farD - hit[j].nearD); --j) { std::swap(hit[j - 1], hit[j]); } }   // LONGEST chord first
+            else if (order == 8) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].farD > hit[j].farD; --j) { std::swap(hit[j - 1], hit[j]); } }   // largest EXIT distance first
             else if (order == 4) { }                                    // reverse storage order (the highest slot first)
             else if (order == 5) { static uint32_t lc = 12345u; for (int i = numHit - 1; i > 0; --i) { lc = lc * 1664525u + 1013904223u; std::swap(hit[i], hit[(lc >> 16) % (uint32_t)(i + 1)]); } }   // random order
             else if (order == 3)
@@ -208,7 +211,7 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             if (numHit == 0)
             {
                 if (stack.empty()) have = false;
-                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } }
+                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cur.nearD >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
             }
             else
             {
@@ -234,7 +237,7 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             if (have)
             {
                 if (stack.empty()) have = false;
-                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } }
+                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cur.nearD >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
             }
         }
     }
@@ -259,6 +262,7 @@ static Ray makeRay(const float o[3], const float d[3], float offset, float tmax,
 int main(int argc, char** argv)
 {
     const std::string dir = argc > 1 ? argv[1] : "/tmp/walk_model";
+    gCullOnPop = argc > 2 && atoi(argv[2]) != 0;
     size_t numNodes = 0, numTris = 0, numRays = 0; float sun[3];
     { FILE* f = fopen((dir + "/meta.txt").c_str(), "r"); if (!f || fscanf(f, "%zu %zu %zu %f %f %f", &numNodes, &numTris, &numRays, &sun[0], &sun[1], &sun[2]) != 6) { fprintf(stderr, "no meta.txt in %s\n", dir.c_str()); return 1; } fclose(f); }
     gNodes.resize(numNodes); gTris.resize(numTris);
@@ -299,6 +303,8 @@ int main(int argc, char** argv)
         { "W4  16-bit planes, REVERSE storage order", 4, false, false, 4, false },
         { "W4  16-bit planes, RANDOM order", 4, false, false, 5, false },
         { "W4  16-bit planes, FARTHEST child first", 4, false, false, 6, false },
+        { "W4  16-bit planes, LONGEST chord first", 4, false, false, 7, false },
+        { "W4  16-bit planes, largest EXIT distance first", 4, false, false, 8, false },
         { "W8  8-bit planes, FARTHEST child first", 8, false, true, 6, true },
         { "W8  8-bit planes, REVERSE storage order", 8, false, true, 4, true },
     };
