@@ -804,15 +804,19 @@ def assert_quant_identical(img, img2, counters, ref, ref2, ref_counters):
     assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0   # the reference's counters belong to its own walk
 
 
-@pytest.mark.parametrize("dense", ["0", "1", "front-to-back"])
+@pytest.mark.parametrize("dense", ["0", "1", "front-to-back", "any-hit-nearest-first"])
 def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dense):
     """k_trace_wide (4-wide collapse of the same tree, conservative 16-bit boxes, exact leaf gate, runner-up tracking, exact re-trace,
     stack-overflow hand-over) gives the reference's hits: images and ray / shadow-ray / hit counters identical to the oracle's binary-tree
-    walk, with the dense and with the slot-per-pixel path state, and only a small fraction of the rays needs the exact re-trace."""
+    walk, with the dense and with the slot-per-pixel path state, and only a small fraction of the rays needs the exact re-trace.
+    Round 6: any-hit rays walk the FARTHEST child they enter first by default (occlusion is an OR over the candidates: the order cannot
+    change a result); the last case runs them nearest first like closest-hit rays (RTGPU_ANYHIT_FAR_FIRST=0) -- same bits either way."""
     monkeypatch.setenv("RTGPU_WIDE", "1")
     monkeypatch.setenv("RTGPU_NO_DENSE", "1" if dense == "0" else "0")
     if dense == "front-to-back":
         monkeypatch.setenv("RTGPU_WIDE_REVERSE", "0")   # (the default takes a launch's queue from its end)
+    if dense == "any-hit-nearest-first":
+        monkeypatch.setenv("RTGPU_ANYHIT_FAR_FIRST", "0")
     w, h = 128, 72
     scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000, with_analytic=False)
     out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=8)
@@ -1043,8 +1047,10 @@ def test_two_level_scenes_with_the_counters_off(built, monkeypatch):
     the rays it does not decide to the binary-tree kernel; and with RTGPU_WIDE2=0 the binary walk without the counting code, where a wave's
     idle lanes take over subtrees of its longest any-hit rays at the end of a launch.  Images and ray counters are the oracle's either way."""
     w, h = 192, 108
-    for wide2 in ("1", "0"):
-        monkeypatch.setenv("RTGPU_WIDE2", wide2)
+    for wide2 in ("1", "0", "1 any-hit nearest first"):
+        monkeypatch.setenv("RTGPU_WIDE2", wide2[0])
+        monkeypatch.setenv("RTGPU_ANYHIT_FAR_FIRST", "0" if "nearest" in wide2 else "1")   # (round 6: any-hit rays walk the farthest entered child first by default)
+        wide2 = wide2[0]
         scene, camera = scene_zoo.mesh_scene(w / h, triangles=20000)
         out = run_quant(scene, camera, w, h, passes=3, max_ray_depth=6)
         assert_quant_identical(*out)

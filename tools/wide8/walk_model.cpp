@@ -28,6 +28,7 @@ struct Tri { float v0[3], e1[3], e2[3]; };
 struct RayIn { float o[3], d[3], dist, bounce, p[3], n[3]; };
 struct Ray { float o[3], d[3], inv[3], tmax; bool anyHit; uint32_t oct; };
 
+static int gCullBits = 0;   // > 0: the deferred distance is kept as the top gCullBits bits of the float below its sign (a lower bound)
 static bool gCullOnPop = false;   // the deferred entry carries its entry distance and is dropped at the pop if a hit found meanwhile lies in front of it
 static std::vector<Node> gNodes;
 static std::vector<Tri> gTris;
@@ -37,6 +38,68 @@ static inline double area(uint32_t n)
 {
     const double ex = (double)gNodes[n].mx[0] - gNodes[n].mn[0], ey = (double)gNodes[n].mx[1] - gNodes[n].mn[1], ez = (double)gNodes[n].mx[2] - gNodes[n].mn[2];
     return ex * ey + ey * ez + ez * ex;
+}
+
+// ---- topology optimisation of the binary tree ABOVE its leaves (the leaves -- exact boxes, triangle runs -- stay the reference's): tree rotations that lower the
+// surface-area cost, bottom-up, a few sweeps (Kensler 2008).  Any tree over the same leaves is a legal walk for the 4-wide kernel (its boxes are conservative and
+// the leaf gates are the reference's), so this is purely a visit-count question.
+struct BN { float mn[3], mx[3]; int l, r; uint32_t child, leaves; };
+static inline double areaOf(const float mn[3], const float mx[3]) { const double ex = (double)mx[0] - mn[0], ey = (double)mx[1] - mn[1], ez = (double)mx[2] - mn[2]; return ex * ey + ey * ez + ez * ex; }
+static void refit(std::vector<BN>& t, int n) { for (int a = 0; a < 3; ++a) { t[n].mn[a] = fminf(t[t[n].l].mn[a], t[t[n].r].mn[a]); t[n].mx[a] = fmaxf(t[t[n].l].mx[a], t[t[n].r].mx[a]); } }
+static double unionArea(const BN& a, const BN& b) { float mn[3], mx[3]; for (int k = 0; k < 3; ++k) { mn[k] = fminf(a.mn[k], b.mn[k]); mx[k] = fmaxf(a.mx[k], b.mx[k]); } return areaOf(mn, mx); }
+static void optimiseTopology(int sweeps)
+{
+    std::vector<BN> t(gNodes.size());
+    for (size_t n = 0; n < gNodes.size(); ++n)
+    {
+        if (n == 1) continue;
+        BN& b = t[n]; memcpy(b.mn, gNodes[n].mn, 12); memcpy(b.mx, gNodes[n].mx, 12); b.child = gNodes[n].child; b.leaves = gNodes[n].leaves;
+        if (isLeaf((uint32_t)n)) b.l = b.r = -1; else { b.l = (int)gNodes[n].child; b.r = (int)gNodes[n].child + 1; }
+    }
+    auto cost = [&]() { double c = 0; std::vector<int> st; st.push_back(0); while (!st.empty()) { int n = st.back(); st.pop_back(); if (t[n].l < 0) continue; c += areaOf(t[n].mn, t[n].mx); st.push_back(t[n].l); st.push_back(t[n].r); } return c; };
+    const double before = cost();
+    long rotations = 0;
+    for (int sweep = 0; sweep < sweeps; ++sweep)
+    {
+        // post-order
+        std::vector<int> order, st; st.push_back(0);
+        while (!st.empty()) { int n = st.back(); st.pop_back(); if (t[n].l < 0) continue; order.push_back(n); st.push_back(t[n].l); st.push_back(t[n].r); }
+        for (size_t i = order.size(); i-- > 0;)
+        {
+            const int n = order[i];
+            refit(t, n);
+            // best of the four rotations: a child swapped with a grandchild of the other side
+            double bestGain = 1e-12; int bestSide = -1, bestGrand = -1;
+            for (int side = 0; side < 2; ++side)
+            {
+                const int c = side ? t[n].r : t[n].l, o = side ? t[n].l : t[n].r;   // c: the child whose box changes (must be interior), o: the other child
+                if (t[c].l < 0) continue;
+                const double old = areaOf(t[c].mn, t[c].mx);
+                const double g0 = old - unionArea(t[o], t[t[c].r]);   // swap o with c.l: c = {o, c.r}
+                const double g1 = old - unionArea(t[t[c].l], t[o]);   // swap o with c.r: c = {c.l, o}
+                if (g0 > bestGain) { bestGain = g0; bestSide = side; bestGrand = 0; }
+                if (g1 > bestGain) { bestGain = g1; bestSide = side; bestGrand = 1; }
+            }
+            if (bestSide >= 0)
+            {
+                const int c = bestSide ? t[n].r : t[n].l; int& oRef = bestSide ? t[n].l : t[n].r; int& gRef = bestGrand ? t[c].r : t[c].l;
+                std::swap(oRef, gRef); refit(t, c); refit(t, n); rotations++;
+            }
+        }
+    }
+    const double after = cost();
+    // back into the array form (child pairs adjacent, breadth first)
+    std::vector<Node> out; out.resize(2); std::vector<std::pair<int, uint32_t>> todo; todo.push_back({ 0, 0u });
+    for (size_t i = 0; i < todo.size(); ++i)
+    {
+        const int n = todo[i].first; const uint32_t at = todo[i].second;
+        Node nd; memcpy(nd.mn, t[n].mn, 12); memcpy(nd.mx, t[n].mx, 12);
+        if (t[n].l < 0) { nd.child = t[n].child; nd.leaves = t[n].leaves; }
+        else { nd.child = (uint32_t)out.size(); nd.leaves = 0u; out.resize(out.size() + 2); todo.push_back({ t[n].l, nd.child }); todo.push_back({ t[n].r, nd.child + 1u }); }
+        out[at] = nd;
+    }
+    printf("topology optimisation: %d sweeps, %ld rotations, surface-area cost of the interior nodes %.4g -> %.4g (%.3f)\n", sweeps, rotations, before, after, after / before);
+    gNodes = out;
 }
 
 // ---- the 16-bit grid of rt_wide_grid.inl (conservative, a step to spare) ----
@@ -160,6 +223,7 @@ static inline bool triHit(const Ray& r, const Tri& t, float& dist)
     return dist > 0.0f;
 }
 
+static inline float cullKey(float nearD) { if (gCullBits <= 0) return nearD; uint32_t u; memcpy(&u, &nearD, 4); u &= ~((1u << (31 - gCullBits)) - 1u); float f; memcpy(&f, &u, 4); return f; }
 struct Stats
 {
     double rays = 0, interior = 0, leaves = 0, triTests = 0, boxTests = 0, entered = 0, maxStack = 0, stackOver[4] = { 0, 0, 0, 0 }, hits = 0, distMismatch = 0;
@@ -211,7 +275,7 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             if (numHit == 0)
             {
                 if (stack.empty()) have = false;
-                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cur.nearD >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
+                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cullKey(cur.nearD) >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
             }
             else
             {
@@ -237,7 +301,7 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             if (have)
             {
                 if (stack.empty()) have = false;
-                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cur.nearD >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
+                else { cur = stack.back(); stack.pop_back(); if (groupStack) { if (--groupSizes.back() == 0) groupSizes.pop_back(); } while (gCullOnPop && !r.anyHit && cullKey(cur.nearD) >= best) { if (stack.empty()) { have = false; break; } cur = stack.back(); stack.pop_back(); } }
             }
         }
     }
@@ -262,13 +326,15 @@ static Ray makeRay(const float o[3], const float d[3], float offset, float tmax,
 int main(int argc, char** argv)
 {
     const std::string dir = argc > 1 ? argv[1] : "/tmp/walk_model";
-    gCullOnPop = argc > 2 && atoi(argv[2]) != 0;
+    gCullOnPop = argc > 2 && atoi(argv[2]) != 0; gCullBits = argc > 2 && atoi(argv[2]) > 1 ? atoi(argv[2]) : 0;
+    const int topologySweeps = argc > 3 ? atoi(argv[3]) : 0;
     size_t numNodes = 0, numTris = 0, numRays = 0; float sun[3];
     { FILE* f = fopen((dir + "/meta.txt").c_str(), "r"); if (!f || fscanf(f, "%zu %zu %zu %f %f %f", &numNodes, &numTris, &numRays, &sun[0], &sun[1], &sun[2]) != 6) { fprintf(stderr, "no meta.txt in %s\n", dir.c_str()); return 1; } fclose(f); }
     gNodes.resize(numNodes); gTris.resize(numTris);
     std::vector<RayIn> in(numRays);
     auto slurp = [&](const char* name, void* dst, size_t bytes) { FILE* f = fopen((dir + "/" + name).c_str(), "rb"); if (!f || fread(dst, 1, bytes, f) != bytes) { fprintf(stderr, "bad %s\n", name); exit(1); } fclose(f); };
     slurp("nodes.bin", gNodes.data(), numNodes * sizeof(Node)); slurp("tris.bin", gTris.data(), numTris * sizeof(Tri)); slurp("rays.bin", in.data(), numRays * sizeof(RayIn));
+    if (topologySweeps > 0) optimiseTopology(topologySweeps);
     buildGrid();
 
     // the rays: every recorded path segment as a closest-hit ray; from every vertex that hit something a next-event ray -- towards the sun (a 1-degree cone: its axis)
@@ -290,7 +356,7 @@ int main(int argc, char** argv)
 
     struct Variant { const char* name; int width; bool octSlots, planes8; int order; bool group; };
     const Variant variants[] = {
-        { "W4  16-bit planes, distance order (today)", 4, false, false, 0, false },
+        { "W4  16-bit planes, distance order (round 5)", 4, false, false, 0, false },
         { "W4o 16-bit planes, octant order", 4, true, false, 1, false },
         { "W8  16-bit planes, distance order", 8, false, false, 0, true },
         { "W8  16-bit planes, octant order", 8, true, false, 1, true },
@@ -326,12 +392,12 @@ int main(int argc, char** argv)
                 if (kind == 0 && in[i].dist < 1e30f && fabsf(d - in[i].dist) > 2e-3f * fmaxf(1.0f, in[i].dist)) mismatch++;
             }
             if (&v == &variants[0]) base[kind] = s.interior / s.rays;
-            printf("  %-11s interior %6.2f per ray (%.3f of today's), leaf visits %5.2f, triangle tests %5.2f, box tests %6.1f, children entered per visit %.2f, hit %.3f, deepest stack %2.0f (rays over 6 / 8 / 10 / 13 entries: %.0f / %.0f / %.0f / %.0f)%s\n",
+            printf("  %-11s interior %6.2f per ray (%.3f of round 5's), leaf visits %5.2f, triangle tests %5.2f, box tests %6.1f, children entered per visit %.2f, hit %.3f, deepest stack %2.0f (rays over 6 / 8 / 10 / 13 entries: %.0f / %.0f / %.0f / %.0f)%s\n",
                    kind ? "any-hit:" : "closest-hit:", s.interior / s.rays, s.interior / s.rays / base[kind], s.leaves / s.rays, s.triTests / s.rays, s.boxTests / s.rays, s.entered / s.interior, s.hits / s.rays,
                    s.maxStack, s.stackOver[0], s.stackOver[1], s.stackOver[2], s.stackOver[3], kind == 0 ? (std::string("; hit distance differs from the oracle's for ") + std::to_string((long)mismatch) + " rays").c_str() : "");
             both.add(s);
         }
-        printf("  %-11s interior %6.2f per ray (%.3f of today's), leaf visits %5.2f, triangle tests %5.2f\n", "all:", both.interior / both.rays,
+        printf("  %-11s interior %6.2f per ray (%.3f of round 5's), leaf visits %5.2f, triangle tests %5.2f\n", "all:", both.interior / both.rays,
                both.interior / both.rays / ((base[0] * closest.size() + base[1] * shadow.size()) / (closest.size() + shadow.size())), both.leaves / both.rays, both.triTests / both.rays);
     }
     return 0;
