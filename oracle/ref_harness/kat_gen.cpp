@@ -134,7 +134,7 @@ enum
     KAT_FLOAT_NORMAL2 = 6, KAT_HEMISPHERE_COS = 7, KAT_SPHERE = 8, KAT_CIRCLE = 9, KAT_ORTHO_BASIS = 10,
     KAT_FRESNEL_DIELECTRIC = 11, KAT_FRESNEL_METAL = 12, KAT_REFRACT3 = 13, KAT_REFLECT3 = 14,
     KAT_BOX_RAY = 20, KAT_BOX_RAY_TWOSIDED = 21, KAT_TRIANGLE_RAY = 22, KAT_MAKE_RAY = 23, KAT_TRANSFORM_RAY = 24,
-    KAT_FAST_INVERSE = 25,
+    KAT_FAST_INVERSE = 25, KAT_TRANSFORM_SCALED = 26, KAT_FRAME_COMPOSE = 27,
     KAT_SHAPE_INTERSECT = 30, KAT_SHAPE_SAMPLE = 31, KAT_SHAPE_PDF = 32, KAT_SHAPE_EVAL = 33,
     KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41,
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
@@ -265,6 +265,63 @@ static void genGeometry()
     {
         KatWriter k("geom_fast_inverse", KAT_FAST_INVERSE, 16, 16); Lcg g(22);
         for (int i = 0; i < 256; ++i) { float* in = k.addIn(); const Matrix4 m = randomRigid(g); putM(in, m); putM(k.addOut(), m.FastInverseNoScale()); }
+        k.save();
+    }
+    {
+        // Round 6 (review item 6): what Scene::Traverse_Object / EvaluateIntersection (Scene.cpp:128-165, 305-348 -- a translation unit that does not build here) call
+        // on an INSTANCE'S matrices, on rotated AND scaled transforms: Matrix4::TransformPoint / TransformVector, and FastInverseNoScale followed by TransformPoint
+        // (Scene.cpp:313-317: not an inverse once the matrix scales -- the reference's behaviour, pinned as it is)
+        KatWriter k("geom_transform_scaled", KAT_TRANSFORM_SCALED, 20, 12); Lcg g(26);
+        for (int i = 0; i < N; ++i)
+        {
+            Matrix4 m = randomRigid(g);
+            if (i % 3 != 0) { const Vector4 scale = (i % 3 == 1) ? Vector4(g.range(0.25f, 4.0f)) : g.vec(0.25f, 4.0f); for (int r = 0; r < 3; ++r) m.rows[r] = m.rows[r] * (r == 0 ? scale.x : (r == 1 ? scale.y : scale.z)); }
+            const Vector4 v = g.vec(-10.0f, 10.0f);
+            float* in = k.addIn(); putM(in, m); put4(in + 16, v);
+            float* out = k.addOut(); put4(out, m.TransformPoint(v)); put4(out + 4, m.TransformVector(v)); put4(out + 8, m.FastInverseNoScale().TransformPoint(v));
+        }
+        k.save();
+    }
+    {
+        // The frame composition of Scene::EvaluateIntersection, Scene.cpp:311-348, from the reference's own inline functions in the reference's order: local hit
+        // position, normal mapping in the tangent frame (FastNormalized3), Vector4::Orthogonalize + Normalized3 of the tangent, both vectors to world space
+        // (TransformVector), Cross3 for the bitangent.  in: transform[16], ray origin[4], ray direction[4], {distance, normal-mapped?, 0, 0}, local tangent[4],
+        // local normal[4], tangent-space normal of the map[4]; out: local position[4], frame rows 0..3.
+        KatWriter k("frame_compose", KAT_FRAME_COMPOSE, 40, 20); Lcg g(27);
+        for (int i = 0; i < 2 * N; ++i)
+        {
+            Matrix4 transform = randomRigid(g);
+            if (i % 4 == 3) { const float scale = g.range(0.5f, 2.0f); for (int r = 0; r < 3; ++r) transform.rows[r] = transform.rows[r] * scale; }
+            const Ray ray(g.vec(-10.0f, 10.0f), g.dir());
+            const float distance = g.range(0.01f, 50.0f);
+            const bool mapped = (i & 1) != 0;
+            // interpolated vertex data: unit-ish, not exactly orthogonal
+            const Vector4 normal = (g.dir() + g.vec(-0.05f, 0.05f));
+            Vector4 tangent = Vector4::Cross3(normal, g.dir()).Normalized3() + g.vec(-0.1f, 0.1f) + normal * g.range(-0.2f, 0.2f);
+            Vector4 mapNormal = Vector4(g.range(-0.6f, 0.6f), g.range(-0.6f, 0.6f), 0.0f, 0.0f); mapNormal.z = sqrtf(1.0f - mapNormal.x * mapNormal.x - mapNormal.y * mapNormal.y);
+            float* in = k.addIn(); putM(in, transform); put4(in + 16, ray.origin); put4(in + 20, ray.dir); in[24] = distance; in[25] = mapped ? 1.0f : 0.0f;
+            put4(in + 28, tangent); put4(in + 32, normal); put4(in + 36, mapNormal);
+
+            const Matrix4 invTransform = transform.FastInverseNoScale();
+            const Vector4 worldPosition = ray.GetAtDistance(distance);
+            const Vector4 localPosition = invTransform.TransformPoint(worldPosition);
+            Vector4 localSpaceTangent = tangent, localSpaceNormal = normal;
+            const Vector4 localSpaceBitangent = Vector4::Cross3(localSpaceTangent, localSpaceNormal);
+            if (mapped)
+            {
+                Vector4 newNormal = localSpaceTangent * mapNormal.x;
+                newNormal = Vector4::MulAndAdd(localSpaceBitangent, mapNormal.y, newNormal);
+                newNormal = Vector4::MulAndAdd(localSpaceNormal, mapNormal.z, newNormal);
+                localSpaceNormal = newNormal.FastNormalized3();
+            }
+            localSpaceTangent = Vector4::Orthogonalize(localSpaceTangent, localSpaceNormal).Normalized3();
+            Vector4 frame[4];
+            frame[2] = transform.TransformVector(localSpaceNormal);
+            frame[0] = transform.TransformVector(localSpaceTangent);
+            frame[1] = Vector4::Cross3(frame[0], frame[2]);
+            frame[3] = worldPosition;
+            float* out = k.addOut(); put4(out, localPosition); for (int r = 0; r < 4; ++r) put4(out + 4 + 4 * r, frame[r]);
+        }
         k.save();
     }
     {

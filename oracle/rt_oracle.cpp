@@ -137,7 +137,7 @@ enum
     KAT_FLOAT_NORMAL2 = 6, KAT_HEMISPHERE_COS = 7, KAT_SPHERE = 8, KAT_CIRCLE = 9, KAT_ORTHO_BASIS = 10,
     KAT_FRESNEL_DIELECTRIC = 11, KAT_FRESNEL_METAL = 12, KAT_REFRACT3 = 13, KAT_REFLECT3 = 14,
     KAT_BOX_RAY = 20, KAT_BOX_RAY_TWOSIDED = 21, KAT_TRIANGLE_RAY = 22, KAT_MAKE_RAY = 23, KAT_TRANSFORM_RAY = 24,
-    KAT_FAST_INVERSE = 25,
+    KAT_FAST_INVERSE = 25, KAT_TRANSFORM_SCALED = 26, KAT_FRAME_COMPOSE = 27,
     KAT_SHAPE_INTERSECT = 30, KAT_SHAPE_SAMPLE = 31, KAT_SHAPE_PDF = 32, KAT_SHAPE_EVAL = 33,
     KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41,
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51,
@@ -196,6 +196,22 @@ int rto_kat(int func, const float* in, int inStride, float* out, int outStride, 
             putV4(o, l.origin); putV4(o + 4, l.dir); putV4(o + 8, l.invDir); putV4(o + 12, l.originDivDir); break;
         }
         case KAT_FAST_INVERSE: { const M4 m = fastInverseNoScale(loadM4(i)); for (int k = 0; k < 4; ++k) putV4(o + 4 * k, m.r[k]); break; }
+        case KAT_TRANSFORM_SCALED:   // in: matrix[16] (rotation x scale + translation), v[4]  out: TransformPoint, TransformVector, FastInverseNoScale().TransformPoint
+        {
+            const M4 m = loadM4(i); const V4 v = load4(i + 16);
+            putV4(o, transformPoint(m, v)); putV4(o + 4, transformVector(m, v)); putV4(o + 8, transformPoint(fastInverseNoScale(m), v)); break;
+        }
+        case KAT_FRAME_COMPOSE:      // Scene::EvaluateIntersection's frame, Scene.cpp:311-348 (layout: kat_gen.cpp)
+        {
+            const M4 transform = loadM4(i);
+            Ray ray; ray.origin = load4(i + 16); ray.dir = load4(i + 20); ray.invDir = zero4(); ray.originDivDir = zero4();
+            const V4 worldPosition = rayAt(ray, i[24]);
+            M4 frame;
+            composeShadingFrame(transform, worldPosition, load4(i + 28), load4(i + 32), i[25] != 0.0f, load4(i + 36), frame);
+            putV4(o, transformPoint(fastInverseNoScale(transform), worldPosition));
+            for (int k = 0; k < 4; ++k) putV4(o + 4 + 4 * k, frame.r[k]);
+            break;
+        }
         case KAT_BOX_RAY:         // in: origin[4], direction[4] (unnormalized), bmin[3], bmax[3]
         {
             const Ray ray = makeRay(load4(i), load4(i + 4));

@@ -772,6 +772,25 @@ static inline V4 materialGetNormalVector(const RtSceneDesc* d, const RtMaterial&
     return lerp4(V4(0.0f, 0.0f, 1.0f, 0.0f), normal, splat(mat.normalMapStrength));
 }
 
+// The tail of Scene::EvaluateIntersection, Scene.cpp:322-348: normal mapping in the local tangent frame, the tangent made orthogonal to the (mapped) normal,
+// both taken to world space.  Pinned on its own by frame_compose.kat (the reference's inline functions composed in this order by oracle/ref_harness/kat_gen.cpp).
+static inline void composeShadingFrame(const M4& transform, V4 worldPosition, V4 localSpaceTangent, V4 localSpaceNormal, bool mapped, V4 localNormal, M4& frame)
+{
+    const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
+    if (mapped)
+    {
+        V4 newNormal = localSpaceTangent * localNormal.x;
+        newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
+        newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
+        localSpaceNormal = fastNormalized3(newNormal);
+    }
+    localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
+    frame.r[2] = transformVector(transform, localSpaceNormal);
+    frame.r[0] = transformVector(transform, localSpaceTangent);
+    frame.r[1] = cross3(frame.r[0], frame.r[2]);
+    frame.r[3] = worldPosition;
+}
+
 // Scene::EvaluateIntersection, Scene.cpp:305-365
 static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ray, const Hit& hit, Intersection& out, Counters& cnt)
 {
@@ -794,22 +813,9 @@ static inline void sceneEvaluateIntersection(const RtSceneDesc* d, const Ray& ra
         else { shapeEvaluateIntersection(obj.shapeKind, obj.shapeParam, obj.shapeParam2, out); cnt.c[C_ANALYTIC_HITS]++; }
     }
 
-    V4 localSpaceTangent = out.frame.r[0];
-    V4 localSpaceNormal = out.frame.r[2];
-    const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
-    if (out.material != RT_NO_MATERIAL && d->materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
-    {
-        const V4 localNormal = materialGetNormalVector(d, d->materials[out.material], out.texCoord);
-        V4 newNormal = localSpaceTangent * localNormal.x;
-        newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
-        newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
-        localSpaceNormal = fastNormalized3(newNormal);
-    }
-    localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
-    out.frame.r[2] = transformVector(transform, localSpaceNormal);
-    out.frame.r[0] = transformVector(transform, localSpaceTangent);
-    out.frame.r[1] = cross3(out.frame.r[0], out.frame.r[2]);
-    out.frame.r[3] = worldPosition;
+    const bool mapped = out.material != RT_NO_MATERIAL && d->materials[out.material].normalMapTexture != RT_NO_TEXTURE;   // normal mapping, :327-337
+    const V4 localNormal = mapped ? materialGetNormalVector(d, d->materials[out.material], out.texCoord) : zero4();
+    composeShadingFrame(transform, worldPosition, out.frame.r[0], out.frame.r[2], mapped, localNormal, out.frame);
 }
 
 // =====================================================================================================

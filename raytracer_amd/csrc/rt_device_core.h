@@ -641,6 +641,26 @@ RT_DEV V4 materialGetNormalVector(const RtSceneDesc& d, const RtMaterial& mat, V
     return lerp4(V4(0.0f, 0.0f, 1.0f, 0.0f), normal, splat(mat.normalMapStrength));
 }
 
+
+// The tail of Scene::EvaluateIntersection, Scene.cpp:322-348: normal mapping in the local tangent frame, the tangent made orthogonal to the (mapped) normal, both
+// taken to world space.  Held against the reference on its own by frame_compose.kat (rtgpu_kat, tests/test_gpu_kat.py).
+RT_DEV void composeShadingFrame(const M4& transform, V4 worldPosition, V4 localSpaceTangent, V4 localSpaceNormal, bool mapped, V4 localNormal, M4& frame)
+{
+    if (mapped)
+    {
+        const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
+        V4 newNormal = localSpaceTangent * localNormal.x;
+        newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
+        newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
+        localSpaceNormal = fastNormalized3(newNormal);
+    }
+    localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
+    frame.r[2] = transformVector(transform, localSpaceNormal);
+    frame.r[0] = transformVector(transform, localSpaceTangent);
+    frame.r[1] = cross3(frame.r[0], frame.r[2]);
+    frame.r[3] = worldPosition;
+}
+
 // Scene::EvaluateIntersection, Scene.cpp:305-365
 // kLean: the scene class the shading kernels are specialised for (rtgpu_upload_scene decides), two independent properties:
 //   RT_LEAN(k)     -- only mesh shapes (no analytic shapes, no finite lights among the objects: a hit can only be a mesh triangle), only
@@ -677,22 +697,10 @@ __device__ __forceinline__ static void sceneEvaluateIntersection(const RtSceneDe
         else { shapeEvaluateIntersection(obj.shapeKind, obj.shapeParam, obj.shapeParam2, out); cnt.c[C_ANALYTIC_HITS]++; }
     }
 
-    V4 localSpaceTangent = out.frame.r[0];
-    V4 localSpaceNormal = out.frame.r[2];
-    if (RT_TEXTURED(kLean) && out.material != RT_NO_MATERIAL && d.materials[out.material].normalMapTexture != RT_NO_TEXTURE)   // normal mapping, :327-337
-    {
-        const V4 localSpaceBitangent = cross3(localSpaceTangent, localSpaceNormal);
-        const V4 localNormal = materialGetNormalVector<kLean>(d, d.materials[out.material], out.texCoord);
-        V4 newNormal = localSpaceTangent * localNormal.x;
-        newNormal = mulAdd(localSpaceBitangent, localNormal.y, newNormal);
-        newNormal = mulAdd(localSpaceNormal, localNormal.z, newNormal);
-        localSpaceNormal = fastNormalized3(newNormal);
-    }
-    localSpaceTangent = normalized3(orthogonalize(localSpaceTangent, localSpaceNormal));   // :342
-    out.frame.r[2] = transformVector(transform, localSpaceNormal);
-    out.frame.r[0] = transformVector(transform, localSpaceTangent);
-    out.frame.r[1] = cross3(out.frame.r[0], out.frame.r[2]);
-    out.frame.r[3] = worldPosition;
+    const bool mapped = RT_TEXTURED(kLean) && out.material != RT_NO_MATERIAL && d.materials[out.material].normalMapTexture != RT_NO_TEXTURE;   // normal mapping, :327-337
+    V4 localNormal = zero4();
+    if (mapped) localNormal = materialGetNormalVector<kLean>(d, d.materials[out.material], out.texCoord);
+    composeShadingFrame(transform, worldPosition, out.frame.r[0], out.frame.r[2], mapped, localNormal, out.frame);
 }
 
 // =====================================================================================================

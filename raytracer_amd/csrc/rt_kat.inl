@@ -56,6 +56,22 @@ __global__ void __launch_bounds__(64) k_kat(const RtSceneDesc scene, uint32_t fu
         katPut(o, l.origin); katPut(o + 4, l.dir); katPut(o + 8, l.invDir); katPut(o + 12, l.originDivDir); break;
     }
     case KAT_FAST_INVERSE: { const M4 m = fastInverseNoScale(loadM4(i)); for (int k = 0; k < 4; ++k) katPut(o + 4 * k, m.r[k]); break; }
+    case KAT_TRANSFORM_SCALED:   // in: matrix[16] (rotation x scale + translation), v[4]  out: TransformPoint, TransformVector, FastInverseNoScale().TransformPoint
+    {
+        const M4 m = loadM4(i); const V4 v = load4(i + 16);
+        katPut(o, transformPoint(m, v)); katPut(o + 4, transformVector(m, v)); katPut(o + 8, transformPoint(fastInverseNoScale(m), v)); break;
+    }
+    case KAT_FRAME_COMPOSE:      // Scene::EvaluateIntersection's frame, Scene.cpp:311-348 (record layout: tests/golden/README.md): the function the shading kernels call
+    {
+        const M4 transform = loadM4(i);
+        Ray ray; ray.origin = load4(i + 16); ray.dir = load4(i + 20); ray.invDir = zero4(); ray.originDivDir = zero4();
+        const V4 worldPosition = rayAt(ray, i[24]);
+        M4 frame;
+        composeShadingFrame(transform, worldPosition, load4(i + 28), load4(i + 32), i[25] != 0.0f, load4(i + 36), frame);
+        katPut(o, transformPoint(fastInverseNoScale(transform), worldPosition));
+        for (int k = 0; k < 4; ++k) katPut(o + 4 + 4 * k, frame.r[k]);
+        break;
+    }
     case KAT_BOX_RAY:         // in: origin[4], direction[4] (unnormalized), bmin[3], bmax[3]; both slab-test forms of the traversal kernels
     {
         const Ray ray = makeRay(load4(i), load4(i + 4));

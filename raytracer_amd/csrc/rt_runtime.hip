@@ -1888,7 +1888,7 @@ RTGPU_API int rtgpu_kat(RtgpuContext* c, uint32_t func, const float* in, uint32_
         { KAT_SIN_LANE, 1, 1 }, { KAT_SINCOS, 1, 4 }, { KAT_FASTLOG, 1, 1 }, { KAT_FASTACOS, 1, 1 }, { KAT_FASTATAN2, 2, 1 }, { KAT_FLOAT_NORMAL2, 2, 4 },
         { KAT_HEMISPHERE_COS, 2, 4 }, { KAT_SPHERE, 2, 4 }, { KAT_CIRCLE, 2, 4 }, { KAT_ORTHO_BASIS, 4, 8 }, { KAT_FRESNEL_DIELECTRIC, 2, 1 },
         { KAT_FRESNEL_METAL, 3, 1 }, { KAT_REFRACT3, 9, 4 }, { KAT_REFLECT3, 8, 4 }, { KAT_BOX_RAY, 14, 2 }, { KAT_BOX_RAY_TWOSIDED, 14, 3 },
-        { KAT_TRIANGLE_RAY, 17, 4 }, { KAT_MAKE_RAY, 8, 12 }, { KAT_TRANSFORM_RAY, 24, 16 }, { KAT_FAST_INVERSE, 16, 16 }, { KAT_SHAPE_INTERSECT, 13, 4 },
+        { KAT_TRIANGLE_RAY, 17, 4 }, { KAT_MAKE_RAY, 8, 12 }, { KAT_TRANSFORM_RAY, 24, 16 }, { KAT_FAST_INVERSE, 16, 16 }, { KAT_TRANSFORM_SCALED, 20, 12 }, { KAT_FRAME_COMPOSE, 40, 20 }, { KAT_SHAPE_INTERSECT, 13, 4 },
         { KAT_SHAPE_SAMPLE, 12, 8 }, { KAT_SHAPE_PDF, 13, 1 }, { KAT_SHAPE_EVAL, 13, 16 },
         { KAT_LIGHT_ILLUMINATE, (uint32_t)(sizeof(RtLight) / 4) + 19, 11 }, { KAT_LIGHT_RADIANCE, (uint32_t)(sizeof(RtLight) / 4) + 13, 5 },
         { KAT_LIGHT_EMIT, (uint32_t)(sizeof(RtLight) / 4) + 5, 15 }, { KAT_LIGHT_ILLUMINATE_BIDIR, (uint32_t)(sizeof(RtLight) / 4) + 19, 12 },

@@ -10,7 +10,7 @@ enum
     KAT_FLOAT_NORMAL2 = 6, KAT_HEMISPHERE_COS = 7, KAT_SPHERE = 8, KAT_CIRCLE = 9, KAT_ORTHO_BASIS = 10,
     KAT_FRESNEL_DIELECTRIC = 11, KAT_FRESNEL_METAL = 12, KAT_REFRACT3 = 13, KAT_REFLECT3 = 14,
     KAT_BOX_RAY = 20, KAT_BOX_RAY_TWOSIDED = 21, KAT_TRIANGLE_RAY = 22, KAT_MAKE_RAY = 23, KAT_TRANSFORM_RAY = 24,
-    KAT_FAST_INVERSE = 25,
+    KAT_FAST_INVERSE = 25, KAT_TRANSFORM_SCALED = 26, KAT_FRAME_COMPOSE = 27,
     KAT_SHAPE_INTERSECT = 30, KAT_SHAPE_SAMPLE = 31, KAT_SHAPE_PDF = 32, KAT_SHAPE_EVAL = 33,
     KAT_LIGHT_ILLUMINATE = 40, KAT_LIGHT_RADIANCE = 41, KAT_LIGHT_EMIT = 42, KAT_LIGHT_ILLUMINATE_BIDIR = 43, KAT_LIGHT_RADIANCE_BIDIR = 44,
     KAT_BSDF_SAMPLE = 50, KAT_BSDF_EVALUATE = 51, KAT_BSDF_PDFS = 52,

@@ -12,7 +12,7 @@ _lib = None
 
 KAT = dict(SIN_LANE=1, SINCOS=2, FASTLOG=3, FASTACOS=4, FASTATAN2=5, FLOAT_NORMAL2=6, HEMISPHERE_COS=7, SPHERE=8, CIRCLE=9,
            ORTHO_BASIS=10, FRESNEL_DIELECTRIC=11, FRESNEL_METAL=12, REFRACT3=13, REFLECT3=14, BOX_RAY=20, BOX_RAY_TWOSIDED=21,
-           TRIANGLE_RAY=22, MAKE_RAY=23, TRANSFORM_RAY=24, FAST_INVERSE=25, SHAPE_INTERSECT=30, SHAPE_SAMPLE=31, SHAPE_PDF=32,
+           TRIANGLE_RAY=22, MAKE_RAY=23, TRANSFORM_RAY=24, FAST_INVERSE=25, TRANSFORM_SCALED=26, FRAME_COMPOSE=27, SHAPE_INTERSECT=30, SHAPE_SAMPLE=31, SHAPE_PDF=32,
            SHAPE_EVAL=33, LIGHT_ILLUMINATE=40, LIGHT_RADIANCE=41, BSDF_SAMPLE=50, BSDF_EVALUATE=51, CAMERA_RAY=60)
 
 
