@@ -129,7 +129,7 @@ def test_roofline_block_is_a_fraction_of_a_roof(built, steps, warmup):
     roof = d["roofline"]
     print(json.dumps({k: roof.get(k) for k in ("kernel", "avg_launch_ms", "profiled_avg_launch_ms", "achieved", "frac", "request_rate_over_hbm_peak", "reference_walk_frac",
                                                 "frac_of_binding_ceiling", "bound", "traffic_over_compulsory")}), d["value"], d["frame_in_hbm"])
-    assert roof["kernel"] == "k_trace_wide" and roof["traffic"] is not None, roof.get("traffic_error")
+    assert roof["kernel"] == "k_trace_wide" and roof["traffic"] is not None, (roof.get("traffic_error"), r.stderr[-1500:])
     assert 0.0 < roof["frac"] <= 1.0 and roof["frac"] == roof["traffic_frac"] and abs(roof["achieved"] - roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
     assert roof["request_rate_over_hbm_peak"] is not None, roof.get("algorithmic_model")
     assert roof["request_rate_over_hbm_peak"] > roof["frac"]            # the caches answer most requests
