@@ -98,28 +98,78 @@ def make_viewport(ra, args, scene, device, shard=None):
 
 
 def init_process_group(dist, backend, device=None, timeout_s=600):
-    """The N > 1 run's process group: RCCL (`nccl`) as asked, and -- if the communicator does not come up on this node (initialisation or the first barrier
-    raises) -- gloo with host-staged tile exchange instead of no measurement at all: the exchange is 24.9 MB once per timed region, the passes do not
-    communicate.  Returns (backend in use, reason for a fallback or None).  A rank whose peers failed sees its own barrier time out and falls back too."""
+    """The N > 1 run's process group: RCCL (`nccl`) as asked, and -- if the communicator does not come up on this node -- gloo with host-staged tile exchange
+    instead of no measurement at all: the exchange is 24.9 MB once per timed region, the passes do not communicate.  Returns (backend in use, reason for a
+    fallback or None).
+
+    Round 6 (advisor): the ranks AGREE on the fallback explicitly instead of finding out through a barrier's time-out.  A side TCPStore on MASTER_PORT + 1
+    (BENCH_SIDE_PORT overrides; rank 0 serves) carries one flag per rank -- "my RCCL group came up" or the exception -- written BEFORE the first collective; a
+    rank whose peer reported a failure (or did not report within the time-out) never enters the barrier it would hang in.  The gloo group of the fallback
+    rendezvouses through that side store under its own prefix, so nothing a half-initialised RCCL group left in the default store can be in its way.  If the
+    side store itself cannot be set up (the port is taken), every rank sees that alike (rank 0 cannot serve, the others cannot connect) and the round-5
+    behaviour remains: try, and fall back on whatever raises.  The first barrier still decides (a communicator can fail inside it): its time-out is the
+    group's, `timeout_s`."""
     import datetime
     if backend != "nccl":
         dist.init_process_group(backend)
         return backend, None
-    try:
-        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=timeout_s))
-        dist.barrier()
-        return "nccl", None
-    except Exception as e:   # noqa: BLE001 -- whatever the communication library throws: the fallback decides, the reason goes into the JSON line
-        reason = "nccl process group failed on rank %s: %r" % (os.environ.get("RANK", "?"), e)
-        sys.stderr.write("[bench] %s -- falling back to gloo (host-staged tile exchange)\n" % reason)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    side = None
+    if world > 1:
         try:
-            if dist.is_initialized():
-                dist.destroy_process_group()
-        except Exception:   # noqa: BLE001
-            pass
+            port = int(os.environ.get("BENCH_SIDE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+            side = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=60), wait_for_workers=False)
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("[bench] rank %d: no side store for the backend agreement (%r): falling back on exceptions only\n" % (rank, e))
+            side = None
+    ok, reason = True, None
+    stand_in = os.environ.get("BENCH_TEST_NCCL_STAND_IN")   # test hook (tests/test_multi_rank_cpu.py): a backend that comes up where there is no GPU plays RCCL's part
+    try:
+        if os.environ.get("BENCH_TEST_FAIL_NCCL_ON_RANK") == str(rank):   # test hook: a one-sided failure
+            raise RuntimeError("simulated RCCL failure on rank %d (BENCH_TEST_FAIL_NCCL_ON_RANK)" % rank)
+        if stand_in:
+            dist.init_process_group(stand_in, timeout=datetime.timedelta(seconds=timeout_s))
+        else:
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=timeout_s))
+    except Exception as e:   # noqa: BLE001 -- whatever the communication library throws: the fallback decides, the reason goes into the JSON line
+        ok, reason = False, "nccl process group failed on rank %d: %r" % (rank, e)
+    if side is not None:
+        try:
+            side.set("bench_nccl_%d" % rank, "ok" if ok else reason[:400])
+            for r in range(world):
+                try:
+                    side.wait(["bench_nccl_%d" % r], datetime.timedelta(seconds=timeout_s + 60))
+                    flag = side.get("bench_nccl_%d" % r).decode(errors="replace")
+                except Exception:   # noqa: BLE001
+                    flag = "rank %d did not report its RCCL group within %d s" % (r, timeout_s + 60)
+                if flag != "ok" and ok:
+                    ok, reason = False, "nccl process group failed on a peer: " + flag
+        except Exception as e:   # noqa: BLE001 -- the side store died: decide alone, as before
+            sys.stderr.write("[bench] rank %d: backend agreement failed (%r)\n" % (rank, e))
+    if ok:
+        try:
+            dist.barrier()
+            return (stand_in or "nccl"), None
+        except Exception as e:   # noqa: BLE001
+            ok, reason = False, "nccl process group failed in its first barrier on rank %d: %r" % (rank, e)
+    sys.stderr.write("[bench] %s -- falling back to gloo (host-staged tile exchange)\n" % reason)
+    try:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:   # noqa: BLE001
+        pass
+    # torch names the default group after a per-process counter that every ATTEMPT advances: a rank whose RCCL attempt got as far as taking a name and a rank whose
+    # attempt failed earlier would look for each other under different store keys and wait for ever.  Same counter on every rank before the fallback.
+    try:
+        dist.distributed_c10d._world.group_count = 1
+    except Exception:   # noqa: BLE001 -- a torch without that field: the symmetric case (every rank failed alike) still works
+        pass
+    if side is not None:
+        dist.init_process_group("gloo", store=dist.PrefixStore("bench_gloo_fallback", side), rank=rank, world_size=world)
+    else:
         dist.init_process_group("gloo")
-        dist.barrier()
-        return "gloo", reason[:500]
+    dist.barrier()
+    return "gloo", reason[:500]
 
 
 def device_tensor(ptr, num_floats, torch):

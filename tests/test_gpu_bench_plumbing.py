@@ -20,8 +20,10 @@ def test_device_tensor_view_and_rccl_reduce(built):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port); os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"
+    # bench.py's own set-up (round 6: explicit agreement on the backend for N > 1; at N = 1 the RCCL group, its first barrier, no fallback)
+    backend, why = bench.init_process_group(dist, "nccl", torch.device("cuda", 0), timeout_s=120)
+    assert backend == "nccl" and why is None, (backend, why)
     try:
         x = torch.arange(1024, dtype=torch.float32, device="cuda")
         t = bench.device_tensor(x.data_ptr(), x.numel(), torch)

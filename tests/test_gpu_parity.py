@@ -118,6 +118,52 @@ def test_axis_parallel_next_event_rays(built, walk, orientation):
     assert_identical(*run_both(scene, camera, w, h, walk=walk, passes=2, max_ray_depth=4, light_sampling_all=True, dimensions=64))
 
 
+def _sliver_mesh_under_a_delta_sun(aspect, orientation, num_slivers=6000, seed=11):
+    """A floor and two walls under a delta sun, filled with near-degenerate SLIVER triangles: one long edge almost along a coordinate axis (1 to 6 units, bent off it
+    by 1e-6 ... 1e-3), a third vertex 1e-5 ... 1e-2 away from the first -- extents on the short axes down to the grid's resolution, many of them lying within
+    rounding distance of the fixed coordinate of an axis-parallel next-event ray (the hit points they are cast from lie ON such slivers)."""
+    rng = np.random.RandomState(seed)
+    mb = scenes.MeshBuilder()
+    mb.add_grid((-6.0, 0.0, 6.0), (12.0, 0, 0), (0, 0, -12.0), 6, 6, 0, 4.0)        # floor
+    mb.add_grid((-6.0, 0.0, -6.0), (12.0, 0, 0), (0, 6.0, 0), 6, 3, 1, 4.0)         # back wall (normal +z)
+    mb.add_grid((-6.0, 0.0, 6.0), (0, 0, -12.0), (0, 6.0, 0), 6, 3, 1, 4.0)         # left wall (normal +x)
+    pos, idx, nrm, tan, uv, mat = mb.arrays()
+    a = np.stack([rng.uniform(-5, 5, num_slivers), rng.uniform(0.05, 4.0, num_slivers), rng.uniform(-5, 5, num_slivers)], -1)
+    axis = rng.randint(0, 3, num_slivers)
+    long_edge = np.zeros((num_slivers, 3)); long_edge[np.arange(num_slivers), axis] = rng.uniform(1.0, 6.0, num_slivers) * rng.choice([-1.0, 1.0], num_slivers)
+    long_edge += rng.standard_normal((num_slivers, 3)) * (10.0 ** rng.uniform(-6, -3, num_slivers))[:, None]
+    short_edge = rng.standard_normal((num_slivers, 3)); short_edge /= np.linalg.norm(short_edge, axis=1, keepdims=True)
+    short_edge *= (10.0 ** rng.uniform(-5, -2, num_slivers))[:, None]
+    p = np.stack([a, a + long_edge, a + short_edge], 1).reshape(-1, 3)
+    n = np.cross(long_edge, short_edge); n /= np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-30)
+    t = long_edge / np.linalg.norm(long_edge, axis=1, keepdims=True)
+    base = len(pos)
+    pos = np.concatenate([pos, p.astype(np.float32)]); nrm = np.concatenate([nrm, np.repeat(n, 3, 0).astype(np.float32)]); tan = np.concatenate([tan, np.repeat(t, 3, 0).astype(np.float32)])
+    uv = np.concatenate([uv, np.tile(np.array([[0, 0], [1, 0], [0, 1]], dtype=np.float32), (num_slivers, 1))])
+    idx = np.concatenate([idx, (base + np.arange(3 * num_slivers, dtype=np.uint32)).reshape(-1, 3)]); mat = np.concatenate([mat, np.full(num_slivers, 2, dtype=np.uint32)])
+    scene = ra.Scene()
+    mats = [scene.add_material("diffuse", c) for c in ((0.7, 0.7, 0.7), (0.6, 0.5, 0.4), (0.8, 0.3, 0.2))]
+    scene.add_mesh(pos, idx.astype(np.uint32), nrm, tan, uv, mat.astype(np.uint32), mats)
+    scene.add_background_light((0.3, 0.4, 0.5))
+    scene.add_directional_light((8.0, 7.5, 7.0), np.float32(0.0), ra.transform_from_euler((0.0, 0.0, 0.0), orientation))
+    scene.build()
+    return scene, ra.Camera((4.5, 2.5, 4.5), (15.0, 225.0, 0.0), aspect, 70.0)
+
+
+@pytest.mark.parametrize("orientation", [(90.0, 0.0, 0.0), (0.0, 0.0, 0.0), (80.0, 0.0, 0.0)])
+def test_axis_parallel_rays_among_sliver_triangles(built, walk, orientation):
+    """Round-5 advisor: the counters-off binary walk skips boxes clearly off the fixed coordinate of an axis-parallel ray (boxNearDegenerateAxes, a 2^-7 margin),
+    relying on two facts -- the builder's boxes bound their triangles' vertices in float, and Moeller-Trumbore accepts only points of the triangle.  An
+    ill-conditioned sliver is where that could break.  6000 of them (extents down to 1e-5, long edges bent 1e-6 off an axis) under a delta sun straight down / along
+    z / in a coordinate plane: the library's default walk (prune active) and the reference's counting walk (untouched) both give the oracle's image and ray
+    counters -- so the pruned walk and the unpruned one agree on exactly the rays the argument is about."""
+    w, h = 128, 80
+    scene, camera = _sliver_mesh_under_a_delta_sun(w / h, orientation)
+    out = run_both(scene, camera, w, h, walk=walk, passes=3, max_ray_depth=5)
+    assert_identical(*out)
+    assert out[2]["numShadowRays"] > out[2]["numShadowRaysHit"] > 0 and out[2]["numMeshHits"] > 0
+
+
 def test_mesh_two_level_bvh_bit_exact(built, walk):
     """Triangle mesh instance + analytic instances: mesh BVH traversal, Moller-Trumbore, barycentric frames."""
     w, h = 160, 90

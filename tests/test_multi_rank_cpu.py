@@ -22,8 +22,14 @@ from raytracer_amd import scenes
 import oracle_lib
 import bench
 # bench.py's own set-up of the process group: RCCL as asked, gloo (host-staged exchange) if the communicator does not come up -- which is the case here (no GPU)
-backend, why = bench.init_process_group(dist, os.environ.get("WORKER_BACKEND", "gloo"), timeout_s=60)
-if os.environ.get("WORKER_BACKEND") == "nccl":
+backend, why = bench.init_process_group(dist, os.environ.get("WORKER_BACKEND", "gloo"), timeout_s=int(os.environ.get("WORKER_TIMEOUT_S", "60")))
+if os.environ.get("BENCH_TEST_FAIL_NCCL_ON_RANK") is not None:
+    # a ONE-SIDED failure: the other rank's group would have come up (gloo stands in for RCCL; it waits for its peer inside init until the group's time-out, where
+    # RCCL's lazy communicator would return at once and learn of the failure from the peer's flag); both ranks must end on the fallback and say why
+    assert backend == "gloo" and why and "nccl process group failed" in why, (backend, why)
+elif os.environ.get("BENCH_TEST_NCCL_STAND_IN"):
+    assert backend == "gloo" and why is None        # (the stand-in group came up on every rank: no fallback, the agreement said yes)
+elif os.environ.get("WORKER_BACKEND") == "nccl":
     assert backend == "gloo" and why and "nccl process group failed" in why, (backend, why)
 else:
     assert backend == "gloo" and why is None
@@ -58,11 +64,12 @@ dist.destroy_process_group()
 import pytest
 
 
-@pytest.mark.parametrize("exchange", ["gather", "send_recv", "nccl_fallback"])
+@pytest.mark.parametrize("exchange", ["gather", "send_recv", "nccl_fallback", "nccl_one_sided_failure", "nccl_agreed"])
 def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path, exchange):
     """exchange = send_recv: the fallback bench.py takes when the gather collective does not come up on a fabric (BENCH_GATHER=send_recv forces it):
     grouped isend / irecv of the same packed tiles -- the same frame.  nccl_fallback: the ranks ask for RCCL where there is none (this container has no
-    GPU): bench.init_process_group falls back to gloo on every rank, says why, and the frame is the same."""
+    GPU): bench.init_process_group falls back to gloo on every rank, says why, and the frame is the same.  nccl_one_sided_failure / nccl_agreed: the explicit
+    agreement of round 6 (a flag per rank in a side store before the first collective), with one rank failing and with none."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import raytracer_amd as ra
     from raytracer_amd import scenes
@@ -85,8 +92,15 @@ def test_two_rank_tile_sharding_matches_single_rank(built, tmp_path, exchange):
         env["BENCH_GATHER"] = "send_recv"
     if exchange == "nccl_fallback":
         env["WORKER_BACKEND"] = "nccl"
+    if exchange == "nccl_one_sided_failure":
+        # round 6 (advisor): rank 1's RCCL group fails, rank 0's would come up (gloo stands in for RCCL where there is no GPU) and waits for its peer inside
+        # init -- until the group's time-out (12 s here); the flags in the side store then send BOTH ranks to the gloo fallback, which rendezvouses through the
+        # side store under its own prefix
+        env.update(WORKER_BACKEND="nccl", BENCH_TEST_NCCL_STAND_IN="gloo", BENCH_TEST_FAIL_NCCL_ON_RANK="1", WORKER_TIMEOUT_S="12")
+    if exchange == "nccl_agreed":
+        env.update(WORKER_BACKEND="nccl", BENCH_TEST_NCCL_STAND_IN="gloo")   # every rank's group comes up: the agreement says yes, no fallback
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", {"gather": "29541", "send_recv": "29543", "nccl_fallback": "29545"}[exchange], str(script), ROOT, out], env=env, timeout=600)
+                           "--master-port", {"gather": "29541", "send_recv": "29543", "nccl_fallback": "29545", "nccl_one_sided_failure": "29547", "nccl_agreed": "29549"}[exchange], str(script), ROOT, out], env=env, timeout=600)
     data = np.load(out)
     reduced = data[:-1].reshape(h, w, 3)
     assert np.array_equal(reduced.view(np.uint32), whole.view(np.uint32))
