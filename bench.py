@@ -97,7 +97,7 @@ def make_viewport(ra, args, scene, device, shard=None):
     return vp
 
 
-def init_process_group(dist, backend, device=None, timeout_s=600):
+def init_process_group(dist, backend, device=None, timeout_s=300):
     """The N > 1 run's process group: RCCL (`nccl`) as asked, and -- if the communicator does not come up on this node -- gloo with host-staged tile exchange
     instead of no measurement at all: the exchange is 24.9 MB once per timed region, the passes do not communicate.  Returns (backend in use, reason for a
     fallback or None).
