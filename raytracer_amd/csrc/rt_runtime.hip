@@ -1137,10 +1137,12 @@ static void launchTraceWide(RtgpuContext* c, hipStream_t stream, const Paths& pa
     // re-trace launch (the stack-overflow path, which the benchmark frame never takes).  As a schedule it moves time, it does not save any: what k_trace_wide's drain
     // loses (-5.6 % at N = 8) the re-trace launches gain, with or without k_trace_monster behind them (profiles/r05_drain_abort_ab.txt)
     if (const char* e = getenv("RTGPU_WIDE_DRAIN_ABORT")) tune.drainAbortAfter = (uint32_t)atoi(e);
-    // the work queue is taken from its END: the any-hit requests first, the closest-hit rays last.  A launch ends with the drain of its last rays, and unoccluded
-    // next-event rays -- no hit ever shortens them -- are the long ones: trace -1 %, 1/8 and 1/4 shards +2 % end to end (profiles/r05_claim_order_ab.txt).
-    // RTGPU_WIDE_REVERSE=0: front to back (read per launch: the tests run both orders)
-    tune.reverseOrder = 1u;
+    // The order the work queue {closest-hit rays of bounce k, any-hit requests of bounce k - 1} is taken in: a launch ends with the drain of its last rays, so the
+    // SHORT rays belong at the end.  Round 5 took it from its END (any-hit requests first): unoccluded next-event rays, which no hit ever shortens, were the long
+    // ones (trace -1 %, shards +2 %, profiles/r05_claim_order_ab.txt).  Round 6's far-first order made any-hit rays the short ones (9.9 interior visits against a
+    // closest-hit ray's 17), and the queue is taken front to back again: trace 47.5 -> 45.5 ms per 25 passes, +1 % at 256 passes, +2 % on a 1/8 shard
+    // (profiles/r06_claim_order_ab.txt).  RTGPU_WIDE_REVERSE=1: from the end (read per launch: the tests run both orders)
+    tune.reverseOrder = 0u;
     if (const char* e = getenv("RTGPU_WIDE_REVERSE")) tune.reverseOrder = (uint32_t)atoi(e);
     // any-hit rays walk the FARTHEST child they enter first (rt_trace_wide.inl: occlusion is an OR over the candidates, and the occluders of a ray that starts on a
     // surface are far from it); RTGPU_ANYHIT_FAR_FIRST=0: nearest first like closest-hit rays (read per launch: the tests run both orders)

@@ -41,7 +41,7 @@ struct WideTuning
     uint32_t chunkMin;                                        // smallest piece of the work queue a wave claims at once
     uint32_t localExact;                                      // != 0: a block traces the rays its walk does not decide itself (k_trace_wide; RTGPU_LOCAL_EXACT=0: off)
     uint32_t drainAbortAfter;                                 // != 0: a wave whose work queue ran dry this many loop iterations ago hands the rays it still walks to the binary-tree kernel
-    uint32_t reverseOrder;                                    // != 0: the queue is taken from its end (any-hit requests first, closest-hit rays last: the launch's drain is then made of rays that hits shorten)
+    uint32_t reverseOrder;                                    // != 0: the queue is taken from its end (any-hit requests first, closest-hit rays last); 0 (default since round 6): front to back -- the launch's drain is then made of the any-hit rays, the short ones under the far-first order
     uint32_t anyHitFarFirst;                                  // != 0: an any-hit ray walks the FARTHEST child it enters next (round 6; RTGPU_ANYHIT_FAR_FIRST=0: nearest, as closest-hit rays do)
 };
 

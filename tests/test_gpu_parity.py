@@ -850,7 +850,7 @@ def assert_quant_identical(img, img2, counters, ref, ref2, ref_counters):
     assert counters["numRayBoxTests"] == 0 and counters["numRayTriangleTests"] == 0   # the reference's counters belong to its own walk
 
 
-@pytest.mark.parametrize("dense", ["0", "1", "front-to-back", "any-hit-nearest-first"])
+@pytest.mark.parametrize("dense", ["0", "1", "back-to-front", "any-hit-nearest-first"])
 def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dense):
     """k_trace_wide (4-wide collapse of the same tree, conservative 16-bit boxes, exact leaf gate, runner-up tracking, exact re-trace,
     stack-overflow hand-over) gives the reference's hits: images and ray / shadow-ray / hit counters identical to the oracle's binary-tree
@@ -859,8 +859,8 @@ def test_wide_traversal_bit_exact_on_single_mesh_scenes(built, monkeypatch, dens
     change a result); the last case runs them nearest first like closest-hit rays (RTGPU_ANYHIT_FAR_FIRST=0) -- same bits either way."""
     monkeypatch.setenv("RTGPU_WIDE", "1")
     monkeypatch.setenv("RTGPU_NO_DENSE", "1" if dense == "0" else "0")
-    if dense == "front-to-back":
-        monkeypatch.setenv("RTGPU_WIDE_REVERSE", "0")   # (the default takes a launch's queue from its end)
+    if dense == "back-to-front":
+        monkeypatch.setenv("RTGPU_WIDE_REVERSE", "1")   # (round 5's default: a launch's queue taken from its end; round 6 takes it front to back)
     if dense == "any-hit-nearest-first":
         monkeypatch.setenv("RTGPU_ANYHIT_FAR_FIRST", "0")
     w, h = 128, 72
