@@ -262,6 +262,7 @@ static float walk(const WTree& t, const Ray& r, int order, bool groupStack, Stat
             else if (order == 6) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].nearD > hit[j].nearD; --j) { std::swap(hit[j - 1], hit[j]); } }   // FARTHEST first
             else if (order == 7) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && (hit[j - 1].farD - hit[j - 1].nearD) > (hit[j].farD - hit[j].nearD); --j) { std::swap(hit[j - 1], hit[j]); } }   // LONGEST chord first
             else if (order == 8) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && hit[j - 1].farD > hit[j].farD; --j) { std::swap(hit[j - 1], hit[j]); } }   // largest EXIT distance first
+            else if (order == 9) { for (int i = 1; i < numHit; ++i) for (int j = i; j > 0 && slotKey[j - 1] > slotKey[j]; --j) { std::swap(hit[j - 1], hit[j]); std::swap(slotKey[j - 1], slotKey[j]); } }   // REVERSE octant order (the slot farthest along the ray first)
             else if (order == 4) { }                                    // reverse storage order (the highest slot first)
             else if (order == 5) { static uint32_t lc = 12345u; for (int i = numHit - 1; i > 0; --i) { lc = lc * 1664525u + 1013904223u; std::swap(hit[i], hit[(lc >> 16) % (uint32_t)(i + 1)]); } }   // random order
             else if (order == 3)
@@ -373,6 +374,8 @@ int main(int argc, char** argv)
         { "W4  16-bit planes, largest EXIT distance first", 4, false, false, 8, false },
         { "W8  8-bit planes, FARTHEST child first", 8, false, true, 6, true },
         { "W8  8-bit planes, REVERSE storage order", 8, false, true, 4, true },
+        { "W8  8-bit planes, REVERSE octant order (any-hit rays only are meaningful)", 8, true, true, 9, true },
+        { "W4  16-bit planes, REVERSE octant order (any-hit rays only are meaningful)", 4, true, false, 9, false },
     };
     double base[2] = { 0, 0 };
     for (const Variant& v : variants)
