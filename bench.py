@@ -97,7 +97,23 @@ def make_viewport(ra, args, scene, device, shard=None):
     return vp
 
 
-def init_process_group(dist, backend, device=None, timeout_s=300):
+def open_side_store(dist, connect_timeout_s=120):
+    """The side TCPStore of init_process_group's backend agreement: MASTER_PORT + 1 (BENCH_SIDE_PORT overrides), rank 0 serves.  main() opens it FIRST -- before
+    rank 0 builds the library, which can take a minute while the other ranks are already waiting -- so that every rank finds it within seconds.  None if it
+    cannot be set up (the port is taken: rank 0 cannot bind, the others cannot connect): every rank then sees the same thing and the agreement is skipped."""
+    import datetime
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    try:
+        port = int(os.environ.get("BENCH_SIDE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+        side = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=connect_timeout_s), wait_for_workers=False)
+        side.set("bench_side_hello_%d" % rank, "1")     # (a foreign service on that port fails here, not in the middle of the agreement)
+        return side
+    except Exception as e:   # noqa: BLE001
+        sys.stderr.write("[bench] rank %d: no side store for the backend agreement (%r): the fallback is decided by exceptions only\n" % (rank, e))
+        return None
+
+
+def init_process_group(dist, backend, device=None, timeout_s=300, side=None):
     """The N > 1 run's process group: RCCL (`nccl`) as asked, and -- if the communicator does not come up on this node -- gloo with host-staged tile exchange
     instead of no measurement at all: the exchange is 24.9 MB once per timed region, the passes do not communicate.  Returns (backend in use, reason for a
     fallback or None).
@@ -114,14 +130,8 @@ def init_process_group(dist, backend, device=None, timeout_s=300):
         dist.init_process_group(backend)
         return backend, None
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    side = None
-    if world > 1:
-        try:
-            port = int(os.environ.get("BENCH_SIDE_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
-            side = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=60), wait_for_workers=False)
-        except Exception as e:   # noqa: BLE001
-            sys.stderr.write("[bench] rank %d: no side store for the backend agreement (%r): falling back on exceptions only\n" % (rank, e))
-            side = None
+    if side is None and world > 1:
+        side = open_side_store(dist)
     ok, reason = True, None
     stand_in = os.environ.get("BENCH_TEST_NCCL_STAND_IN")   # test hook (tests/test_multi_rank_cpu.py): a backend that comes up where there is no GPU plays RCCL's part
     try:
@@ -165,9 +175,9 @@ def init_process_group(dist, backend, device=None, timeout_s=300):
     except Exception:   # noqa: BLE001 -- a torch without that field: the symmetric case (every rank failed alike) still works
         pass
     if side is not None:
-        dist.init_process_group("gloo", store=dist.PrefixStore("bench_gloo_fallback", side), rank=rank, world_size=world)
+        dist.init_process_group("gloo", store=dist.PrefixStore("bench_gloo_fallback", side), rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     else:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
     dist.barrier()
     return "gloo", reason[:500]
 
@@ -519,6 +529,8 @@ def main():
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
+    # (N > 1, RCCL asked for) the side store of the backend agreement, before rank 0's build keeps the other ranks waiting
+    side_store = open_side_store(dist) if (world > 1 and os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl") else None
     if rank == 0 and not args.pmc_child and not args.walk_diag_child:
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):   # stdout carries the one JSON line and nothing else
@@ -539,7 +551,7 @@ def main():
     init_s = 0.0
     if world > 1:
         t_init = time.perf_counter()
-        backend, backend_fallback = init_process_group(dist, backend, torch.device("cuda", local_rank))
+        backend, backend_fallback = init_process_group(dist, backend, torch.device("cuda", local_rank), side=side_store)
         dist.barrier()
         torch.cuda.synchronize()
         init_s = time.perf_counter() - t_init    # communicator set-up + the first barrier: outside the timed region, reported per rank

@@ -139,11 +139,6 @@ struct BatchLane
     uint32_t* queueCounts = nullptr;
     uint32_t queueCountCapacity = 0;
     hipEvent_t accumulated = nullptr;   // recorded after the lane's k_accumulate
-    // RTGPU_CU_SPLIT (round 6, an experiment: DESIGN 4 "CU partition"): the lane's traversal launches go to a stream confined to one set of CUs, everything else
-    // to a stream confined to the rest (or to `stream` itself), ordered by events
-    hipStream_t travStream = nullptr, auxStream = nullptr;
-    hipEvent_t splitEvents[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    uint32_t splitEventNext = 0;
 };
 
 struct RtgpuContext
@@ -210,8 +205,6 @@ struct RtgpuContext
     // the next one grows by 8 passes up to 24 (8 -> 2100, 16 -> 2125-2190, 24 -> 2195-2210 Msamples/s over 256 passes); any
     // synchronising call starts over at the base size, so a caller that renders few passes between read-backs keeps the small batches.
     uint32_t passBatchBase = 8;
-    uint32_t cuSplitAux = 0, cuSplitTrav = 0;   // RTGPU_CU_SPLIT: CUs of the two partitions (0: no partition)
-    bool cuSplitAuxMasked = true;
     size_t laneBudgetBytes = (size_t)32 << 30;   // device memory one batch lane may take: 32 GB, less on a device that could not hold four such lanes
     uint32_t batchesAtThisSize = 0;    // full batches submitted at the current passBatch
     uint32_t batchesSinceSync = 0;     // batches submitted since the last synchronising call (their lanes are busy)
@@ -482,36 +475,6 @@ RTGPU_API int rtgpu_create(int deviceIndex, RtgpuContext** outCtx)
         e = acquireStream(c->device, &c->lanes[i].stream);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->lanes[i].accumulated, hipEventDisableTiming);
     }
-    // RTGPU_CU_SPLIT=K (experiment, review item 3 of round 5): K CUs (a multiple of 8: K / 8 per XCD under either layout) are kept for the short kernels --
-    // shade, generate, accumulate, re-trace -- and the persistent traversal launches are confined to the other numCUs - K (hipExtStreamCreateWithCUMask).
-    // RTGPU_CU_SPLIT_LAYOUT=0: the K highest mask bits, 1: every (numCUs / K)-th bit.  RTGPU_CU_SPLIT_AUX=0: the short kernels stay on the lane's ordinary
-    // (unconfined) stream: they may also use what the traversal leaves free on its own CUs.
-    if (const char* env = getenv("RTGPU_CU_SPLIT"))
-    {
-        const uint32_t k = (uint32_t)atoi(env);
-        if (k >= 8u && k % 8u == 0u && k * 2u <= c->numCUs && c->numCUs % 32u == 0u)
-        {
-            const bool strided = getenv("RTGPU_CU_SPLIT_LAYOUT") && atoi(getenv("RTGPU_CU_SPLIT_LAYOUT")) != 0;
-            c->cuSplitAuxMasked = !(getenv("RTGPU_CU_SPLIT_AUX") && atoi(getenv("RTGPU_CU_SPLIT_AUX")) == 0);
-            std::vector<uint32_t> travMask(c->numCUs / 32u, 0u), auxMask(c->numCUs / 32u, 0u);
-            const uint32_t period = c->numCUs / k;
-            for (uint32_t cu = 0; cu < c->numCUs; ++cu)
-            {
-                const bool aux = strided ? (cu % period == period - 1u) : (cu >= c->numCUs - k);
-                (aux ? auxMask : travMask)[cu / 32u] |= 1u << (cu % 32u);
-            }
-            for (uint32_t i = 0; i < c->numLanes && e == hipSuccess; ++i)
-            {
-                e = hipExtStreamCreateWithCUMask(&c->lanes[i].travStream, (uint32_t)travMask.size(), travMask.data());
-                if (e == hipSuccess && c->cuSplitAuxMasked) e = hipExtStreamCreateWithCUMask(&c->lanes[i].auxStream, (uint32_t)auxMask.size(), auxMask.data());
-                for (int k2 = 0; k2 < 8 && e == hipSuccess; ++k2) e = hipEventCreateWithFlags(&c->lanes[i].splitEvents[k2], hipEventDisableTiming);
-            }
-            c->cuSplitAux = k; c->cuSplitTrav = c->numCUs - k;
-            if (getenv("RTGPU_VERBOSE") && atoi(getenv("RTGPU_VERBOSE")) != 0)
-                fprintf(stderr, "[rtgpu] CU partition: %u CUs traversal / %u CUs short kernels (%s layout, short kernels %s)\n", c->cuSplitTrav, c->cuSplitAux, strided ? "strided" : "contiguous",
-                        c->cuSplitAuxMasked ? "confined" : "unconfined");
-        }
-    }
     if (e == hipSuccess) e = hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(c->counters, 0, 16 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->deviceFlags, 16 * sizeof(uint32_t), hipHostMallocMapped);
@@ -618,9 +581,6 @@ RTGPU_API void rtgpu_destroy(RtgpuContext* c)
         if (c->lanes[i].queueCounts) (void)hipFree(c->lanes[i].queueCounts);
         if (c->lanes[i].denseCounts) (void)hipFree(c->lanes[i].denseCounts);
         if (c->lanes[i].accumulated) (void)hipEventDestroy(c->lanes[i].accumulated);
-        for (int k = 0; k < 8; ++k) if (c->lanes[i].splitEvents[k]) (void)hipEventDestroy(c->lanes[i].splitEvents[k]);
-        if (c->lanes[i].travStream) { (void)hipStreamSynchronize(c->lanes[i].travStream); (void)hipStreamDestroy(c->lanes[i].travStream); }
-        if (c->lanes[i].auxStream) { (void)hipStreamSynchronize(c->lanes[i].auxStream); (void)hipStreamDestroy(c->lanes[i].auxStream); }
     }
     if (c->counters) (void)hipFree(c->counters);
     if (c->deviceFlags) (void)hipHostFree(c->deviceFlags);
@@ -1284,23 +1244,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
 
     const uint32_t totalSlots = c->numSlots * numPasses;
     static const uint32_t shadeBlocksPerCU = getenv("RTGPU_SHADE_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_SHADE_BLOCKS_PER_CU")) : 8u;   // tuning knob
-    // RTGPU_CU_SPLIT: this lane's launches hop between two CU-confined streams (dense path state only); grids are sized for the CUs a stream may use
-    const bool cuSplit = c->cuSplitAux != 0u && l.travStream != nullptr && c->denseAllowed && c->debugMode < 0 && maxLights <= RT_DENSE_MAX_LIGHTS && l.paths2.base != nullptr;
-    const uint32_t allCUs = c->numCUs, auxCUs = cuSplit && c->cuSplitAuxMasked ? c->cuSplitAux : c->numCUs, travCUs = cuSplit ? c->cuSplitTrav : c->numCUs;
-    hipStream_t const shortStream = cuSplit && l.auxStream ? l.auxStream : l.stream;   // generate, shade, re-trace, accumulate
-    hipStream_t const walkStream = cuSplit ? l.travStream : l.stream;                  // the persistent traversal launches
-    hipStream_t onStream = l.stream;
-    // moves the lane's launch sequence to another stream: what was queued so far happens before what is queued next
-    auto hop = [&](hipStream_t to) -> hipError_t
-    {
-        if (to == onStream) return hipSuccess;
-        hipEvent_t ev = l.splitEvents[l.splitEventNext++ & 7u];
-        hipError_t err = hipEventRecord(ev, onStream);
-        if (err == hipSuccess) err = hipStreamWaitEvent(to, ev, 0);
-        onStream = to;
-        return err;
-    };
-    const uint32_t maxBlocks = auxCUs * shadeBlocksPerCU;
+    const uint32_t maxBlocks = c->numCUs * shadeBlocksPerCU;
     const uint32_t blocksNeeded = (totalSlots + RT_BLOCK - 1) / RT_BLOCK;
     const uint32_t pixelBlocks = (c->numSlots + RT_BLOCK - 1) / RT_BLOCK;
     const dim3 grid(blocksNeeded < maxBlocks ? blocksNeeded : maxBlocks), pixelGrid(pixelBlocks < maxBlocks ? pixelBlocks : maxBlocks), block(RT_BLOCK);
@@ -1309,7 +1253,7 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
     // blocks simply queue (there is no inter-block dependency, only the atomic cursor)
     // LDS stack capacity in entries per lane: 24 (6 blocks per CU), 32 (4-5) or 64 (2); the scene's BVH depth decides
     const uint32_t stackClass = c->traversalStackNeed <= 24 ? 24u : (c->traversalStackNeed <= 32 ? 32u : 64u);
-    const dim3 travGrid(travCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u))));
+    const dim3 travGrid(c->numCUs * (c->travBlocksPerCU ? c->travBlocksPerCU : (stackClass == 24u ? 5u : (stackClass == 32u ? 4u : 2u))));
     uint32_t* pathCounts = l.queueCounts;
     uint32_t* shadowCounts = l.queueCounts + l.queueCountCapacity;
     uint32_t* cursors = l.queueCounts + 2 * l.queueCountCapacity;
@@ -1329,10 +1273,9 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
         static const bool fullPrimaryEnv = getenv("RTGPU_FULL_PRIMARY") && atoi(getenv("RTGPU_FULL_PRIMARY")) != 0;
         const bool leanPrimary = !fullPrimaryEnv;
         HIP_TRY(hipMemsetAsync(l.denseCounts, 0, (size_t)plane * (l.queueCountCapacity + 1u) * sizeof(uint32_t), l.stream));
-        HIP_TRY(hop(shortStream));
         {
-            LaunchTimer t(c, onStream, KC_GENERATE);
-            hipLaunchKernelGGL(k_generate_dense, grid, block, 0, onStream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters,
+            LaunchTimer t(c, l.stream, KC_GENERATE);
+            hipLaunchKernelGGL(k_generate_dense, grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, l.paths, c->slotPixel, totalSlots, shardCapacity, l.denseCounts, c->counters,
                                leanPrimary ? 0u : 1u);
         }
         const bool haveNee = c->numLights != 0 && !c->plainPathTracer;
@@ -1349,11 +1292,10 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                                         (getenv("RTGPU_ANYHIT_FAR_FIRST") && atoi(getenv("RTGPU_ANYHIT_FAR_FIRST")) == 0) ? 0u : 1u };
                 static const uint32_t tailBlocksPerCU = getenv("RTGPU_TAIL_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("RTGPU_TAIL_BLOCKS_PER_CU")) : 4u;   // tuning knob
                 uint32_t tailBlocks = (totalSlots + RT_TAIL_PATHS - 1u) / RT_TAIL_PATHS;   // never more blocks than chunks of the whole batch
-                if (tailBlocks > travCUs * tailBlocksPerCU) tailBlocks = travCUs * tailBlocksPerCU;
+                if (tailBlocks > c->numCUs * tailBlocksPerCU) tailBlocks = c->numCUs * tailBlocksPerCU;
                 const dim3 tailGrid(tailBlocks ? tailBlocks : 1u);
-                HIP_TRY(hop(walkStream));
-                LaunchTimer t(c, onStream, KC_TAIL);
-#define RT_LAUNCH_TAIL(L, P) hipLaunchKernelGGL((k_tail<L, P>), tailGrid, block, 0, onStream, c->sceneDev, c->wide, passesDev, c->numSlots, in, args, l.home, c->counters)
+                LaunchTimer t(c, l.stream, KC_TAIL);
+#define RT_LAUNCH_TAIL(L, P) hipLaunchKernelGGL((k_tail<L, P>), tailGrid, block, 0, l.stream, c->sceneDev, c->wide, passesDev, c->numSlots, in, args, l.home, c->counters)
                 if (c->plainPathTracer) RT_LAUNCH_TAIL(0, true);
                 else if (c->leanScene == 1) RT_LAUNCH_TAIL(1, false); else if (c->leanScene == 2) RT_LAUNCH_TAIL(2, false);
                 else if (c->leanScene == 3) RT_LAUNCH_TAIL(3, false); else if (c->leanScene == 4) RT_LAUNCH_TAIL(4, false); else RT_LAUNCH_TAIL(0, false);
@@ -1367,26 +1309,20 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
                 tune.denseCounts = haveClosest ? l.denseCounts + (size_t)plane * depth : nullptr; tune.denseShardCapacity = shardCapacity;
                 const uint32_t* tsq = haveShadow ? l.shadowQueues[(depth - 1u) & 1u] : nullptr;
                 const uint32_t* tsc = haveShadow ? shadowCounts + (depth - 1u) : nullptr;
-#define RT_LAUNCH_TRACE_DENSE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, onStream, c->sceneDev, in, (const uint32_t*)nullptr, (const uint32_t*)nullptr, tsq, tsc, cursors + depth, c->counters, tune)
+#define RT_LAUNCH_TRACE_DENSE(S, C) hipLaunchKernelGGL((k_trace<S, C>), travGrid, block, 0, l.stream, c->sceneDev, in, (const uint32_t*)nullptr, (const uint32_t*)nullptr, tsq, tsc, cursors + depth, c->counters, tune)
                 if (useWide(c))
                 {
                     // the 4-wide tree serves the launch; what it does not trust goes through the binary-tree kernel right behind it (a small grid: few rays)
                     uint32_t* exactCounts = l.queueCounts + 4 * l.queueCountCapacity;
                     uint32_t* exactShadowCounts = l.queueCounts + 5 * l.queueCountCapacity;
                     uint32_t* exactCursors = l.queueCounts + 6 * l.queueCountCapacity;
-                    HIP_TRY(hop(walkStream));
-                    c->numCUs = travCUs;     // (the launch helpers size their grids from it)
-                    launchTraceWide(c, onStream, in, nullptr, nullptr, tsq, tsc, cursors + depth, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, 0.0001f,
+                    launchTraceWide(c, l.stream, in, nullptr, nullptr, tsq, tsc, cursors + depth, l.exactQueue, exactCounts + depth, l.exactShadowQueue, exactShadowCounts + depth, 0.0001f,
                                     tune.denseCounts, shardCapacity, true, depth);
-                    HIP_TRY(hop(shortStream));
-                    c->numCUs = auxCUs;
-                    launchRetrace(c, l, onStream, in, depth, stackClass, l.queues[0]);
-                    c->numCUs = allCUs;
+                    launchRetrace(c, l, l.stream, in, depth, stackClass, l.queues[0]);
                 }
                 else
                 {
-                HIP_TRY(hop(walkStream));
-                LaunchTimer t(c, onStream, KC_TRACE);
+                LaunchTimer t(c, l.stream, KC_TRACE);
                 if (stackClass == 24u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(24, true); else RT_LAUNCH_TRACE_DENSE(24, false); }
                 else if (stackClass == 32u) { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(32, true); else RT_LAUNCH_TRACE_DENSE(32, false); }
                 else { if (c->countIntersections) RT_LAUNCH_TRACE_DENSE(64, true); else RT_LAUNCH_TRACE_DENSE(64, false); }
@@ -1396,9 +1332,8 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             // bounce `depth`: shades the live paths; folds the visibility results of the previous bounce's zombies in (the last round does only that)
             const DenseCounts dc = { l.denseCounts + (size_t)plane * depth, l.denseCounts + (size_t)plane * (depth + 1u), shardCapacity, c->deviceFlags,
                                      leanPrimary && depth == 0u ? c->slotPixel : nullptr };
-            HIP_TRY(hop(shortStream));
-            LaunchTimer t(c, onStream, KC_SHADE);
-#define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, onStream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
+            LaunchTimer t(c, l.stream, KC_SHADE);
+#define RT_LAUNCH_SHADE_DENSE(L, P, A) hipLaunchKernelGGL((k_shade_dense<L, P, A>), grid, block, 0, l.stream, c->sceneDev, passesDev, c->numSlots, in, out, dc, \
                                                      l.shadowQueues[depth & 1u], shadowCounts + depth, l.home, c->counters)
             if (c->plainPathTracer) RT_LAUNCH_SHADE_DENSE(0, true, false);
             else if (denseAll) { if (c->leanScene == 1) RT_LAUNCH_SHADE_DENSE(1, false, true); else if (c->leanScene == 2) RT_LAUNCH_SHADE_DENSE(2, false, true); else if (c->leanScene == 4) RT_LAUNCH_SHADE_DENSE(4, false, true); else RT_LAUNCH_SHADE_DENSE(0, false, true); }
@@ -1406,13 +1341,11 @@ static int flushBatch(RtgpuContext* c, uint32_t maxPasses)
             else if (c->leanScene == 3) RT_LAUNCH_SHADE_DENSE(3, false, false); else if (c->leanScene == 4) RT_LAUNCH_SHADE_DENSE(4, false, false); else RT_LAUNCH_SHADE_DENSE(0, false, false);
 #undef RT_LAUNCH_SHADE_DENSE
         }
-        HIP_TRY(hop(shortStream));
-        if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(onStream, c->lanes[c->lastAccumulateLane].accumulated, 0));
+        if (c->lastAccumulateLane >= 0 && c->lastAccumulateLane != laneIndex) HIP_TRY(hipStreamWaitEvent(l.stream, c->lanes[c->lastAccumulateLane].accumulated, 0));
         {
-            LaunchTimer t(c, onStream, KC_ACCUMULATE);
-            hipLaunchKernelGGL(k_accumulate_home, pixelGrid, block, 0, onStream, l.home, c->slotPixel, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
+            LaunchTimer t(c, l.stream, KC_ACCUMULATE);
+            hipLaunchKernelGGL(k_accumulate_home, pixelGrid, block, 0, l.stream, l.home, c->slotPixel, c->numSlots, numPasses, c->sum, c->secondary, c->width, passesDev);
         }
-        HIP_TRY(hop(l.stream));   // the lane's own stream is what everything else orders itself against (seed events, `accumulated`, synchronising calls)
     }
     else
     {
