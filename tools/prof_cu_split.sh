@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6, review item 3: CU-partitioned streams (RTGPU_CU_SPLIT, rt_runtime.hip) against the default lane overlap, on one box, at the driver's command.
+# Round 6, review item 3: CU-partitioned streams (RTGPU_CU_SPLIT) against the default lane overlap, on one box, at the driver's command.  The experiment's code is NOT in the
+# library any more (measured slower everywhere): apply profiles/r06_cu_split_experiment.patch to raytracer_amd/csrc/rt_runtime.hip and rebuild first.
 #   bash tools/prof_cu_split.sh [out=gpurun_out/r06/cu_split_ab.txt] [steps=20] [warmup=5]
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
