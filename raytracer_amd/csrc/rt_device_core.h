@@ -334,6 +334,12 @@ RT_DEV bool intersectBoxRayNoNaN(const Ray& ray, float minx, float miny, float m
 // the reference's nodes in the reference's order, every leaf that holds a hit is still visited, the accepted hits and their order are the reference's.
 // "Clearly off": by more than 2^-7 of the magnitudes involved (>= the box's extent in that axis), five decimal orders above the rounding of the tests.
 // Not applied when the intersection counters are on (they count the reference's own box tests).
+// ASSUMPTIONS, stated (round-5 advisor): (1) every node's box bounds the stored float vertices of the triangles below it -- true of the reference's builder, which
+// unions the triangles' own float boxes upwards (BVHBuilder.cpp: leaf boxes from the vertices, interior boxes by Box(a, b)), and of any tree uploaded through the
+// reference's API; a hand-made RtSceneDesc whose boxes do not bound their triangles is outside the contract for this walk AND the reference's; (2) a point
+// Moeller-Trumbore accepts lies within rounding distance of the triangle, i.e. well inside the 2^-7 margin even for slivers.  Held by
+// test_axis_parallel_next_event_rays and, on 6000 near-degenerate slivers under axis-parallel suns, test_axis_parallel_rays_among_sliver_triangles: the pruned walk
+// (counters off) and the unpruned one (counters on) both return the oracle's image and counters.
 RT_DEV bool boxNearDegenerateAxes(const Ray& r, float minx, float miny, float minz, float maxx, float maxy, float maxz)
 {
     const uint32_t inf = 0x7f800000u;
