@@ -789,7 +789,7 @@ def main():
             #   reference_walk_*         SURVEY 8(d)'s literal model (32 B per box test + 36 B per triangle test of the REFERENCE'S binary walk): a work measure,
             #                            non-physical as a rate (> 1 x peak: this kernel walks another tree -- 17 visits where the binary walk makes 29 -- out of the caches).
             #   bound / ceilings / frac_of_binding_ceiling   which measured ceiling (HBM, VALU issue, cache fetch) the kernel is nearest to, and the counters behind it.
-            roof = {"bound": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "definition": "r6: frac = measured HBM traffic fraction (BENCH_r05's frac is request_rate_over_hbm_peak here)",
+            roof = {"bound": "hbm", "roof": "hbm", "kernel": kernel_name, "peak": HBM_PEAK_GBS, "unit": "GB/s", "definition": "r6: frac = measured HBM traffic fraction (BENCH_r05's frac is request_rate_over_hbm_peak here)",
                     "avg_launch_ms": per_launch_s * 1000.0, "launches": launches,
                     "reference_walk_bytes_per_launch": per_launch_bytes, "reference_walk_GBs": algorithmic_gbs,
                     "calibration": CALIBRATION,

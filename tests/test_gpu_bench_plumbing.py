@@ -94,6 +94,7 @@ def test_bench_line_names_every_switch_that_changed_its_work(built):
     # as a work measure only, labelled non-physical
     r = d["roofline"]
     assert r["kernel"] == "k_trace_wide" and r["avg_launch_ms"] > 0 and "FETCH_SIZE_true_bytes_per_reported_byte" in r["calibration"]
+    assert r["roof"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"    # `frac` is always a fraction of THIS roof; `bound` names the nearest measured ceiling
     assert r["frac"] is None and r["achieved"] is None and r["algorithmic_bytes_per_launch"] is None and str(r["algorithmic_model"]).startswith("n/a")
     assert r["request_rate_over_hbm_peak"] is None and r["traffic"] is None and r["reference_walk_bytes_per_launch"] > 0 and "non-physical" in r["reference_walk_note"]
 
