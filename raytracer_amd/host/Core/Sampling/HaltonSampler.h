@@ -26,6 +26,7 @@ public:
 
 private:
     uint64 Permute(uint32 i, uint32 j) const { return mPermutations[i][mDigit[i][j]]; }
+    void UpdatePlace(uint32 dimension, int32 place);   // one partial sum of the scrambled radical inverse (HaltonSampler.cpp)
     void InitPrimes();
     void InitStart();
     void InitPowerBuffer();

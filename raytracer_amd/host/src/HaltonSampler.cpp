@@ -104,43 +104,39 @@ void HaltonSequence::InitPermutation()
     }
 }
 
-void HaltonSequence::InitExpansion()   // :61-82
+// The scrambled radical inverse of a dimension is kept as partial sums: mRnd[d][j] = the contribution of digit places j, j + 1, ... -- so that a step of the
+// sequence touches only the places whose digits changed.  One place: the permuted digit over base^(j + 1), added to the sum of the higher places.  The double
+// expression is the reference's (HaltonSampler.cpp:78, :96, :103: `d * 1.0 / power`, then added to the right-hand neighbour): the seeds are these doubles.
+void HaltonSequence::UpdatePlace(uint32 dimension, int32 place)
 {
-    for (uint32 i = 0; i < mDimensions; i++)
+    const uint64 scrambled = Permute(dimension, (uint32)place);
+    mRnd[dimension][place] = mRnd[dimension][place + 1] + scrambled * 1.0 / mPowerBuffer[dimension][place];
+}
+
+// the digit string of (start - 1), least significant place first, then every partial sum from the most significant place down (:61-82)
+void HaltonSequence::InitExpansion()
+{
+    for (uint32 dimension = 0; dimension < mDimensions; dimension++)
     {
-        uint64 n = mStarts[i] - 1;
-        int32 j = 0;
-        while (n > 0)
-        {
-            mDigit[i][j] = n % mBase[i];
-            n = n / mBase[i];
-            j++;
-        }
-        j--;
-        while (j >= 0)
-        {
-            const uint64 d = Permute(i, (uint32)j);
-            mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
-            j--;
-        }
+        const uint64 base = mBase[dimension];
+        int32 places = 0;
+        for (uint64 rest = mStarts[dimension] - 1; rest > 0; rest /= base) mDigit[dimension][places++] = rest % base;
+        for (int32 place = places - 1; place >= 0; --place) UpdatePlace(dimension, place);
     }
 }
 
-void HaltonSequence::NextSample()   // :84-106
+// the digit string plus one: the places below the first one that does not overflow wrap to zero; the partial sums of the places that changed are rebuilt from
+// the highest of them down (:84-106)
+void HaltonSequence::NextSample()
 {
-    for (uint32 i = 0; i < mDimensions; i++)
+    for (uint32 dimension = 0; dimension < mDimensions; dimension++)
     {
-        int32 j = 0;
-        while (mDigit[i][j] + 1 >= mBase[i]) j++;
-        mDigit[i][j]++;
-        uint64 d = Permute(i, (uint32)j);
-        mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
-        for (j = j - 1; j >= 0; j--)
-        {
-            mDigit[i][j] = 0;
-            d = Permute(i, (uint32)j);
-            mRnd[i][j] = mRnd[i][j + 1] + d * 1.0 / mPowerBuffer[i][j];
-        }
+        std::vector<uint64>& digits = mDigit[dimension];
+        int32 carry = 0;
+        while (digits[carry] + 1 >= mBase[dimension]) ++carry;
+        digits[carry]++;
+        std::fill(digits.begin(), digits.begin() + carry, (uint64)0);
+        for (int32 place = carry; place >= 0; --place) UpdatePlace(dimension, place);
     }
 }
 
