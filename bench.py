@@ -736,7 +736,9 @@ def main():
             metric = "Msamples/sec (path segments of camera + light sub-paths) at %dx%d, rough-glass BDPT" % (w, h)
         else:
             what = ("procedural Sponza-class mesh (%d triangles, 8 diffuse materials)" % scene.desc.contents.numTriangles) if args.workload.startswith("sponza") else args.workload
-            label = "configs[2]: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::%s" % (what, args.depth, w, h, "All, dimensions 128" if args.workload == "sponza-all" else "Single")
+            which = {"sponza": "configs[2]", "sponza-all": "configs[2] (path-exact variant)", "sponza-textured": "configs[2] (textured variant)", "cornell": "configs[0] scene (Cornell box)",
+                     "sphere": "configs[1]", "zoo": "test scene (every light x every BSDF; not a BASELINE config)"}.get(args.workload, args.workload)
+            label = "%s: %s, PathTracerMIS, %d bounces, %dx%d, LightSamplingStrategy::%s" % (which, what, args.depth, w, h, "All, dimensions 128" if args.workload == "sponza-all" else "Single")
             if args.workload == "sponza-textured":
                 label += " + albedo / normal maps on all materials, HDR environment map"
             metric = "Msamples/sec (paths x bounces) at %dx%d, Sponza-class PT-MIS" % (w, h)
