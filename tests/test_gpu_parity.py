@@ -164,6 +164,20 @@ def test_axis_parallel_rays_among_sliver_triangles(built, walk, orientation):
     assert out[2]["numShadowRays"] > out[2]["numShadowRaysHit"] > 0 and out[2]["numMeshHits"] > 0
 
 
+def test_axis_parallel_ray_over_an_analytic_box_keeps_the_reference_s_bogus_hit(built, walk):
+    """Round 6, found by the soak (tools/oracle_fuzz.py seed 9606, case 765; tools/oracle_fuzz_replay.py reproduces it): a diffuse bounce off an axis-aligned wall
+    whose cosine sample returns a direction with an EXACTLY zero y component travels horizontally a metre above a BoxShape -- and the reference reports a hit on the
+    box's top face: BoxShape::Intersect evaluates 0 * inf for the dropped axis and _mm_min_ps / _mm_max_ps keep the NaN's partner (the reference's own renderer,
+    oracle/_ref/ref_render, gives this pixel 0 like the oracle).  Rounds 5's prune of boxes "clearly off an axis-parallel ray's fixed coordinate" skipped the
+    top-level box and let the ray fly on (6 more path segments, a lit pixel).  The prune is sound for triangles (Moeller-Trumbore accepts only points of the
+    triangle) and is applied inside meshes only now.  Both walks against the oracle, bit for bit, on the frame of the soak's case."""
+    w, h = 128, 72
+    scene, camera = scene_zoo.mesh_scene(w / h, triangles=8000)
+    out = run_both(scene, camera, w, h, walk=walk, passes=1, seed=677459682, max_ray_depth=10, min_russian_roulette_depth=4, dimensions=64, use_blue_noise=False)
+    assert_identical(*out)
+    assert out[3][21, 113].max() == 0.0 and out[0][21, 113].max() == 0.0      # the pixel whose path ends on the box it never touched
+
+
 def test_mesh_two_level_bvh_bit_exact(built, walk):
     """Triangle mesh instance + analytic instances: mesh BVH traversal, Moller-Trumbore, barycentric frames."""
     w, h = 160, 90
