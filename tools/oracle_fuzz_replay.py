@@ -2,6 +2,7 @@
 against the oracle, under the environment as it is.  For chasing a soak mismatch:
    python tools/oracle_fuzz_replay.py <seed> list [max cases]              prints index + parameters of every case
    python tools/oracle_fuzz_replay.py <seed> <index> [<index> ...]         renders those cases; prints differing words, first differing pixels, counters
+   (FUZZ_KINDS=6 for seeds run by tools/oracle_fuzz.py since the end of round 6: its stream draws from six scene kinds, before that from five)
 Test infrastructure (uses the oracle)."""
 import ctypes as C
 import os
@@ -15,15 +16,20 @@ from raytracer_amd import scenes
 import oracle_lib, scene_zoo
 
 
-def stream(seed, limit):
+def stream(seed, limit=None, kinds=5):
+    """The case stream of a seed.  kinds = 5: the stream of rounds 1-6 (old seeds replay as they ran); kinds = 6 adds the all-lights x all-BSDFs scene of analytic
+    shapes (tests/scene_zoo.py all_lights_scene) -- tools/oracle_fuzz.py's default since the end of round 6."""
     rng = np.random.RandomState(seed)
-    for index in range(limit):
-        kind = rng.randint(5)
+    index = -1
+    while limit is None or index + 1 < limit:
+        index += 1
+        kind = rng.randint(kinds)
         w, h = [(64, 48), (128, 72), (160, 96), (96, 160)][rng.randint(4)]
         if kind == 0: make = ("sponza", int(rng.choice([300, 3000, 20000])), int(rng.randint(1, 1000)), False, False)
         elif kind == 4: make = ("sponza", int(rng.choice([300, 3000])), int(rng.randint(1, 1000)), True, bool(rng.randint(2)))
         elif kind == 1: make = ("mesh_scene", int(rng.choice([2000, 8000])))
         elif kind == 2: make = ("cornell",)
+        elif kind == 5: make = ("zoo",)
         else: make = ("sphere",)
         cam = None
         if kind in (0, 4):
@@ -37,13 +43,20 @@ def stream(seed, limit):
         yield index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule
 
 
-def render(case):
+def build(case):
     index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule = case
     if make[0] == "sponza": scene, camera = scenes.sponza_class(w / h, make[1], seed=make[2], textured=make[3], extra_texture=make[4])
     elif make[0] == "mesh_scene": scene, camera = scene_zoo.mesh_scene(w / h, triangles=make[1])
     elif make[0] == "cornell": scene, camera = scenes.cornell_box(w / h)
+    elif make[0] == "zoo": scene, camera = scene_zoo.all_lights_scene(w / h)
     else: scene, camera = scenes.sphere_area_light(w / h)
     if cam: camera = ra.Camera(cam[0], cam[1], w / h, cam[2])
+    return scene, camera
+
+
+def render(case, quiet=False):
+    index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule = case
+    scene, camera = build(case)
     bn = ra.load_blue_noise()
     desc = scene.desc; desc.contents.blueNoise = bn.ctypes.data
     vp = ra.Viewport(w, h, seed=vp_seed, **args)
@@ -58,21 +71,26 @@ def render(case):
     img, img2 = vp.sum_buffer(secondary=True)
     c = vp.counters()
     diff = np.argwhere(img.view(np.uint32) != ref.view(np.uint32))
+    names = ra.COUNTER_NAMES[:4] if not counters_on else ra.COUNTER_NAMES[:12]
+    same = len(diff) == 0 and np.array_equal(img2.view(np.uint32), ref2.view(np.uint32)) and all(c[n] == int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:12]) if n in names)
+    if quiet:
+        return same, len(diff)
     print("case %d: %d differing words; counters gpu %s oracle %s" % (index, len(diff), {n: c[n] for n in ra.COUNTER_NAMES[:4]}, {n: int(cnt[i]) for i, n in enumerate(ra.COUNTER_NAMES[:4])}),
           "retraced", c.get("numRetracedRays"), flush=True)
     for y, x, ch in diff[:6]:
         print("   pixel (%d, %d) channel %d: gpu %.9g oracle %.9g" % (x, y, ch, img[y, x, ch], ref[y, x, ch]))
-    return len(diff)
+    return same, len(diff)
 
 
 if __name__ == "__main__":
     seed = int(sys.argv[1])
+    kinds = int(os.environ.get("FUZZ_KINDS", "5"))     # 6: the stream tools/oracle_fuzz.py draws since the end of round 6 (it prints the value to use with every mismatch)
     if sys.argv[2] == "list":
-        for case in stream(seed, int(sys.argv[3]) if len(sys.argv) > 3 else 1000):
+        for case in stream(seed, int(sys.argv[3]) if len(sys.argv) > 3 else 1000, kinds):
             print(case)
     else:
         wanted = set(int(a) for a in sys.argv[2:])
-        for case in stream(seed, max(wanted) + 1):
+        for case in stream(seed, max(wanted) + 1, kinds):
             if case[0] in wanted:
                 print(case, "env", {k: v for k, v in os.environ.items() if k.startswith("RTGPU_")})
                 render(case)
