@@ -10,10 +10,10 @@ from raytracer_amd import scenes
 import oracle_lib, scene_zoo
 
 
-def run(budget=300.0, seed=1, min_cases=0, log=print, kinds=6):
+def run(budget=300.0, seed=1, min_cases=0, log=print, kinds=7):
     """Random cases until `budget` seconds are used up (and at least `min_cases`); returns (cases, mismatches, default-walk cases).  The case stream and the
-    rendering of a case live in tools/oracle_fuzz_replay.py, which can replay any single case of a seed (`kinds`: 6 since the end of round 6 -- the zoo of every
-    light x every BSDF joined the five scene kinds of rounds 1-6; a mismatch line names seed, index and kinds)."""
+    rendering of a case live in tools/oracle_fuzz_replay.py, which can replay any single case of a seed (`kinds`: 7 since the end of round 6 -- the zoo of every
+    light x every BSDF joined the five scene kinds of rounds 1-6, and the two-level scenes get random cameras too; a mismatch line names seed, index and kinds)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import oracle_fuzz_replay as replay
     t_end = time.time() + budget

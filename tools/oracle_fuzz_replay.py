@@ -18,12 +18,13 @@ import oracle_lib, scene_zoo
 
 def stream(seed, limit=None, kinds=5):
     """The case stream of a seed.  kinds = 5: the stream of rounds 1-6 (old seeds replay as they ran); kinds = 6 adds the all-lights x all-BSDFs scene of analytic
-    shapes (tests/scene_zoo.py all_lights_scene) -- tools/oracle_fuzz.py's default since the end of round 6."""
+    shapes (tests/scene_zoo.py all_lights_scene); kinds = 7: that, and random cameras for the two-level scenes too -- tools/oracle_fuzz.py's default since the end of
+    round 6 (a mismatch line names seed, index and kinds)."""
     rng = np.random.RandomState(seed)
     index = -1
     while limit is None or index + 1 < limit:
         index += 1
-        kind = rng.randint(kinds)
+        kind = rng.randint(min(kinds, 6))
         w, h = [(64, 48), (128, 72), (160, 96), (96, 160)][rng.randint(4)]
         if kind == 0: make = ("sponza", int(rng.choice([300, 3000, 20000])), int(rng.randint(1, 1000)), False, False)
         elif kind == 4: make = ("sponza", int(rng.choice([300, 3000])), int(rng.randint(1, 1000)), True, bool(rng.randint(2)))
@@ -34,6 +35,13 @@ def stream(seed, limit=None, kinds=5):
         cam = None
         if kind in (0, 4):
             cam = ((float(rng.uniform(-13, 13)), float(rng.uniform(0.3, 10)), float(rng.uniform(-5, 5))), (float(rng.uniform(-60, 60)), float(rng.uniform(0, 360)), 0.0), float(rng.uniform(30, 100)))
+        elif kinds >= 7 and kind in (1, 2, 5):
+            # kinds = 7 (end of round 6): the two-level scenes seen from a camera somewhere around their own one too (the mismatch of seed 9606 was a geometric
+            # coincidence of ONE fixed camera: more viewpoints, more coincidences)
+            base = {1: ((-12.5, 2.2, 0.6), (4.0, 82.0, 0.0), 65.0, (2.0, 1.2, 2.0)), 2: ((0.0, 0.0, 6.0), (0.0, 180.0, 0.0), 40.0, (0.6, 0.6, 1.5)), 5: ((0.5, 2.5, 9.0), (12.0, 180.0, 0.0), 55.0, (3.0, 1.5, 2.5))}[kind]
+            jitter = [float(rng.uniform(-1.0, 1.0)) for _ in range(6)]
+            if rng.randint(4) != 0:
+                cam = (tuple(base[0][a] + jitter[a] * base[3][a] for a in range(3)), (base[1][0] + 15.0 * jitter[3], base[1][1] + 30.0 * jitter[4], 0.0), base[2] * (1.0 + 0.4 * jitter[5]))
         args = dict(max_ray_depth=int(rng.choice([0, 2, 6, 10])), min_russian_roulette_depth=int(rng.choice([1, 4, 20])), light_sampling_all=bool(rng.randint(2)),
                     dimensions=int(rng.choice([16, 64, 128])), use_blue_noise=bool(rng.randint(2)))
         passes = int(rng.choice([1, 2, 4]))
@@ -84,7 +92,7 @@ def render(case, quiet=False):
 
 if __name__ == "__main__":
     seed = int(sys.argv[1])
-    kinds = int(os.environ.get("FUZZ_KINDS", "5"))     # 6: the stream tools/oracle_fuzz.py draws since the end of round 6 (it prints the value to use with every mismatch)
+    kinds = int(os.environ.get("FUZZ_KINDS", "5"))     # 6 / 7: the streams tools/oracle_fuzz.py drew at the end of round 6 (it prints the value to use with every mismatch)
     if sys.argv[2] == "list":
         for case in stream(seed, int(sys.argv[3]) if len(sys.argv) > 3 else 1000, kinds):
             print(case)
