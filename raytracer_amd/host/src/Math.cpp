@@ -96,35 +96,43 @@ Matrix4 Matrix4::operator*(const Matrix4& b) const
     return r;
 }
 
-// General inverse through 2x2 sub-determinants of the row pairs (Laplace expansion).
+// General inverse as adjugate / determinant.  The inverse is an INPUT of the device path (RtObject::invTransform,
+// RtLight::invTransform), so a render only matches the reference's bit for bit if every rounding of it does: the reference
+// (Core/Math/Matrix4.cpp:123-248) rounds each cofactor as six triple products (e * p) * s summed left to right, and the 3x3
+// minor is expanded along its first remaining column, rows ascending.  Written as that expansion rather than as the usual
+// 2x2 sub-determinant sharing (which is as accurate but rounds differently: tests/golden/host_inverse.kat, tools/reference_fuzz.py).
 Matrix4 Matrix4::Inverse() const
 {
     const float* m = &rows[0].x;
-    const float s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
-    const float s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
-    const float c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
-    const float c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
-    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-    const float inv = 1.0f / det;
-    Matrix4 r;
-    float* o = &r.rows[0].x;
-    o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * inv;
-    o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * inv;
-    o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * inv;
-    o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * inv;
-    o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * inv;
-    o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * inv;
-    o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * inv;
-    o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * inv;
-    o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * inv;
-    o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * inv;
-    o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * inv;
-    o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * inv;
-    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * inv;
-    o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * inv;
-    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * inv;
-    o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * inv;
-    return r;
+    float adj[16];
+    for (int r = 0; r < 4; ++r)
+    {
+        for (int c = 0; c < 4; ++c)
+        {
+            // adj[r][c] = (-1)^(r+c) * minor with row c and column r struck out
+            int rr[3], cc[3];
+            for (int i = 0, k = 0; i < 4; ++i) if (i != c) rr[k++] = i;
+            for (int i = 0, k = 0; i < 4; ++i) if (i != r) cc[k++] = i;
+            float sign = ((r + c) & 1) ? -1.0f : 1.0f;
+            float sum = 0.0f;
+            for (int a = 0; a < 3; ++a)
+            {
+                const int lo = rr[a == 0 ? 1 : 0], hi = rr[a == 2 ? 1 : 2];   // the two rows left, ascending
+                const float e = sign * m[4 * rr[a] + cc[0]];
+                const float t0 = (e * m[4 * lo + cc[1]]) * m[4 * hi + cc[2]];
+                const float t1 = (e * m[4 * lo + cc[2]]) * m[4 * hi + cc[1]];
+                sum = (a == 0) ? t0 - t1 : (sum + t0) - t1;
+                sign = -sign;
+            }
+            adj[4 * r + c] = sum;
+        }
+    }
+    float det = m[0] * adj[0] + m[1] * adj[4] + m[2] * adj[8] + m[3] * adj[12];
+    det = 1.0f / det;
+    Matrix4 out;
+    float* o = &out.rows[0].x;
+    for (int i = 0; i < 16; ++i) o[i] = adj[i] * det;
+    return out;
 }
 
 Box Matrix4::TransformBox(const Box& box) const
