@@ -353,13 +353,15 @@ int main(int argc, char** argv)
     {
         const float* t = r.array<float>(3); const float* e = r.array<float>(3);
         const float fov = r.get<float>(), aspect = r.get<float>();
-        const uint32 dof = r.get<uint32>(); const float focal = r.get<float>(), aperture = r.get<float>(); (void)r.get<uint32>();
+        const uint32 dof = r.get<uint32>(); const float focal = r.get<float>(), aperture = r.get<float>(); const uint32 bokeh = r.get<uint32>();
         if (!r.ok) return 2;
         Vector4 orientation(e[0], e[1], e[2], 0.0f);
         orientation *= (RT_PI / 180.0f);
         camera.SetTransform(Transform(Vector4(t[0], t[1], t[2], 0.0f), Quaternion::FromEulerAngles(orientation.ToFloat3())));
         camera.SetPerspective(aspect, fov);
         camera.mDOF.enable = dof != 0; camera.mDOF.focalPlaneDistance = focal; camera.mDOF.aperture = aperture;
+        if (bokeh > 2u) return 2;   // circle, hexagon, square (Camera.h:21-28); NGon is commented out in the reference, Texture needs a bitmap
+        camera.mDOF.bokehShape = (BokehShape)bokeh;
     }
 
     // bitmap textures: Bitmap::Init copies the texels; BitmapTexture(bitmap) is the constructor Demo/MeshLoader.cpp uses (default filter)

@@ -391,6 +391,7 @@ class Camera:
     def set_lens(self, bokeh_shape=0, barrel_const=0.01, barrel_variable=0.0):
         """DOFSettings::bokehShape (0 circle, 1 hexagon, 2 square) and the barrel-distortion factors of rt::Camera."""
         host_lib().rth_camera_set_lens(self._h, C.c_uint32(bokeh_shape), C.c_float(barrel_const), C.c_float(barrel_variable))
+        self.settings.update(bokeh_shape=int(bokeh_shape), barrel_const=float(barrel_const), barrel_variable=float(barrel_variable))
 
 
 class Viewport:

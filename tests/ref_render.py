@@ -89,7 +89,7 @@ def export_scene(path, scene, camera, width, height, passes, threads, max_ray_de
         f.write(struct.pack("<14I", width, height, passes, threads, max_ray_depth, min_rr_depth, dimensions, int(use_blue_noise), int(light_sampling_all),
                             len(materials), len(meshes), len(objects), len(lights), int(dump_image)))
         f.write(struct.pack("<2fQ2I", aa_spread, 0.0, seed, len(textures), 0))
-        f.write(struct.pack("<3f3f2fI2fI", *c["translation"], *c["orientation_deg"], c["fov_rad"], c["aspect"], int(c["dof"]), c["focal_plane_distance"], c["aperture"], 0))
+        f.write(struct.pack("<3f3f2fI2fI", *c["translation"], *c["orientation_deg"], c["fov_rad"], c["aspect"], int(c["dof"]), c["focal_plane_distance"], c["aperture"], int(c.get("bokeh_shape", 0))))
         for group in (textures, materials, meshes, objects, lights):
             for blob in group:
                 f.write(blob)

@@ -32,6 +32,12 @@ def run(budget=120.0, seed=1, kinds=7, log=print):
             if make[0] == "sponza" and make[3]:
                 continue     # (textured variants: the exporter writes bitmap textures, a second of work per case -- the fixed fixtures cover them)
             scene, camera = replay.build(case)
+            # lens settings are this tool's own draw (the replay stream stays what the recorded seeds mean): a third of the cases with depth of field, all three
+            # bokeh shapes.  (Barrel distortion with a variable factor draws from the reference's entropy-seeded generator: not comparable.)
+            lens = np.random.default_rng([seed, index, 77])
+            if lens.random() < 0.34:
+                camera.set_lens(int(lens.integers(0, 3)))
+                camera.set_dof(True, float(np.float32(lens.uniform(1.0, 12.0))), float(np.float32(lens.uniform(0.01, 0.3))))
             single_light = scene.desc.contents.numLights <= 1
             sampling_all = True if not single_light else args["light_sampling_all"]
             # the reference draws from an entropy-seeded per-thread generator once a path has used up its sampler dimensions (GenericSampler::GetInt's fallback):
