@@ -114,7 +114,12 @@ def run(scene_path, threads=None, passes=None, timeout=900):
         shutil.rmtree(tree, ignore_errors=True)
     if r.returncode != 0:
         raise RuntimeError("ref_render failed (%d): %s" % (r.returncode, r.stderr[-500:]))
-    stats = json.loads(r.stdout.strip().splitlines()[-1])
+    line = r.stdout.strip().splitlines()[-1]
+    try:
+        stats = json.loads(line)
+    except ValueError:
+        # a frame with a NaN / inf pixel prints its mean as `nan` / `inf`, which JSON has no word for
+        stats = json.loads(line.replace("-nan", "NaN").replace("nan", "NaN").replace("-inf", "-Infinity").replace("inf", "Infinity"))
     raw = np.fromfile(out_path, dtype=np.uint8)
     head = raw[:32].view(np.uint32)
     assert head[0] == 0x54554F52

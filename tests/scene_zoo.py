@@ -139,3 +139,82 @@ def many_lights_scene(aspect, num_point_lights=14):
     s.add_background_light((0.05, 0.06, 0.08))
     s.build()
     return s, ra.Camera((0.0, 1.5, 7.0), (8.0, 180.0, 0.0), aspect, 50.0)
+
+
+def _look_at_euler(position, target=(0.0, 0.0, 0.0)):
+    """Euler angles (degrees, the JSON convention of the reference's cameras: yaw 180 looks down -z, positive pitch looks down) that point a camera at `target`."""
+    f = np.asarray(target, np.float64) - np.asarray(position, np.float64)
+    f /= np.linalg.norm(f)
+    return float(np.degrees(np.arcsin(-f[1]))), float(np.degrees(np.arctan2(f[0], f[2]))), 0.0
+
+
+def bumpy_patch(rng, n):
+    """A height-field patch of 2 n^2 triangles with vertex normals, tangents and texture coordinates (a mesh whose triangles are in general position)."""
+    g = np.linspace(-1.0, 1.0, n + 1)
+    x, z = np.meshgrid(g, g, indexing="xy")
+    a, b, c = rng.uniform(1.0, 4.0, size=3)
+    y = 0.25 * np.sin(a * x + 0.3) * np.cos(b * z) + 0.1 * np.sin(c * (x + z)) + rng.uniform(-0.02, 0.02, size=x.shape)
+    pos = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    dy_dx = np.gradient(y, g, axis=1); dy_dz = np.gradient(y, g, axis=0)
+    nrm = np.stack([-dy_dx, np.ones_like(y), -dy_dz], axis=-1).reshape(-1, 3)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    tan = np.stack([np.ones_like(y), dy_dx, np.zeros_like(y)], axis=-1).reshape(-1, 3)
+    tan = (tan / np.linalg.norm(tan, axis=1, keepdims=True)).astype(np.float32)
+    uv = np.stack([(x + 1.0) * 0.5, (z + 1.0) * 0.5], axis=-1).reshape(-1, 2).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="xy")
+    v0 = (j * (n + 1) + i).reshape(-1); v1 = v0 + 1; v2 = v0 + (n + 1); v3 = v2 + 1
+    idx = np.concatenate([np.stack([v0, v2, v1], axis=1), np.stack([v1, v2, v3], axis=1)]).astype(np.uint32)
+    return pos, idx, nrm, tan, uv
+
+
+def random_scene(aspect, seed):
+    """A scene drawn from `seed` alone: 3..8 materials over all BSDFs with random parameters, 4..13 analytic shapes and 0..2 bumpy mesh patches under GENERAL rotations,
+    a floor, 1..4 lights of random type, transform and parameters, a camera somewhere on a shell around it.  The fixed scenes of the soaks hold translations and quarter
+    turns almost everywhere; the host mirror's differently-rounded matrix inverse (round 6) hid behind exactly that."""
+    rng = np.random.RandomState(seed)
+    s = ra.Scene()
+
+    def colour(lo=0.05, hi=0.95):
+        return tuple(float(v) for v in rng.uniform(lo, hi, size=3))
+
+    def pose(spread=(5.0, 2.5, 5.0), lift=0.5):
+        t = (float(rng.uniform(-spread[0], spread[0])), float(lift + rng.uniform(-spread[1], spread[1])), float(rng.uniform(-spread[2], spread[2])))
+        r = tuple(float(v) for v in rng.uniform(-180.0, 180.0, size=3)) if rng.randint(5) else (0.0, float(90.0 * rng.randint(4)), 0.0)
+        return ra.transform_from_euler(t, r)
+
+    names = [n for n in ra.BSDF_NAMES if n != "null"]
+    mats = []
+    for _ in range(rng.randint(3, 9)):
+        emission = colour(0.0, 0.6) if rng.randint(6) == 0 else (0.0, 0.0, 0.0)
+        mats.append(s.add_material(names[rng.randint(len(names))], colour(), emission, roughness=float(rng.choice([0.0, 0.02, rng.uniform(0.03, 1.0)])),
+                                   metalness=float(rng.uniform(0.0, 1.0)), ior=float(rng.uniform(1.05, 2.2)), k=float(rng.uniform(0.5, 6.0))))
+    if rng.randint(4) == 0:
+        mats.append(s.add_material("null", (0.0, 0.0, 0.0), emission=colour(0.1, 0.8)))
+    floor = s.add_material("diffuse" if rng.randint(2) else "roughPlastic", colour(0.3, 0.8), roughness=float(rng.uniform(0.05, 0.6)))
+    s.add_rect((12.0, 12.0), ra.transform_from_euler((0.0, -2.5, 0.0), (-90.0, float(rng.uniform(-180.0, 180.0)), 0.0)), floor)
+    for _ in range(rng.randint(4, 14)):
+        m = mats[rng.randint(len(mats))]
+        kind = rng.randint(3)
+        if kind == 0: s.add_sphere(float(rng.uniform(0.3, 1.4)), pose(), m)
+        elif kind == 1: s.add_box(tuple(float(v) for v in rng.uniform(0.2, 1.3, size=3)), pose(), m)
+        else: s.add_rect(tuple(float(v) for v in rng.uniform(0.4, 2.0, size=2)), pose(), m)
+    for _ in range(rng.randint(3)):
+        pos, idx, nrm, tan, uv = bumpy_patch(rng, int(rng.choice([6, 14, 30])))
+        pos = pos * np.float32(rng.uniform(1.0, 3.5))
+        table = [mats[rng.randint(len(mats))] for _ in range(rng.randint(1, 4))]
+        s.add_mesh(pos, idx, nrm, tan, uv, rng.randint(len(table), size=idx.shape[0]).astype(np.uint32), table, pose())
+    for _ in range(rng.randint(1, 5)):
+        kind = rng.randint(7)
+        if kind == 0: s.add_area_light("rect", [float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))], colour(2.0, 12.0), pose((4.0, 1.0, 4.0), 4.0))
+        elif kind == 1: s.add_area_light("sphere", [float(rng.uniform(0.15, 0.8))], colour(2.0, 10.0), pose((4.0, 1.0, 4.0), 3.0))
+        elif kind == 2: s.add_area_light("box", [float(v) for v in rng.uniform(0.15, 0.6, size=3)], colour(1.0, 8.0), pose((4.0, 1.0, 4.0), 3.0))
+        elif kind == 3: s.add_point_light(colour(8.0, 30.0), pose((4.0, 1.0, 4.0), 3.5))
+        elif kind == 4: s.add_spot_light(colour(20.0, 80.0), float(rng.uniform(0.2, 1.2)), pose((4.0, 1.0, 4.0), 4.0))
+        elif kind == 5: s.add_directional_light(colour(1.0, 4.0), float(rng.choice([0.001, 0.02, rng.uniform(0.03, 0.3)])), pose())
+        else: s.add_background_light(colour(0.05, 0.8))
+    s.build()
+    radius, height, turn = rng.uniform(7.0, 13.0), rng.uniform(-1.0, 6.0), rng.uniform(0.0, 2.0 * np.pi)
+    position = (float(radius * np.sin(turn)), float(height), float(radius * np.cos(turn)))
+    target = tuple(float(v) for v in rng.uniform(-1.5, 1.5, size=3))
+    cam = ra.Camera(position, _look_at_euler(position, target), aspect, float(rng.uniform(35.0, 75.0)))
+    return s, cam

@@ -19,18 +19,20 @@ import oracle_lib, scene_zoo
 def stream(seed, limit=None, kinds=5):
     """The case stream of a seed.  kinds = 5: the stream of rounds 1-6 (old seeds replay as they ran); kinds = 6 adds the all-lights x all-BSDFs scene of analytic
     shapes (tests/scene_zoo.py all_lights_scene); kinds = 7: that, and random cameras for the two-level scenes too -- tools/oracle_fuzz.py's default since the end of
-    round 6 (a mismatch line names seed, index and kinds)."""
+    round 6 (a mismatch line names seed, index and kinds); kinds = 8 adds tests/scene_zoo.py random_scene (random materials, shapes, mesh patches, lights, all under general
+    rotations) as a seventh scene kind."""
     rng = np.random.RandomState(seed)
     index = -1
     while limit is None or index + 1 < limit:
         index += 1
-        kind = rng.randint(min(kinds, 6))
+        kind = rng.randint(7 if kinds >= 8 else min(kinds, 6))
         w, h = [(64, 48), (128, 72), (160, 96), (96, 160)][rng.randint(4)]
         if kind == 0: make = ("sponza", int(rng.choice([300, 3000, 20000])), int(rng.randint(1, 1000)), False, False)
         elif kind == 4: make = ("sponza", int(rng.choice([300, 3000])), int(rng.randint(1, 1000)), True, bool(rng.randint(2)))
         elif kind == 1: make = ("mesh_scene", int(rng.choice([2000, 8000])))
         elif kind == 2: make = ("cornell",)
         elif kind == 5: make = ("zoo",)
+        elif kind == 6: make = ("random", int(rng.randint(1, 1 << 30)))
         else: make = ("sphere",)
         cam = None
         if kind in (0, 4):
@@ -57,6 +59,7 @@ def build(case):
     elif make[0] == "mesh_scene": scene, camera = scene_zoo.mesh_scene(w / h, triangles=make[1])
     elif make[0] == "cornell": scene, camera = scenes.cornell_box(w / h)
     elif make[0] == "zoo": scene, camera = scene_zoo.all_lights_scene(w / h)
+    elif make[0] == "random": scene, camera = scene_zoo.random_scene(w / h, make[1])
     else: scene, camera = scenes.sphere_area_light(w / h)
     if cam: camera = ra.Camera(cam[0], cam[1], w / h, cam[2])
     return scene, camera

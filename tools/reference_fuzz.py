@@ -3,7 +3,7 @@ tools/oracle_fuzz_replay.py (random scenes, cameras, sizes, depths, roulette set
 Viewport::Render / PathTracerMIS / traversal / shading objects, one thread -- and by the oracle in its x86 approximation mode (the reference's _mm_rcp_ss / _mm_rsqrt_ps
 through the host's instructions).  Expected: every pixel and the ray counters bit for bit.  LightSamplingStrategy::All is forced (under `Single` with several lights the
 reference picks the light with an entropy-seeded per-thread generator: not a function of the seed).
-   python tools/reference_fuzz.py [seconds] [seed] [kinds]
+   python tools/reference_fuzz.py [seconds] [seed] [kinds] [only this scene kind, e.g. random]
 Test infrastructure; nothing here is on the product path."""
 import os
 import sys
@@ -18,7 +18,7 @@ import ref_render
 import oracle_fuzz_replay as replay
 
 
-def run(budget=120.0, seed=1, kinds=7, log=print):
+def run(budget=120.0, seed=1, kinds=8, log=print, only=None):
     ok, signature = oracle_lib.set_x86_approximations(True)
     assert ok, "this CPU cannot evaluate the reference's approximate instructions"
     bn = ra.load_blue_noise()
@@ -29,6 +29,8 @@ def run(budget=120.0, seed=1, kinds=7, log=print):
             if time.time() >= t_end:
                 break
             index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule = case
+            if only and make[0] != only:
+                continue
             if make[0] == "sponza" and make[3]:
                 continue     # (textured variants: the exporter writes bitmap textures, a second of work per case -- the fixed fixtures cover them)
             scene, camera = replay.build(case)
@@ -75,6 +77,6 @@ def run(budget=120.0, seed=1, kinds=7, log=print):
 
 
 if __name__ == "__main__":
-    cases, bad, signature = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 7)
+    cases, bad, signature = run(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1, int(sys.argv[3]) if len(sys.argv) > 3 else 8, only=sys.argv[4] if len(sys.argv) > 4 else None)
     print("cases %d, mismatches %d (approximation tables %08x %08x)" % (cases, bad, signature[0], signature[1]))
     sys.exit(1 if bad else 0)
