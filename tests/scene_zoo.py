@@ -169,7 +169,8 @@ def bumpy_patch(rng, n):
 
 def random_scene(aspect, seed):
     """A scene drawn from `seed` alone: 3..8 materials over all BSDFs with random parameters, 4..13 analytic shapes and 0..2 bumpy mesh patches under GENERAL rotations,
-    a floor, 1..4 lights of random type, transform and parameters, a camera somewhere on a shell around it.  The fixed scenes of the soaks hold translations and quarter
+    a floor, 1..4 lights of random type, transform and parameters, a camera somewhere on a shell around it; in a third of the scenes bitmap textures on random material
+    slots (normal maps too) and possibly an environment map.  The fixed scenes of the soaks hold translations and quarter
     turns almost everywhere; the host mirror's differently-rounded matrix inverse (round 6) hid behind exactly that."""
     rng = np.random.RandomState(seed)
     s = ra.Scene()
@@ -191,6 +192,28 @@ def random_scene(aspect, seed):
     if rng.randint(4) == 0:
         mats.append(s.add_material("null", (0.0, 0.0, 0.0), emission=colour(0.1, 0.8)))
     floor = s.add_material("diffuse" if rng.randint(2) else "roughPlastic", colour(0.3, 0.8), roughness=float(rng.uniform(0.05, 0.6)))
+    mats_all = mats + [floor]
+    # bitmap textures (a draw of their own: geometry, lights and camera of a seed do not depend on it): in a third of the scenes 1..4 bitmaps of assorted texel formats
+    # on random slots of random materials -- normal maps among them (Scene.cpp:328-337, the rsqrt site) -- and possibly an environment map for a background light.
+    # Default filter, no palette: what the reference's public constructor gives and tests/ref_render.py exports.
+    trng = np.random.RandomState((seed * 2654435761 + 12345) % (1 << 31))
+    env_map = None
+    if trng.randint(3) == 0:
+        def bitmap():
+            h, w = int(trng.randint(2, 40)), int(trng.randint(2, 40))
+            fmt = ["R8G8B8A8_UNorm", "B8G8R8A8_UNorm", "B8G8R8_UNorm", "R8_UNorm", "R16_UNorm", "R32G32B32_Float", "R32G32B32A32_Float"][trng.randint(7)]
+            if fmt in ("R8G8B8A8_UNorm", "B8G8R8A8_UNorm"): px = trng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+            elif fmt == "B8G8R8_UNorm": px = trng.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+            elif fmt == "R8_UNorm": px = trng.randint(0, 256, size=(h, w)).astype(np.uint8)
+            elif fmt == "R16_UNorm": px = trng.randint(0, 65536, size=(h, w)).astype(np.uint16)
+            elif fmt == "R32G32B32_Float": px = trng.uniform(0.0, 1.0, size=(h, w, 3)).astype(np.float32)
+            else: px = trng.uniform(0.0, 1.0, size=(h, w, 4)).astype(np.float32)
+            return s.add_bitmap_texture(px, fmt, linear_space=bool(trng.randint(2)) or px.dtype != np.uint8)
+        for _ in range(trng.randint(1, 5)):
+            slot = ["baseColor", "emission", "roughness", "metalness", "normal", "normal"][trng.randint(6)]
+            s.set_material_texture(mats_all[trng.randint(len(mats_all))], slot, bitmap(), strength=float(trng.uniform(0.2, 1.5)))
+        if trng.randint(2):
+            env_map = s.add_bitmap_texture(trng.uniform(0.0, 2.0, size=(int(trng.randint(2, 24)), int(trng.randint(2, 48)), 3)).astype(np.float32), "R32G32B32_Float")
     s.add_rect((12.0, 12.0), ra.transform_from_euler((0.0, -2.5, 0.0), (-90.0, float(rng.uniform(-180.0, 180.0)), 0.0)), floor)
     for _ in range(rng.randint(4, 14)):
         m = mats[rng.randint(len(mats))]
@@ -211,7 +234,7 @@ def random_scene(aspect, seed):
         elif kind == 3: s.add_point_light(colour(8.0, 30.0), pose((4.0, 1.0, 4.0), 3.5))
         elif kind == 4: s.add_spot_light(colour(20.0, 80.0), float(rng.uniform(0.2, 1.2)), pose((4.0, 1.0, 4.0), 4.0))
         elif kind == 5: s.add_directional_light(colour(1.0, 4.0), float(rng.choice([0.001, 0.02, rng.uniform(0.03, 0.3)])), pose())
-        else: s.add_background_light(colour(0.05, 0.8))
+        else: s.add_background_light(colour(0.05, 0.8), texture=env_map)
     s.build()
     radius, height, turn = rng.uniform(7.0, 13.0), rng.uniform(-1.0, 6.0), rng.uniform(0.0, 2.0 * np.pi)
     position = (float(radius * np.sin(turn)), float(height), float(radius * np.cos(turn)))
