@@ -52,7 +52,7 @@ def run(budget=120.0, seed=1, kinds=8, log=print, only=None):
                 continue
             args = dict(args, max_ray_depth=min(args["max_ray_depth"], deepest))
             path = "/tmp/reference_fuzz_%d.bin" % os.getpid()
-            ref_render.export_scene(path, scene, camera, w, h, 1, 1, args["max_ray_depth"], min_rr_depth=args["min_russian_roulette_depth"], dimensions=dims,
+            ref_render.export_scene(path, scene, camera, w, h, passes, 1, args["max_ray_depth"], min_rr_depth=args["min_russian_roulette_depth"], dimensions=dims,
                                     use_blue_noise=args["use_blue_noise"], light_sampling_all=sampling_all, seed=vp_seed)
             stats, out = ref_render.run(path, threads=1)
             os.remove(path)
@@ -60,10 +60,13 @@ def run(budget=120.0, seed=1, kinds=8, log=print, only=None):
             vp = ra.Viewport(w, h, seed=vp_seed, max_ray_depth=args["max_ray_depth"], min_russian_roulette_depth=args["min_russian_roulette_depth"], light_sampling_all=sampling_all,
                              dimensions=dims, use_blue_noise=args["use_blue_noise"])
             vp.reset()
-            p = vp.next_pass_params(camera)
             img = np.zeros((h, w, 3), dtype=np.float32); cnt = np.zeros(16, dtype=np.uint64)
-            oracle_lib.render_pass(scene.desc, p, w, h, img, None, cnt, threads=min(32, os.cpu_count() or 1))
-            seeds = np.ctypeslib.as_array(p.seed, shape=(p.numDimensions,))
+            seeds = None
+            for _ in range(passes):     # the stream's 1 / 2 / 4 passes: the sum buffer after all of them (the Halton sequence's progression is the host mirror's)
+                p = vp.next_pass_params(camera)
+                if seeds is None:
+                    seeds = np.ctypeslib.as_array(p.seed, shape=(p.numDimensions,)).copy()
+                oracle_lib.render_pass(scene.desc, p, w, h, img, None, cnt, threads=min(32, os.cpu_count() or 1))
             differing = int(np.count_nonzero((img.view(np.uint32) != out["image"].view(np.uint32)).any(axis=2)))
             same = differing == 0 and np.array_equal(seeds, out["first_pass_seeds"]) and int(cnt[0]) == out["numRays"] and int(cnt[1]) == out["numShadowRays"] and int(cnt[2]) == out["numShadowRaysHit"]
             cases += 1
