@@ -20,6 +20,6 @@ def test_oracle_equals_the_reference_renderer_on_random_cases(built):
         pytest.skip("this CPU cannot evaluate the reference's approximate instructions")
     import reference_fuzz
     lines = []
-    cases, bad, _ = reference_fuzz.run(budget=20.0, seed=3, kinds=7, log=lambda *a: lines.append(" ".join(str(x) for x in a)))
-    assert cases >= 5
+    cases, bad, _ = reference_fuzz.run(budget=20.0, seed=3, kinds=8, min_cases=12, log=lambda *a: lines.append(" ".join(str(x) for x in a)))
+    assert cases >= 12
     assert bad == 0, "\n".join(lines)

@@ -18,7 +18,7 @@ import ref_render
 import oracle_fuzz_replay as replay
 
 
-def run(budget=120.0, seed=1, kinds=8, log=print, only=None):
+def run(budget=120.0, seed=1, kinds=8, log=print, only=None, min_cases=0):
     ok, signature = oracle_lib.set_x86_approximations(True)
     assert ok, "this CPU cannot evaluate the reference's approximate instructions"
     bn = ra.load_blue_noise()
@@ -26,7 +26,7 @@ def run(budget=120.0, seed=1, kinds=8, log=print, only=None):
     cases = bad = 0
     try:
         for case in replay.stream(seed, None, kinds):
-            if time.time() >= t_end:
+            if time.time() >= t_end and cases >= min_cases:
                 break
             index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule = case
             if only and make[0] != only:
