@@ -215,6 +215,15 @@ def random_scene(aspect, seed):
         if trng.randint(2):
             env_map = s.add_bitmap_texture(trng.uniform(0.0, 2.0, size=(int(trng.randint(2, 24)), int(trng.randint(2, 48)), 3)).astype(np.float32), "R32G32B32_Float")
     s.add_rect((12.0, 12.0), ra.transform_from_euler((0.0, -2.5, 0.0), (-90.0, float(rng.uniform(-180.0, 180.0)), 0.0)), floor)
+    # a room around it in half of the scenes (a draw of its own again): closed scenes keep paths alive to the depth limit, open ones lose most rays to the sky
+    rrng = np.random.RandomState((seed * 40503 + 977) % (1 << 31))
+    room = None
+    if rrng.randint(2):
+        half, turn = float(rrng.uniform(7.0, 9.0)), float(rrng.uniform(-180.0, 180.0))
+        room = half
+        for t, r in (((0.0, 2.0 * half - 2.5, 0.0), (90.0, turn, 0.0)), ((half, half - 2.5, 0.0), (0.0, -90.0, 0.0)), ((-half, half - 2.5, 0.0), (0.0, 90.0, 0.0)),
+                     ((0.0, half - 2.5, half), (0.0, 180.0, 0.0)), ((0.0, half - 2.5, -half), (0.0, 0.0, 0.0))):
+            s.add_rect((half, half), ra.transform_from_euler(t, r), mats_all[rrng.randint(len(mats_all))])
     for _ in range(rng.randint(4, 14)):
         m = mats[rng.randint(len(mats))]
         kind = rng.randint(3)
@@ -237,6 +246,8 @@ def random_scene(aspect, seed):
         else: s.add_background_light(colour(0.05, 0.8), texture=env_map)
     s.build()
     radius, height, turn = rng.uniform(7.0, 13.0), rng.uniform(-1.0, 6.0), rng.uniform(0.0, 2.0 * np.pi)
+    if room is not None:
+        radius = min(radius, room - 0.75)      # the camera stands inside the room
     position = (float(radius * np.sin(turn)), float(height), float(radius * np.cos(turn)))
     target = tuple(float(v) for v in rng.uniform(-1.5, 1.5, size=3))
     cam = ra.Camera(position, _look_at_euler(position, target), aspect, float(rng.uniform(35.0, 75.0)))
