@@ -117,7 +117,8 @@ typedef enum RtObjectKind
 typedef struct RtObject
 {
     float    transform[16];     /* local -> world, ISceneObject::mTransform         */
-    float    invTransform[16];  /* world -> local, Matrix4::Inverse() of the above  (SceneObject.cpp:22) */
+    float    invTransform[16];  /* world -> local, Matrix4::Inverse() of the above  (SceneObject.cpp:22).  Pass the reference's OWN inverse (GetInverseTransform()):
+                                   the library never recomputes it, and a differently rounded inverse changes rendered bits (1-2 ulp under general rotations) */
     uint32_t objectKind;        /* RtObjectKind */
     uint32_t shapeKind;         /* RtShapeKind (for lights: shape of the area light; unused for point/spot) */
     uint32_t materialIndex;     /* default material (shapes); RT_NO_MATERIAL for lights */
