@@ -229,7 +229,7 @@ def random_scene(aspect, seed):
         kind = rng.randint(3)
         if kind == 0: s.add_sphere(float(rng.uniform(0.3, 1.4)), pose(), m)
         elif kind == 1: s.add_box(tuple(float(v) for v in rng.uniform(0.2, 1.3, size=3)), pose(), m)
-        else: s.add_rect(tuple(float(v) for v in rng.uniform(0.4, 2.0, size=2)), pose(), m)
+        else: s.add_rect(tuple(float(v) for v in rng.uniform(0.4, 2.0, size=2)), pose(), m, tex_scale=tuple(float(v) for v in rrng.uniform(0.2, 3.0, size=2)))
     for _ in range(rng.randint(3)):
         pos, idx, nrm, tan, uv = bumpy_patch(rng, int(rng.choice([6, 14, 30])))
         pos = pos * np.float32(rng.uniform(1.0, 3.5))
