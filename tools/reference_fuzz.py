@@ -31,8 +31,8 @@ def run(budget=120.0, seed=1, kinds=8, log=print, only=None, min_cases=0):
             index, kind, w, h, make, cam, args, passes, counters_on, vp_seed, schedule = case
             if only and make[0] != only:
                 continue
-            if make[0] == "sponza" and make[3]:
-                continue     # (textured variants: the exporter writes bitmap textures, a second of work per case -- the fixed fixtures cover them)
+            if make[0] == "sponza" and make[3] and not os.environ.get("REFERENCE_FUZZ_TEXTURED_SPONZA"):
+                continue     # (textured atrium variants: a second of exporting per case; REFERENCE_FUZZ_TEXTURED_SPONZA=1 includes them -- random scenes carry bitmaps anyway)
             scene, camera = replay.build(case)
             # lens settings are this tool's own draw (the replay stream stays what the recorded seeds mean): a third of the cases with depth of field, all three
             # bokeh shapes.  (Barrel distortion with a variable factor draws from the reference's entropy-seeded generator: not comparable.)
@@ -52,8 +52,11 @@ def run(budget=120.0, seed=1, kinds=8, log=print, only=None, min_cases=0):
                 continue
             args = dict(args, max_ray_depth=min(args["max_ray_depth"], deepest))
             path = "/tmp/reference_fuzz_%d.bin" % os.getpid()
-            ref_render.export_scene(path, scene, camera, w, h, passes, 1, args["max_ray_depth"], min_rr_depth=args["min_russian_roulette_depth"], dimensions=dims,
-                                    use_blue_noise=args["use_blue_noise"], light_sampling_all=sampling_all, seed=vp_seed)
+            try:
+                ref_render.export_scene(path, scene, camera, w, h, passes, 1, args["max_ray_depth"], min_rr_depth=args["min_russian_roulette_depth"], dimensions=dims,
+                                        use_blue_noise=args["use_blue_noise"], light_sampling_all=sampling_all, seed=vp_seed)
+            except (KeyError, ValueError):
+                continue     # a texture kind the exporter does not write (checkerboard / noise / mix, filters other than the default: the harness builds plain bitmaps only)
             stats, out = ref_render.run(path, threads=1)
             os.remove(path)
             scene.desc.contents.blueNoise = bn.ctypes.data
